@@ -1,0 +1,433 @@
+"""Synthetic config models + the quantiser restatement.
+
+The reference ships structure-only `benchmark/models/*_benchmark.tmfile` (no weights)
+and its quantisation tool needs OpenCV, so the quantised configs are synthesised:
+
+  * topologies are written out here (node-for-node the same graphs the reference benchmarks:
+    tests/test_models_structure.py diffs them against the reference files when those are present),
+  * weights: fp32 N(0, sqrt(2/fan_in)), bias U(-0.1, 0.1), numpy PCG64 seeded 0x5EED0000+node index,
+  * int8 quantisation mirrors tools/quantize/quant_save_graph.cpp:355-613 (min-max calibration):
+    activations per-tensor symmetric (zp 0, scale = absmax/127), weights per-out-channel
+    scale = max|w|/127 (:526-536), q = round(w/scale) clamp +-127 (:541-556), bias int32
+    round(b/(in_scale*w_scale[c])) (:581-601); pass-through ops share scales (:440-470).
+
+Calibration uses a plain fp32 forward in torch (CPU) -- it only decides the scales; it is not an
+oracle and nothing in the product path depends on it.
+"""
+import numpy as np
+
+from . import tm2
+from .tm2 import DT_FP32, DT_INT8, DT_INT32, DT_UINT8, Graph
+
+SEED0 = 0x5EED0000
+
+
+# --------------------------------------------------------------------------------------
+# fp32 graph construction helpers
+# --------------------------------------------------------------------------------------
+class _B:
+    """fp32 graph builder with seeded synthetic weights."""
+
+    def __init__(self, name, in_dims):
+        self.g = Graph(name=name)
+        self.cur = self.g.add_input("data", in_dims, DT_FP32)
+
+    def _rng(self):
+        return np.random.default_rng(SEED0 + len(self.g.nodes))
+
+    def dims(self, t):
+        return self.g.tensors[t].dims
+
+    def conv(self, name, x, cout, k, s=1, p=0, group=1, act=-1, bias=True, dil=1):
+        cin = self.dims(x)[1]
+        rng = self._rng()
+        fan_in = (cin // group) * k * k
+        w = rng.normal(0.0, np.sqrt(2.0 / fan_in), size=(cout, cin // group, k, k)).astype(np.float32)
+        ins = [x, self.g.add_const(name + "/weight", w, DT_FP32)]
+        if bias:
+            b = rng.uniform(-0.1, 0.1, size=(cout,)).astype(np.float32)
+            ins.append(self.g.add_const(name + "/bias", b, DT_FP32))
+        n, _, h, wd = self.dims(x)
+        oh = (h - dil * (k - 1) - 1 + 2 * p) // s + 1
+        ow = (wd - dil * (k - 1) - 1 + 2 * p) // s + 1
+        y = self.g.add_tensor(name + "/0", [n, cout, oh, ow], DT_FP32)
+        self.g.add_node(name, "Convolution", ins, [y], kernel_h=k, kernel_w=k, stride_h=s, stride_w=s,
+                        dilation_h=dil, dilation_w=dil, input_channel=cin, output_channel=cout, group=group,
+                        activation=act, pad_h0=p, pad_w0=p, pad_h1=p, pad_w1=p)
+        return y
+
+    def pool(self, name, x, alg, k, s, p=0, glob=0, caffe=0):
+        n, c, h, w = self.dims(x)
+        if glob:
+            oh = ow = 1
+        else:
+            oh, _, _ = pool_out(h, k, s, p, caffe)
+            ow, _, _ = pool_out(w, k, s, p, caffe)
+        y = self.g.add_tensor(name + "/0", [n, c, oh, ow], DT_FP32)
+        self.g.add_node(name, "Pooling", [x], [y], alg=alg, kernel_h=k, kernel_w=k, stride_h=s, stride_w=s,
+                        **{"global": glob}, caffe_flavor=caffe, pad_h0=p, pad_w0=p, pad_h1=p, pad_w1=p)
+        return y
+
+    def fc(self, name, x, nout):
+        d = self.dims(x)
+        hidden = int(np.prod(d[1:]))
+        rng = self._rng()
+        w = rng.normal(0.0, np.sqrt(2.0 / hidden), size=(nout, hidden)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, size=(nout,)).astype(np.float32)
+        ins = [x, self.g.add_const(name + "/weight", w, DT_FP32), self.g.add_const(name + "/bias", b, DT_FP32)]
+        y = self.g.add_tensor(name + "/0", [d[0], nout], DT_FP32)
+        self.g.add_node(name, "FullyConnected", ins, [y], num_output=nout)
+        return y
+
+    def relu(self, name, x, slope=0.0):
+        y = self.g.add_tensor(name + "/0", list(self.dims(x)), DT_FP32)
+        self.g.add_node(name, "ReLU", [x], [y], negative_slope=slope)
+        return y
+
+    def eltwise_sum(self, name, a, b):
+        y = self.g.add_tensor(name + "/0", list(self.dims(a)), DT_FP32)
+        self.g.add_node(name, "Eltwise", [a, b], [y], type=tm2.ELT_SUM, caffe_flavor=1)
+        return y
+
+    def concat(self, name, xs, axis=1):
+        d = list(self.dims(xs[0]))
+        d[axis] = sum(self.dims(x)[axis] for x in xs)
+        y = self.g.add_tensor(name + "/0", d, DT_FP32)
+        self.g.add_node(name, "Concat", xs, [y], axis=axis)
+        return y
+
+    def dropout(self, name, x):
+        y = self.g.add_tensor(name + "/0", list(self.dims(x)), DT_FP32)
+        self.g.add_node(name, "Dropout", [x], [y])
+        return y
+
+    def softmax(self, name, x, axis=1):
+        y = self.g.add_tensor(name + "/0", list(self.dims(x)), DT_FP32)
+        self.g.add_node(name, "Softmax", [x], [y], axis=axis)
+        return y
+
+    def upsample(self, name, x, scale=2):
+        n, c, h, w = self.dims(x)
+        y = self.g.add_tensor(name + "/0", [n, c, h * scale, w * scale], DT_FP32)
+        self.g.add_node(name, "Upsample", [x], [y], scale=float(scale))
+        return y
+
+    def finish(self, outs):
+        for o in outs:
+            for ni, n in enumerate(self.g.nodes):
+                if o in n.outputs:
+                    self.g.output_nodes.append(ni)
+        return self.g
+
+
+def _cdiv(a, b):
+    """C integer division (truncates toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b > 0) else -q
+
+
+def pool_out(inp, k, s, pad, caffe):
+    """Output size + real pads (source/operator/prototype/pooling_param.h:59-105)."""
+    if pad >= 0:
+        if caffe == 1:
+            out = 2 + _cdiv(inp - k + 2 * pad - 1, s)
+            if pad > 0 and (out - 1) * s >= inp + pad:
+                out -= 1
+        elif caffe == 2:
+            out = 1 + _cdiv(inp - k + pad, s)
+        else:
+            out = 1 + _cdiv(inp - k + 2 * pad, s)
+    else:
+        out = 1 + _cdiv(inp - 1, s)
+    total = (out - 1) * s + k
+    pad_num = max(total - inp, 0)
+    p0 = pad_num // 2 if pad < 0 else pad
+    p1 = pad_num - pad
+    return out, p0, p1
+
+
+# --------------------------------------------------------------------------------------
+# topologies
+# --------------------------------------------------------------------------------------
+def mobilenet_v1_fp32(batch=1, res=224, classes=1000):
+    """MobileNet-v1 1.0 (benchmark/models/mobilenet_benchmark.tmfile: 28 conv + global avgpool;
+    BN/scale/ReLU folded into the convs, classifier `fc7` is a 1x1 conv)."""
+    b = _B("mobilenet_v1", [batch, 3, res, res])
+    x = b.conv("conv1", b.cur, 32, 3, 2, 1, act=0)
+    cfg = [("2_1", 64, 1), ("2_2", 128, 2), ("3_1", 128, 1), ("3_2", 256, 2), ("4_1", 256, 1), ("4_2", 512, 2),
+           ("5_1", 512, 1), ("5_2", 512, 1), ("5_3", 512, 1), ("5_4", 512, 1), ("5_5", 512, 1),
+           ("5_6", 1024, 2), ("6", 1024, 1)]
+    for tag, cout, s in cfg:
+        cin = b.dims(x)[1]
+        x = b.conv("conv%s/dw" % tag, x, cin, 3, s, 1, group=cin, act=0)
+        x = b.conv("conv%s/sep" % tag, x, cout, 1, 1, 0, act=0)
+    x = b.pool("pool6", x, tm2.POOL_AVG, 2, 1, 0, glob=1, caffe=1)
+    x = b.conv("fc7", x, classes, 1, 1, 0, act=-1)
+    return b.finish([x])
+
+
+def resnet50_fp32(batch=1, res=224, classes=1000):
+    """ResNet-50 v1 caffe style (benchmark/models/resnet50_benchmark.tmfile: 53 conv, 16 eltwise,
+    16 standalone relu after the adds, max+avg pool, fc, softmax). Stride-2 sits on the first 1x1."""
+    b = _B("resnet50", [batch, 3, res, res])
+    x = b.conv("conv1", b.cur, 64, 7, 2, 3, act=0)
+    x = b.pool("pool1", x, tm2.POOL_MAX, 3, 2, 0, caffe=1)
+    stages = [(2, 64, 256, 3, 1), (3, 128, 512, 4, 2), (4, 256, 1024, 6, 2), (5, 512, 2048, 3, 2)]
+    for st, mid, out, reps, stride in stages:
+        for r in range(reps):
+            tag = "res%d%s" % (st, "abcdef"[r])
+            s = stride if r == 0 else 1
+            if r == 0:
+                sc = b.conv(tag + "_branch1", x, out, 1, s, 0, act=-1)
+            else:
+                sc = x
+            y = b.conv(tag + "_branch2a", x, mid, 1, s, 0, act=0)
+            y = b.conv(tag + "_branch2b", y, mid, 3, 1, 1, act=0)
+            y = b.conv(tag + "_branch2c", y, out, 1, 1, 0, act=-1)
+            x = b.eltwise_sum(tag, sc, y)
+            x = b.relu(tag + "_relu", x)
+    x = b.pool("pool5", x, tm2.POOL_AVG, 7, 1, 0, glob=1, caffe=1)
+    x = b.fc("fc1000", x, classes)
+    x = b.softmax("prob", x)
+    return b.finish([x])
+
+
+def squeezenet_v11_fp32(batch=1, res=227, classes=1000):
+    """SqueezeNet v1.1 (benchmark/models/squeezenet_v1.1_benchmark.tmfile)."""
+    b = _B("squeezenet_v1.1", [batch, 3, res, res])
+    x = b.conv("conv1", b.cur, 64, 3, 2, 0, act=0)
+    x = b.pool("pool1", x, tm2.POOL_MAX, 3, 2, 0, caffe=1)
+
+    def fire(tag, x, sq, ex):
+        s = b.conv(tag + "/squeeze1x1", x, sq, 1, act=0)
+        e1 = b.conv(tag + "/expand1x1", s, ex, 1, act=0)
+        e3 = b.conv(tag + "/expand3x3", s, ex, 3, 1, 1, act=0)
+        return b.concat(tag + "/concat", [e1, e3])
+
+    x = fire("fire2", x, 16, 64)
+    x = fire("fire3", x, 16, 64)
+    x = b.pool("pool3", x, tm2.POOL_MAX, 3, 2, 0, caffe=1)
+    x = fire("fire4", x, 32, 128)
+    x = fire("fire5", x, 32, 128)
+    x = b.pool("pool5", x, tm2.POOL_MAX, 3, 2, 0, caffe=1)
+    x = fire("fire6", x, 48, 192)
+    x = fire("fire7", x, 48, 192)
+    x = fire("fire8", x, 64, 256)
+    x = fire("fire9", x, 64, 256)
+    x = b.dropout("drop9", x)
+    x = b.conv("conv10", x, classes, 1, act=0)
+    x = b.pool("pool10", x, tm2.POOL_AVG, 2, 1, 0, glob=1, caffe=1)
+    x = b.softmax("prob", x)
+    return b.finish([x])
+
+
+def yolov3_tiny_fp32(batch=1, res=416, nout=255):
+    """YOLOv3-tiny (benchmark/models/yolov3_tiny_benchmark.tmfile: 13 conv, leaky ReLUs kept as
+    separate nodes, 6 maxpool, route/upsample/concat, two 1x1 heads)."""
+    b = _B("yolov3_tiny", [batch, 3, res, res])
+    x = b.cur
+
+    def cbl(i, x, cout, k):
+        y = b.conv("conv%d" % i, x, cout, k, 1, k // 2, act=-1)
+        return b.relu("leaky%d" % i, y, 0.1)
+
+    chans = [16, 32, 64, 128, 256, 512]
+    route8 = None
+    for i, c in enumerate(chans):
+        x = cbl(i, x, c, 3)
+        if i == 4:
+            route8 = x
+        if i < 5:
+            x = b.pool("maxpool%d" % i, x, tm2.POOL_MAX, 2, 2, 0)
+        else:
+            x = b.pool("maxpool%d" % i, x, tm2.POOL_MAX, 2, 1, -1)     # darknet 'same' stride-1 maxpool
+    x = cbl(6, x, 1024, 3)
+    x13 = cbl(7, x, 256, 1)
+    y = cbl(8, x13, 512, 3)
+    head1 = b.conv("conv9", y, nout, 1, act=-1)
+    z = cbl(10, x13, 128, 1)
+    z = b.upsample("upsample", z, 2)
+    z = b.concat("route", [z, route8])
+    z = cbl(11, z, 256, 3)
+    head2 = b.conv("conv12", z, nout, 1, act=-1)
+    return b.finish([head2, head1])
+
+
+# --------------------------------------------------------------------------------------
+# fp32 forward (calibration only)
+# --------------------------------------------------------------------------------------
+def fp32_forward(g: Graph, x: np.ndarray):
+    """Plain fp32 forward of the IR; returns {tensor idx: ndarray}. Calibration aid, not an oracle."""
+    import torch
+    import torch.nn.functional as F
+
+    vals = {}
+    for ti, t in enumerate(g.tensors):
+        if t.ttype == tm2.TT_CONST:
+            vals[ti] = torch.from_numpy(np.asarray(t.data, dtype=np.float32))
+    for n in g.nodes:
+        op, p = n.op, n.params
+        if op == "Const":
+            continue
+        if op == "InputOp":
+            vals[n.outputs[0]] = torch.from_numpy(x.astype(np.float32))
+            continue
+        a = vals[n.inputs[0]]
+        if op == "Convolution":
+            w = vals[n.inputs[1]]
+            bias = vals[n.inputs[2]] if len(n.inputs) > 2 else None
+            a = F.pad(a, (p["pad_w0"], p["pad_w1"], p["pad_h0"], p["pad_h1"]))
+            y = F.conv2d(a, w, bias, stride=(p["stride_h"], p["stride_w"]),
+                         dilation=(p["dilation_h"], p["dilation_w"]), groups=p["group"])
+            act = p["activation"]
+            if act == 0:
+                y = torch.relu(y)
+            elif act > 0:
+                y = torch.clamp(y, 0, 6)
+        elif op == "Pooling":
+            if p["global"]:
+                y = a.mean(dim=(2, 3), keepdim=True) if p["alg"] == 1 else a.amax(dim=(2, 3), keepdim=True)
+            else:
+                od = g.tensors[n.outputs[0]].dims
+                k, s = p["kernel_h"], p["stride_h"]
+                _, p0h, p1h = pool_out(a.shape[2], k, s, p["pad_h0"], p["caffe_flavor"])
+                _, p0w, p1w = pool_out(a.shape[3], k, s, p["pad_w0"], p["caffe_flavor"])
+                if p["alg"] == 0:
+                    ap = F.pad(a, (p0w, max(p1w, 0) + k, p0h, max(p1h, 0) + k), value=float("-inf"))
+                    y = F.max_pool2d(ap, k, s)[:, :, :od[2], :od[3]]
+                else:
+                    ap = F.pad(a, (p0w, max(p1w, 0) + k, p0h, max(p1h, 0) + k))
+                    ones = F.pad(torch.ones_like(a), (p0w, max(p1w, 0) + k, p0h, max(p1h, 0) + k))
+                    y = (F.avg_pool2d(ap, k, s) / F.avg_pool2d(ones, k, s).clamp_min(1e-9))[:, :, :od[2], :od[3]]
+        elif op == "FullyConnected":
+            w = vals[n.inputs[1]]
+            y = a.reshape(a.shape[0], -1) @ w.t()
+            if len(n.inputs) > 2:
+                y = y + vals[n.inputs[2]]
+        elif op == "ReLU":
+            y = torch.where(a < 0, a * p.get("negative_slope", 0.0), a)
+        elif op == "ReLU6":
+            y = torch.clamp(a, 0, 6)
+        elif op == "Eltwise":
+            bb = vals[n.inputs[1]]
+            y = {tm2.ELT_SUM: a + bb, tm2.ELT_PROD: a * bb, tm2.ELT_MAX: torch.maximum(a, bb),
+                 tm2.ELT_SUB: a - bb}[p["type"]]
+        elif op == "Concat":
+            y = torch.cat([vals[i] for i in n.inputs], dim=p.get("axis", 1))
+        elif op == "Dropout":
+            y = a
+        elif op == "Softmax":
+            y = torch.softmax(a, dim=p.get("axis", 1))
+        elif op == "Upsample":
+            s = int(p.get("scale", 2))
+            y = a.repeat_interleave(s, dim=2).repeat_interleave(s, dim=3)
+        elif op == "Flatten":
+            y = a.reshape(a.shape[0], -1)
+        else:
+            raise NotImplementedError(op)
+        vals[n.outputs[0]] = y
+    return {k: v.numpy() for k, v in vals.items()}
+
+
+# --------------------------------------------------------------------------------------
+# quantiser restatement
+# --------------------------------------------------------------------------------------
+PASS_THROUGH = ("Dropout", "Flatten", "Reshape", "Permute")
+
+
+def synth_input(g: Graph, seed=1234, dtype=DT_INT8):
+    """Seeded uniform input over the full quantised range (SURVEY §8d 'Inputs')."""
+    dims = g.tensors[g.nodes[g.input_nodes[0]].outputs[0]].dims
+    rng = np.random.default_rng(seed)
+    if dtype == DT_INT8:
+        return rng.integers(-127, 128, size=dims, dtype=np.int64).astype(np.int8)
+    if dtype == DT_UINT8:
+        return rng.integers(0, 256, size=dims, dtype=np.int64).astype(np.uint8)
+    return rng.uniform(-1, 1, size=dims).astype(np.float32)
+
+
+def quantize_int8(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0) -> Graph:
+    """fp32 IR -> int8 IR following quant_save_graph.cpp:355-613 (see module docstring)."""
+    if calib_q is None:
+        calib_q = synth_input(gf, 1234, DT_INT8)
+    acts = fp32_forward(gf, calib_q.astype(np.float32) * np.float32(in_scale))
+    g = Graph(name=gf.name + "_int8")
+    g.input_nodes, g.output_nodes = list(gf.input_nodes), list(gf.output_nodes)
+    # activation scales
+    scale = {}
+    for ti, t in enumerate(gf.tensors):
+        if t.ttype == tm2.TT_CONST:
+            continue
+        if t.ttype == tm2.TT_INPUT:
+            scale[ti] = np.float32(in_scale)
+        else:
+            amax = float(np.abs(acts[ti]).max())
+            scale[ti] = np.float32(max(amax, 1e-6) / 127.0)
+    # pass-through ops share the producer's scale; relu (slope 0) and max-pool too (:440-470)
+    for n in gf.nodes:
+        if n.op in PASS_THROUGH or (n.op == "ReLU" and n.params.get("negative_slope", 0.0) == 0.0) \
+                or (n.op == "Pooling" and n.params["alg"] == 0):
+            scale[n.outputs[0]] = scale[n.inputs[0]]
+    # concat inputs share the output scale (:440-470): propagate backwards to the producers
+    for n in reversed(gf.nodes):
+        if n.op == "Concat":
+            for i in n.inputs:
+                scale[i] = scale[n.outputs[0]]
+    for n in gf.nodes:      # re-share after concat adjustment
+        if n.op in PASS_THROUGH or (n.op == "ReLU" and n.params.get("negative_slope", 0.0) == 0.0) \
+                or (n.op == "Pooling" and n.params["alg"] == 0):
+            scale[n.inputs[0]] = scale[n.outputs[0]]
+    wq = {}
+    for n in gf.nodes:
+        if n.op in ("Convolution", "FullyConnected"):
+            wt = gf.tensors[n.inputs[1]]
+            w = np.asarray(wt.data, dtype=np.float32)
+            w2 = w.reshape(w.shape[0], -1)
+            ws = (np.abs(w2).max(axis=1) / np.float32(127.0)).astype(np.float32)
+            ws = np.where(ws == 0, np.float32(1e-8), ws).astype(np.float32)
+            q = np.clip(np.round(w2 / ws[:, None]), -127, 127).astype(np.int8).reshape(w.shape)
+            wq[n.inputs[1]] = (q, ws)
+            if len(n.inputs) > 2:
+                bf = np.asarray(gf.tensors[n.inputs[2]].data, dtype=np.float32)
+                bs = (scale[n.inputs[0]] * ws).astype(np.float32)
+                bq = np.round(bf / bs).astype(np.int64).clip(-2 ** 31 + 1, 2 ** 31 - 1).astype(np.int32)
+                wq[n.inputs[2]] = (bq, bs)
+    for ti, t in enumerate(gf.tensors):
+        if t.ttype == tm2.TT_CONST:
+            if ti in wq:
+                q, s = wq[ti]
+                dt = DT_INT32 if q.dtype == np.int32 else DT_INT8
+                g.tensors.append(tm2.Tensor(t.name, list(t.dims), dt, tm2.TT_CONST, q,
+                                            [float(v) for v in s], [0] * len(s)))
+            else:
+                g.tensors.append(tm2.Tensor(t.name, list(t.dims), t.dtype, t.ttype, t.data))
+        else:
+            g.tensors.append(tm2.Tensor(t.name, list(t.dims), DT_INT8, t.ttype, None, [float(scale[ti])], [0]))
+    for n in gf.nodes:
+        g.nodes.append(tm2.Node(n.name, n.op, list(n.inputs), list(n.outputs), dict(n.params)))
+    return g
+
+
+def set_batch(g: Graph, batch: int) -> Graph:
+    """Re-shape every var/input tensor to a new batch (== set_tensor_shape + infer_shape)."""
+    for t in g.tensors:
+        if t.ttype != tm2.TT_CONST and t.dims:
+            t.dims = [batch] + list(t.dims[1:])
+    return g
+
+
+BUILDERS = {
+    "mobilenet_v1": mobilenet_v1_fp32,
+    "resnet50": resnet50_fp32,
+    "squeezenet_v1.1": squeezenet_v11_fp32,
+    "yolov3_tiny": yolov3_tiny_fp32,
+}
+
+
+def build(name, dtype="int8", batch=1, **kw) -> Graph:
+    gf = BUILDERS[name](batch=1, **kw)
+    if dtype == "fp32":
+        return set_batch(gf, batch)
+    if dtype == "int8":
+        return set_batch(quantize_int8(gf), batch)
+    raise NotImplementedError(dtype)
