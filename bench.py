@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of int8 MobileNet-v1 224x224 on N MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one forward pass of the hot path over one batch (default batch 1 = BASELINE configs[1]) of
+synthetic int8 input that is already resident in HBM.  Weights: the seeded synthetic int8 model written
+as a real tmfile; at N>1 rank 0 RCCL-broadcasts the tmfile bytes once (north_star), every rank loads them
+with the native loader, the images are sharded (each rank owns its own batch, weak scaling) and the
+outputs are all-gathered over RCCL every step, double-buffered so the gather of step k overlaps step k+1.
+
+Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on
+both sides, MAX over ranks.  value = N * batch * K / t.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel family, algorithmic bytes / average launch duration measured with HIP
+                events on the launch stream in this same process (tamd_graph_profile), vs the HBM peak
+  cpu_baseline  the REAL reference CPU backend (oracle/_ref, built from the unmodified sources) timed on
+                this host's cores on a bounded sample (rank 0, N=1 only); falls back to the C oracle port
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 MFMA peak (2x bf16 2.5 PF)
+
+
+class _CAI:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
+    ap.add_argument("--model", default="mobilenet_v1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from tengine_amd import capi, models, tm2
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- model: rank 0 synthesises the int8 tmfile, RCCL broadcast of the raw bytes ----------------
+    if rank == 0:
+        g = models.build(args.model, "int8", args.batch)
+        tm_bytes = tm2.write_tm2(g)
+    if world > 1:
+        n = torch.tensor([len(tm_bytes) if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.broadcast(n, 0)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(tm_bytes), dtype=torch.uint8))
+        dist.broadcast(buf, 0)            # RCCL over xGMI, once, outside the timed loop
+        tm_bytes = bytes(buf.cpu().numpy().tobytes())
+    g = tm2.read_tm2(tm_bytes)
+
+    gr = capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank)
+    x = models.synth_input(g, 1000 + rank)       # each rank owns its own shard of images
+    gr.set_input(x)
+    gr.upload()                                  # inputs resident in HBM before the timed region
+    gr.sync()
+
+    ext = torch.cuda.ExternalStream(gr.stream(), device=torch.device("cuda", local_rank))
+    out_ptr, out_bytes = gr.output_device(0)
+    out_view = torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda")
+    slots, gathered, works = None, None, [None, None]
+    if world > 1:
+        slots = [torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gathered = [torch.empty(out_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+    def step(k):
+        gr.launch()
+        if world > 1:
+            s = k & 1
+            with torch.cuda.stream(ext):
+                if works[s] is not None:
+                    works[s].wait()              # slot s free again (gather of step k-2 done)
+                slots[s].copy_(out_view, non_blocking=True)
+                works[s] = dist.all_gather_into_tensor(gathered[s], slots[s], async_op=True)
+
+    def drain():
+        if world > 1:
+            with torch.cuda.stream(ext):
+                for w in works:
+                    if w is not None:
+                        w.wait()
+        gr.sync()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, same process) -----------
+    roofline = None
+    if rank == 0:
+        prof = gr.profile(20)
+        fam = {}
+        for k in prof:
+            f = fam.setdefault(k["kernel"], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            f["ms"] += k["ms"]; f["bytes"] += k["bytes"]; f["macs"] += k["macs"]; f["launches"] += 1
+        dom = max(fam, key=lambda n: fam[n]["ms"])
+        d = fam[dom]
+        t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = 2.0 * d["macs"] / (MFMA_I8_PEAK_TOPS * 1e12)
+        if t_hbm >= t_mfma:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+        else:
+            ach = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": ach / MFMA_I8_PEAK_TOPS}
+        roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+                         "traffic": None,
+                         "kernel_time_share": d["ms"] / max(sum(f["ms"] for f in fam.values()), 1e-12),
+                         "sum_kernel_ms_per_step": sum(f["ms"] for f in fam.values())})
+
+    # ---- CPU baseline: the real reference backend on this host's cores (rank 0, N=1 only) ----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds)
+
+    out = gr.download()[0]
+    gr.close()
+    if rank == 0:
+        value = world * args.batch * args.steps / el
+        line = {
+            "metric": "images/sec int8 MobileNet-v1 224x224", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "%s int8 224x224 batch=%d per GPU (BASELINE configs[1]), weights = seeded synthetic "
+                                   "tmfile, input resident in HBM, hipGraph replay" % (args.model, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
+        }
+        if cpu:
+            line["speedup_vs_cpu_reference"] = value / cpu["value"] if cpu["value"] else None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tm_bytes, g, x, batch, budget_s):
+    """Reference `source/device/cpu` path through create_graph/prerun/run_graph on the host cores."""
+    import numpy as np
+    threads = os.cpu_count() or 1
+    try:
+        from oracle import ref_capi
+        if not ref_capi.available():
+            raise FileNotFoundError
+        rg = ref_capi.RefGraph(tm_bytes, ref_capi.MODE_INT8, threads)
+        rg.set_input(x)
+        rg.run()                                   # warm-up (weight packing, pool alloc)
+        ts, t_end = [], time.perf_counter() + budget_s
+        while time.perf_counter() < t_end or len(ts) < 3:
+            t0 = time.perf_counter()
+            rg.run()
+            ts.append(time.perf_counter() - t0)
+        rg.close()
+        return {"value": batch / min(ts), "unit": "images/s", "cores": threads, "kind": "reference",
+                "sample": "%d timed run_graph() calls of the same tmfile/input (batch %d), min %.1f ms, mean %.1f ms, "
+                          "reference CPU backend built -O3 -mfma -fopenmp from the unmodified sources"
+                          % (len(ts), batch, 1e3 * min(ts), 1e3 * float(np.mean(ts)))}
+    except (FileNotFoundError, OSError):
+        from oracle import oracle
+        oracle.run_graph(g, x)
+        ts, t_end = [], time.perf_counter() + budget_s
+        while time.perf_counter() < t_end or len(ts) < 3:
+            t0 = time.perf_counter()
+            oracle.run_graph(g, x)
+            ts.append(time.perf_counter() - t0)
+        return {"value": batch / min(ts), "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": "%d timed oracle passes (batch %d), min %.1f ms" % (len(ts), batch, 1e3 * min(ts))}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+/*
+ * tengine_amd.h -- C ABI of the MI355X (gfx950) device backend for Tengine's quantised CNN hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no C++/torch types.  Every entry
+ * point names the reference interface it replaces (paths relative to the reference root):
+ *
+ *   reference (source/device/device.h:40-108)          this library
+ *   ---------------------------------------------------------------------------------------------
+ *   interface.init / release_device                     tamd_init / tamd_shutdown
+ *   serializer load_mem  (tm2_serializer.c:915-936)     tamd_graph_load_tm2        (same tmfile bytes)
+ *   create_graph_node/tensor (c_api.c)                  tamd_graph_add_tensor / tamd_graph_add_node
+ *   allocator.describe (cuda_device.cc:47-83)           tamd_op_supported
+ *   interface.pre_run  (scheduler.c:49-59)              tamd_graph_prerun
+ *   interface.run      (scheduler.c:134)                tamd_graph_run  (host in -> H2D -> launches -> D2H)
+ *   interface.post_run / release_graph                  tamd_graph_destroy
+ *   set_tensor_buffer / get_tensor_buffer (c_api.c)     tamd_graph_set_input / tamd_graph_get_output
+ *
+ * The Tengine device plugin (tengine_amd/device/hip_device.cc -> register_hip_device(), the
+ * symbol name cmake/registry.cmake:11-31 derives from `hip_device.cc`) is a thin translator from
+ * `struct subgraph` onto this ABI; see INTEGRATION.md.
+ *
+ * Conventions follow the reference: every int function returns 0 on success, a negative value on
+ * failure (c_api.c:463-497); tamd_last_error() gives the message.  Tensors cross the boundary in
+ * the reference's layouts (activations NCHW, conv weights OIHW, FC weights [out][hidden], int32
+ * bias, per-tensor activation scales, per-out-channel weight scales); the NHWC / MFMA-packed device
+ * layouts are private to the backend.
+ */
+#ifndef TENGINE_AMD_H
+#define TENGINE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAMD_API __attribute__((visibility("default")))
+
+/* data types == TENGINE_DT_* (source/api/c_api.h:58-63) */
+enum { TAMD_DT_FP32 = 0, TAMD_DT_FP16 = 1, TAMD_DT_INT8 = 2, TAMD_DT_UINT8 = 3, TAMD_DT_INT32 = 4 };
+/* tensor types == TENSOR_TYPE_* (c_api.h:70-74) */
+enum { TAMD_TT_VAR = 1, TAMD_TT_CONST = 2, TAMD_TT_INPUT = 3 };
+
+/* operator codes of this ABI (the plugin maps OP_* of source/operator/op.h:38-145 onto these;
+ * the tm2 loader maps TM2_OPTYPE_* of tm2_format.h:157-264) */
+enum {
+    TAMD_OP_INPUT = 0,
+    TAMD_OP_CONST = 1,
+    TAMD_OP_CONV = 2,    /* param: tamd_conv_param  */
+    TAMD_OP_FC = 3,      /* param: tamd_fc_param    */
+    TAMD_OP_POOL = 4,    /* param: tamd_pool_param  */
+    TAMD_OP_RELU = 5,    /* param: tamd_relu_param  */
+    TAMD_OP_ELTWISE = 6, /* param: tamd_eltwise_param */
+    TAMD_OP_CONCAT = 7,  /* param: tamd_concat_param */
+    TAMD_OP_DROPOUT = 8, /* identity */
+    TAMD_OP_UPSAMPLE = 9,/* param: tamd_upsample_param */
+    TAMD_OP_RELU6 = 10,
+    TAMD_OP_FLATTEN = 11,
+    TAMD_OP_SOFTMAX = 12, /* fp32 only */
+    TAMD_OP_NUM
+};
+
+/* field meaning == struct conv_param (source/operator/prototype/convolution_param.h:28-45);
+ * activation: -1 none, 0 relu, 1 relu1, 6 relu6 */
+typedef struct tamd_conv_param {
+    int kernel_h, kernel_w, stride_h, stride_w;
+    int pad_h0, pad_h1, pad_w0, pad_w1;
+    int dilation_h, dilation_w;
+    int input_channel, output_channel, group, activation;
+} tamd_conv_param;
+
+typedef struct tamd_fc_param { int num_output; } tamd_fc_param;             /* fc_param.h */
+
+/* == struct pool_param (pooling_param.h:34-57): pool_method 0 max / 1 avg; pads are the *original*
+ * (model) pads, resolved exactly like infer_shape (pooling.c:36-100) */
+typedef struct tamd_pool_param {
+    int pool_method, kernel_h, kernel_w, stride_h, stride_w;
+    int pad_h0, pad_h1, pad_w0, pad_w1;
+    int global, caffe_flavor;
+} tamd_pool_param;
+
+typedef struct tamd_relu_param { float negative_slope; } tamd_relu_param;   /* relu_param.h */
+typedef struct tamd_eltwise_param { int type; int caffe_flavor; float shift, power, scale; } tamd_eltwise_param;
+typedef struct tamd_concat_param { int axis; } tamd_concat_param;
+typedef struct tamd_upsample_param { float scale; } tamd_upsample_param;
+
+/* == the quantisation-relevant part of struct tensor (source/graph/tensor.h:43-102) */
+typedef struct tamd_tensor_desc {
+    int dtype;            /* TAMD_DT_*                                            */
+    int ttype;            /* TAMD_TT_*                                            */
+    int dim_num;
+    int dims[8];          /* NCHW / OIHW / [out][hidden] / [n]                    */
+    const void* data;     /* const payload (host, copied at prerun), else NULL    */
+    int quant_num;        /* 0 none, 1 per-tensor, N per-channel                  */
+    const float* scales;  /* quant_num entries                                    */
+    const int* zero_points;
+    const char* name;     /* optional                                             */
+} tamd_tensor_desc;
+
+typedef struct tamd_node_desc {
+    int op;               /* TAMD_OP_*                                            */
+    int input_num;
+    const int* inputs;    /* tensor indices                                       */
+    int output_num;
+    const int* outputs;
+    const void* param;    /* op specific struct above, or NULL                    */
+    const char* name;
+} tamd_node_desc;
+
+/* == the device option blob passed through set_context_device (first field is dev_name by the
+ * reference's convention, trt_define.h:35-41 / scheduler.c:49-57) */
+typedef struct tamd_options {
+    const char* dev_name; /* "HIP"                                                */
+    int gpu_index;        /* HIP device ordinal                                   */
+    int use_hip_graph;    /* 1: capture the launch list into a hipGraph (default) */
+    int profile;          /* 1: honour TG_DEBUG_TIME-style per-node timing        */
+} tamd_options;
+
+typedef struct tamd_graph tamd_graph;
+
+/* ---- device -------------------------------------------------------------------------------- */
+TAMD_API int tamd_device_count(void);
+TAMD_API int tamd_init(int gpu_index);
+TAMD_API int tamd_shutdown(void);
+TAMD_API const char* tamd_last_error(void);
+TAMD_API const char* tamd_version(void);
+/* 1 if (op, dtype) can run on the device -- what allocator.describe publishes */
+TAMD_API int tamd_op_supported(int op, int dtype);
+
+/* ---- graph construction ------------------------------------------------------------------- */
+TAMD_API tamd_graph* tamd_graph_create(void);
+TAMD_API int tamd_graph_add_tensor(tamd_graph* g, const tamd_tensor_desc* desc);  /* -> tensor index or <0 */
+TAMD_API int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* desc);      /* -> node index or <0   */
+TAMD_API int tamd_graph_set_inputs(tamd_graph* g, int n, const int* tensor_ids);
+TAMD_API int tamd_graph_set_outputs(tamd_graph* g, int n, const int* tensor_ids);
+/* parse tmfile-v2 bytes (the reference's own model format); the buffer may be freed afterwards */
+TAMD_API tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size);
+/* re-shape the batch dimension of every input (== set_tensor_shape + infer_shape) before prerun */
+TAMD_API int tamd_graph_set_batch(tamd_graph* g, int batch);
+
+/* ---- execution ---------------------------------------------------------------------------- */
+TAMD_API int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt);
+TAMD_API int tamd_graph_input_num(const tamd_graph* g);
+TAMD_API int tamd_graph_output_num(const tamd_graph* g);
+/* dims/dtype of graph input / output `idx` (NCHW); returns dim_num */
+TAMD_API int tamd_graph_input_desc(const tamd_graph* g, int idx, int* dims8, int* dtype);
+TAMD_API int tamd_graph_output_desc(const tamd_graph* g, int idx, int* dims8, int* dtype, float* scale, int* zero_point);
+/* host NCHW buffers; the input pointer is re-read at every run (tm_benchmark.cc:95-102 semantics) */
+TAMD_API int tamd_graph_set_input(tamd_graph* g, int idx, const void* host_nchw, size_t bytes);
+TAMD_API int tamd_graph_set_output(tamd_graph* g, int idx, void* host_nchw, size_t bytes);
+/* H2D inputs -> kernels -> D2H outputs; returns when outputs are complete (scheduler is synchronous) */
+TAMD_API int tamd_graph_run(tamd_graph* g);
+/* HBM-resident variants (measurement, multi-GPU harness): stage inputs once, launch without copies */
+TAMD_API int tamd_graph_upload_inputs(tamd_graph* g);
+TAMD_API int tamd_graph_launch(tamd_graph* g);            /* async on the graph's stream          */
+TAMD_API int tamd_graph_sync(tamd_graph* g);
+TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
+/* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather) */
+TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);
+TAMD_API void* tamd_graph_stream(tamd_graph* g);          /* hipStream_t                           */
+/* time `iters` back-to-back launches with HIP events on the graph's stream -> total ms */
+TAMD_API int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms);
+
+/* ---- introspection / profiling ------------------------------------------------------------ */
+typedef struct tamd_kernel_info {
+    char node[64];        /* graph node name                                     */
+    char kernel[48];      /* device kernel family                                */
+    double macs;          /* multiply-accumulates of this launch                 */
+    double bytes;         /* algorithmic bytes: in + out + weights (+bias)       */
+    float ms;             /* average duration (tamd_graph_profile)               */
+} tamd_kernel_info;
+TAMD_API int tamd_graph_kernel_num(const tamd_graph* g);
+/* eager per-launch timing with hipEvent pairs on the graph's stream, averaged over `iters` */
+TAMD_API int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out);
+/* copy any tensor back to host in NCHW (debug / layer-by-layer parity, cf. TG_DEBUG_DATA) */
+TAMD_API int tamd_graph_read_tensor(tamd_graph* g, int tensor_idx, void* host_nchw, size_t bytes);
+TAMD_API int tamd_graph_tensor_num(const tamd_graph* g);
+TAMD_API int tamd_graph_tensor_desc(const tamd_graph* g, int tensor_idx, int* dims8, int* dtype);
+
+TAMD_API void tamd_graph_destroy(tamd_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,221 @@
+"""TEST INFRASTRUCTURE ONLY -- Python face of the CPU oracle restatement (oracle/tg_oracle.c) and a
+graph-level runner that executes a tengine_amd.tm2.Graph node by node in NCHW, choosing per conv
+node the formula the reference's own kernel selection would use.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(HERE, "libtg_oracle.so")
+_lib = None
+
+DT_FP32, DT_INT8, DT_UINT8, DT_INT32 = 0, 2, 3, 4
+CONV_HCL, CONV_REF = 0, 1
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "tg_oracle.c")
+        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+            build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def conv_variant(batch, p, cin, cout):
+    g = p.get("group", 1)
+    return lib().orc_conv_int8_variant(batch, g, cin // g, cout // g, p["kernel_h"], p["kernel_w"], p["stride_h"],
+                                       p["stride_w"], p.get("pad_h0", 0), p.get("pad_h1", 0), p.get("pad_w0", 0),
+                                       p.get("pad_w1", 0), p.get("dilation_h", 1), p.get("dilation_w", 1))
+
+
+def conv_out_dims(xd, wd, p):
+    """source/operator/prototype/convolution.c:35-145 (explicit-pad branch)."""
+    n, _, h, w = xd
+    oh = (h - p.get("dilation_h", 1) * (p["kernel_h"] - 1) - 1 + p.get("pad_h0", 0) + p.get("pad_h1", 0)) // p["stride_h"] + 1
+    ow = (w - p.get("dilation_w", 1) * (p["kernel_w"] - 1) - 1 + p.get("pad_w0", 0) + p.get("pad_w1", 0)) // p["stride_w"] + 1
+    return [n, wd[0], max(oh, 1), max(ow, 1)]
+
+
+def conv2d_int8(x, w, bias, p, in_scale, w_scales, out_scale, variant=None):
+    x = np.ascontiguousarray(x, np.int8)
+    w = np.ascontiguousarray(w, np.int8)
+    n, cin, h, wd = x.shape
+    od = conv_out_dims(x.shape, w.shape, p)
+    if variant is None:
+        variant = conv_variant(n, p, cin, od[1])
+    y = np.empty(od, np.int8)
+    ws = np.ascontiguousarray(w_scales, np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.int32)
+    rc = lib().orc_conv2d_int8(_p(x), _p(w), _p(b), _p(y), n, cin, h, wd, od[1], od[2], od[3], p["kernel_h"],
+                               p["kernel_w"], p["stride_h"], p["stride_w"], p.get("pad_h0", 0), p.get("pad_w0", 0),
+                               p.get("dilation_h", 1), p.get("dilation_w", 1), p.get("group", 1),
+                               p.get("activation", -1), C.c_float(in_scale), _p(ws), C.c_float(out_scale), variant)
+    assert rc == 0
+    return y
+
+
+def conv2d_fp32(x, w, bias, p):
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    n, cin, h, wd = x.shape
+    od = conv_out_dims(x.shape, w.shape, p)
+    y = np.empty(od, np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = lib().orc_conv2d_fp32(_p(x), _p(w), _p(b), _p(y), n, cin, h, wd, od[1], od[2], od[3], p["kernel_h"],
+                               p["kernel_w"], p["stride_h"], p["stride_w"], p.get("pad_h0", 0), p.get("pad_w0", 0),
+                               p.get("dilation_h", 1), p.get("dilation_w", 1), p.get("group", 1),
+                               p.get("activation", -1))
+    assert rc == 0
+    return y
+
+
+def fc_int8(x, w, bias, in_scale, w_scales, out_scale):
+    x = np.ascontiguousarray(x, np.int8).reshape(x.shape[0], -1)
+    w = np.ascontiguousarray(w, np.int8)
+    y = np.empty((x.shape[0], w.shape[0]), np.int8)
+    ws = np.ascontiguousarray(w_scales, np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.int32)
+    lib().orc_fc_int8(_p(x), _p(w), _p(b), _p(y), x.shape[0], x.shape[1], w.shape[0], C.c_float(in_scale), _p(ws),
+                      C.c_float(out_scale))
+    return y
+
+
+def fc_fp32(x, w, bias):
+    x = np.ascontiguousarray(x, np.float32).reshape(x.shape[0], -1)
+    w = np.ascontiguousarray(w, np.float32)
+    y = np.empty((x.shape[0], w.shape[0]), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    lib().orc_fc_fp32(_p(x), _p(w), _p(b), _p(y), x.shape[0], x.shape[1], w.shape[0])
+    return y
+
+
+def pool_resolve(xd, p):
+    """infer_shape of Pooling (source/operator/prototype/pooling.c:36-100 + pooling_param.h:59-105):
+    returns (out_h, out_w, kernel_h, kernel_w, stride_h, stride_w, pad_h0, pad_w0)."""
+    from tengine_amd.models import pool_out
+    n, c, h, w = xd
+    kh, kw, sh, sw = p["kernel_h"], p["kernel_w"], p["stride_h"], p["stride_w"]
+    ph0, pw0 = p.get("pad_h0", 0), p.get("pad_w0", 0)
+    glob = p.get("global", 0)
+    if kh == h and kw == w and ph0 == 0 and pw0 == 0 and p.get("pad_h1", 0) == 0 and p.get("pad_w1", 0) == 0:
+        glob = 1
+    if glob:
+        return 1, 1, h, w, 1, 1, 0, 0
+    caffe = p.get("caffe_flavor", 0)
+    oh, rh0, _ = pool_out(h, kh, sh, ph0, caffe)
+    ow, rw0, _ = pool_out(w, kw, sw, pw0, caffe)
+    if caffe == 2:
+        rh0, rw0 = ph0 // 2, pw0 // 2
+    return oh, ow, kh, kw, sh, sw, rh0, rw0
+
+
+def pool_int8(x, p, in_scale, out_scale):
+    x = np.ascontiguousarray(x, np.int8)
+    n, c, h, w = x.shape
+    oh, ow, kh, kw, sh, sw, ph0, pw0 = pool_resolve(x.shape, p)
+    y = np.empty((n, c, oh, ow), np.int8)
+    rc = lib().orc_pool_int8(_p(x), _p(y), n, c, h, w, oh, ow, kh, kw, sh, sw, ph0, pw0, p["alg"],
+                             p.get("caffe_flavor", 0), C.c_float(in_scale), C.c_float(out_scale))
+    assert rc == 0
+    return y
+
+
+def pool_fp32(x, p):
+    x = np.ascontiguousarray(x, np.float32)
+    n, c, h, w = x.shape
+    oh, ow, kh, kw, sh, sw, ph0, pw0 = pool_resolve(x.shape, p)
+    y = np.empty((n, c, oh, ow), np.float32)
+    rc = lib().orc_pool_fp32(_p(x), _p(y), n, c, h, w, oh, ow, kh, kw, sh, sw, ph0, pw0, p["alg"],
+                             p.get("caffe_flavor", 0))
+    assert rc == 0
+    return y
+
+
+def relu_int8(x, slope, in_scale, out_scale):
+    x = np.ascontiguousarray(x, np.int8)
+    y = np.empty_like(x)
+    lib().orc_relu_int8(_p(x), _p(y), C.c_size_t(x.size), C.c_float(slope), C.c_float(in_scale), C.c_float(out_scale))
+    return y
+
+
+def eltwise_int8(a, b, etype, sa, sb, out_scale):
+    a = np.ascontiguousarray(a, np.int8)
+    b = np.ascontiguousarray(b, np.int8)
+    assert a.shape == b.shape
+    y = np.empty_like(a)
+    rc = lib().orc_eltwise_int8(_p(a), _p(b), _p(y), C.c_size_t(a.size), etype, C.c_float(sa), C.c_float(sb),
+                                C.c_float(out_scale))
+    assert rc == 0
+    return y
+
+
+def run_graph(g, x, keep_all=False):
+    """Execute a tm2.Graph on the oracle. Returns ({tensor idx: ndarray} if keep_all else list of outputs)."""
+    from tengine_amd import tm2
+    T = g.tensors
+    vals = {i: t.data for i, t in enumerate(T) if t.ttype == tm2.TT_CONST}
+    sc = lambda i: np.float32(T[i].scales[0])
+    for n in g.nodes:
+        op, p = n.op, n.params
+        if op == "Const":
+            continue
+        if op == "InputOp":
+            vals[n.outputs[0]] = x
+            continue
+        i0, o0 = n.inputs[0], n.outputs[0]
+        a = vals[i0]
+        dt = T[o0].dtype
+        if op == "Convolution":
+            w = vals[n.inputs[1]]
+            b = vals[n.inputs[2]] if len(n.inputs) > 2 else None
+            if dt == DT_INT8:
+                y = conv2d_int8(a, w, b, p, sc(i0), T[n.inputs[1]].scales, sc(o0))
+            elif dt == DT_FP32:
+                y = conv2d_fp32(a, w, b, p)
+            else:
+                raise NotImplementedError("oracle conv dtype %d" % dt)
+        elif op == "FullyConnected":
+            w = vals[n.inputs[1]]
+            b = vals[n.inputs[2]] if len(n.inputs) > 2 else None
+            y = fc_int8(a, w, b, sc(i0), T[n.inputs[1]].scales, sc(o0)) if dt == DT_INT8 else fc_fp32(a, w, b)
+        elif op == "Pooling":
+            y = pool_int8(a, p, sc(i0), sc(o0)) if dt == DT_INT8 else pool_fp32(a, p)
+        elif op == "ReLU":
+            if dt == DT_INT8:
+                y = relu_int8(a, p.get("negative_slope", 0.0), sc(i0), sc(o0))
+            else:
+                s = np.float32(p.get("negative_slope", 0.0))
+                y = np.where(a < 0, a * s, a).astype(np.float32)
+        elif op == "Eltwise":
+            b2 = vals[n.inputs[1]]
+            if dt == DT_INT8:
+                y = eltwise_int8(a, b2, p["type"], sc(i0), sc(n.inputs[1]), sc(o0))
+            else:
+                y = {tm2.ELT_SUM: a + b2, tm2.ELT_PROD: a * b2, tm2.ELT_SUB: a - b2, tm2.ELT_MAX: np.maximum(a, b2)}[p["type"]]
+        elif op == "Dropout":
+            y = a
+        elif op == "Softmax" and dt == DT_FP32:
+            ax = p.get("axis", 1)
+            e = np.exp(a - a.max(axis=ax, keepdims=True))
+            y = (e / e.sum(axis=ax, keepdims=True)).astype(np.float32)
+        else:
+            raise NotImplementedError("oracle op %s dtype %d" % (op, dt))
+        vals[o0] = y
+    if keep_all:
+        return vals
+    return [vals[g.nodes[ni].outputs[0]] for ni in g.output_nodes]

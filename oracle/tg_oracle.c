@@ -1,0 +1,335 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of the reference's arithmetic for the
+ * int8 / fp32 Conv2D + FC hot path and the glue ops of the config graphs.  Plain C, NCHW buffers,
+ * no dependency on the reference tree.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may call into this file; the product (tengine_amd/) never links it.
+ *
+ * Pinning: tests/test_oracle_vs_reference.py runs every function here side by side with the real
+ * reference library (oracle/_ref, built from the unmodified sources by oracle/build_ref.py) on
+ * seeded random layers and whole models -- bit-exact for int8 -- and tests/test_golden_kat.py
+ * checks it against the inline known-answer vectors of the reference's own device tests
+ * (tests/op/test_opendla_op_convolution.cpp etc., restated in tests/golden/).
+ *
+ * Each function cites the reference file:line it follows (paths relative to the reference root,
+ * source/device/cpu/op/...).  All float arithmetic is binary32, one rounding per written
+ * operation, never fused: build with -ffp-contract=off (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* which formula the reference's kernel selection (score()) lands on -- SURVEY §8 a1:
+ *   conv_hcl_x86.c:351-371      group==1, dtype in {fp32,u8,i8}            -> ORC_CONV_HCL (A1)
+ *   conv_dw_hcl_x86.c:508-543   dw 3x3 s1|s2, batch 1, sym pad, dil 1       -> ORC_CONV_HCL (A1, same epilogue text)
+ *   conv_ref.c:197-200          everything else                             -> ORC_CONV_REF (A2)           */
+enum { ORC_CONV_HCL = 0, ORC_CONV_REF = 1 };
+
+ORC_API int orc_conv_int8_variant(int batch, int group, int cin_g, int cout_g, int kh, int kw, int sh, int sw,
+                                  int ph0, int ph1, int pw0, int pw1, int dh, int dw)
+{
+    if (group == 1)
+        return ORC_CONV_HCL;
+    if (kh == kw && batch == 1 && group > 1 && cin_g == 1 && cout_g == 1 && ph0 == ph1 && pw0 == pw1 && dh == 1
+        && dw == 1 && kh == 3 && ((sh == 1 && sw == 1) || (sh == 2 && sw == 2)))
+        return ORC_CONV_HCL;
+    return ORC_CONV_REF;
+}
+
+static inline int8_t sat_i8(int v)
+{
+    if (v > 127) v = 127;
+    if (v < -127) v = -127;
+    return (int8_t)v;
+}
+
+/* Requantising epilogue.
+ * A1  conv/x86/conv_kernel_x86.c:1826-1889 == conv/x86/conv_dw_hcl_x86.c:197-261,373-436
+ *     f = (float)(acc+bias) * in_scale * w_scale[c]   (two multiplies, in that order)
+ *     act==0 -> relu ; act>0 -> clamp [0,6] (ANY positive code) ; q = round(f / out_scale) ; clamp +-127
+ * A2  conv/conv_kernel_ref_int8.c:72-78,137-167
+ *     f = (float)(acc+bias) * (in_scale*w_scale[c])   (pre-multiplied) ; act>=0: relu unless act==1,
+ *     act==1 -> clamp[-1,1], act==6 -> min 6 ; q = round(f/out_scale) ; clamp +-127                      */
+static inline int8_t requant_conv(int32_t acc, float in_scale, float w_scale, float out_scale, int act, int variant)
+{
+    float f;
+    if (variant == ORC_CONV_HCL)
+    {
+        f = (float)acc * in_scale;
+        f = f * w_scale;
+        if (act == 0 && f < 0) f = 0;
+        if (act > 0)
+        {
+            if (f < 0) f = 0;
+            if (f > 6) f = 6;
+        }
+    }
+    else
+    {
+        float d = in_scale * w_scale;
+        f = (float)acc * d;
+        if (act >= 0)
+        {
+            if (f < 0 && act != 1) f = 0;
+            if (f > 1 && act == 1) f = 1;
+            if (f > 6 && act == 6) f = 6;
+            if (f < -1 && act == 1) f = -1;
+        }
+    }
+    float q = f / out_scale;
+    return sat_i8((int)round((double)q));
+}
+
+/* int8 convolution, NCHW input [n][cin][h][w], OIHW weight [cout][cin/group][kh][kw], int32 bias.
+ * Integer part: conv_kernel_x86.c:187-242 (im2col: top/left pad = pad_h0/pad_w0, out-of-image taps
+ * contribute 0) + :1008-1630 (sgemm_i8, exact int32) ; dw: conv_dw_hcl_x86.c:97-269 ; naive:
+ * conv_kernel_ref_int8.c:86-136.  All three compute the same exact integer sum.                        */
+ORC_API int orc_conv2d_int8(const int8_t* x, const int8_t* w, const int32_t* bias, int8_t* y, int n, int cin, int h,
+                            int wd, int cout, int oh, int ow, int kh, int kw, int sh, int sw, int ph0, int pw0,
+                            int dh, int dw, int group, int act, float in_scale, const float* w_scales,
+                            float out_scale, int variant)
+{
+    int cin_g = cin / group, cout_g = cout / group;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < n; b++)
+        for (int oc = 0; oc < cout; oc++)
+        {
+            int g = oc / cout_g;
+            const int8_t* wk = w + (size_t)oc * cin_g * kh * kw;
+            for (int oy = 0; oy < oh; oy++)
+                for (int ox = 0; ox < ow; ox++)
+                {
+                    int32_t acc = 0;
+                    for (int kc = 0; kc < cin_g; kc++)
+                    {
+                        const int8_t* xc = x + ((size_t)b * cin + (size_t)g * cin_g + kc) * h * wd;
+                        for (int ky = 0; ky < kh; ky++)
+                        {
+                            int iy = oy * sh - ph0 + ky * dh;
+                            if (iy < 0 || iy >= h) continue;
+                            for (int kx = 0; kx < kw; kx++)
+                            {
+                                int ix = ox * sw - pw0 + kx * dw;
+                                if (ix < 0 || ix >= wd) continue;
+                                acc += (int32_t)xc[iy * wd + ix] * (int32_t)wk[(kc * kh + ky) * kw + kx];
+                            }
+                        }
+                    }
+                    if (bias) acc += bias[oc];
+                    y[(((size_t)b * cout + oc) * oh + oy) * ow + ox] =
+                        requant_conv(acc, in_scale, w_scales[oc], out_scale, act, variant);
+                }
+        }
+    return 0;
+}
+
+/* int8 fully connected -- fc/fc_ref.c:209-297:  r[o] = (in_scale*w_scale[o]) / out_scale ;
+ * y = sat(roundf((float)(acc+bias[o]) * r[o]), +-127).  weight [out][hidden] (need_trans==0).           */
+ORC_API int orc_fc_int8(const int8_t* x, const int8_t* w, const int32_t* bias, int8_t* y, int batch, int hidden,
+                        int nout, float in_scale, const float* w_scales, float out_scale)
+{
+#pragma omp parallel for
+    for (int o = 0; o < nout; o++)
+    {
+        float r = (in_scale * w_scales[o]) / out_scale;
+        for (int b = 0; b < batch; b++)
+        {
+            int32_t acc = bias ? bias[o] : 0;
+            for (int j = 0; j < hidden; j++) acc += (int32_t)x[(size_t)b * hidden + j] * (int32_t)w[(size_t)o * hidden + j];
+            float f = (float)acc * r;
+            y[(size_t)b * nout + o] = sat_i8((int)roundf(f));
+        }
+    }
+    return 0;
+}
+
+/* int8 pooling, NCHW -- pooling/pooling_kernel_ref_int8.c:84-189.
+ * max: y = round((float)max_q * (in_scale/out_scale)) ; avg: f=(float)sum*in_scale; f=f/(float)pool_size;
+ * y = round(f/out_scale) ; pool_size counts in-image taps unless caffe_flavor (then the padded window
+ * clipped to in+pad).  method 0 max, 1 avg (pooling_param.h:28-32).                                       */
+ORC_API int orc_pool_int8(const int8_t* x, int8_t* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw,
+                          int sh, int sw, int ph0, int pw0, int method, int caffe_flavor, float in_scale,
+                          float out_scale)
+{
+    float requant = in_scale / out_scale;
+    for (int b = 0; b < n; b++)
+        for (int ch = 0; ch < c; ch++)
+        {
+            const int8_t* xc = x + ((size_t)b * c + ch) * h * w;
+            for (int py = 0; py < oh; py++)
+                for (int px = 0; px < ow; px++)
+                {
+                    int hs = py * sh - ph0, he = hs + kh;
+                    if (he > h + ph0) he = h + ph0;
+                    int ws = px * sw - pw0, we = ws + kw;
+                    if (we > w + pw0) we = w + pw0;
+                    int pool_size = 1;
+                    if (caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    if (hs < 0) hs = 0;
+                    if (ws < 0) ws = 0;
+                    if (he > h) he = h;
+                    if (we > w) we = w;
+                    if (!caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    int8_t* out = y + (((size_t)b * c + ch) * oh + py) * ow + px;
+                    if (method == 0)
+                    {
+                        int8_t m = xc[hs * w + ws];
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++)
+                                if (xc[iy * w + ix] > m) m = xc[iy * w + ix];
+                        *out = sat_i8((int)round((double)((float)m * requant)));
+                    }
+                    else
+                    {
+                        int32_t s = 0;
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++) s += xc[iy * w + ix];
+                        float f = (float)s * in_scale;
+                        f = f / (float)pool_size;
+                        *out = sat_i8((int)round((double)(f / out_scale)));
+                    }
+                }
+        }
+    return 0;
+}
+
+/* int8 relu / leaky relu -- relu/relu_kernel_ref_int8.c:40-94:
+ * f=(float)q*in_scale ; f<0 ? f*slope(or 0) : f ; y = round(f/out_scale) clamp +-127                    */
+ORC_API int orc_relu_int8(const int8_t* x, int8_t* y, size_t count, float slope, float in_scale, float out_scale)
+{
+    for (size_t i = 0; i < count; i++)
+    {
+        float f = (float)x[i] * in_scale;
+        if (f < 0) f = (slope == 0) ? 0 : f * slope;
+        y[i] = sat_i8((int)round((double)(f / out_scale)));
+    }
+    return 0;
+}
+
+/* int8 eltwise, same-shape operands -- eltwise/eltwise_ref.c:589-640,833-837:
+ * a=(float)qa*sa ; b=(float)qb*sb ; f = a (+|*|max|-) b ; y = round(f/out_scale) clamp +-127
+ * type codes: eltwise_param.h (0 PROD, 2 SUM, 4 SUB, 6 MAX)                                              */
+ORC_API int orc_eltwise_int8(const int8_t* a, const int8_t* b, int8_t* y, size_t count, int type, float sa,
+                             float sb, float out_scale)
+{
+    for (size_t i = 0; i < count; i++)
+    {
+        float fa = (float)a[i] * sa, fb = (float)b[i] * sb, f;
+        switch (type)
+        {
+        case 0: f = fa * fb; break;
+        case 2: f = fa + fb; break;
+        case 4: f = fa - fb; break;
+        case 6: f = fa > fb ? fa : fb; break;
+        default: return -1;
+        }
+        y[i] = sat_i8((int)round((double)(f / out_scale)));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 (tolerance 1e-4, order-free): conv = im2col+sgemm+bias+relu/relu6 (conv_kernel_x86.c:1632-1701),
+ * fc (fc_ref.c:52-83), pooling (pooling_kernel_ref_fp32.c).  Accumulated in double here so the oracle is
+ * the *more* accurate side of the 1e-4 comparison.
+ * ---------------------------------------------------------------------------------------------- */
+ORC_API int orc_conv2d_fp32(const float* x, const float* w, const float* bias, float* y, int n, int cin, int h, int wd,
+                            int cout, int oh, int ow, int kh, int kw, int sh, int sw, int ph0, int pw0, int dh, int dw,
+                            int group, int act)
+{
+    int cin_g = cin / group, cout_g = cout / group;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < n; b++)
+        for (int oc = 0; oc < cout; oc++)
+        {
+            int g = oc / cout_g;
+            const float* wk = w + (size_t)oc * cin_g * kh * kw;
+            for (int oy = 0; oy < oh; oy++)
+                for (int ox = 0; ox < ow; ox++)
+                {
+                    double acc = 0;
+                    for (int kc = 0; kc < cin_g; kc++)
+                    {
+                        const float* xc = x + ((size_t)b * cin + (size_t)g * cin_g + kc) * h * wd;
+                        for (int ky = 0; ky < kh; ky++)
+                        {
+                            int iy = oy * sh - ph0 + ky * dh;
+                            if (iy < 0 || iy >= h) continue;
+                            for (int kx = 0; kx < kw; kx++)
+                            {
+                                int ix = ox * sw - pw0 + kx * dw;
+                                if (ix < 0 || ix >= wd) continue;
+                                acc += (double)xc[iy * wd + ix] * (double)wk[(kc * kh + ky) * kw + kx];
+                            }
+                        }
+                    }
+                    if (bias) acc += bias[oc];
+                    float f = (float)acc;
+                    if (act == 0 && f < 0) f = 0;
+                    if (act > 0)
+                    {
+                        if (f < 0) f = 0;
+                        if (f > 6) f = 6;
+                    }
+                    y[(((size_t)b * cout + oc) * oh + oy) * ow + ox] = f;
+                }
+        }
+    return 0;
+}
+
+ORC_API int orc_fc_fp32(const float* x, const float* w, const float* bias, float* y, int batch, int hidden, int nout)
+{
+#pragma omp parallel for
+    for (int o = 0; o < nout; o++)
+        for (int b = 0; b < batch; b++)
+        {
+            double acc = bias ? bias[o] : 0;
+            for (int j = 0; j < hidden; j++) acc += (double)x[(size_t)b * hidden + j] * (double)w[(size_t)o * hidden + j];
+            y[(size_t)b * nout + o] = (float)acc;
+        }
+    return 0;
+}
+
+ORC_API int orc_pool_fp32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh,
+                          int sw, int ph0, int pw0, int method, int caffe_flavor)
+{
+    for (int b = 0; b < n; b++)
+        for (int ch = 0; ch < c; ch++)
+        {
+            const float* xc = x + ((size_t)b * c + ch) * h * w;
+            for (int py = 0; py < oh; py++)
+                for (int px = 0; px < ow; px++)
+                {
+                    int hs = py * sh - ph0, he = hs + kh;
+                    if (he > h + ph0) he = h + ph0;
+                    int ws = px * sw - pw0, we = ws + kw;
+                    if (we > w + pw0) we = w + pw0;
+                    int pool_size = 1;
+                    if (caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    if (hs < 0) hs = 0;
+                    if (ws < 0) ws = 0;
+                    if (he > h) he = h;
+                    if (we > w) we = w;
+                    if (!caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    float* out = y + (((size_t)b * c + ch) * oh + py) * ow + px;
+                    if (method == 0)
+                    {
+                        float m = xc[hs * w + ws];
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++)
+                                if (xc[iy * w + ix] > m) m = xc[iy * w + ix];
+                        *out = m;
+                    }
+                    else
+                    {
+                        double s = 0;
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++) s += xc[iy * w + ix];
+                        *out = (float)(s / pool_size);
+                    }
+                }
+        }
+    return 0;
+}

@@ -1,0 +1,89 @@
+"""Builds the in-tree native artefacts with hipcc for gfx950 (cross-compiles without a GPU):
+
+  tengine_amd/lib/libtengine_amd.so      HIP kernels + planner/executor + tm2 loader, C ABI of include/tengine_amd.h
+  tengine_amd/lib/libtengine_hip_device.so   the Tengine device plugin (register_hip_device), only where the
+                                         reference headers are present (it compiles against source/*.h; the
+                                         prebuilt .so travels to the GPU box)
+
+-ffp-contract=off and no fast-math are REQUIRED: the requantising epilogues must round exactly like the
+reference's scalar C.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+SOURCES = ["conv_igemm.hip", "dwconv.hip", "conv_direct.hip", "misc_kernels.hip", "graph.hip", "tm2_reader.cc"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_core(verbose=False, force=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+              [os.path.join(ROOT, "include", "tengine_amd.h")]
+
+    def one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src + ".o")
+        if not force and not _newer(obj, [path] + headers):
+            return obj, None
+        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cc") else []) + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose and r.stderr:
+            sys.stderr.write(r.stderr)
+        return obj, (r.stderr if r.returncode else None)
+
+    objs, errs = [], []
+    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        for obj, err in ex.map(one, SOURCES):
+            objs.append(obj)
+            if err:
+                errs.append(err)
+    if errs:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errs))
+    lib = os.path.join(LIBDIR, "libtengine_amd.so")
+    if force or _newer(lib, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+def build_plugin(ref="/root/reference", verbose=False, force=False):
+    """Tengine device plugin; needs the reference headers at build time only."""
+    src = os.path.join(HERE, "device", "hip_device.cc")
+    if not os.path.isdir(os.path.join(ref, "source")) or not os.path.exists(src):
+        return None
+    gen = os.path.join(ROOT, "oracle", "_ref", "gen")
+    lib = os.path.join(LIBDIR, "libtengine_hip_device.so")
+    if not force and not _newer(lib, [src, os.path.join(ROOT, "include", "tengine_amd.h")]):
+        return lib
+    cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ref, "source"),
+           "-I" + gen, "-I" + os.path.join(ROOT, "include"), src, "-o", lib,
+           "-L" + LIBDIR, "-ltengine_amd", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return lib
+
+
+def build_all(verbose=False, force=False):
+    core = build_core(verbose, force)
+    plugin = build_plugin(verbose=verbose, force=force)
+    return core, plugin
+
+
+if __name__ == "__main__":
+    print(build_all(verbose=True, force="--force" in sys.argv))

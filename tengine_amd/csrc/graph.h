@@ -1,0 +1,81 @@
+// Host-side graph IR, planner and executor of the backend (private).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/tengine_amd.h"
+#include "kernels.h"
+
+namespace tamd {
+
+void set_error(const char* fmt, ...);
+
+struct HTensor {               // host IR tensor == the parts of struct tensor the backend reads
+    int dtype = 0, ttype = TAMD_TT_VAR;
+    std::vector<int> dims;     // NCHW etc.
+    std::vector<uint8_t> data; // const payload (copied)
+    std::vector<float> scales;
+    std::vector<int> zps;
+    std::string name;
+    // device view (valid after prerun for var/input tensors)
+    void* dptr = nullptr;      // base of the NHWC buffer this tensor lives in
+    int n = 0, h = 0, w = 0, c = 0;
+    int cs = 0;                // channel stride of the *buffer* (bytes per pixel for int8)
+    int c_off = 0;             // channel offset inside the buffer pixel (concat-by-offset views)
+    bool is_view = false;      // aliases another tensor's buffer
+    bool nchw_raw = false;     // graph input kept in NCHW for a direct first conv
+    size_t elems() const { size_t e = 1; for (int d : dims) e *= (size_t)d; return e; }
+};
+
+union NodeParam {
+    tamd_conv_param conv;
+    tamd_fc_param fc;
+    tamd_pool_param pool;
+    tamd_relu_param relu;
+    tamd_eltwise_param elt;
+    tamd_concat_param concat;
+    tamd_upsample_param ups;
+};
+
+struct HNode {
+    int op = 0;
+    std::vector<int> in, out;
+    NodeParam p{};
+    std::string name;
+};
+
+struct Step {                  // one device launch of the compiled plan
+    std::string node, kernel;
+    double macs = 0, bytes = 0;
+    std::function<hipError_t(hipStream_t)> fn;
+};
+
+struct IOBind {
+    int tensor = -1;
+    const void* host_in = nullptr;   // re-read at every run
+    void* host_out = nullptr;
+    size_t bytes = 0;
+    void* stage = nullptr;           // device buffer in the reference's NCHW order
+    void* pinned = nullptr;          // pinned host bounce buffer
+};
+
+}  // namespace tamd
+
+struct tamd_graph {
+    std::vector<tamd::HTensor> tensors;
+    std::vector<tamd::HNode> nodes;
+    std::vector<tamd::IOBind> inputs, outputs;
+    std::vector<tamd::Step> steps;      // compute launches
+    std::vector<tamd::Step> in_steps;   // input layout launches (after H2D)
+    std::vector<tamd::Step> out_steps;  // output layout launches (before D2H)
+    std::vector<void*> dev_allocs;
+    hipStream_t stream = nullptr;
+    hipGraph_t hgraph = nullptr;
+    hipGraphExec_t hexec = nullptr;
+    tamd_options opt{};
+    bool prepared = false;
+    int gpu = 0;
+};

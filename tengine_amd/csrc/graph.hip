@@ -1,0 +1,830 @@
+// Graph IR, shape inference, planner and executor behind the C ABI of include/tengine_amd.h.
+//
+// Mirrors what a Tengine device backend does between pre_run and run (CUDA pattern:
+// source/device/cuda/cuda_executor.cc:136-204), re-designed for MI355X:
+//   prerun : infer shapes (restating source/operator/prototype/*.c), choose NHWC device layouts,
+//            repack weights once (the role of conv_hcl_prerun, conv_kernel_x86.c:2137-2209), compile
+//            the node list into a launch list and capture it into ONE hipGraph;
+//   run    : H2D inputs -> hipGraphLaunch -> D2H outputs on a private stream, pinned bounce buffers.
+#include "graph.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "epilogue.h"
+
+namespace tamd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (getenv("TAMD_VERBOSE")) fprintf(stderr, "tengine_amd: %s\n", g_err);
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+static inline int esize(int dt) { return (dt == TAMD_DT_FP32 || dt == TAMD_DT_INT32) ? 4 : (dt == TAMD_DT_FP16 ? 2 : 1); }
+static int cdiv_c(int a, int b) { return a / b; }  // C semantics (truncation), as the reference
+
+// ---------------------------------------------------------------------------------------------
+// shape inference (restating the reference's infer_shape functions)
+// ---------------------------------------------------------------------------------------------
+// pooling_param.h:59-105
+static int pool_out_size(int input, int kernel, int stride, int pad, int caffe)
+{
+    int output = 1;
+    if (pad >= 0) {
+        if (caffe == 1) {
+            output = 2 + cdiv_c(input - kernel + 2 * pad - 1, stride);
+            if (pad > 0 && ((output - 1) * stride >= input + pad)) output--;
+        } else if (caffe == 2)
+            output = 1 + cdiv_c(input - kernel + pad, stride);
+        else
+            output = 1 + cdiv_c(input - kernel + 2 * pad, stride);
+    } else
+        output = 1 + cdiv_c(input - 1, stride);
+    return output;
+}
+static void pool_real_pads(int out, int in, int kernel, int stride, int pad_org, int* pad0, int* pad1)
+{
+    int total = (out - 1) * stride + kernel;
+    int pad_num = total - in;
+    if (pad_num < 0) pad_num = 0;
+    if (pad_org < 0) { *pad0 = pad_num / 2; *pad1 = pad_num - pad_org; }
+    else { *pad0 = pad_org; *pad1 = pad_num - pad_org; }
+}
+
+struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
+// pooling.c:36-100
+static PoolGeom pool_geom(const tamd_pool_param& p, int h, int w)
+{
+    PoolGeom g{};
+    int glob = p.global;
+    if (p.kernel_h == h && p.kernel_w == w && p.pad_w0 == 0 && p.pad_w1 == 0 && p.pad_h0 == 0 && p.pad_h1 == 0) glob = 1;
+    if (glob) { g = {1, 1, h, w, 1, 1, 0, 0}; return g; }
+    int caffe = p.caffe_flavor & ~0x100;
+    g.oh = pool_out_size(h, p.kernel_h, p.stride_h, p.pad_h0, p.caffe_flavor);
+    g.ow = pool_out_size(w, p.kernel_w, p.stride_w, p.pad_w0, p.caffe_flavor);
+    g.kh = p.kernel_h; g.kw = p.kernel_w; g.sh = p.stride_h; g.sw = p.stride_w;
+    int d;
+    if (caffe != 2) {
+        pool_real_pads(g.oh, h, p.kernel_h, p.stride_h, p.pad_h0, &g.ph0, &d);
+        pool_real_pads(g.ow, w, p.kernel_w, p.stride_w, p.pad_w0, &g.pw0, &d);
+    } else { g.ph0 = p.pad_h0 / 2; g.pw0 = p.pad_w0 / 2; }
+    return g;
+}
+
+static int infer_shapes(tamd_graph* g)
+{
+    for (auto& n : g->nodes) {
+        if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST) continue;
+        if (n.in.empty() || n.out.empty()) { set_error("node %s has no io", n.name.c_str()); return -1; }
+        HTensor& x = g->tensors[n.in[0]];
+        HTensor& y = g->tensors[n.out[0]];
+        switch (n.op) {
+        case TAMD_OP_CONV: {   // convolution.c:35-145
+            if (x.dims.size() != 4) { set_error("conv %s: input is not 4-D", n.name.c_str()); return -1; }
+            tamd_conv_param& p = n.p.conv;
+            if (p.kernel_w == 0) { p.kernel_w = 1; p.pad_w0 = p.pad_w1 = 0; }
+            if (p.kernel_h == 0) p.kernel_h = 1;
+            if (p.stride_w == 0) p.stride_w = 1;
+            if (p.stride_h == 0) p.stride_h = 1;
+            if (p.dilation_h == 0) p.dilation_h = 1;
+            if (p.dilation_w == 0) p.dilation_w = 1;
+            p.input_channel = x.dims[1];
+            const HTensor& w = g->tensors[n.in[1]];
+            int h = x.dims[2], wd = x.dims[3], oh, ow;
+            if (p.pad_h0 < 0) {
+                oh = (h - 1) / p.stride_h + 1;
+                int pad_num = (oh - 1) * p.stride_h + p.kernel_h - h;
+                if (p.pad_h0 == -1) { p.pad_h0 = pad_num / 2; p.pad_h1 = pad_num - pad_num / 2; }
+                else { p.pad_h1 = pad_num / 2; p.pad_h0 = pad_num - pad_num / 2; }
+            } else
+                oh = (h - p.dilation_h * (p.kernel_h - 1) - 1 + p.pad_h0 + p.pad_h1) / p.stride_h + 1;
+            if (p.pad_w0 < 0) {
+                ow = (wd - 1) / p.stride_w + 1;
+                int pad_num = (ow - 1) * p.stride_w + p.kernel_w - wd;
+                if (p.pad_w0 == -1) { p.pad_w0 = pad_num / 2; p.pad_w1 = pad_num - pad_num / 2; }
+                else { p.pad_w1 = pad_num / 2; p.pad_w0 = pad_num - pad_num / 2; }
+            } else
+                ow = (wd - p.dilation_w * (p.kernel_w - 1) - 1 + p.pad_w0 + p.pad_w1) / p.stride_w + 1;
+            y.dims = {x.dims[0], w.dims[0], oh ? oh : 1, ow ? ow : 1};
+            break;
+        }
+        case TAMD_OP_FC: {
+            int nout = n.p.fc.num_output ? n.p.fc.num_output : g->tensors[n.in[1]].dims[0];
+            y.dims = {x.dims[0], nout};
+            break;
+        }
+        case TAMD_OP_POOL: {
+            PoolGeom pg = pool_geom(n.p.pool, x.dims[2], x.dims[3]);
+            y.dims = {x.dims[0], x.dims[1], pg.oh, pg.ow};
+            break;
+        }
+        case TAMD_OP_RELU: case TAMD_OP_RELU6: case TAMD_OP_ELTWISE: case TAMD_OP_DROPOUT: case TAMD_OP_SOFTMAX:
+            y.dims = x.dims;
+            break;
+        case TAMD_OP_CONCAT: {
+            int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)x.dims.size() : n.p.concat.axis;
+            y.dims = x.dims;
+            int s = 0;
+            for (int i : n.in) s += g->tensors[i].dims[ax];
+            y.dims[ax] = s;
+            break;
+        }
+        case TAMD_OP_UPSAMPLE: {
+            int sc = (int)n.p.ups.scale;
+            y.dims = {x.dims[0], x.dims[1], x.dims[2] * sc, x.dims[3] * sc};
+            break;
+        }
+        case TAMD_OP_FLATTEN: {
+            int f = 1;
+            for (size_t i = 1; i < x.dims.size(); i++) f *= x.dims[i];
+            y.dims = {x.dims[0], f};
+            break;
+        }
+        default:
+            set_error("infer_shape: unsupported op %d (%s)", n.op, n.name.c_str());
+            return -1;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------------------------
+static int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
+{
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(p, bytes));
+    g->dev_allocs.push_back(*p);
+    if (zero) HIPCHK(hipMemset(*p, 0, bytes));
+    return 0;
+}
+
+template <typename T>
+static int upload(tamd_graph* g, const std::vector<T>& host, T** dev)
+{
+    void* p = nullptr;
+    if (dev_alloc(g, &p, host.size() * sizeof(T), false)) return -1;
+    HIPCHK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (T*)p;
+    return 0;
+}
+
+static void nhwc_geom(HTensor& t)
+{
+    if (t.dims.size() == 4) { t.n = t.dims[0]; t.c = t.dims[1]; t.h = t.dims[2]; t.w = t.dims[3]; }
+    else if (t.dims.size() == 2) { t.n = t.dims[0]; t.c = t.dims[1]; t.h = t.w = 1; }
+    else { t.n = 1; t.c = (int)t.elems(); t.h = t.w = 1; }
+}
+
+static int count_consumers(const tamd_graph* g, int tensor)
+{
+    int c = 0;
+    for (auto& n : g->nodes)
+        for (int i : n.in) c += (i == tensor);
+    for (auto& o : g->outputs) c += (o.tensor == tensor);
+    return c;
+}
+
+// which formula the reference's score() selection lands on (conv_hcl_x86.c:351-371,
+// conv_dw_hcl_x86.c:508-543, conv_ref.c:197-200)
+static int conv_mode(const tamd_conv_param& p, int batch, int cin, int cout)
+{
+    if (p.group == 1) return RQ_CONV_HCL;
+    int cin_g = cin / p.group, cout_g = cout / p.group;
+    if (p.kernel_h == p.kernel_w && batch == 1 && p.group > 1 && cin_g == 1 && cout_g == 1 && p.pad_h0 == p.pad_h1
+        && p.pad_w0 == p.pad_w1 && p.dilation_h == 1 && p.dilation_w == 1 && p.kernel_h == 3
+        && ((p.stride_h == 1 && p.stride_w == 1) || (p.stride_h == 2 && p.stride_w == 2)))
+        return RQ_CONV_HCL;
+    return RQ_CONV_REF;
+}
+
+static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
+{
+    HTensor& x = g->tensors[n.in[0]];
+    HTensor& w = g->tensors[n.in[1]];
+    HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+    HTensor& y = g->tensors[n.out[0]];
+    if (x.dtype != TAMD_DT_INT8 || w.dtype != TAMD_DT_INT8 || y.dtype != TAMD_DT_INT8) {
+        set_error("conv/fc %s: only int8 is implemented on the device in this round (dtype %d)", n.name.c_str(), x.dtype);
+        return -1;
+    }
+    if (x.scales.empty() || y.scales.empty() || w.scales.empty()) { set_error("%s: missing quant params", n.name.c_str()); return -1; }
+    tamd_conv_param p{};
+    int mode;
+    if (as_fc) {   // FC == "valid" convolution whose kernel covers the whole input map; weight [out][c*h*w]
+        p.kernel_h = x.h; p.kernel_w = x.w; p.stride_h = p.stride_w = 1; p.dilation_h = p.dilation_w = 1;
+        p.group = 1; p.activation = -1; p.input_channel = x.c; p.output_channel = y.c;
+        mode = RQ_FC;
+        if ((size_t)w.elems() != (size_t)y.c * x.c * x.h * x.w || w.dims[0] != y.c) {
+            set_error("fc %s: transposed / mismatching weight layout is not supported", n.name.c_str());
+            return -1;
+        }
+    } else {
+        p = n.p.conv;
+        mode = conv_mode(p, x.n, x.c, y.c);
+    }
+    const int cout = y.c, cin = x.c, group = p.group;
+    const int cin_g = cin / group;
+    const float in_scale = x.scales[0], out_scale = y.scales[0];
+    std::vector<float> ws(cout);
+    for (int i = 0; i < cout; i++) ws[i] = w.scales.size() == (size_t)cout ? w.scales[i] : w.scales[0];
+    const int8_t* wd = (const int8_t*)w.data.data();
+    const int32_t* bd = b ? (const int32_t*)b->data.data() : nullptr;
+    const int KH = p.kernel_h, KW = p.kernel_w;
+    const double macs = (double)y.n * y.h * y.w * cout * cin_g * KH * KW;
+    const double abytes = (double)x.n * x.h * x.w * cin + (double)y.n * y.h * y.w * cout + (double)cout * cin_g * KH * KW + 4.0 * cout;
+
+    Step st;
+    st.node = n.name; st.macs = macs; st.bytes = abytes;
+    const bool is_dw = (group > 1 && group == cin && cout == cin);
+    if (x.nchw_raw || group != 1) {
+        if (!x.nchw_raw && is_dw && KH == 3 && KW == 3 && p.dilation_h == 1 && p.dilation_w == 1 && p.stride_h == p.stride_w
+            && (p.stride_h == 1 || p.stride_h == 2)) {
+            // ---- depthwise 3x3 ----
+            const int cw = rup(cin, 16);
+            std::vector<int8_t> wp((size_t)9 * cw, 0);
+            for (int c = 0; c < cin; c++)
+                for (int k = 0; k < 9; k++) wp[(size_t)k * cw + c] = wd[(size_t)c * 9 + k];
+            std::vector<int32_t> bp(cw, 0);
+            std::vector<float> sp(cw, 1.f);
+            for (int c = 0; c < cin; c++) { bp[c] = bd ? bd[c] : 0; sp[c] = ws[c]; }
+            DwArgs a{};
+            int8_t* dw_; int32_t* db_; float* ds_;
+            if (upload(g, wp, &dw_) || upload(g, bp, &db_) || upload(g, sp, &ds_)) return -1;
+            a.x = (const int8_t*)x.dptr + x.c_off; a.w = dw_; a.bias = db_; a.wscale = ds_;
+            a.y = (int8_t*)y.dptr;
+            a.N = x.n; a.H = x.h; a.W = x.w; a.C = cin; a.cs_in = x.cs; a.cw = cw; a.OH = y.h; a.OW = y.w;
+            a.ldc = y.cs; a.c_off = y.c_off; a.S = p.stride_h; a.PH = p.pad_h0; a.PW = p.pad_w0;
+            a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+            st.kernel = "dwconv3x3_i8";
+            st.fn = [a](hipStream_t s) { return launch_dwconv3x3(a, s); };
+        } else {
+            // ---- generic direct (first layer from NCHW, grouped, non-3x3 depthwise) ----
+            std::vector<int8_t> wv(wd, wd + w.elems());
+            std::vector<float> sp(ws);
+            DirectArgs a{};
+            int8_t* dw_; float* ds_; int32_t* db_ = nullptr;
+            if (upload(g, wv, &dw_) || upload(g, sp, &ds_)) return -1;
+            if (bd) { std::vector<int32_t> bv(bd, bd + cout); if (upload(g, bv, &db_)) return -1; }
+            a.x = (const int8_t*)x.dptr + (x.nchw_raw ? 0 : x.c_off); a.w = dw_; a.bias = db_; a.wscale = ds_;
+            a.y = (int8_t*)y.dptr;
+            a.N = x.n; a.C = cin; a.H = x.h; a.W = x.w; a.cs_in = x.nchw_raw ? 0 : x.cs;
+            a.OH = y.h; a.OW = y.w; a.cout = cout; a.ldc = y.cs; a.c_off = y.c_off;
+            a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+            a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = group;
+            a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+            st.kernel = "conv_direct_i8";
+            st.fn = [a](hipStream_t s) { return launch_conv_direct(a, s); };
+        }
+    } else {
+        // ---- implicit GEMM on MFMA ----
+        const int ckp = rup(cin, 16);
+        const int ktot = KH * KW * ckp;
+        const int kpad = rup(ktot, 128);
+        const int cout_pad = rup(cout, 128);
+        if (KH * KW > 128) { set_error("conv %s: kernel %dx%d too large", n.name.c_str(), KH, KW); return -1; }
+        std::vector<int8_t> wp((size_t)cout_pad * kpad, 0);
+        for (int co = 0; co < cout; co++)
+            for (int ci = 0; ci < cin; ci++)
+                for (int ky = 0; ky < KH; ky++)
+                    for (int kx = 0; kx < KW; kx++)
+                        wp[(size_t)co * kpad + (size_t)(ky * KW + kx) * ckp + ci] = wd[(((size_t)co * cin + ci) * KH + ky) * KW + kx];
+        std::vector<int32_t> bp(cout_pad, 0);
+        std::vector<float> sp(cout_pad, 1.f);
+        for (int c = 0; c < cout; c++) { bp[c] = bd ? bd[c] : 0; sp[c] = ws[c]; }
+        ConvArgs a{};
+        int8_t* dw_; int32_t* db_; float* ds_;
+        if (upload(g, wp, &dw_) || upload(g, bp, &db_) || upload(g, sp, &ds_)) return -1;
+        a.x = (const int8_t*)x.dptr + x.c_off; a.w = dw_; a.bias = db_; a.wscale = ds_; a.y = (int8_t*)y.dptr;
+        a.N = x.n; a.H = x.h; a.W = x.w; a.cs_in = x.cs; a.ckp = ckp; a.OH = y.h; a.OW = y.w; a.cout = cout;
+        a.ldc = y.cs; a.c_off = y.c_off; a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
+        a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.DH = p.dilation_h; a.DW = p.dilation_w; a.cin = cin; a.ktot = ktot; a.kpad = kpad;
+        a.M = y.n * y.h * y.w; a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+        st.kernel = conv_igemm_kernel_name(a);
+        st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };
+    }
+    g->steps.push_back(st);
+    return 0;
+}
+
+static int plan(tamd_graph* g)
+{
+    // ---- 1. geometry + device buffers for every non-const tensor -------------------------------
+    for (auto& t : g->tensors) if (t.ttype != TAMD_TT_CONST) nhwc_geom(t);
+    // concat outputs own a buffer; their inputs become views when layouts allow (concat-by-offset:
+    // concat/concat_kernel_ref_int8.c with in_scale == out_scale is a pure copy)
+    std::vector<int> view_of(g->tensors.size(), -1), view_off(g->tensors.size(), 0);
+    for (auto& n : g->nodes) {
+        if (n.op != TAMD_OP_CONCAT) continue;
+        HTensor& y = g->tensors[n.out[0]];
+        int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+        if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+        int off = 0;
+        for (int i : n.in) {
+            HTensor& x = g->tensors[i];
+            bool ok = (x.c % 16 == 0) && x.dtype == y.dtype && !x.scales.empty() && !y.scales.empty()
+                      && x.scales[0] == y.scales[0] && x.ttype == TAMD_TT_VAR && view_of[i] < 0;
+            if (!ok) { set_error("concat %s: input %s cannot be written in place (channels %% 16, scale)", n.name.c_str(), x.name.c_str()); return -1; }
+            view_of[i] = n.out[0];
+            view_off[i] = off;
+            off += x.c;
+        }
+    }
+    // identity ops alias their input
+    std::vector<int> alias_of(g->tensors.size(), -1);
+    for (auto& n : g->nodes) {
+        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) {
+            HTensor& x = g->tensors[n.in[0]];
+            if (n.op == TAMD_OP_FLATTEN && x.h * x.w != 1) { set_error("flatten %s of a %dx%d map is not supported on the device", n.name.c_str(), x.h, x.w); return -1; }
+            alias_of[n.out[0]] = n.in[0];
+        }
+    }
+    // graph inputs: NCHW staging; first conv with <=4 channels reads NCHW directly
+    for (auto& io : g->inputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems() * esize(t.dtype);
+        if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        bool direct = (t.dims.size() == 4 && t.c <= 4 && count_consumers(g, io.tensor) == 1);
+        if (direct) {
+            for (auto& n : g->nodes)
+                if (n.op == TAMD_OP_CONV && n.in[0] == io.tensor && n.p.conv.group != 1) direct = false;
+                else if (n.op != TAMD_OP_CONV && !n.in.empty() && n.in[0] == io.tensor) direct = false;
+        }
+        if (direct) { t.nchw_raw = true; t.dptr = io.stage; t.cs = 0; }
+    }
+    for (size_t i = 0; i < g->tensors.size(); i++) {
+        HTensor& t = g->tensors[i];
+        if (t.ttype == TAMD_TT_CONST || t.nchw_raw) continue;
+        if (view_of[i] >= 0 || alias_of[i] >= 0) continue;
+        if (t.dtype != TAMD_DT_INT8) { set_error("tensor %s: dtype %d not supported on the device yet", t.name.c_str(), t.dtype); return -1; }
+        t.cs = rup(t.c, 16);
+        if (dev_alloc(g, &t.dptr, (size_t)t.n * t.h * t.w * t.cs, true)) return -1;
+    }
+    // resolve views / aliases (nodes are in topological order; resolve chains iteratively)
+    for (int pass = 0; pass < 4; pass++)
+        for (size_t i = 0; i < g->tensors.size(); i++) {
+            HTensor& t = g->tensors[i];
+            if (view_of[i] >= 0) {
+                HTensor& o = g->tensors[view_of[i]];
+                t.dptr = o.dptr; t.cs = o.cs; t.c_off = o.c_off + view_off[i]; t.is_view = true;
+            } else if (alias_of[i] >= 0) {
+                HTensor& o = g->tensors[alias_of[i]];
+                t.dptr = o.dptr; t.cs = o.cs; t.c_off = o.c_off; t.is_view = o.is_view;
+            }
+        }
+    // input layout steps
+    for (auto& io : g->inputs) {
+        HTensor& t = g->tensors[io.tensor];
+        if (t.nchw_raw) continue;
+        LayoutArgs a{io.stage, t.dptr, t.n, t.c, t.h, t.w, t.cs, esize(t.dtype)};
+        Step st; st.node = t.name; st.kernel = "nchw_to_nhwc";
+        st.fn = [a](hipStream_t s) { return launch_nchw_to_nhwc(a, s); };
+        g->in_steps.push_back(st);
+    }
+    // ---- 2. compile nodes ---------------------------------------------------------------------
+    std::vector<char> fused(g->nodes.size(), 0);
+    for (size_t ni = 0; ni < g->nodes.size(); ni++) {
+        HNode& n = g->nodes[ni];
+        if (fused[ni]) continue;
+        switch (n.op) {
+        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_CONCAT:
+            break;
+        case TAMD_OP_CONV:
+            if (plan_conv(g, n, false)) return -1;
+            break;
+        case TAMD_OP_FC:
+            if (plan_conv(g, n, true)) return -1;
+            break;
+        case TAMD_OP_POOL: {
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            PoolGeom pg = pool_geom(n.p.pool, x.h, x.w);
+            PoolArgs a{};
+            a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr;
+            a.N = x.n; a.H = x.h; a.W = x.w; a.C = x.c; a.cs_in = x.cs; a.OH = y.h; a.OW = y.w; a.ldc = y.cs; a.c_off = y.c_off;
+            a.KH = pg.kh; a.KW = pg.kw; a.SH = pg.sh; a.SW = pg.sw; a.PH = pg.ph0; a.PW = pg.pw0;
+            a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
+            a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
+            const PoolArgs av = a;
+            Step st; st.node = n.name; st.kernel = "pool_i8";
+            st.bytes = (double)x.n * x.h * x.w * x.c + (double)y.n * y.h * y.w * y.c;
+            st.fn = [av](hipStream_t s) { return launch_pool(av, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_RELU: {
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            if (x.is_view || y.is_view) { set_error("relu %s on a concat view is not supported", n.name.c_str()); return -1; }
+            ReluArgs a{(const int8_t*)x.dptr, (int8_t*)y.dptr, (size_t)x.n * x.h * x.w * x.cs, n.p.relu.negative_slope, x.scales[0], y.scales[0]};
+            Step st; st.node = n.name; st.kernel = "relu_i8"; st.bytes = 2.0 * x.n * x.h * x.w * x.c;
+            st.fn = [a](hipStream_t s) { return launch_relu(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_ELTWISE: {
+            HTensor& xa = g->tensors[n.in[0]];
+            HTensor& xb = g->tensors[n.in[1]];
+            HTensor* y = &g->tensors[n.out[0]];
+            if (xa.is_view || xb.is_view || y->is_view || xa.dims != xb.dims) { set_error("eltwise %s: views / broadcast not supported", n.name.c_str()); return -1; }
+            EltArgs a{};
+            a.a = (const int8_t*)xa.dptr; a.b = (const int8_t*)xb.dptr; a.count = (size_t)xa.n * xa.h * xa.w * xa.cs;
+            a.type = n.p.elt.type; a.sa = xa.scales[0]; a.sb = xb.scales[0]; a.out_scale = y->scales[0];
+            if (a.type != 0 && a.type != 2 && a.type != 4 && a.type != 6) { set_error("eltwise %s: type %d unsupported", n.name.c_str(), a.type); return -1; }
+            std::string kname = "eltwise_i8";
+            double bytes = 3.0 * xa.n * xa.h * xa.w * xa.c;
+            // fuse the standalone ReLU that follows (ResNet: 16 x eltwise -> relu), SURVEY §8f-1
+            if (count_consumers(g, n.out[0]) == 1) {
+                for (size_t nj = ni + 1; nj < g->nodes.size(); nj++) {
+                    HNode& r = g->nodes[nj];
+                    if (r.op == TAMD_OP_RELU && r.in[0] == n.out[0] && r.p.relu.negative_slope == 0.f) {
+                        HTensor& ry = g->tensors[r.out[0]];
+                        if (ry.is_view) break;
+                        a.fuse_relu = 1; a.relu_out_scale = ry.scales[0];
+                        y = &ry; fused[nj] = 1; kname = "eltwise_relu_i8";
+                        break;
+                    }
+                }
+            }
+            a.y = (int8_t*)y->dptr;
+            Step st; st.node = n.name; st.kernel = kname; st.bytes = bytes;
+            st.fn = [a](hipStream_t s) { return launch_eltwise(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        default:
+            set_error("op %d (%s) is not supported on the device", n.op, n.name.c_str());
+            return -1;
+        }
+    }
+    // ---- 3. outputs: NHWC -> the reference's NCHW order ------------------------------------------
+    for (auto& io : g->outputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems() * esize(t.dtype);
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        if (t.h * t.w == 1 && t.cs == t.c && t.c_off == 0) { io.stage = t.dptr; continue; }
+        if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
+        LayoutArgs a{(const int8_t*)t.dptr + t.c_off, io.stage, t.n, t.c, t.h, t.w, t.cs, esize(t.dtype)};
+        Step st; st.node = t.name; st.kernel = "nhwc_to_nchw";
+        st.fn = [a](hipStream_t s) { return launch_nhwc_to_nchw(a, s); };
+        g->out_steps.push_back(st);
+    }
+    return 0;
+}
+
+static int run_steps(tamd_graph* g, hipStream_t s)
+{
+    for (auto* v : {&g->in_steps, &g->steps, &g->out_steps})
+        for (auto& st : *v) {
+            hipError_t e = st.fn(s);
+            if (e != hipSuccess) { set_error("launch %s (%s) failed: %s", st.kernel.c_str(), st.node.c_str(), hipGetErrorString(e)); return -1; }
+        }
+    return 0;
+}
+
+}  // namespace tamd
+
+using namespace tamd;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int tamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tamd_init(int gpu_index)
+{
+    int n = tamd_device_count();
+    if (n <= 0) { set_error("no HIP device visible: the tengine_amd backend needs an MI355X (it has no CPU fallback)"); return -1; }
+    if (gpu_index < 0 || gpu_index >= n) { set_error("gpu_index %d out of range (%d devices)", gpu_index, n); return -1; }
+    HIPCHK(hipSetDevice(gpu_index));
+    return 0;
+}
+
+int tamd_shutdown(void) { return 0; }
+const char* tamd_last_error(void) { return g_err; }
+const char* tamd_version(void) { return "tengine_amd 0.1 (gfx950)"; }
+
+int tamd_op_supported(int op, int dtype)
+{
+    if (dtype != TAMD_DT_INT8) return 0;
+    switch (op) {
+    case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
+    case TAMD_OP_ELTWISE: case TAMD_OP_CONCAT: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
+        return 1;
+    default:
+        return 0;
+    }
+}
+
+tamd_graph* tamd_graph_create(void) { return new tamd_graph(); }
+
+int tamd_graph_add_tensor(tamd_graph* g, const tamd_tensor_desc* d)
+{
+    if (!g || !d) return -1;
+    HTensor t;
+    t.dtype = d->dtype; t.ttype = d->ttype;
+    t.dims.assign(d->dims, d->dims + d->dim_num);
+    if (d->name) t.name = d->name;
+    if (d->quant_num > 0 && d->scales) {
+        t.scales.assign(d->scales, d->scales + d->quant_num);
+        if (d->zero_points) t.zps.assign(d->zero_points, d->zero_points + d->quant_num);
+        else t.zps.assign(d->quant_num, 0);
+    }
+    if (d->ttype == TAMD_TT_CONST) {
+        size_t bytes = t.elems() * esize(t.dtype);
+        t.data.resize(bytes);
+        if (d->data) memcpy(t.data.data(), d->data, bytes);     // NULL payload == zero-filled (tm2_serializer.c:240-246)
+    }
+    g->tensors.push_back(std::move(t));
+    return (int)g->tensors.size() - 1;
+}
+
+int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* d)
+{
+    if (!g || !d) return -1;
+    HNode n;
+    n.op = d->op;
+    if (d->name) n.name = d->name;
+    for (int i = 0; i < d->input_num; i++) {
+        if (d->inputs[i] < 0 || d->inputs[i] >= (int)g->tensors.size()) { set_error("node %s: bad input tensor", n.name.c_str()); return -1; }
+        n.in.push_back(d->inputs[i]);
+    }
+    for (int i = 0; i < d->output_num; i++) {
+        if (d->outputs[i] < 0 || d->outputs[i] >= (int)g->tensors.size()) { set_error("node %s: bad output tensor", n.name.c_str()); return -1; }
+        n.out.push_back(d->outputs[i]);
+    }
+    if (d->param) {
+        switch (d->op) {
+        case TAMD_OP_CONV: n.p.conv = *(const tamd_conv_param*)d->param; break;
+        case TAMD_OP_FC: n.p.fc = *(const tamd_fc_param*)d->param; break;
+        case TAMD_OP_POOL: n.p.pool = *(const tamd_pool_param*)d->param; break;
+        case TAMD_OP_RELU: n.p.relu = *(const tamd_relu_param*)d->param; break;
+        case TAMD_OP_ELTWISE: n.p.elt = *(const tamd_eltwise_param*)d->param; break;
+        case TAMD_OP_CONCAT: n.p.concat = *(const tamd_concat_param*)d->param; break;
+        case TAMD_OP_UPSAMPLE: n.p.ups = *(const tamd_upsample_param*)d->param; break;
+        default: break;
+        }
+    }
+    g->nodes.push_back(std::move(n));
+    return (int)g->nodes.size() - 1;
+}
+
+int tamd_graph_set_inputs(tamd_graph* g, int n, const int* ids)
+{
+    g->inputs.clear();
+    for (int i = 0; i < n; i++) { IOBind b; b.tensor = ids[i]; g->inputs.push_back(b); }
+    return 0;
+}
+
+int tamd_graph_set_outputs(tamd_graph* g, int n, const int* ids)
+{
+    g->outputs.clear();
+    for (int i = 0; i < n; i++) { IOBind b; b.tensor = ids[i]; g->outputs.push_back(b); }
+    return 0;
+}
+
+int tamd_graph_set_batch(tamd_graph* g, int batch)
+{
+    if (g->prepared) { set_error("set_batch after prerun"); return -1; }
+    for (auto& io : g->inputs) g->tensors[io.tensor].dims[0] = batch;
+    return 0;
+}
+
+int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
+{
+    if (!g) return -1;
+    if (g->prepared) return 0;
+    tamd_options o{};
+    o.dev_name = "HIP"; o.gpu_index = 0; o.use_hip_graph = 1; o.profile = 0;
+    if (opt) o = *opt;     // options may be NULL (scheduler.c:49-59)
+    g->opt = o;
+    if (tamd_init(o.gpu_index)) return -1;
+    g->gpu = o.gpu_index;
+    HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    if (infer_shapes(g)) return -1;
+    if (plan(g)) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    if (o.use_hip_graph) {
+        // one warm eager pass (module load), then capture compute + output layout launches
+        if (run_steps(g, g->stream)) return -1;
+        HIPCHK(hipStreamSynchronize(g->stream));
+        HIPCHK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+        int rc = run_steps(g, g->stream);
+        hipError_t e = hipStreamEndCapture(g->stream, &g->hgraph);
+        if (rc) return -1;
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&g->hexec, g->hgraph, nullptr, nullptr, 0));
+    }
+    g->prepared = true;
+    return 0;
+}
+
+int tamd_graph_input_num(const tamd_graph* g) { return (int)g->inputs.size(); }
+int tamd_graph_output_num(const tamd_graph* g) { return (int)g->outputs.size(); }
+
+static int fill_desc(const HTensor& t, int* dims8, int* dtype)
+{
+    for (size_t i = 0; i < t.dims.size() && i < 8; i++) dims8[i] = t.dims[i];
+    if (dtype) *dtype = t.dtype;
+    return (int)t.dims.size();
+}
+
+int tamd_graph_input_desc(const tamd_graph* g, int idx, int* dims8, int* dtype)
+{
+    if (idx < 0 || idx >= (int)g->inputs.size()) return -1;
+    return fill_desc(g->tensors[g->inputs[idx].tensor], dims8, dtype);
+}
+
+int tamd_graph_output_desc(const tamd_graph* g, int idx, int* dims8, int* dtype, float* scale, int* zp)
+{
+    if (idx < 0 || idx >= (int)g->outputs.size()) return -1;
+    const HTensor& t = g->tensors[g->outputs[idx].tensor];
+    if (scale) *scale = t.scales.empty() ? 0.f : t.scales[0];
+    if (zp) *zp = t.zps.empty() ? 0 : t.zps[0];
+    return fill_desc(t, dims8, dtype);
+}
+
+int tamd_graph_set_input(tamd_graph* g, int idx, const void* host, size_t bytes)
+{
+    if (idx < 0 || idx >= (int)g->inputs.size()) { set_error("bad input index"); return -1; }
+    if (g->prepared && bytes != g->inputs[idx].bytes) { set_error("input %d: %zu bytes given, %zu expected", idx, bytes, g->inputs[idx].bytes); return -1; }
+    g->inputs[idx].host_in = host;
+    return 0;
+}
+
+int tamd_graph_set_output(tamd_graph* g, int idx, void* host, size_t bytes)
+{
+    if (idx < 0 || idx >= (int)g->outputs.size()) { set_error("bad output index"); return -1; }
+    if (g->prepared && bytes != g->outputs[idx].bytes) { set_error("output %d: %zu bytes given, %zu expected", idx, bytes, g->outputs[idx].bytes); return -1; }
+    g->outputs[idx].host_out = host;
+    return 0;
+}
+
+int tamd_graph_upload_inputs(tamd_graph* g)
+{
+    if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    for (auto& io : g->inputs) {
+        if (!io.host_in) { set_error("input buffer not set"); return -1; }
+        memcpy(io.pinned, io.host_in, io.bytes);
+        HIPCHK(hipMemcpyAsync(io.stage, io.pinned, io.bytes, hipMemcpyHostToDevice, g->stream));
+    }
+    return 0;
+}
+
+int tamd_graph_launch(tamd_graph* g)
+{
+    if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    if (g->hexec) { HIPCHK(hipGraphLaunch(g->hexec, g->stream)); return 0; }
+    return run_steps(g, g->stream);
+}
+
+int tamd_graph_sync(tamd_graph* g) { HIPCHK(hipStreamSynchronize(g->stream)); return 0; }
+
+int tamd_graph_download_outputs(tamd_graph* g)
+{
+    for (auto& io : g->outputs) HIPCHK(hipMemcpyAsync(io.pinned, io.stage, io.bytes, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    for (auto& io : g->outputs)
+        if (io.host_out) memcpy(io.host_out, io.pinned, io.bytes);
+    return 0;
+}
+
+int tamd_graph_run(tamd_graph* g)
+{
+    if (tamd_graph_upload_inputs(g)) return -1;
+    if (tamd_graph_launch(g)) return -1;
+    return tamd_graph_download_outputs(g);
+}
+
+int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
+{
+    if (idx < 0 || idx >= (int)g->outputs.size() || !g->prepared) return -1;
+    *dptr = g->outputs[idx].stage;
+    *bytes = g->outputs[idx].bytes;
+    return 0;
+}
+
+void* tamd_graph_stream(tamd_graph* g) { return (void*)g->stream; }
+
+int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms)
+{
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g->stream));
+    for (int i = 0; i < iters; i++)
+        if (tamd_graph_launch(g)) return -1;
+    HIPCHK(hipEventRecord(e1, g->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(total_ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
+int tamd_graph_kernel_num(const tamd_graph* g) { return (int)g->steps.size(); }
+
+int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out)
+{
+    if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    int n = std::min((int)g->steps.size(), max_out);
+    std::vector<hipEvent_t> ev(2 * g->steps.size());
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    std::vector<double> acc(g->steps.size(), 0.0);
+    for (int it = 0; it < iters; it++) {
+        for (size_t i = 0; i < g->steps.size(); i++) {
+            HIPCHK(hipEventRecord(ev[2 * i], g->stream));
+            hipError_t e = g->steps[i].fn(g->stream);
+            if (e != hipSuccess) { set_error("profile launch failed: %s", hipGetErrorString(e)); return -1; }
+            HIPCHK(hipEventRecord(ev[2 * i + 1], g->stream));
+        }
+        HIPCHK(hipStreamSynchronize(g->stream));
+        for (size_t i = 0; i < g->steps.size(); i++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    for (int i = 0; i < n; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        snprintf(out[i].node, sizeof(out[i].node), "%s", g->steps[i].node.c_str());
+        snprintf(out[i].kernel, sizeof(out[i].kernel), "%s", g->steps[i].kernel.c_str());
+        out[i].macs = g->steps[i].macs;
+        out[i].bytes = g->steps[i].bytes;
+        out[i].ms = (float)(acc[i] / iters);
+    }
+    return n;
+}
+
+int tamd_graph_tensor_num(const tamd_graph* g) { return (int)g->tensors.size(); }
+
+int tamd_graph_tensor_desc(const tamd_graph* g, int idx, int* dims8, int* dtype)
+{
+    if (idx < 0 || idx >= (int)g->tensors.size()) return -1;
+    return fill_desc(g->tensors[idx], dims8, dtype);
+}
+
+int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
+{
+    if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
+    HTensor& t = g->tensors[idx];
+    if (t.ttype == TAMD_TT_CONST) { memcpy(host, t.data.data(), std::min(bytes, t.data.size())); return 0; }
+    size_t need = t.elems() * esize(t.dtype);
+    if (bytes != need) { set_error("read_tensor: %zu bytes given, %zu needed", bytes, need); return -1; }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (t.nchw_raw) { HIPCHK(hipMemcpy(host, t.dptr, need, hipMemcpyDeviceToHost)); return 0; }
+    void* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, need));
+    LayoutArgs a{(const int8_t*)t.dptr + t.c_off, tmp, t.n, t.c, t.h, t.w, t.cs, esize(t.dtype)};
+    hipError_t e = launch_nhwc_to_nchw(a, g->stream);
+    if (e != hipSuccess) { hipFree(tmp); set_error("layout launch failed"); return -1; }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(hipMemcpy(host, tmp, need, hipMemcpyDeviceToHost));
+    hipFree(tmp);
+    return 0;
+}
+
+void tamd_graph_destroy(tamd_graph* g)
+{
+    if (!g) return;
+    if (g->stream) hipStreamSynchronize(g->stream);
+    if (g->hexec) hipGraphExecDestroy(g->hexec);
+    if (g->hgraph) hipGraphDestroy(g->hgraph);
+    for (void* p : g->dev_allocs) hipFree(p);
+    for (auto& io : g->inputs) if (io.pinned) hipHostFree(io.pinned);
+    for (auto& io : g->outputs) if (io.pinned) hipHostFree(io.pinned);
+    if (g->stream) hipStreamDestroy(g->stream);
+    delete g;
+}
+
+}  // extern "C"

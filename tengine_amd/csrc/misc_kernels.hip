@@ -1,0 +1,200 @@
+// Bandwidth-bound glue ops of the config graphs, int8 NHWC on device.
+// Each follows the reference's dequant -> fp32 -> requant formula op for op (bit-exact), vectorised
+// 4..16 bytes per lane with lanes along the contiguous channel dimension.
+#include "epilogue.h"
+#include "kernels.h"
+
+namespace tamd {
+
+__device__ __forceinline__ int sxb(unsigned v, int b) { return (int)(signed char)((v >> (8 * b)) & 0xff); }
+
+// ---- pooling: pooling/pooling_kernel_ref_int8.c:84-189 ---------------------------------------------
+// max: y = round((float)max_q * (in_scale/out_scale)); avg: f=(float)sum*in_scale; f=f/(float)pool_size;
+// y = round(f/out_scale); pool_size = in-image taps unless caffe_flavor (window clipped to in+pad).
+__global__ __launch_bounds__(256) void pool_i8_kernel(PoolArgs a)
+{
+    const int cg = (a.C + 3) / 4;          // channel groups of THIS tensor (it may be a view in a wider buffer)
+    const long total = (long)a.N * a.OH * a.OW * cg;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % cg); idx /= cg;
+    const int px = (int)(idx % a.OW); idx /= a.OW;
+    const int py = (int)(idx % a.OH);
+    const int n = (int)(idx / a.OH);
+
+    int hs = py * a.SH - a.PH, he = hs + a.KH;
+    if (he > a.H + a.PH) he = a.H + a.PH;
+    int ws = px * a.SW - a.PW, we = ws + a.KW;
+    if (we > a.W + a.PW) we = a.W + a.PW;
+    int pool_size = 1;
+    if (a.caffe_flavor) pool_size = (he - hs) * (we - ws);
+    hs = hs > 0 ? hs : 0;
+    ws = ws > 0 ? ws : 0;
+    he = he < a.H ? he : a.H;
+    we = we < a.W ? we : a.W;
+    if (!a.caffe_flavor) pool_size = (he - hs) * (we - ws);
+
+    const int8_t* xn = a.x + (size_t)n * a.H * a.W * a.cs_in + c4 * 4;
+    int q[4];
+    if (a.method == 0) {
+        const unsigned f0 = *reinterpret_cast<const unsigned*>(xn + ((size_t)hs * a.W + ws) * a.cs_in);
+        int m[4] = {sxb(f0, 0), sxb(f0, 1), sxb(f0, 2), sxb(f0, 3)};
+        for (int iy = hs; iy < he; iy++)
+            for (int ix = ws; ix < we; ix++) {
+                const unsigned v = *reinterpret_cast<const unsigned*>(xn + ((size_t)iy * a.W + ix) * a.cs_in);
+#pragma unroll
+                for (int b = 0; b < 4; b++) { int t = sxb(v, b); m[b] = m[b] > t ? m[b] : t; }
+            }
+        const float rq = __fdiv_rn(a.in_scale, a.out_scale);
+#pragma unroll
+        for (int b = 0; b < 4; b++) q[b] = round_sat(__fmul_rn((float)m[b], rq));
+    } else {
+        int s[4] = {0, 0, 0, 0};
+        for (int iy = hs; iy < he; iy++)
+            for (int ix = ws; ix < we; ix++) {
+                const unsigned v = *reinterpret_cast<const unsigned*>(xn + ((size_t)iy * a.W + ix) * a.cs_in);
+#pragma unroll
+                for (int b = 0; b < 4; b++) s[b] += sxb(v, b);
+            }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            float f = __fmul_rn((float)s[b], a.in_scale);
+            f = __fdiv_rn(f, (float)pool_size);
+            q[b] = round_sat(__fdiv_rn(f, a.out_scale));
+        }
+    }
+    *reinterpret_cast<unsigned*>(a.y + (((size_t)n * a.OH + py) * a.OW + px) * a.ldc + a.c_off + c4 * 4) =
+        pack4(q[0], q[1], q[2], q[3]);
+}
+
+hipError_t launch_pool(const PoolArgs& a, hipStream_t s)
+{
+    const long total = (long)a.N * a.OH * a.OW * ((a.C + 3) / 4);
+    hipLaunchKernelGGL(pool_i8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- eltwise (+ optionally the standalone ReLU that follows it in ResNet): eltwise_ref.c:589-640,833-837
+// a=(float)qa*sa ; b=(float)qb*sb ; f = a op b ; y = round(f/out_scale) clamp +-127
+// fused relu (relu_kernel_ref_int8.c:40-94 applied to y): f2=(float)y*out_scale ; f2<0 -> 0 ;
+// y2 = round(f2/relu_out_scale)
+__global__ __launch_bounds__(256) void eltwise_i8_kernel(EltArgs a)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= a.count) return;
+    const uint4 va = *reinterpret_cast<const uint4*>(a.a + i);
+    const uint4 vb = *reinterpret_cast<const uint4*>(a.b + i);
+    const unsigned pa[4] = {va.x, va.y, va.z, va.w}, pb[4] = {vb.x, vb.y, vb.z, vb.w};
+    unsigned out[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        int q[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const float fa = __fmul_rn((float)sxb(pa[d], b), a.sa), fb = __fmul_rn((float)sxb(pb[d], b), a.sb);
+            float f;
+            switch (a.type) {
+            case 0: f = __fmul_rn(fa, fb); break;
+            case 2: f = __fadd_rn(fa, fb); break;
+            case 4: f = __fsub_rn(fa, fb); break;
+            default: f = fa > fb ? fa : fb; break;
+            }
+            int y = round_sat(__fdiv_rn(f, a.out_scale));
+            if (a.fuse_relu) {
+                float f2 = __fmul_rn((float)y, a.out_scale);
+                f2 = f2 < 0.f ? 0.f : f2;
+                y = round_sat(__fdiv_rn(f2, a.relu_out_scale));
+            }
+            q[b] = y;
+        }
+        out[d] = pack4(q[0], q[1], q[2], q[3]);
+    }
+    *reinterpret_cast<uint4*>(a.y + i) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+hipError_t launch_eltwise(const EltArgs& a, hipStream_t s)
+{
+    const size_t n16 = (a.count + 15) / 16;
+    hipLaunchKernelGGL(eltwise_i8_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- relu / leaky relu: relu/relu_kernel_ref_int8.c:40-94 -------------------------------------------
+__global__ __launch_bounds__(256) void relu_i8_kernel(ReluArgs a)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= a.count) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(a.x + i);
+    const unsigned pv[4] = {v.x, v.y, v.z, v.w};
+    unsigned out[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        int q[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            float f = __fmul_rn((float)sxb(pv[d], b), a.in_scale);
+            if (f < 0.f) f = (a.slope == 0.f) ? 0.f : __fmul_rn(f, a.slope);
+            q[b] = round_sat(__fdiv_rn(f, a.out_scale));
+        }
+        out[d] = pack4(q[0], q[1], q[2], q[3]);
+    }
+    *reinterpret_cast<uint4*>(a.y + i) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+hipError_t launch_relu(const ReluArgs& a, hipStream_t s)
+{
+    const size_t n16 = (a.count + 15) / 16;
+    hipLaunchKernelGGL(relu_i8_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- layout at the subgraph edges (the IR is NCHW: source/operator/prototype/convolution.c:60-70) ----
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
+{
+    const long total = (long)a.N * a.H * a.W * a.cs;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % a.cs);
+    long p = idx / a.cs;
+    const int w = (int)(p % a.W); p /= a.W;
+    const int h = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    T v = 0;
+    if (c < a.C) v = reinterpret_cast<const T*>(a.src)[(((size_t)n * a.C + c) * a.H + h) * a.W + w];
+    reinterpret_cast<T*>(a.dst)[idx] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(LayoutArgs a)
+{
+    const long total = (long)a.N * a.C * a.H * a.W;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % a.W);
+    long p = idx / a.W;
+    const int h = (int)(p % a.H); p /= a.H;
+    const int c = (int)(p % a.C);
+    const int n = (int)(p / a.C);
+    reinterpret_cast<T*>(a.dst)[idx] = reinterpret_cast<const T*>(a.src)[(((size_t)n * a.H + h) * a.W + w) * a.cs + c];
+}
+
+hipError_t launch_nchw_to_nhwc(const LayoutArgs& a, hipStream_t s)
+{
+    const long total = (long)a.N * a.H * a.W * a.cs;
+    dim3 g((unsigned)((total + 255) / 256));
+    if (a.elem == 1) hipLaunchKernelGGL(nchw_to_nhwc_kernel<int8_t>, g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s)
+{
+    const long total = (long)a.N * a.C * a.H * a.W;
+    dim3 g((unsigned)((total + 255) / 256));
+    if (a.elem == 1) hipLaunchKernelGGL(nhwc_to_nchw_kernel<int8_t>, g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace tamd

@@ -14,6 +14,9 @@ and its quantisation tool needs OpenCV, so the quantised configs are synthesised
 Calibration uses a plain fp32 forward in torch (CPU) -- it only decides the scales; it is not an
 oracle and nothing in the product path depends on it.
 """
+import json
+import os
+
 import numpy as np
 
 from . import tm2
@@ -177,16 +180,13 @@ def resnet50_fp32(batch=1, res=224, classes=1000):
         for r in range(reps):
             tag = "res%d%s" % (st, "abcdef"[r])
             s = stride if r == 0 else 1
-            if r == 0:
-                sc = b.conv(tag + "_branch1", x, out, 1, s, 0, act=-1)
-            else:
-                sc = x
             y = b.conv(tag + "_branch2a", x, mid, 1, s, 0, act=0)
             y = b.conv(tag + "_branch2b", y, mid, 3, 1, 1, act=0)
             y = b.conv(tag + "_branch2c", y, out, 1, 1, 0, act=-1)
+            sc = b.conv(tag + "_branch1", x, out, 1, s, 0, act=-1) if r == 0 else x
             x = b.eltwise_sum(tag, sc, y)
             x = b.relu(tag + "_relu", x)
-    x = b.pool("pool5", x, tm2.POOL_AVG, 7, 1, 0, glob=1, caffe=1)
+    x = b.pool("pool5", x, tm2.POOL_AVG, 7, 1, 0, glob=0, caffe=1)
     x = b.fc("fc1000", x, classes)
     x = b.softmax("prob", x)
     return b.finish([x])
@@ -200,8 +200,8 @@ def squeezenet_v11_fp32(batch=1, res=227, classes=1000):
 
     def fire(tag, x, sq, ex):
         s = b.conv(tag + "/squeeze1x1", x, sq, 1, act=0)
+        e3 = b.conv(tag + "/expand3x3", s, ex, 3, 1, 1, act=0)      # node order as in the reference file
         e1 = b.conv(tag + "/expand1x1", s, ex, 1, act=0)
-        e3 = b.conv(tag + "/expand3x3", s, ex, 3, 1, 1, act=0)
         return b.concat(tag + "/concat", [e1, e3])
 
     x = fire("fire2", x, 16, 64)
@@ -346,11 +346,21 @@ def synth_input(g: Graph, seed=1234, dtype=DT_INT8):
     return rng.uniform(-1, 1, size=dims).astype(np.float32)
 
 
-def quantize_int8(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0) -> Graph:
-    """fp32 IR -> int8 IR following quant_save_graph.cpp:355-613 (see module docstring)."""
+def calibrate_absmax(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0):
+    """min-max calibration pass: {tensor name: absmax} of one fp32 forward on the seeded input."""
     if calib_q is None:
         calib_q = synth_input(gf, 1234, DT_INT8)
     acts = fp32_forward(gf, calib_q.astype(np.float32) * np.float32(in_scale))
+    return {t.name: float(np.abs(acts[ti]).max()) for ti, t in enumerate(gf.tensors)
+            if t.ttype == tm2.TT_VAR}
+
+
+def quantize_int8(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0, table=None) -> Graph:
+    """fp32 IR -> int8 IR following quant_save_graph.cpp:355-613 (see module docstring).
+    `table` = {tensor name: absmax} from a previous calibration (the quant tool's .table file); with it
+    the result is bit-reproducible on any host (no fp32 forward is run)."""
+    if table is None:
+        table = calibrate_absmax(gf, calib_q, in_scale)
     g = Graph(name=gf.name + "_int8")
     g.input_nodes, g.output_nodes = list(gf.input_nodes), list(gf.output_nodes)
     # activation scales
@@ -361,8 +371,7 @@ def quantize_int8(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0) -
         if t.ttype == tm2.TT_INPUT:
             scale[ti] = np.float32(in_scale)
         else:
-            amax = float(np.abs(acts[ti]).max())
-            scale[ti] = np.float32(max(amax, 1e-6) / 127.0)
+            scale[ti] = np.float32(max(float(table[t.name]), 1e-6) / 127.0)
     # pass-through ops share the producer's scale; relu (slope 0) and max-pool too (:440-470)
     for n in gf.nodes:
         if n.op in PASS_THROUGH or (n.op == "ReLU" and n.params.get("negative_slope", 0.0) == 0.0) \
@@ -424,10 +433,27 @@ BUILDERS = {
 }
 
 
+CALIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "calib")
+
+
+def calib_table(name, gf=None, write=False):
+    """Committed calibration tables (tengine_amd/calib/<model>_int8.json == the quant tool's scale
+    table): make the synthetic int8 models bit-identical on every host."""
+    path = os.path.join(CALIB_DIR, "%s_int8.json" % name)
+    if os.path.exists(path) and not write:
+        return json.load(open(path))
+    table = calibrate_absmax(gf if gf is not None else BUILDERS[name]())
+    if write:
+        os.makedirs(CALIB_DIR, exist_ok=True)
+        json.dump(table, open(path, "w"), indent=0, sort_keys=True)
+    return table
+
+
 def build(name, dtype="int8", batch=1, **kw) -> Graph:
     gf = BUILDERS[name](batch=1, **kw)
     if dtype == "fp32":
         return set_batch(gf, batch)
     if dtype == "int8":
-        return set_batch(quantize_int8(gf), batch)
+        table = calib_table(name, gf) if not kw else None
+        return set_batch(quantize_int8(gf, table=table), batch)
     raise NotImplementedError(dtype)

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The real reference library (oracle/_ref), skipped where it was never built."""
+    from oracle import ref_capi
+    if not ref_capi.available():
+        pytest.skip("oracle/_ref/libtengine-lite.so not built (needs /root/reference once)")
+    return ref_capi

@@ -1,0 +1,30 @@
+"""Generates the committed golden fixtures by running the REAL reference (oracle/_ref, built from the
+unmodified /root/reference sources by oracle/build_ref.py) on the seeded synthetic models.
+Run here (where /root/reference exists):  python tests/golden/make_golden.py
+The fixtures are tiny (model outputs only); the models themselves are re-synthesised from seeds."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import build_ref, ref_capi  # noqa: E402
+from tengine_amd import models, tm2     # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    build_ref.build()
+    for name, batch, seed in [("mobilenet_v1", 1, 7)]:
+        g = models.build(name, "int8", batch)
+        x = models.synth_input(g, seed)
+        out = ref_capi.run_model(tm2.write_tm2(g), x, ref_capi.MODE_INT8, os.cpu_count())[0]
+        path = os.path.join(HERE, "%s_int8_seed%d.npy" % (name, seed))
+        np.save(path, out)
+        print(path, out.shape, out.dtype, "absmax", np.abs(out.astype(int)).max())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""Seeded single-op and small-graph builders shared by the CPU and GPU parity tests.
+Every case is expressed as tmfile bytes so the reference, the oracle and the HIP backend all
+consume the same model."""
+import numpy as np
+
+from tengine_amd import tm2
+from tengine_amd.tm2 import DT_INT8, DT_INT32, Graph
+
+
+def _scales(rng, n, lo=0.002, hi=0.02):
+    return [float(np.float32(v)) for v in rng.uniform(lo, hi, size=n)]
+
+
+def conv_graph(seed, n, cin, h, w, cout, k, s=1, p=0, group=1, act=0, bias=True, dil=1, kw=None, pw=None):
+    rng = np.random.default_rng(seed)
+    kh, kw = k, (k if kw is None else kw)
+    ph, pw = p, (p if pw is None else pw)
+    g = Graph(name="conv_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, cin, h, w], DT_INT8, [xs], [0])
+    wq = rng.integers(-127, 128, size=(cout, cin // group, kh, kw)).astype(np.int8)
+    ws = _scales(rng, cout)
+    ins = [x, g.add_const("w", wq, DT_INT8, ws, [0] * cout)]
+    if bias:
+        bq = rng.integers(-2000, 2000, size=(cout,)).astype(np.int32)
+        ins.append(g.add_const("b", bq, DT_INT32, [1.0], [0]))
+    oh = (h - dil * (kh - 1) - 1 + 2 * ph) // s + 1
+    ow = (w - dil * (kw - 1) - 1 + 2 * pw) // s + 1
+    # output scale sized so results spread over the int8 range without saturating everywhere
+    fan = (cin // group) * kh * kw
+    os_ = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(fan) * 73.0 / 60.0))
+    y = g.add_tensor("out", [n, cout, oh, ow], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+    ni = g.add_node("conv", "Convolution", ins, [y], kernel_h=kh, kernel_w=kw, stride_h=s, stride_w=s,
+                    dilation_h=dil, dilation_w=dil, input_channel=cin, output_channel=cout, group=group,
+                    activation=act, pad_h0=ph, pad_w0=pw, pad_h1=ph, pad_w1=pw)
+    g.output_nodes = [ni]
+    xin = rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+    return g, xin
+
+
+def fc_graph(seed, n, hidden_dims, nout, bias=True):
+    rng = np.random.default_rng(seed)
+    g = Graph(name="fc_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n] + list(hidden_dims), DT_INT8, [xs], [0])
+    hidden = int(np.prod(hidden_dims))
+    wq = rng.integers(-127, 128, size=(nout, hidden)).astype(np.int8)
+    ws = _scales(rng, nout)
+    ins = [x, g.add_const("w", wq, DT_INT8, ws, [0] * nout)]
+    if bias:
+        ins.append(g.add_const("b", rng.integers(-2000, 2000, size=(nout,)).astype(np.int32), DT_INT32, [1.0], [0]))
+    os_ = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(hidden) * 73.0 / 60.0))
+    y = g.add_tensor("out", [n, nout], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+    ni = g.add_node("fc", "FullyConnected", ins, [y], num_output=nout)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=[n] + list(hidden_dims)).astype(np.int8)
+
+
+def pool_graph(seed, n, c, h, w, alg, k, s, p=0, glob=0, caffe=0, same_scale=False):
+    from tengine_amd.models import pool_out
+    rng = np.random.default_rng(seed)
+    g = Graph(name="pool_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, c, h, w], DT_INT8, [xs], [0])
+    if glob:
+        oh = ow = 1
+    else:
+        oh, _, _ = pool_out(h, k, s, p, caffe)
+        ow, _, _ = pool_out(w, k, s, p, caffe)
+    os_ = xs if same_scale else float(np.float32(xs * rng.uniform(0.4, 1.3)))
+    y = g.add_tensor("out", [n, c, oh, ow], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+    ni = g.add_node("pool", "Pooling", [x], [y], alg=alg, kernel_h=k, kernel_w=k, stride_h=s, stride_w=s,
+                    **{"global": glob}, caffe_flavor=caffe, pad_h0=p, pad_w0=p, pad_h1=p, pad_w1=p)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)
+
+
+def eltwise_relu_graph(seed, n, c, h, w, with_relu=True, etype=tm2.ELT_SUM):
+    """two 1x1 convs -> eltwise -> [relu]; mirrors a ResNet block tail."""
+    rng = np.random.default_rng(seed)
+    g, xin = conv_graph(seed, n, c, h, w, c, 1, act=-1)
+    g.output_nodes = []
+    x = g.nodes[g.input_nodes[0]].outputs[0]
+    a = g.nodes[-1].outputs[0]
+    wq = rng.integers(-127, 128, size=(c, c, 1, 1)).astype(np.int8)
+    ws = _scales(rng, c)
+    wt = g.add_const("w2", wq, DT_INT8, ws, [0] * c)
+    sb = float(np.float32(g.tensors[a].scales[0] * 1.37))
+    b = g.add_tensor("out2", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [sb], [0])
+    g.add_node("conv2", "Convolution", [x, wt], [b], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1,
+               dilation_w=1, input_channel=c, output_channel=c, group=1, activation=-1, pad_h0=0, pad_w0=0,
+               pad_h1=0, pad_w1=0)
+    so = float(np.float32(g.tensors[a].scales[0] * 1.9))
+    e = g.add_tensor("sum", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [so], [0])
+    ni = g.add_node("elt", "Eltwise", [a, b], [e], type=etype, caffe_flavor=1)
+    if with_relu:
+        r = g.add_tensor("relu", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [so], [0])
+        ni = g.add_node("relu", "ReLU", [e], [r], negative_slope=0.0)
+    g.output_nodes = [ni]
+    return g, xin

@@ -1,0 +1,88 @@
+"""Pins the oracle restatement (oracle/tg_oracle.c) against the REAL reference library built from the
+unmodified sources (oracle/_ref, see oracle/build_ref.py): bit-exact for int8, on seeded random layers
+covering every kernel-selection branch of the reference and on whole models."""
+import numpy as np
+import pytest
+
+from helpers import conv_graph, eltwise_relu_graph, fc_graph, pool_graph
+from oracle import oracle
+from tengine_amd import models, tm2
+
+CONV_CASES = [
+    # (n, cin, h, w, cout, k, s, p, group, act, bias, dil)   -> reference kernel
+    (1, 32, 14, 14, 64, 1, 1, 0, 1, 0, True, 1),      # hcl 1x1
+    (1, 64, 9, 11, 48, 1, 1, 0, 1, -1, False, 1),     # hcl 1x1 no bias / no act
+    (2, 16, 8, 8, 32, 1, 2, 0, 1, 6, True, 1),        # hcl 1x1 stride 2, relu6, batch 2
+    (1, 3, 32, 32, 32, 3, 2, 1, 1, 0, True, 1),       # first layer 3x3 s2
+    (1, 16, 13, 13, 24, 3, 1, 1, 1, 0, True, 1),      # hcl 3x3
+    (2, 8, 12, 12, 16, 3, 1, 2, 1, 1, True, 2),       # dilation 2, act code 1 (treated as relu6 by hcl)
+    (1, 3, 40, 40, 16, 7, 2, 3, 1, 0, True, 1),       # 7x7 s2 (ResNet stem)
+    (1, 32, 16, 16, 32, 3, 1, 1, 32, 0, True, 1),     # dw s1 batch 1 -> dw_hcl
+    (1, 48, 15, 15, 48, 3, 2, 1, 48, 0, True, 1),     # dw s2 batch 1 -> dw_hcl
+    (2, 32, 10, 10, 32, 3, 1, 1, 32, 0, True, 1),     # dw batch 2 -> ref_conv_int8 (other epilogue)
+    (1, 32, 10, 10, 32, 3, 1, 1, 32, 1, True, 1),     # dw act=1: hcl treats as relu6
+    (2, 32, 10, 10, 32, 3, 1, 1, 32, 1, True, 1),     # dw batch 2 act=1: ref clamps [-1,1]
+    (1, 16, 9, 9, 32, 3, 1, 1, 4, 0, True, 1),        # grouped (non-dw) -> ref
+    (1, 24, 9, 9, 24, 5, 1, 2, 24, 6, True, 1),       # dw 5x5 -> ref, relu6
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_int8_oracle_equals_reference(ref, case):
+    n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
+    for seed in (11, 12):
+        g, x = conv_graph(seed, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
+        want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 2)[0]
+        got = oracle.run_graph(g, x)[0]
+        assert want.shape == got.shape
+        assert np.array_equal(want, got), "mismatches: %d / %d" % (np.count_nonzero(want != got), want.size)
+        assert np.count_nonzero(got) > got.size // 8      # non-degenerate
+
+
+@pytest.mark.parametrize("case", [(1, (64,), 10), (3, (32, 2, 2), 17), (2, (2048,), 100)])
+def test_fc_int8_oracle_equals_reference(ref, case):
+    n, hd, nout = case
+    g, x = fc_graph(5, n, hd, nout)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want.reshape(got.shape), got)
+
+
+POOL_CASES = [
+    # n, c, h, w, alg, k, s, p, glob, caffe
+    (1, 32, 7, 7, 1, 7, 1, 0, 1, 1),      # global avg (MobileNet / ResNet tail)
+    (2, 16, 14, 14, 0, 3, 2, 0, 0, 1),    # caffe max 3x3 s2 (ResNet pool1 / SqueezeNet)
+    (1, 16, 15, 15, 0, 3, 2, 1, 0, 0),    # padded max
+    (1, 8, 12, 12, 1, 3, 2, 1, 0, 0),     # padded avg, pool_size counts in-image taps
+    (1, 8, 12, 12, 1, 3, 2, 1, 0, 1),     # caffe avg, pool_size counts the padded window
+    (1, 8, 13, 13, 0, 2, 2, 0, 0, 0),     # yolo maxpool
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=[str(c) for c in POOL_CASES])
+def test_pool_int8_oracle_equals_reference(ref, case):
+    n, c, h, w, alg, k, s, p, glob, caffe = case
+    g, x = pool_graph(3, n, c, h, w, alg, k, s, p, glob, caffe)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert want.shape == got.shape and np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("with_relu", [False, True])
+def test_eltwise_relu_int8_oracle_equals_reference(ref, with_relu):
+    g, x = eltwise_relu_graph(9, 2, 32, 6, 6, with_relu)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want, got)
+
+
+def test_mobilenet_v1_int8_whole_model(ref):
+    g = models.build("mobilenet_v1", "int8", 1)
+    x = models.synth_input(g, 7)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 4)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want, got)
+    assert np.abs(got.astype(int)).max() > 60
+    # thread-count independence of the reference int8 path (SURVEY §8c determinism)
+    assert np.array_equal(want, ref.run_model(b, x, ref.MODE_INT8, 1)[0])
