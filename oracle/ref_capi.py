@@ -97,7 +97,10 @@ class RefGraph:
         self.ctx = None
         if device:
             self.ctx = L.create_context(b"tamd", 1)
-            rc = L.set_context_device(self.ctx, device.encode(), dev_opt, 0 if dev_opt is None else C.sizeof(dev_opt))
+            self._dev_opt = dev_opt      # keep alive: the context stores the pointer
+            rc = L.set_context_device(self.ctx, device.encode(),
+                                      None if dev_opt is None else C.cast(C.pointer(dev_opt), C.c_void_p),
+                                      0 if dev_opt is None else C.sizeof(dev_opt))
             if rc != 0:
                 raise RuntimeError("set_context_device(%s) failed" % device)
         self.g = self._create(L, len(tm_bytes))

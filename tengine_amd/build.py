@@ -21,9 +21,9 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["conv_igemm.hip", "dwconv.hip", "conv_direct.hip", "misc_kernels.hip", "graph.hip", "tm2_reader.cc"]
+SOURCES = ["conv_igemm.hip", "gemm_direct.hip", "conv_first.hip", "dwconv.hip", "conv_direct.hip", "misc_kernels.hip", "graph.hip", "tm2_reader.cc"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 
 
 def _newer(target, deps):
@@ -68,12 +68,18 @@ def build_plugin(ref="/root/reference", verbose=False, force=False):
     src = os.path.join(HERE, "device", "hip_device.cc")
     if not os.path.isdir(os.path.join(ref, "source")) or not os.path.exists(src):
         return None
-    gen = os.path.join(ROOT, "oracle", "_ref", "gen")
     lib = os.path.join(LIBDIR, "libtengine_hip_device.so")
     if not force and not _newer(lib, [src, os.path.join(ROOT, "include", "tengine_amd.h")]):
         return lib
+    # the one configured header the reference's internal headers include (source/defines.h.in)
+    import re
+    gen = os.path.join(LIBDIR, "gen")
+    os.makedirs(gen, exist_ok=True)
+    defines = re.sub(r"#cmakedefine (\w+)", r"#define \1", open(os.path.join(ref, "source", "defines.h.in")).read())
+    open(os.path.join(gen, "defines.h"), "w").write(defines)
     cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ref, "source"),
-           "-I" + gen, "-I" + os.path.join(ROOT, "include"), src, "-o", lib,
+           "-I" + os.path.join(ref, "source", "operator", "prototype"), "-I" + gen,
+           "-I" + os.path.join(ROOT, "include"), src, "-o", lib,
            "-L" + LIBDIR, "-ltengine_amd", "-Wl,-rpath,$ORIGIN"]
     subprocess.check_call(cmd)
     return lib

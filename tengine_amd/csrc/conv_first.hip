@@ -1,0 +1,119 @@
+// First-layer int8 convolution straight from the graph's NCHW input (C <= 4: MobileNet conv1 3x3 s2,
+// ResNet / SqueezeNet stems 7x7 / 3x3 s2) on MFMA, writing NHWC.
+//
+// Replaces the reference's im2col_int8 + sgemm_i8 + epilogue for these layers
+// (source/device/cpu/op/conv/x86/conv_kernel_x86.c:187-242, :1008-1630, :1826-1889) and removes the
+// separate NCHW->NHWC pass a layout-converting backend would need at the subgraph edge.
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * P[pixel][k] with k = (c*KH+ky)*KW+kx -- exactly the
+// OIHW order of the model's weight tensor, so weight rows are used as stored (zero padded to 32 k).
+// The im2col patch P is never materialised: each lane gathers the 16 patch bytes of its MFMA operand
+// from the (L1/L2 resident, 150 KB/img) input with a k -> (plane, dy, dx) table in LDS; out-of-image
+// taps read as 0 (== the reference's zero padding).  One wave = one 32-pixel tile x all output
+// channels, so the gathered operand is reused for every cout tile.  K is tiny (27..196) and the layer
+// is bandwidth/latency shaped; the point of MFMA here is to keep the VALU free for the gather.
+#include "epilogue.h"
+#include "kernels.h"
+
+namespace tamd {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// CT = cout tiles of 32 (cout_pad = 32*CT)
+template <int CT>
+__global__ __launch_bounds__(256) void conv_first_i8_kernel(FirstArgs a)
+{
+    __shared__ int lut[256];             // k -> (c << 16) | (dy << 8) | dx ; 0x80000000 marks padding k
+    const int t = threadIdx.x;
+    const int kreal = a.C * a.KH * a.KW;
+    if (t < a.kp) {
+        int v = (int)0x80000000;
+        if (t < kreal) {
+            const int kx = t % a.KW, r = t / a.KW;
+            const int ky = r % a.KH, c = r / a.KH;
+            v = (c << 16) | ((ky * a.DH) << 8) | (kx * a.DW);
+        }
+        lut[t] = v;
+    }
+    __syncthreads();
+
+    const int lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long M = (long)a.N * a.OH * a.OW;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    const long m0 = tile * 32;
+    if (m0 >= M) return;
+    const long m = m0 + l31;
+    const bool mvalid = m < M;
+    const int ohw = a.OH * a.OW;
+    const long mm = mvalid ? m : 0;
+    const int n = (int)(mm / ohw);
+    const int rem = (int)(mm - (long)n * ohw);
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
+    const int8_t* xn = a.x + (size_t)n * a.C * a.H * a.W;
+    const int hw = a.H * a.W;
+
+    v16i acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0;
+
+    const int nk = a.kp / 32;
+    for (int ks = 0; ks < nk; ks++) {
+        const int kb = ks * 32 + hi * 16;
+        unsigned pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int d = lut[kb + e];
+            const int c = (d >> 16) & 0xff, dy = (d >> 8) & 0xff, dx = d & 0xff;
+            const int iy = iy0 + dy, ix = ix0 + dx;
+            const bool ok = mvalid && d >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            int v = 0;
+            if (ok) v = (int)xn[(size_t)c * hw + (size_t)iy * a.W + ix];
+            pk[e >> 2] |= ((unsigned)(v & 0xff)) << (8 * (e & 3));
+        }
+        v4i bf = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+#pragma unroll
+        for (int i = 0; i < CT; i++) {
+            const v4i af = *reinterpret_cast<const v4i*>(a.w + (size_t)(i * 32 + l31) * a.kp + kb);
+            acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[i], 0, 0, 0);
+        }
+    }
+
+    // epilogue (C/D layout: col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> cout)
+#pragma unroll
+    for (int i = 0; i < CT; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int c0 = i * 32 + 8 * g4 + 4 * hi;
+            const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
+            const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
+            int q0 = requant(acc[i][4 * g4 + 0] + b4.x, a.in_scale, s4.x, a.out_scale, a.act, a.mode);
+            int q1 = requant(acc[i][4 * g4 + 1] + b4.y, a.in_scale, s4.y, a.out_scale, a.act, a.mode);
+            int q2 = requant(acc[i][4 * g4 + 2] + b4.z, a.in_scale, s4.z, a.out_scale, a.act, a.mode);
+            int q3 = requant(acc[i][4 * g4 + 3] + b4.w, a.in_scale, s4.w, a.out_scale, a.act, a.mode);
+            if (mvalid && c0 < a.c_limit)
+                *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = pack4(q0, q1, q2, q3);
+        }
+}
+
+hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s)
+{
+    const long M = (long)a.N * a.OH * a.OW;
+    const long tiles = (M + 31) / 32;
+    dim3 grid((unsigned)((tiles + 3) / 4));
+    const int ct = (a.cout + 31) / 32;
+    switch (ct) {
+    case 1: hipLaunchKernelGGL(conv_first_i8_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(conv_first_i8_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(conv_first_i8_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(conv_first_i8_kernel<4>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tamd

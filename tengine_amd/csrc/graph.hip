@@ -257,7 +257,27 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
     Step st;
     st.node = n.name; st.macs = macs; st.bytes = abytes;
     const bool is_dw = (group > 1 && group == cin && cout == cin);
-    if (x.nchw_raw || group != 1) {
+    if (x.nchw_raw && group == 1 && cin <= 4 && cin * KH * KW <= 224 && cout <= 128
+        && p.dilation_h * (KH - 1) < 256 && p.dilation_w * (KW - 1) < 256) {
+        // ---- first layer from the NCHW graph input on MFMA ----
+        const int kreal = cin * KH * KW, kp = rup(kreal, 32), cpad = rup(cout, 32);
+        std::vector<int8_t> wp((size_t)cpad * kp, 0);
+        for (int co = 0; co < cout; co++) memcpy(&wp[(size_t)co * kp], wd + (size_t)co * kreal, kreal);   // OIHW row as stored
+        std::vector<int32_t> bp(cpad, 0);
+        std::vector<float> sp(cpad, 1.f);
+        for (int c = 0; c < cout; c++) { bp[c] = bd ? bd[c] : 0; sp[c] = ws[c]; }
+        FirstArgs a{};
+        int8_t* dw_; int32_t* db_; float* ds_;
+        if (upload(g, wp, &dw_) || upload(g, bp, &db_) || upload(g, sp, &ds_)) return -1;
+        a.x = (const int8_t*)x.dptr; a.w = dw_; a.bias = db_; a.wscale = ds_; a.y = (int8_t*)y.dptr;
+        a.N = x.n; a.C = cin; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.ldc = y.cs; a.c_off = y.c_off;
+        a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
+        a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.DH = p.dilation_h; a.DW = p.dilation_w; a.kp = kp;
+        a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+        st.kernel = "conv_first_i8";
+        st.fn = [a](hipStream_t s) { return launch_conv_first(a, s); };
+    } else if (x.nchw_raw || group != 1) {
         if (!x.nchw_raw && is_dw && KH == 3 && KW == 3 && p.dilation_h == 1 && p.dilation_w == 1 && p.stride_h == p.stride_w
             && (p.stride_h == 1 || p.stride_h == 2)) {
             // ---- depthwise 3x3 ----
@@ -300,7 +320,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         // ---- implicit GEMM on MFMA ----
         const int ckp = rup(cin, 16);
         const int ktot = KH * KW * ckp;
-        const int kpad = rup(ktot, 128);
+        const int kpad = rup(ktot, 64);
         const int cout_pad = rup(cout, 128);
         if (KH * KW > 128) { set_error("conv %s: kernel %dx%d too large", n.name.c_str(), KH, KW); return -1; }
         std::vector<int8_t> wp((size_t)cout_pad * kpad, 0);
@@ -321,8 +341,13 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.cin = cin; a.ktot = ktot; a.kpad = kpad;
         a.M = y.n * y.h * y.w; a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
-        st.kernel = conv_igemm_kernel_name(a);
-        st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };
+        if (gemm_direct_applicable(a)) {
+            st.kernel = "gemm_direct_i8";
+            st.fn = [a](hipStream_t s) { return launch_gemm_direct(a, s); };
+        } else {
+            st.kernel = conv_igemm_kernel_name(a);
+            st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };
+        }
     }
     g->steps.push_back(st);
     return 0;
@@ -380,6 +405,15 @@ static int plan(tamd_graph* g)
         if (view_of[i] >= 0 || alias_of[i] >= 0) continue;
         if (t.dtype != TAMD_DT_INT8) { set_error("tensor %s: dtype %d not supported on the device yet", t.name.c_str(), t.dtype); return -1; }
         t.cs = rup(t.c, 16);
+        // a 1x1-map graph output written by conv/fc/pool (dword stores) keeps its channels dense, so the
+        // NHWC buffer IS the reference's NCHW order and no output layout pass is needed
+        if (t.h * t.w == 1 && t.c % 4 == 0 && count_consumers(g, (int)i) == 1) {
+            bool is_out = false, dword_producer = false;
+            for (auto& o : g->outputs) is_out |= (o.tensor == (int)i);
+            for (auto& n : g->nodes)
+                if (!n.out.empty() && n.out[0] == (int)i) dword_producer = (n.op == TAMD_OP_CONV || n.op == TAMD_OP_FC || n.op == TAMD_OP_POOL);
+            if (is_out && dword_producer) t.cs = t.c;
+        }
         if (dev_alloc(g, &t.dptr, (size_t)t.n * t.h * t.w * t.cs, true)) return -1;
     }
     // resolve views / aliases (nodes are in topological order; resolve chains iteratively)

@@ -56,6 +56,19 @@ struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-i
     int act, mode;
 };
 
+struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on MFMA
+    const int8_t* x;       // NCHW
+    const int8_t* w;       // [cout_pad32][kp], k = (c*KH+ky)*KW+kx (OIHW order), zero padded
+    const int32_t* bias;   // [cout_pad32]
+    const float* wscale;   // [cout_pad32]
+    int8_t* y;             // NHWC
+    int N, C, H, W, OH, OW, cout, ldc, c_off, c_limit;
+    int KH, KW, SH, SW, PH, PW, DH, DW;
+    int kp;                // roundup(C*KH*KW, 32) <= 256
+    float in_scale, out_scale;
+    int act, mode;
+};
+
 struct PoolArgs {
     const int8_t* x; int8_t* y;
     int N, H, W, C, cs_in, OH, OW, ldc, c_off;
@@ -84,6 +97,9 @@ struct LayoutArgs {        // NCHW <-> NHWC(cs) int8 / generic element size
 // launchers (return hipError_t of the launch)
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvArgs& a);   // tile shape the launcher will pick
+hipError_t launch_gemm_direct(const ConvArgs& a, hipStream_t s);   // 1x1, small-M / latency-bound shapes
+bool gemm_direct_applicable(const ConvArgs& a);
+hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);

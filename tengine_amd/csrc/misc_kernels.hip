@@ -67,8 +67,61 @@ __global__ __launch_bounds__(256) void pool_i8_kernel(PoolArgs a)
         pack4(q[0], q[1], q[2], q[3]);
 }
 
+// global pooling (window == whole map, no padding): 16 pixel lanes x 16 channel quads per block, LDS
+// tree-free reduce; same formulas as above with pool_size = H*W.
+__global__ __launch_bounds__(256) void global_pool_i8_kernel(PoolArgs a)
+{
+    __shared__ int red[16][16][4];
+    const int t = threadIdx.x;
+    const int cq = t & 15, pl = t >> 4;
+    const int c4 = blockIdx.x * 16 + cq;
+    const int n = blockIdx.y;
+    const int cg = (a.C + 3) / 4;
+    const int hw = a.H * a.W;
+    const bool cvalid = c4 < cg;
+    int s[4] = {0, 0, 0, 0};
+    if (a.method == 0) s[0] = s[1] = s[2] = s[3] = -128;
+    if (cvalid) {
+        const int8_t* xn = a.x + (size_t)n * hw * a.cs_in + c4 * 4;
+        for (int p = pl; p < hw; p += 16) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(xn + (size_t)p * a.cs_in);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int e = sxb(v, b);
+                s[b] = a.method == 0 ? (s[b] > e ? s[b] : e) : s[b] + e;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) red[pl][cq][b] = s[b];
+    __syncthreads();
+    if (pl != 0 || !cvalid) return;
+    int q[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int r = red[0][cq][b];
+        for (int k = 1; k < 16; k++) {
+            const int e = red[k][cq][b];
+            r = a.method == 0 ? (r > e ? r : e) : r + e;
+        }
+        if (a.method == 0) {
+            q[b] = round_sat(__fmul_rn((float)r, __fdiv_rn(a.in_scale, a.out_scale)));
+        } else {
+            float f = __fmul_rn((float)r, a.in_scale);
+            f = __fdiv_rn(f, (float)hw);
+            q[b] = round_sat(__fdiv_rn(f, a.out_scale));
+        }
+    }
+    *reinterpret_cast<unsigned*>(a.y + (size_t)n * a.ldc + a.c_off + c4 * 4) = pack4(q[0], q[1], q[2], q[3]);
+}
+
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s)
 {
+    if (a.OH == 1 && a.OW == 1 && a.KH == a.H && a.KW == a.W && a.PH == 0 && a.PW == 0) {
+        const int cg = (a.C + 3) / 4;
+        hipLaunchKernelGGL(global_pool_i8_kernel, dim3((cg + 15) / 16, a.N), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long total = (long)a.N * a.OH * a.OW * ((a.C + 3) / 4);
     hipLaunchKernelGGL(pool_i8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -1,0 +1,404 @@
+// Tengine device plugin "HIP": the drop-in boundary of SURVEY §8(b).
+//
+// Exports register_hip_device() / unregister_hip_device() -- the names cmake/registry.cmake:11-31
+// derives from a file called hip_device.cc, so the same file works in-tree (one line in
+// source/device/CMakeLists.txt) or as a plugin loaded with
+//   load_tengine_plugin("hip", "libtengine_hip_device.so", "register_hip_device")   (source/api/plugin.c:88-159)
+// against a Tengine built with all symbols visible.  Compiled against the reference's own headers
+// (struct device / subgraph / tensor are plain C structs the backends read directly), it
+// translates one `struct subgraph` into a tamd_graph (include/tengine_amd.h) at pre_run and moves
+// bytes at run.  No kernel code lives here.
+//
+//   interface.init/pre_run/run/post_run/release_graph/release_device   device.h:40-65
+//   allocator.describe                                                 device.h:71-84, cuda_device.cc:47-83 (pattern)
+//   optimizer.split_graph                                              c_api.c:468-498 caller, split.c:140,314,536 helpers
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <vector>
+
+extern "C" {
+#include "api/c_api.h"
+#include "device/device.h"
+#include "executer/executer.h"
+#include "graph/graph.h"
+#include "graph/node.h"
+#include "graph/subgraph.h"
+#include "graph/tensor.h"
+#include "module/module.h"
+#include "operator/op.h"
+#include "optimizer/split.h"
+#include "utility/log.h"
+#include "utility/sys_port.h"
+#include "utility/vector.h"
+// operator parameter structs (source/operator/prototype/)
+#include "concat_param.h"
+#include "convolution_param.h"
+#include "eltwise_param.h"
+#include "fc_param.h"
+#include "pooling_param.h"
+#include "relu_param.h"
+}
+
+#include "tengine_amd.h"
+
+#define HIP_DEV_NAME "HIP"
+
+namespace {
+
+struct HipSubgraph {
+    tamd_graph* g = nullptr;
+    std::vector<uint16_t> in_ir, out_ir;   // ir tensor indices of the subgraph inputs / outputs, in tamd order
+};
+
+// OP_* (source/operator/op.h:38-145) -> TAMD_OP_*
+int map_op(int op)
+{
+    switch (op) {
+    case OP_INPUT: return TAMD_OP_INPUT;
+    case OP_CONST: return TAMD_OP_CONST;
+    case OP_CONV: return TAMD_OP_CONV;
+    case OP_FC: return TAMD_OP_FC;
+    case OP_POOL: return TAMD_OP_POOL;
+    case OP_RELU: return TAMD_OP_RELU;
+    case OP_ELTWISE: return TAMD_OP_ELTWISE;
+    case OP_CONCAT: return TAMD_OP_CONCAT;
+    case OP_DROPOUT: return TAMD_OP_DROPOUT;
+    default: return -1;
+    }
+}
+
+const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT};
+
+bool op_supported(int op)
+{
+    for (int o : kSupportedOps)
+        if (o == op) return true;
+    return false;
+}
+
+int hip_dev_init(struct device* dev)
+{
+    (void)dev;
+    // registration must succeed on hosts without a GPU too (the CPU device keeps working); the
+    // device is probed when a subgraph is actually assigned to it (pre_run fails loudly then).
+    return 0;
+}
+
+int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
+{
+    (void)dev;
+    struct graph* ir = subgraph->graph;
+    HipSubgraph* hs = new HipSubgraph();
+    hs->g = tamd_graph_create();
+    std::map<int, int> tmap;   // ir tensor index -> tamd tensor index
+
+    auto is_sub_input = [&](uint16_t t) {
+        for (int i = 0; i < subgraph->input_num; i++)
+            if (subgraph->input_tensor_list[i] == t) return true;
+        return false;
+    };
+    auto add_tensor = [&](uint16_t idx) -> int {
+        auto it = tmap.find(idx);
+        if (it != tmap.end()) return it->second;
+        struct tensor* t = get_ir_graph_tensor(ir, idx);
+        tamd_tensor_desc d;
+        memset(&d, 0, sizeof(d));
+        d.dtype = t->data_type;
+        d.ttype = t->tensor_type;
+        if (t->tensor_type == TENSOR_TYPE_VAR && is_sub_input(idx)) d.ttype = TAMD_TT_INPUT;   // produced by another subgraph
+        d.dim_num = t->dim_num;
+        for (int i = 0; i < t->dim_num && i < 8; i++) d.dims[i] = t->dims[i];
+        d.data = (t->tensor_type == TENSOR_TYPE_CONST) ? t->data : nullptr;
+        d.quant_num = t->quant_param_num;
+        float one_scale = t->scale;
+        int one_zp = t->zero_point;
+        if (t->quant_param_num == 1) { d.scales = &one_scale; d.zero_points = &one_zp; }
+        else if (t->quant_param_num > 1) { d.scales = t->scale_list; d.zero_points = t->zp_list; }
+        d.name = t->name;
+        int id = tamd_graph_add_tensor(hs->g, &d);
+        tmap[idx] = id;
+        return id;
+    };
+
+    for (int i = 0; i < subgraph->node_num; i++) {
+        struct node* n = get_ir_graph_node(ir, subgraph->node_list[i]);
+        int op = map_op(n->op.type);
+        if (op < 0) {
+            TLOG_ERR("Tengine HIP: op %d (%s) is not supported on the device\n", n->op.type, n->name ? n->name : "?");
+            tamd_graph_destroy(hs->g);
+            delete hs;
+            return -1;
+        }
+        std::vector<int> ins, outs;
+        for (int k = 0; k < n->input_num; k++) ins.push_back(add_tensor(n->input_tensors[k]));
+        for (int k = 0; k < n->output_num; k++) outs.push_back(add_tensor(n->output_tensors[k]));
+        tamd_conv_param cp;
+        tamd_pool_param pp;
+        tamd_fc_param fp;
+        tamd_relu_param rp;
+        tamd_eltwise_param ep;
+        tamd_concat_param ccp;
+        const void* param = nullptr;
+        switch (op) {
+        case TAMD_OP_CONV: {
+            const struct conv_param* p = (const struct conv_param*)n->op.param_mem;
+            cp = {p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0, p->pad_h1, p->pad_w0, p->pad_w1,
+                  p->dilation_h, p->dilation_w, p->input_channel, p->output_channel, p->group, p->activation};
+            param = &cp;
+            break;
+        }
+        case TAMD_OP_POOL: {
+            const struct pool_param* p = (const struct pool_param*)n->op.param_mem;
+            // hand over the ORIGINAL (model) pads: the backend re-resolves them like infer_shape does
+            pp = {p->pool_method, p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0_org, p->pad_h1_org,
+                  p->pad_w0_org, p->pad_w1_org, p->global, p->caffe_flavor};
+            if (p->global) {   // infer_shape already rewrote kernel/stride for global pooling (pooling.c:52-66)
+                pp.pad_h0 = pp.pad_h1 = pp.pad_w0 = pp.pad_w1 = 0;
+            }
+            param = &pp;
+            break;
+        }
+        case TAMD_OP_FC: fp.num_output = ((const struct fc_param*)n->op.param_mem)->num_output; param = &fp; break;
+        case TAMD_OP_RELU: rp.negative_slope = ((const struct relu_param*)n->op.param_mem)->negative_slope; param = &rp; break;
+        case TAMD_OP_ELTWISE: {
+            const struct eltwise_param* p = (const struct eltwise_param*)n->op.param_mem;
+            ep = {p->type, p->caffe_flavor, p->shift, p->power, p->scale};
+            param = &ep;
+            break;
+        }
+        case TAMD_OP_CONCAT: ccp.axis = ((const struct concat_param*)n->op.param_mem)->axis; param = &ccp; break;
+        default: break;
+        }
+        tamd_node_desc nd;
+        memset(&nd, 0, sizeof(nd));
+        nd.op = op; nd.input_num = (int)ins.size(); nd.inputs = ins.data(); nd.output_num = (int)outs.size();
+        nd.outputs = outs.data(); nd.param = param; nd.name = n->name;
+        if (tamd_graph_add_node(hs->g, &nd) < 0) {
+            TLOG_ERR("Tengine HIP: %s\n", tamd_last_error());
+            tamd_graph_destroy(hs->g);
+            delete hs;
+            return -1;
+        }
+    }
+    std::vector<int> gi, go;
+    for (int i = 0; i < subgraph->input_num; i++) {
+        uint16_t t = subgraph->input_tensor_list[i];
+        struct tensor* it = get_ir_graph_tensor(ir, t);
+        if (it->tensor_type == TENSOR_TYPE_CONST) continue;
+        if (!tmap.count(t)) continue;
+        gi.push_back(tmap[t]);
+        hs->in_ir.push_back(t);
+    }
+    for (int i = 0; i < subgraph->output_num; i++) {
+        uint16_t t = subgraph->output_tensor_list[i];
+        if (!tmap.count(t)) continue;
+        go.push_back(tmap[t]);
+        hs->out_ir.push_back(t);
+    }
+    tamd_graph_set_inputs(hs->g, (int)gi.size(), gi.data());
+    tamd_graph_set_outputs(hs->g, (int)go.size(), go.data());
+
+    tamd_options opt;
+    opt.dev_name = HIP_DEV_NAME; opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    if (options) {   // options may be NULL (scheduler.c:49-59); else the blob of set_context_device
+        const tamd_options* o = (const tamd_options*)options;
+        if (o->dev_name && 0 == strcmp(o->dev_name, HIP_DEV_NAME)) opt = *o;
+    }
+    const char* env = getenv("TG_HIP_DEVICE");
+    if (env) opt.gpu_index = atoi(env);
+    if (tamd_graph_prerun(hs->g, &opt) != 0) {
+        TLOG_ERR("Tengine HIP: prerun failed: %s\n", tamd_last_error());
+        tamd_graph_destroy(hs->g);
+        delete hs;
+        return -1;
+    }
+    // subgraph outputs must leave valid host bytes in ir_tensor->data (SURVEY §8b "Ownership")
+    for (uint16_t t : hs->out_ir) {
+        struct tensor* ot = get_ir_graph_tensor(ir, t);
+        if (ot->data == nullptr) {
+            ot->data = sys_malloc((size_t)ot->elem_num * ot->elem_size);
+            ot->free_host_mem = 1;
+        }
+    }
+    subgraph->device_graph = hs;
+    return 0;
+}
+
+int hip_dev_run(struct device* dev, struct subgraph* subgraph)
+{
+    (void)dev;
+    HipSubgraph* hs = (HipSubgraph*)subgraph->device_graph;
+    if (!hs) return -1;
+    struct graph* ir = subgraph->graph;
+    for (size_t i = 0; i < hs->in_ir.size(); i++) {      // pointers are re-read at every run (tm_benchmark.cc:95-102)
+        struct tensor* t = get_ir_graph_tensor(ir, hs->in_ir[i]);
+        if (!t->data) { TLOG_ERR("Tengine HIP: input tensor %s has no buffer\n", t->name); return -1; }
+        if (tamd_graph_set_input(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) {
+            TLOG_ERR("Tengine HIP: %s\n", tamd_last_error());
+            return -1;
+        }
+    }
+    for (size_t i = 0; i < hs->out_ir.size(); i++) {
+        struct tensor* t = get_ir_graph_tensor(ir, hs->out_ir[i]);
+        if (tamd_graph_set_output(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) {
+            TLOG_ERR("Tengine HIP: %s\n", tamd_last_error());
+            return -1;
+        }
+    }
+    if (tamd_graph_run(hs->g) != 0) {
+        TLOG_ERR("Tengine HIP: run failed: %s\n", tamd_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+int hip_release_graph(struct device* dev, void* device_graph)
+{
+    (void)dev;
+    HipSubgraph* hs = (HipSubgraph*)device_graph;
+    if (hs) {
+        tamd_graph_destroy(hs->g);
+        delete hs;
+    }
+    return 0;
+}
+
+int hip_dev_postrun(struct device* dev, struct subgraph* subgraph)
+{
+    hip_release_graph(dev, subgraph->device_graph);
+    subgraph->device_graph = nullptr;
+    return 0;
+}
+
+int hip_dev_release(struct device* dev)
+{
+    (void)dev;
+    return tamd_shutdown();
+}
+
+int hip_describe(struct device* device, struct vector* allowed_ops, struct vector* blocked_ops, struct vector* precision)
+{
+    (void)device;
+    for (int op : kSupportedOps) push_vector_data(allowed_ops, &op);
+    for (int i = 0; i < OP_BUILTIN_LAST; i++)
+        if (!op_supported(i)) push_vector_data(blocked_ops, &i);
+    int p = TENGINE_DT_INT8;
+    push_vector_data(precision, &p);
+    return 0;
+}
+
+int hip_evaluation(struct device* device, struct subgraph* sub_graph, struct vector* tensors, struct vector* nodes)
+{
+    (void)device; (void)sub_graph; (void)tensors; (void)nodes;
+    return 0;
+}
+
+int hip_allocate(struct device* device, struct subgraph* sub_graph)
+{
+    if (nullptr == device) return -1;
+    sub_graph->input_wait_count = 0;
+    for (int i = 0; i < sub_graph->input_num; i++) {
+        struct tensor* tensor = get_ir_graph_tensor(sub_graph->graph, sub_graph->input_tensor_list[i]);
+        if (tensor->tensor_type == TENSOR_TYPE_VAR) sub_graph->input_wait_count++;
+    }
+    return 0;
+}
+
+int hip_release(struct device* device, struct subgraph* sub_graph)
+{
+    (void)sub_graph;
+    return device ? 0 : -1;
+}
+
+// everything this round's kernels cannot express goes back to the CPU device instead of failing at pre_run
+bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
+{
+    for (int j = 0; j < sg->node_num; j++) {
+        struct node* n = get_ir_graph_node(ir, sg->node_list[j]);
+        if (!op_supported(n->op.type)) return false;
+        for (int k = 0; k < n->output_num; k++) {
+            struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
+            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8) return false;
+            if (t->tensor_type != TENSOR_TYPE_CONST && t->quant_param_num != 1) return false;
+        }
+        if (n->op.type == OP_ELTWISE) {
+            int ty = ((const struct eltwise_param*)n->op.param_mem)->type;
+            if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
+        }
+        if (n->op.type == OP_CONCAT && ((const struct concat_param*)n->op.param_mem)->axis != 1) return false;
+    }
+    return true;
+}
+
+int hip_split_graph(struct graph* ir_graph)
+{
+    struct device* cur_dev = ir_graph->attribute->context->device;
+    if (0 != strcmp(HIP_DEV_NAME, cur_dev->name)) return -1;
+
+    struct vector* allowed_ops = create_vector(sizeof(int), nullptr);
+    struct vector* blocked_ops = create_vector(sizeof(int), nullptr);
+    struct vector* precision = create_vector(sizeof(int), nullptr);
+    cur_dev->allocator->describe(cur_dev, allowed_ops, blocked_ops, precision);
+    split_graph_node_to_sub_graph(ir_graph, allowed_ops, blocked_ops, precision);
+    release_vector(allowed_ops);
+    release_vector(blocked_ops);
+    release_vector(precision);
+
+    // split.c's precision test lets every quantised tensor through (split.c:53-66): hand subgraphs the
+    // device cannot run (uint8 / fp32 / exotic params) back to the CPU device before IO generation
+    for (int i = 0; i < get_vector_num(ir_graph->subgraph_list); i++) {
+        struct subgraph* sg = *(struct subgraph**)get_vector_data(ir_graph->subgraph_list, i);
+        if (sg->device == cur_dev && !subgraph_runs_on_device(ir_graph, sg)) sg->device = find_default_device();
+    }
+
+    generate_sub_graph_io(ir_graph);
+    add_sub_graph_to_ir_graph(ir_graph);
+
+    for (int i = 0; i < (uint16_t)get_vector_num(ir_graph->subgraph_list); i++) {
+        struct subgraph* sub_graph = *(struct subgraph**)get_vector_data(ir_graph->subgraph_list, i);
+        sub_graph->index = i;
+        for (uint16_t j = 0; j < sub_graph->node_num; j++) {
+            struct node* ir_node = get_ir_graph_node(ir_graph, sub_graph->node_list[j]);
+            ir_node->subgraph_idx = sub_graph->index;
+        }
+    }
+    return 0;
+}
+
+struct interface hip_interface = {
+    hip_dev_init, hip_dev_prerun, hip_dev_run, hip_dev_postrun, nullptr, nullptr, hip_release_graph, hip_dev_release,
+};
+struct allocator hip_allocator = {hip_describe, hip_evaluation, hip_allocate, hip_release};
+struct optimizer hip_optimizer = {hip_split_graph, nullptr};
+struct device hip_device = {HIP_DEV_NAME, &hip_interface, &hip_allocator, &hip_optimizer, nullptr, nullptr};
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int register_hip_device(void)
+{
+    int ret = register_device(&hip_device);
+    if (0 != ret) {
+        TLOG_INFO("Tengine plugin %s register failed.\n", hip_device.name);
+        return -1;
+    }
+    TLOG_INFO("Tengine plugin device %s is registered.\n", hip_device.name);
+    return 0;
+}
+
+__attribute__((visibility("default"))) int unregister_hip_device(void)
+{
+    int ret = unregister_device(&hip_device);
+    if (0 != ret) {
+        TLOG_INFO("Tengine plugin %s unregister failed.\n", hip_device.name);
+        return ret;
+    }
+    TLOG_INFO("Tengine plugin device %s is unregistered.\n", hip_device.name);
+    return 0;
+}
+}

@@ -1,0 +1,95 @@
+"""The drop-in boundary: the unmodified reference library loads our device plugin with
+load_tengine_plugin(), `set_context_device(ctx, "HIP", ...)` selects it and create_graph / prerun /
+run_graph work unchanged.  CPU part: registration + loud failure without a GPU.  GPU part: the same
+tmfile on device "HIP" and on the reference CPU device, byte for byte."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import conv_graph, eltwise_relu_graph
+from tengine_amd import capi, models, tm2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGIN = os.path.join(ROOT, "tengine_amd", "lib", "libtengine_hip_device.so")
+
+_loaded = False
+
+
+def _load_plugin(ref):
+    global _loaded
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plugin not built (needs the reference headers once)")
+    L = ref.lib()
+    if not _loaded:
+        rc = L.load_tengine_plugin(b"hip", PLUGIN.encode(), b"register_hip_device")
+        assert rc == 0, "load_tengine_plugin failed"
+        _loaded = True
+    return L
+
+
+class HipOpt(C.Structure):   # == tamd_options; first field dev_name by the reference's convention
+    _fields_ = [("dev_name", C.c_char_p), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
+
+
+def test_plugin_registers_and_is_selectable(ref):
+    L = _load_plugin(ref)
+    ctx = L.create_context(b"t", 1)
+    opt = HipOpt(b"HIP", 0, 1, 0)
+    assert L.set_context_device(ctx, b"HIP", C.byref(opt), C.sizeof(opt)) == 0
+    assert L.set_context_device(ctx, b"NOPE", None, 0) != 0
+
+
+def test_plugin_without_gpu_fails_loudly_not_silently(ref):
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    _load_plugin(ref)
+    g, x = conv_graph(3, 1, 16, 8, 8, 16, 1)
+    rg = ref.RefGraph(tm2.write_tm2(g), ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg.set_input(x)
+    with pytest.raises(RuntimeError):
+        rg.prerun()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["conv3x3", "resblock_tail", "mobilenet_v1"])
+def test_hip_device_equals_reference_cpu_device(ref, case):
+    _load_plugin(ref)
+    if case == "conv3x3":
+        g, x = conv_graph(31, 2, 64, 20, 20, 96, 3, 1, 1)
+    elif case == "resblock_tail":
+        g, x = eltwise_relu_graph(9, 2, 64, 14, 14, True)
+    else:
+        g = models.build("mobilenet_v1", "int8", 1)
+        x = models.synth_input(g, 7)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 4)
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()
+    rg.run()                       # second run re-reads the input pointer, replays the hipGraph
+    again = rg.outputs()
+    rg.close()
+    for w, o, a in zip(want, got, again):
+        assert np.array_equal(w, o) and np.array_equal(w, a)
+
+
+@pytest.mark.gpu
+def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
+    """int8 graph with a Softmax tail: the splitter gives conv->HIP, softmax->CPU (SURVEY §7 'subgraph ping-pong')."""
+    _load_plugin(ref)
+    g, x = conv_graph(5, 1, 32, 6, 6, 10, 1, act=-1)
+    y = g.nodes[-1].outputs[0]
+    o = g.add_tensor("prob", list(g.tensors[y].dims), tm2.DT_INT8, tm2.TT_VAR, None, [1.0 / 127.0], [0])
+    ni = g.add_node("softmax", "Softmax", [y], [o], axis=1)
+    g.output_nodes = [ni]
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 1)[0]
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()[0]
+    rg.close()
+    assert np.array_equal(want, got)
