@@ -73,13 +73,9 @@ def main():
         g = models.build(args.model, "int8", args.batch)
         tm_bytes = tm2.write_tm2(g)
     if world > 1:
-        n = torch.tensor([len(tm_bytes) if rank == 0 else 0], dtype=torch.int64, device="cuda")
-        dist.broadcast(n, 0)
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(tm_bytes), dtype=torch.uint8))
-        dist.broadcast(buf, 0)            # RCCL over xGMI, once, outside the timed loop
-        tm_bytes = bytes(buf.cpu().numpy().tobytes())
+        from tengine_amd import dist as tdist
+        # RCCL over xGMI, once, outside the timed loop (tengine_amd/dist.py; gloo-tested on CPU)
+        tm_bytes = tdist.broadcast_tmfile(tm_bytes if rank == 0 else None, dist, "cuda")
     g = tm2.read_tm2(tm_bytes)
 
     gr = capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank)

@@ -84,20 +84,32 @@ __global__ __launch_bounds__(256) void conv_first_i8_kernel(FirstArgs a)
     }
 
     // epilogue (C/D layout: col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> cout)
+    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < CT; i++)
+    for (int i = 0; i < CT; i++) {
+        unsigned p[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
             const int c0 = i * 32 + 8 * g4 + 4 * hi;
             const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
             const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
-            int q0 = requant(acc[i][4 * g4 + 0] + b4.x, a.in_scale, s4.x, a.out_scale, a.act, a.mode);
-            int q1 = requant(acc[i][4 * g4 + 1] + b4.y, a.in_scale, s4.y, a.out_scale, a.act, a.mode);
-            int q2 = requant(acc[i][4 * g4 + 2] + b4.z, a.in_scale, s4.z, a.out_scale, a.act, a.mode);
-            int q3 = requant(acc[i][4 * g4 + 3] + b4.w, a.in_scale, s4.w, a.out_scale, a.act, a.mode);
-            if (mvalid && c0 < a.c_limit)
-                *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = pack4(q0, q1, q2, q3);
+            p[g4] = requant4(acc[i][4 * g4 + 0] + b4.x, acc[i][4 * g4 + 1] + b4.y, acc[i][4 * g4 + 2] + b4.z,
+                             acc[i][4 * g4 + 3] + b4.w, s4, rq);
         }
+        if (wide) {
+            half_wave_regroup(p);
+            const int c16 = i * 32 + hi * 16;
+            if (mvalid && c16 < a.c_limit)
+                *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + c16) = make_uint4(p[0], p[1], p[2], p[3]);
+        } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int c0 = i * 32 + 8 * g4 + 4 * hi;
+                if (mvalid && c0 < a.c_limit) *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = p[g4];
+            }
+        }
+    }
 }
 
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s)

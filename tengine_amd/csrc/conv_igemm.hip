@@ -17,6 +17,8 @@
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. run on one XCD (private L2) and are
 //     given consecutive cout-tiles of the same pixel-tile, so the activation tile is fetched from
 //     HBM once per XCD and re-read from that XCD's L2.
+#include <stdlib.h>
+
 #include "epilogue.h"
 #include "kernels.h"
 
@@ -173,23 +175,38 @@ __global__ __launch_bounds__(256) void conv_igemm_i8_kernel(ConvArgs a)
 
     // ---- fused epilogue: +bias, requantise (bit-exact, epilogue.h), pack 4 channels, NHWC store ----
     // C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
+    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    // 16-B stores (half-wave regroup) whenever the destination is 16-channel granular; dword stores else
+    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
         const int cb = n0 + (wn * TN + i) * 32;
+        unsigned pp[TM][4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
-            const int c0 = cb + 8 * g4 + 4 * hi;
-            const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
-            const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
+            const int4 b4 = *reinterpret_cast<const int4*>(a.bias + cb + 8 * g4 + 4 * hi);
+            const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + cb + 8 * g4 + 4 * hi);
 #pragma unroll
-            for (int j = 0; j < TM; j++) {
-                const int m = m0 + (wm * TM + j) * 32 + l31;
-                int q0 = requant(acc[i][j][4 * g4 + 0] + b4.x, a.in_scale, s4.x, a.out_scale, a.act, a.mode);
-                int q1 = requant(acc[i][j][4 * g4 + 1] + b4.y, a.in_scale, s4.y, a.out_scale, a.act, a.mode);
-                int q2 = requant(acc[i][j][4 * g4 + 2] + b4.z, a.in_scale, s4.z, a.out_scale, a.act, a.mode);
-                int q3 = requant(acc[i][j][4 * g4 + 3] + b4.w, a.in_scale, s4.w, a.out_scale, a.act, a.mode);
-                if (m < a.M && c0 < a.c_limit)
-                    *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = pack4(q0, q1, q2, q3);
+            for (int j = 0; j < TM; j++)
+                pp[j][g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y,
+                                     acc[i][j][4 * g4 + 2] + b4.z, acc[i][j][4 * g4 + 3] + b4.w, s4, rq);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; j++) {
+            const int m = m0 + (wm * TM + j) * 32 + l31;
+            unsigned p[4] = {pp[j][0], pp[j][1], pp[j][2], pp[j][3]};
+            if (wide) {
+                half_wave_regroup(p);
+                const int c16 = cb + hi * 16;
+                if (m < a.M && c16 < a.c_limit)
+                    *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + c16) = make_uint4(p[0], p[1], p[2], p[3]);
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int c0 = cb + 8 * g4 + 4 * hi;
+                    if (m < a.M && c0 < a.c_limit)
+                        *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = p[g4];
+                }
             }
         }
     }
@@ -213,17 +230,22 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool is1x1)
 // so every tile shape below may be chosen freely.
 static int pick_cfg(const ConvArgs& a)
 {
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
+    if (forced >= 0 && forced <= 4) return forced;
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.cout + bn - 1) / bn); };
-    // biggest tile that still fills the 256 CUs; small problems fall to the small tiles
-    if (blocks(128, 128) >= 512 && a.cout >= 96) return 0;
-    if (blocks(64, 64) >= 256 || a.M > 64) return a.cout <= 32 ? 1 : 2;
+    // biggest tile that still gives every CU a block; small problems fall to the small tiles
+    if (a.cout <= 32) return a.M > 64 ? 1 : 3;
+    if (blocks(128, 128) >= 256 && a.cout >= 96) return 0;
+    if (blocks(128, 64) >= 256) return 4;
+    if (a.M > 64) return 2;
     return 3;
 }
 
 const char* conv_igemm_kernel_name(const ConvArgs& a)
 {
     static const char* names[] = {"conv_igemm_i8<128x128x64>", "conv_igemm_i8<128x32x64>", "conv_igemm_i8<64x64x64>",
-                                  "conv_igemm_i8<32x128x64>"};
+                                  "conv_igemm_i8<32x128x64>", "conv_igemm_i8<128x64x64>"};
     return names[pick_cfg(a)];
 }
 
@@ -234,6 +256,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s)
     case 0: return launch_cfg<128, 128, 64, 2, 2>(a, s, is1x1);
     case 1: return launch_cfg<128, 32, 64, 4, 1>(a, s, is1x1);
     case 2: return launch_cfg<64, 64, 64, 2, 2>(a, s, is1x1);
+    case 4: return launch_cfg<128, 64, 64, 2, 2>(a, s, is1x1);
     default: return launch_cfg<32, 128, 64, 1, 4>(a, s, is1x1);
     }
 }

@@ -5,137 +5,139 @@
 // the depthwise case of ref_conv_int8 (conv/conv_kernel_ref_int8.c:42-177) -- the planner picks the
 // epilogue formula the reference's score() would.
 //
-// HBM-bound work (AI ~ 4.5 op/B): no GEMM reshaping.  Lanes run along the channel dimension (NHWC ->
-// consecutive lanes read consecutive bytes, every wave-level load is one contiguous segment), each
-// lane owns CH channels and a strip of TW output pixels so every input byte fetched is reused for up to
-// 3 horizontal taps from registers; the 3 input rows are the only re-read (L1/L2 hits).  No padded
-// copy is made: out-of-image taps are predicated to 0 (== the reference's explicit zero pad).
+// HBM-bound work (AI ~ 4.5 op/B): no GEMM reshaping, the job is to keep the VALU cost per output byte
+// below the memory time.  Lanes run along the channel dimension (NHWC: consecutive lanes read consecutive
+// dwords of one pixel -> coalesced), one lane = 4 channels x a strip of output pixels.  Per input row the
+// lane loads 4 (or 8) horizontally adjacent pixel dwords {c0..c3} and transposes each 4x4 byte block with
+// 8 v_perm_b32 into per-channel fragments {x0..x3}; a 3-tap row of the filter then is ONE v_dot4_i32_i8
+// against the packed taps {w0,w1,w2,0} (or {0,w0,w1,w2}, or a v_alignbyte window across two fragments):
+// ~2 VALU per output-row instead of 3 sign-extends + 3 multiply-adds.  No padded copy is made:
+// out-of-image pixels are loaded as 0 (== the reference's explicit zero pad).
 #include "epilogue.h"
 #include "kernels.h"
 
 namespace tamd {
 
-template <int NV> struct VecT;
-template <> struct VecT<1> { typedef unsigned type; };
-template <> struct VecT<2> { typedef uint2 type; };
-template <> struct VecT<4> { typedef uint4 type; };
-
-template <int NV> __device__ __forceinline__ void vload(unsigned (&d)[NV], const int8_t* p, bool ok)
+// 4x4 byte transpose: d[p] = pixel p's channels {c0,c1,c2,c3}  ->  x[c] = channel c at pixels {p0,p1,p2,p3}
+// v_perm_b32 D = bytes of {S0(hi):S1(lo)} picked by the selector (0-3 -> S1, 4-7 -> S0)
+__device__ __forceinline__ void transpose4x4(const unsigned (&d)[4], unsigned (&x)[4])
 {
-    typedef typename VecT<NV>::type V;
-    V v;
-    if (ok) v = *reinterpret_cast<const V*>(p);
-    const unsigned* s = reinterpret_cast<const unsigned*>(&v);
-#pragma unroll
-    for (int i = 0; i < NV; i++) d[i] = ok ? s[i] : 0u;
+    const unsigned t0 = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // {d0.c0, d1.c0, d0.c1, d1.c1}
+    const unsigned t1 = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // {d0.c2, d1.c2, d0.c3, d1.c3}
+    const unsigned t2 = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u);   // {d2.c0, d3.c0, d2.c1, d3.c1}
+    const unsigned t3 = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+    x[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);                    // {t0.b0, t0.b1, t2.b0, t2.b1}
+    x[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    x[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    x[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
-__device__ __forceinline__ int sx(unsigned v, int b) { return (int)(signed char)((v >> (8 * b)) & 0xff); }
-
-// NV = dwords per lane (4*NV channels), TW = output pixels per lane along W, S = stride
-template <int NV, int TW, int S>
+// S = stride, NF = 4-pixel fragments per row (1 or 2).  outputs per lane: S1 -> 2 / 6, S2 -> 1 / 3
+template <int S, int NF>
 __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
 {
-    constexpr int CH = 4 * NV;
-    constexpr int COLS = (TW - 1) * S + 3;
-    const int cgs = a.cw / CH;                          // channel groups per pixel
+    constexpr int COLS = 4 * NF;
+    constexpr int TW = (S == 1) ? (COLS - 2) : (NF == 1 ? 1 : 3);
+    const int cgs = a.cw / 4;                             // channel quads per pixel
     const int strips = (a.OW + TW - 1) / TW;
-    const long total = (long)a.N * a.OH * strips * cgs;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cg = (int)(idx % cgs); idx /= cgs;
-    const int st = (int)(idx % strips); idx /= strips;
-    const int oy = (int)(idx % a.OH);
-    const int n = (int)(idx / a.OH);
-    const int c0 = cg * CH;
+    // blockIdx.y/z = output row (n, oy): scalar divisions only; threads of a row = strips x quads
+    const int row = blockIdx.y + blockIdx.z * 32768;
+    if (row >= a.N * a.OH) return;
+    const int n = row / a.OH, oy = row - n * a.OH;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= strips * cgs) return;
+    const int st = idx / cgs, cq = idx - st * cgs;
+    const int c0 = cq * 4;
     const int ox0 = st * TW;
 
-    unsigned wv[9][NV];
+    // packed row taps: wrow[r][c] = {w[r][0], w[r][1], w[r][2], 0} of channel c0+c
+    unsigned wrow[3][4];
 #pragma unroll
-    for (int k = 0; k < 9; k++) vload<NV>(wv[k], a.w + (size_t)k * a.cw + c0, true);
+    for (int r = 0; r < 3; r++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.w + ((size_t)r * a.cw + c0) * 4);
+        wrow[r][0] = v.x; wrow[r][1] = v.y; wrow[r][2] = v.z; wrow[r][3] = v.w;
+    }
 
-    int acc[TW][CH];
+    int acc[TW][4];
 #pragma unroll
-    for (int p = 0; p < TW; p++)
+    for (int j = 0; j < TW; j++)
 #pragma unroll
-        for (int c = 0; c < CH; c++) acc[p][c] = 0;
+        for (int c = 0; c < 4; c++) acc[j][c] = 0;
 
     const int8_t* xn = a.x + (size_t)n * a.H * a.W * a.cs_in + c0;
+    const int ixb = ox0 * S - a.PW;
+    // issue ALL input loads of the 3 x COLS window first (one memory round trip per lane, not three)
+    unsigned raw[3][COLS];
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-        const int iy = oy * S - a.PH + ky;
+    for (int r = 0; r < 3; r++) {
+        const int iy = oy * S - a.PH + r;
         const bool rowok = iy >= 0 && iy < a.H;
-        unsigned xv[COLS][NV];
+        const int8_t* xr = xn + (size_t)(rowok ? iy : 0) * a.W * a.cs_in;
 #pragma unroll
-        for (int col = 0; col < COLS; col++) {
-            const int ix = ox0 * S - a.PW + col;
+        for (int p = 0; p < COLS; p++) {
+            const int ix = ixb + p;
             const bool ok = rowok && ix >= 0 && ix < a.W;
-            vload<NV>(xv[col], xn + ((size_t)(rowok ? iy : 0) * a.W + (ok ? ix : 0)) * a.cs_in, ok);
+            raw[r][p] = ok ? *reinterpret_cast<const unsigned*>(xr + (ok ? ix : 0) * a.cs_in) : 0u;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        unsigned frag[NF][4];
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const unsigned d[4] = {raw[r][4 * f], raw[r][4 * f + 1], raw[r][4 * f + 2], raw[r][4 * f + 3]};
+            transpose4x4(d, frag[f]);
         }
 #pragma unroll
-        for (int p = 0; p < TW; p++)
+        for (int j = 0; j < TW; j++) {
+            constexpr int dummy = 0;
+            const int sc = j * S;                         // first input column of this output's window
+            const int f = sc >> 2, sh = sc & 3;
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-                for (int d = 0; d < NV; d++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        acc[p][4 * d + b] += sx(xv[p * S + kx][d], b) * sx(wv[ky * 3 + kx][d], b);
+            for (int c = 0; c < 4; c++) {
+                unsigned win, wt;
+                if (sh == 0) { win = frag[f][c]; wt = wrow[r][c]; }
+                else if (sh == 1) { win = frag[f][c]; wt = wrow[r][c] << 8; }
+                else { win = __builtin_amdgcn_alignbyte(frag[(f + 1) < NF ? f + 1 : f][c], frag[f][c], sh); wt = wrow[r][c]; }
+                acc[j][c] = __builtin_amdgcn_sdot4((int)win, (int)wt, acc[j][c], false);
+            }
+            (void)dummy;
+        }
     }
 
-    int bias[CH];
-    float ws[CH];
+    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
+    const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
 #pragma unroll
-    for (int d = 0; d < NV; d++) {
-        const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0 + 4 * d);
-        const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0 + 4 * d);
-        bias[4 * d] = b4.x; bias[4 * d + 1] = b4.y; bias[4 * d + 2] = b4.z; bias[4 * d + 3] = b4.w;
-        ws[4 * d] = s4.x; ws[4 * d + 1] = s4.y; ws[4 * d + 2] = s4.z; ws[4 * d + 3] = s4.w;
-    }
-#pragma unroll
-    for (int p = 0; p < TW; p++) {
-        const int ox = ox0 + p;
-        if (ox >= a.OW) break;
-        unsigned out[NV];
-#pragma unroll
-        for (int d = 0; d < NV; d++) {
-            int q[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                q[b] = requant(acc[p][4 * d + b] + bias[4 * d + b], a.in_scale, ws[4 * d + b], a.out_scale, a.act, a.mode);
-            out[d] = pack4(q[0], q[1], q[2], q[3]);
-        }
-        int8_t* yp = a.y + (((size_t)n * a.OH + oy) * a.OW + ox) * a.ldc + a.c_off + c0;
-        typedef typename VecT<NV>::type V;
-        V v;
-        unsigned* vs = reinterpret_cast<unsigned*>(&v);
-#pragma unroll
-        for (int d = 0; d < NV; d++) vs[d] = out[d];
-        *reinterpret_cast<V*>(yp) = v;
+    for (int j = 0; j < TW; j++) {
+        const int ox = ox0 + j;
+        const unsigned p = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, rq);
+        if (ox < a.OW)
+            *reinterpret_cast<unsigned*>(a.y + (((size_t)n * a.OH + oy) * a.OW + ox) * a.ldc + a.c_off + c0) = p;
     }
 }
 
-template <int NV, int TW>
+template <int S, int NF>
 static hipError_t launch_dw(const DwArgs& a, hipStream_t s)
 {
-    const int cgs = a.cw / (4 * NV);
-    const int strips = (a.OW + TW - 1) / TW;
-    const long total = (long)a.N * a.OH * strips * cgs;
-    const int grid = (int)((total + 255) / 256);
-    if (a.S == 1)
-        hipLaunchKernelGGL((dwconv3x3_i8_kernel<NV, TW, 1>), dim3(grid), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((dwconv3x3_i8_kernel<NV, TW, 2>), dim3(grid), dim3(256), 0, s, a);
+    constexpr int TW = (S == 1) ? (4 * NF - 2) : (NF == 1 ? 1 : 3);
+    const int per_row = ((a.OW + TW - 1) / TW) * (a.cw / 4);
+    const int rows = a.N * a.OH;
+    // short rows use smaller blocks so that lanes are not wasted on the tail
+    const int bs = per_row >= 192 ? 256 : (per_row >= 96 ? 128 : 64);
+    dim3 grid((per_row + bs - 1) / bs, rows < 32768 ? rows : 32768, (rows + 32767) / 32768);
+    hipLaunchKernelGGL((dwconv3x3_i8_kernel<S, NF>), grid, dim3(bs), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s)
 {
-    // enough lanes to fill 256 CUs x 8 waves first; then widen per-lane work for register reuse
+    // two-fragment strips (6 / 3 outputs per lane) once there is enough work to fill the chip with them
+    // and the row is long enough not to waste the strip tail; else the short strips
     const long px = (long)a.N * a.OH * a.OW;
-    // cw is a multiple of 16 by construction, so every vector width divides it
-    if (px * (a.cw / 8) / 2 >= 256L * 64) return launch_dw<2, 2>(a, s);
-    return launch_dw<1, 1>(a, s);
+    const bool wide = px * (a.cw / 4) >= 6L * 256 * 256 * 4 && a.OW >= 12;
+    if (a.S == 1) return wide ? launch_dw<1, 2>(a, s) : launch_dw<1, 1>(a, s);
+    return wide ? launch_dw<2, 2>(a, s) : launch_dw<2, 1>(a, s);
 }
 
 }  // namespace tamd

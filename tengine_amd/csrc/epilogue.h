@@ -1,53 +1,137 @@
 // Bit-exact requantising epilogues shared by every int8 kernel (the parity spec).
 // Every float operation below is a single correctly-rounded binary32 op in the reference's written
-// order; the translation unit is compiled with -ffp-contract=off and without fast-math, division is
-// the IEEE sequence (__fdiv_rn), rounding is C round() == half away from zero (roundf).
+// order; the translation unit is compiled with -ffp-contract=off and without fast-math, rounding is
+// C round() == half away from zero.
+//
+// The reference has three conv/fc formulas (A1 x86 "hcl", A2 naive ref, A5 fc).  The planner folds them
+// into ONE branch-free device formula by choosing (m1, m2[c], lo, hi, out_scale):
+//
+//     f = clamp( ((float)(acc+bias) * m1) * m2[c], lo, hi ) ;  q = sat127( round( f / out_scale ) )
+//
+//   A1  conv_kernel_x86.c:1826-1889 == conv_dw_hcl_x86.c:197-261,373-436
+//       f=(float)acc*in_scale*w_scale[c]                       -> m1=in_scale, m2[c]=w_scale[c]
+//       act==0: relu -> [0,+inf) ; act>0 (ANY positive code): [0,6] ; act<0: none
+//   A2  conv_kernel_ref_int8.c:72-78,137-167
+//       f=(float)acc*(in_scale*w_scale[c])                      -> m1=1 (exact), m2[c]=fl(in_scale*w_scale[c])
+//       act==1: [-1,1] ; act==6: [0,6] ; other act>=0: [0,+inf) ; act<0: none
+//   A5  fc_ref.c:224-225,252-257   q=roundf((float)acc * r[c]), r[c]=fl(fl(in_scale*w_scale[c])/out_scale)
+//                                                               -> m1=1, m2[c]=r[c], no clamp, out_scale=1 (x/1 exact)
+// (multiplying by 1.0f and dividing by 1.0f are exact, max/min against +-FLT_MAX are identities.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace tamd {
 
-enum RequantMode {
-    RQ_CONV_HCL = 0,  // A1: conv/x86/conv_kernel_x86.c:1826-1889 == conv_dw_hcl_x86.c:197-261,373-436
-    RQ_CONV_REF = 1,  // A2: conv/conv_kernel_ref_int8.c:72-78,137-167
-    RQ_FC = 2,        // A5: fc/fc_ref.c:224-225,252-257
-};
-
 __device__ __forceinline__ int sat127(int v) { return v > 127 ? 127 : (v < -127 ? -127 : v); }
 
 // round-half-away-from-zero of a binary32 value, then int conversion + clamp [-127,127]
 __device__ __forceinline__ int round_sat(float q) { return sat127((int)roundf(q)); }
 
-// acc already includes the int32 bias (the reference adds bias in int32 before converting)
-__device__ __forceinline__ int requant(int acc, float in_scale, float w_scale, float out_scale, int act, int mode)
+// the reference expression itself: it runs for ~1e-4 of the values only
+__device__ __forceinline__ int exact_round_div_sat(float f, float s) { return round_sat(__fdiv_rn(f, s)); }
+
+// sat127(round(f / s)) -- the reference's `(int)round(f / out_scale)` + clamp -- WITHOUT the ~20-instruction
+// IEEE division on the common path, and still exact:
+//   d = fl(f/s) is what the reference rounds.  With inv = fl(1/s) and t = fl(f*inv):
+//   |t - d| <= |f/s| * 1.5 * 2^-23, i.e. < 2^-15 for |t| < 129.  round(d) can differ from round(t) only
+//   if a rounding boundary k+0.5 lies within that distance of t.  y = |t| + 0.5 (its own rounding error
+//   <= 2^-17) has fract(y) in [2^-14, 1-2^-14] only when t is safely away from every boundary, and then
+//   round_half_away(d) = sign(t) * trunc(y).  For y >= 129, |d| > 128.4 and both sides clamp to +-127.
+//   The remaining ~1e-4 of the values (within 2^-14 of a boundary) take the exact division
+//   (tests/csrc/fast_requant_check.c replays this on the host against the reference expression).
+__device__ __forceinline__ int round_div_sat_fast(float f, float inv, bool& risky)
 {
-    float f;
-    if (mode == RQ_CONV_HCL) {
-        f = __fmul_rn((float)acc, in_scale);
-        f = __fmul_rn(f, w_scale);
-        if (act == 0) f = f < 0.f ? 0.f : f;
-        if (act > 0) { f = f < 0.f ? 0.f : f; f = f > 6.f ? 6.f : f; }
-        return round_sat(__fdiv_rn(f, out_scale));
-    } else if (mode == RQ_CONV_REF) {
-        float d = __fmul_rn(in_scale, w_scale);
-        f = __fmul_rn((float)acc, d);
-        if (act >= 0) {
-            if (f < 0.f && act != 1) f = 0.f;
-            if (f > 1.f && act == 1) f = 1.f;
-            if (f > 6.f && act == 6) f = 6.f;
-            if (f < -1.f && act == 1) f = -1.f;
-        }
-        return round_sat(__fdiv_rn(f, out_scale));
-    } else {
-        float r = __fdiv_rn(__fmul_rn(in_scale, w_scale), out_scale);
-        return round_sat(__fmul_rn((float)acc, r));
-    }
+    const float t = __fmul_rn(f, inv);
+    const float y = __fadd_rn(fabsf(t), 0.5f);
+    const float fr = y - floorf(y);
+    int q = (int)y;
+    q = q > 127 ? 127 : q;
+    q = t < 0.f ? -q : q;
+    risky = (fabsf(fr - 0.5f) > 0.5f - 0x1p-14f) && y < 129.f;
+    return q;
+}
+
+__device__ __forceinline__ int round_div_sat(float f, float s, float inv)
+{
+    bool risky;
+    int q = round_div_sat_fast(f, inv, risky);
+    if (risky) q = exact_round_div_sat(f, s);
+    return q;
+}
+
+struct Rq {            // per-launch requantisation constants (see the header comment)
+    float m1, lo, hi, out_scale, inv_out;
+};
+
+__device__ __forceinline__ Rq make_rq(float m1, float lo, float hi, float out_scale)
+{
+    Rq r;
+    r.m1 = m1; r.lo = lo; r.hi = hi; r.out_scale = out_scale;
+    r.inv_out = __fdiv_rn(1.0f, out_scale);
+    return r;
+}
+
+__device__ __forceinline__ float rq_value(int acc, float m2, const Rq& r)
+{
+    float f = __fmul_rn(__fmul_rn((float)acc, r.m1), m2);
+    return __builtin_amdgcn_fmed3f(f, r.lo, r.hi);          // clamp in one op (lo <= hi always)
+}
+
+// acc already includes the int32 bias (the reference adds bias in int32 before converting)
+__device__ __forceinline__ int requant1(int acc, float m2, const Rq& r)
+{
+    return round_div_sat(rq_value(acc, m2, r), r.out_scale, r.inv_out);
 }
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
 {
     return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24);
+}
+
+// four consecutive channels -> one packed dword; the exact path is taken once for the group
+__device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, const float4& m2, const Rq& r)
+{
+    const float f0 = rq_value(a0, m2.x, r), f1 = rq_value(a1, m2.y, r), f2 = rq_value(a2, m2.z, r), f3 = rq_value(a3, m2.w, r);
+    bool k0, k1, k2, k3;
+    int q0 = round_div_sat_fast(f0, r.inv_out, k0);
+    int q1 = round_div_sat_fast(f1, r.inv_out, k1);
+    int q2 = round_div_sat_fast(f2, r.inv_out, k2);
+    int q3 = round_div_sat_fast(f3, r.inv_out, k3);
+    if (k0 | k1 | k2 | k3) {
+        // rare (~1e-4 of the values): ONE rolled copy of the exact division serves the four slots, so the
+        // slow path costs ~40 instructions of code instead of 4 x 25 per call site
+#pragma unroll 1
+        for (int e = 0; e < 4; e++) {
+            const float fe = e == 0 ? f0 : (e == 1 ? f1 : (e == 2 ? f2 : f3));
+            const bool ke = e == 0 ? k0 : (e == 1 ? k1 : (e == 2 ? k2 : k3));
+            const int qe = round_sat(__fdiv_rn(fe, r.out_scale));
+            if (ke) {
+                q0 = e == 0 ? qe : q0;
+                q1 = e == 1 ? qe : q1;
+                q2 = e == 2 ? qe : q2;
+                q3 = e == 3 ? qe : q3;
+            }
+        }
+    }
+    return pack4(q0, q1, q2, q3);
+}
+
+// 32x32 MFMA C/D layout puts channels 8g + 4hi + {0..3} of one pixel in packed dword p[g] of lane
+// (pixel, hi).  After this exchange lanes 0-31 hold channels [0,16) of the 32-channel tile in p[0..3] and
+// lanes 32-63 hold [16,32): one 16-B store per lane instead of four 4-B stores into four 64-B segments.
+// v_permlane32_swap: lanes 32-63 of vdst <-> lanes 0-31 of src.
+__device__ __forceinline__ void half_wave_regroup(unsigned (&p)[4])
+{
+    auto sw = [](unsigned& vdst, unsigned& src) {
+        auto r = __builtin_amdgcn_permlane32_swap(vdst, src, false, false);
+        vdst = r[0];
+        src = r[1];
+    };
+    sw(p[0], p[1]);      // lower: p0=0-3   p1=4-7   | upper: p0=8-11  p1=12-15
+    sw(p[2], p[3]);      // lower: p2=16-19 p3=20-23 | upper: p2=24-27 p3=28-31
+    sw(p[0], p[2]);      // lower: p2=8-11           | upper: p0=16-19
+    sw(p[1], p[3]);      // lower: p3=12-15          | upper: p1=20-23
 }
 
 }  // namespace tamd

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 
 #include "epilogue.h"
@@ -205,6 +206,8 @@ static int count_consumers(const tamd_graph* g, int tensor)
     return c;
 }
 
+enum { RQ_CONV_HCL = 0, RQ_CONV_REF = 1, RQ_FC = 2 };   // A1 / A2 / A5 of SURVEY Appendix A (epilogue.h)
+
 // which formula the reference's score() selection lands on (conv_hcl_x86.c:351-371,
 // conv_dw_hcl_x86.c:508-543, conv_ref.c:197-200)
 static int conv_mode(const tamd_conv_param& p, int batch, int cin, int cout)
@@ -245,9 +248,26 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
     }
     const int cout = y.c, cin = x.c, group = p.group;
     const int cin_g = cin / group;
-    const float in_scale = x.scales[0], out_scale = y.scales[0];
-    std::vector<float> ws(cout);
+    // fold the reference's three requantisation formulas into (m1, m2[c], lo, hi, out_scale) -- epilogue.h.
+    // Host float arithmetic here is binary32, unfused (-ffp-contract=off), exactly the reference's expressions.
+    const float in_s = x.scales[0], out_s = y.scales[0];
+    std::vector<float> ws(cout);     // becomes m2[c]
     for (int i = 0; i < cout; i++) ws[i] = w.scales.size() == (size_t)cout ? w.scales[i] : w.scales[0];
+    float in_scale = in_s, out_scale = out_s, rq_lo = -FLT_MAX, rq_hi = FLT_MAX;   // in_scale plays m1
+    const int act = p.activation;
+    if (mode == RQ_CONV_HCL) {
+        if (act == 0) rq_lo = 0.f;
+        if (act > 0) { rq_lo = 0.f; rq_hi = 6.f; }
+    } else if (mode == RQ_CONV_REF) {
+        in_scale = 1.0f;
+        for (int i = 0; i < cout; i++) { volatile float d = in_s * ws[i]; ws[i] = d; }
+        if (act == 1) { rq_lo = -1.f; rq_hi = 1.f; }
+        else if (act >= 0) { rq_lo = 0.f; if (act == 6) rq_hi = 6.f; }
+    } else {   // RQ_FC
+        in_scale = 1.0f;
+        for (int i = 0; i < cout; i++) { volatile float d = in_s * ws[i]; volatile float r = d / out_s; ws[i] = r; }
+        out_scale = 1.0f;
+    }
     const int8_t* wd = (const int8_t*)w.data.data();
     const int32_t* bd = b ? (const int32_t*)b->data.data() : nullptr;
     const int KH = p.kernel_h, KW = p.kernel_w;
@@ -274,7 +294,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
         a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.kp = kp;
-        a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+        a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         st.kernel = "conv_first_i8";
         st.fn = [a](hipStream_t s) { return launch_conv_first(a, s); };
     } else if (x.nchw_raw || group != 1) {
@@ -282,9 +302,11 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
             && (p.stride_h == 1 || p.stride_h == 2)) {
             // ---- depthwise 3x3 ----
             const int cw = rup(cin, 16);
-            std::vector<int8_t> wp((size_t)9 * cw, 0);
+            // [3 rows][cw] dwords {w[r][0], w[r][1], w[r][2], 0}: one v_dot4 operand per (row, channel)
+            std::vector<int8_t> wp((size_t)3 * cw * 4, 0);
             for (int c = 0; c < cin; c++)
-                for (int k = 0; k < 9; k++) wp[(size_t)k * cw + c] = wd[(size_t)c * 9 + k];
+                for (int r = 0; r < 3; r++)
+                    for (int kx = 0; kx < 3; kx++) wp[((size_t)r * cw + c) * 4 + kx] = wd[(size_t)c * 9 + r * 3 + kx];
             std::vector<int32_t> bp(cw, 0);
             std::vector<float> sp(cw, 1.f);
             for (int c = 0; c < cin; c++) { bp[c] = bd ? bd[c] : 0; sp[c] = ws[c]; }
@@ -295,7 +317,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
             a.y = (int8_t*)y.dptr;
             a.N = x.n; a.H = x.h; a.W = x.w; a.C = cin; a.cs_in = x.cs; a.cw = cw; a.OH = y.h; a.OW = y.w;
             a.ldc = y.cs; a.c_off = y.c_off; a.S = p.stride_h; a.PH = p.pad_h0; a.PW = p.pad_w0;
-            a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+            a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
             st.kernel = "dwconv3x3_i8";
             st.fn = [a](hipStream_t s) { return launch_dwconv3x3(a, s); };
         } else {
@@ -312,7 +334,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
             a.OH = y.h; a.OW = y.w; a.cout = cout; a.ldc = y.cs; a.c_off = y.c_off;
             a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
             a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = group;
-            a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+            a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
             st.kernel = "conv_direct_i8";
             st.fn = [a](hipStream_t s) { return launch_conv_direct(a, s); };
         }
@@ -340,10 +362,13 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         a.ldc = y.cs; a.c_off = y.c_off; a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
         a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.cin = cin; a.ktot = ktot; a.kpad = kpad;
-        a.M = y.n * y.h * y.w; a.in_scale = in_scale; a.out_scale = out_scale; a.act = p.activation; a.mode = mode;
+        a.M = y.n * y.h * y.w; a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         if (gemm_direct_applicable(a)) {
             st.kernel = "gemm_direct_i8";
             st.fn = [a](hipStream_t s) { return launch_gemm_direct(a, s); };
+        } else if (pw_stream_applicable(a)) {
+            st.kernel = "pw_stream_i8";
+            st.fn = [a](hipStream_t s) { return launch_pw_stream(a, s); };
         } else {
             st.kernel = conv_igemm_kernel_name(a);
             st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };

@@ -26,21 +26,18 @@ struct ConvArgs {
     int ktot;              // KH*KW*ckp
     int kpad;              // weight row stride (multiple of the K tile)
     int M;                 // N*OH*OW
-    float in_scale, out_scale;
-    int act;               // conv_param.activation
-    int mode;              // RequantMode
+    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
 struct DwArgs {
     const int8_t* x;       // NHWC
-    const int8_t* w;       // [9][cw] (tap-major, channel contiguous), cw = roundup(C,16)
+    const int8_t* w;       // [3 rows][cw] dwords {w[r][0],w[r][1],w[r][2],0}, cw = roundup(C,16)
     const int32_t* bias;   // [cw]
     const float* wscale;   // [cw]
     int8_t* y;
     int N, H, W, C, cs_in, cw, OH, OW, ldc, c_off;
     int S, PH, PW;
-    float in_scale, out_scale;
-    int act, mode;
+    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
 struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-input first layers
@@ -52,8 +49,7 @@ struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-i
     int N, C, H, W, cs_in; // cs_in == 0 => x is NCHW (graph input), else NHWC with that stride
     int OH, OW, cout, ldc, c_off;
     int KH, KW, SH, SW, PH, PW, DH, DW, group;
-    float in_scale, out_scale;
-    int act, mode;
+    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
 struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on MFMA
@@ -65,8 +61,7 @@ struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on 
     int N, C, H, W, OH, OW, cout, ldc, c_off, c_limit;
     int KH, KW, SH, SW, PH, PW, DH, DW;
     int kp;                // roundup(C*KH*KW, 32) <= 256
-    float in_scale, out_scale;
-    int act, mode;
+    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
 struct PoolArgs {
@@ -99,6 +94,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvArgs& a);   // tile shape the launcher will pick
 hipError_t launch_gemm_direct(const ConvArgs& a, hipStream_t s);   // 1x1, small-M / latency-bound shapes
 bool gemm_direct_applicable(const ConvArgs& a);
+hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
+bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);

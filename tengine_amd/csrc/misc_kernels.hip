@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void eltwise_i8_kernel(EltArgs a)
     const uint4 va = *reinterpret_cast<const uint4*>(a.a + i);
     const uint4 vb = *reinterpret_cast<const uint4*>(a.b + i);
     const unsigned pa[4] = {va.x, va.y, va.z, va.w}, pb[4] = {vb.x, vb.y, vb.z, vb.w};
+    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
+    const float inv_relu = a.fuse_relu ? __fdiv_rn(1.0f, a.relu_out_scale) : 1.0f;
     unsigned out[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(256) void eltwise_i8_kernel(EltArgs a)
             case 4: f = __fsub_rn(fa, fb); break;
             default: f = fa > fb ? fa : fb; break;
             }
-            int y = round_sat(__fdiv_rn(f, a.out_scale));
+            int y = round_div_sat(f, a.out_scale, inv_out);
             if (a.fuse_relu) {
                 float f2 = __fmul_rn((float)y, a.out_scale);
                 f2 = f2 < 0.f ? 0.f : f2;
-                y = round_sat(__fdiv_rn(f2, a.relu_out_scale));
+                y = round_div_sat(f2, a.relu_out_scale, inv_relu);
             }
             q[b] = y;
         }
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void relu_i8_kernel(ReluArgs a)
     if (i >= a.count) return;
     const uint4 v = *reinterpret_cast<const uint4*>(a.x + i);
     const unsigned pv[4] = {v.x, v.y, v.z, v.w};
+    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
     unsigned out[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void relu_i8_kernel(ReluArgs a)
         for (int b = 0; b < 4; b++) {
             float f = __fmul_rn((float)sxb(pv[d], b), a.in_scale);
             if (f < 0.f) f = (a.slope == 0.f) ? 0.f : __fmul_rn(f, a.slope);
-            q[b] = round_sat(__fdiv_rn(f, a.out_scale));
+            q[b] = round_div_sat(f, a.out_scale, inv_out);
         }
         out[d] = pack4(q[0], q[1], q[2], q[3]);
     }
