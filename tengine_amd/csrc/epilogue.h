@@ -32,31 +32,23 @@ __device__ __forceinline__ int round_sat(float q) { return sat127((int)roundf(q)
 __device__ __forceinline__ int exact_round_div_sat(float f, float s) { return round_sat(__fdiv_rn(f, s)); }
 
 // sat127(round(f / s)) -- the reference's `(int)round(f / out_scale)` + clamp -- WITHOUT the ~20-instruction
-// IEEE division on the common path, and still exact:
-//   d = fl(f/s) is what the reference rounds.  With inv = fl(1/s) and t = fl(f*inv):
-//   |t - d| <= |f/s| * 1.5 * 2^-23, i.e. < 2^-15 for |t| < 129.  round(d) can differ from round(t) only
-//   if a rounding boundary k+0.5 lies within that distance of t.  y = |t| + 0.5 (its own rounding error
-//   <= 2^-17) has fract(y) in [2^-14, 1-2^-14] only when t is safely away from every boundary, and then
-//   round_half_away(d) = sign(t) * trunc(y).  For y >= 129, |d| > 128.4 and both sides clamp to +-127.
-//   The remaining ~1e-4 of the values (within 2^-14 of a boundary) take the exact division
-//   (tests/csrc/fast_requant_check.c replays this on the host against the reference expression).
-__device__ __forceinline__ int round_div_sat_fast(float f, float inv, bool& risky)
-{
-    const float t = __fmul_rn(f, inv);
-    const float y = __fadd_rn(fabsf(t), 0.5f);
-    const float fr = y - floorf(y);
-    int q = (int)y;
-    q = q > 127 ? 127 : q;
-    q = t < 0.f ? -q : q;
-    risky = (fabsf(fr - 0.5f) > 0.5f - 0x1p-14f) && y < 129.f;
-    return q;
-}
+// IEEE division on the common path, and still exact.  d = fl(f/s) is what the reference rounds (half away
+// from zero).  With inv = fl(1/s), c = 0.5 + eps (eps = 2^-14) and ONE fused op
+//     y = fma(f, inv, copysign(c, f))
+// we have, for |f/s| < 128,  | (|y| - c) - |d| | <= |f/s| * 2^-23 + 2^-17 < eps/2, hence
+// |y| in (|d| + 0.5 + eps/2, |d| + 0.5 + 3eps/2): an integer can lie between |d|+0.5 and |y| only if
+// fract(|y|) < 3eps/2.  So whenever fract(|y|) >= 2*eps,  trunc(y) == sign(d) * floor(|d| + 0.5), the reference
+// result; the remaining ~1.2e-4 of the values take the exact division (wave-uniformly skipped when no lane
+// needs it).  tests/csrc/fast_requant_check.c replays this on the host against the reference expression.
+#define TAMD_RQ_EPS 0x1p-14f
 
+// general form (f unbounded): used by pooling / eltwise / relu
 __device__ __forceinline__ int round_div_sat(float f, float s, float inv)
 {
-    bool risky;
-    int q = round_div_sat_fast(f, inv, risky);
-    if (risky) q = exact_round_div_sat(f, s);
+    const float y = __fmaf_rn(f, inv, copysignf(0.5f + TAMD_RQ_EPS, f));
+    int q = sat127((int)y);
+    const float ay = fabsf(y);
+    if (__builtin_amdgcn_fractf(ay) < 2.f * TAMD_RQ_EPS && ay < 129.f) q = exact_round_div_sat(f, s);
     return q;
 }
 
@@ -64,10 +56,15 @@ struct Rq {            // per-launch requantisation constants (see the header co
     float m1, lo, hi, out_scale, inv_out;
 };
 
+// lo/hi additionally fold the +-127 saturation: any f beyond +-127.49*out_scale rounds to +-127 either way,
+// so clamping f there keeps |y| < 128 and the int result needs no further clamp.
 __device__ __forceinline__ Rq make_rq(float m1, float lo, float hi, float out_scale)
 {
     Rq r;
-    r.m1 = m1; r.lo = lo; r.hi = hi; r.out_scale = out_scale;
+    const float lim = __fmul_rn(127.49f, out_scale);
+    r.m1 = m1; r.out_scale = out_scale;
+    r.lo = fmaxf(lo, -lim);
+    r.hi = fminf(hi, lim);
     r.inv_out = __fdiv_rn(1.0f, out_scale);
     return r;
 }
@@ -75,13 +72,25 @@ __device__ __forceinline__ Rq make_rq(float m1, float lo, float hi, float out_sc
 __device__ __forceinline__ float rq_value(int acc, float m2, const Rq& r)
 {
     float f = __fmul_rn(__fmul_rn((float)acc, r.m1), m2);
-    return __builtin_amdgcn_fmed3f(f, r.lo, r.hi);          // clamp in one op (lo <= hi always)
+    return __builtin_amdgcn_fmed3f(f, r.lo, r.hi);          // activation clamp + saturation in one op
+}
+
+// fast path on a pre-clamped f: 4 VALU (bfi, fma, fract, cvt) + the risky compare
+__device__ __forceinline__ int rq_round_fast(float f, const Rq& r, bool& risky)
+{
+    const float y = __fmaf_rn(f, r.inv_out, copysignf(0.5f + TAMD_RQ_EPS, f));
+    risky = __builtin_amdgcn_fractf(fabsf(y)) < 2.f * TAMD_RQ_EPS;
+    return (int)y;
 }
 
 // acc already includes the int32 bias (the reference adds bias in int32 before converting)
 __device__ __forceinline__ int requant1(int acc, float m2, const Rq& r)
 {
-    return round_div_sat(rq_value(acc, m2, r), r.out_scale, r.inv_out);
+    const float f = rq_value(acc, m2, r);
+    bool risky;
+    int q = rq_round_fast(f, r, risky);
+    if (risky) q = exact_round_div_sat(f, r.out_scale);
+    return q;
 }
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
@@ -94,10 +103,10 @@ __device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, con
 {
     const float f0 = rq_value(a0, m2.x, r), f1 = rq_value(a1, m2.y, r), f2 = rq_value(a2, m2.z, r), f3 = rq_value(a3, m2.w, r);
     bool k0, k1, k2, k3;
-    int q0 = round_div_sat_fast(f0, r.inv_out, k0);
-    int q1 = round_div_sat_fast(f1, r.inv_out, k1);
-    int q2 = round_div_sat_fast(f2, r.inv_out, k2);
-    int q3 = round_div_sat_fast(f3, r.inv_out, k3);
+    int q0 = rq_round_fast(f0, r, k0);
+    int q1 = rq_round_fast(f1, r, k1);
+    int q2 = rq_round_fast(f2, r, k2);
+    int q3 = rq_round_fast(f3, r, k3);
     if (k0 | k1 | k2 | k3) {
         // rare (~1e-4 of the values): ONE rolled copy of the exact division serves the four slots, so the
         // slow path costs ~40 instructions of code instead of 4 x 25 per call site
@@ -105,7 +114,7 @@ __device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, con
         for (int e = 0; e < 4; e++) {
             const float fe = e == 0 ? f0 : (e == 1 ? f1 : (e == 2 ? f2 : f3));
             const bool ke = e == 0 ? k0 : (e == 1 ? k1 : (e == 2 ? k2 : k3));
-            const int qe = round_sat(__fdiv_rn(fe, r.out_scale));
+            const int qe = exact_round_div_sat(fe, r.out_scale);
             if (ke) {
                 q0 = e == 0 ? qe : q0;
                 q1 = e == 1 ? qe : q1;

@@ -449,11 +449,34 @@ def calib_table(name, gf=None, write=False):
     return table
 
 
-def build(name, dtype="int8", batch=1, **kw) -> Graph:
+def strip_tail(g: Graph, ops=("Softmax",)) -> Graph:
+    """Cut trailing nodes of the given types (what Tengine's splitter hands to the CPU device,
+    e.g. the Softmax after ResNet's fc1000): the graph output becomes their input."""
+    changed = True
+    while changed:
+        changed = False
+        for k, ni in enumerate(list(g.output_nodes)):
+            n = g.nodes[ni]
+            if n.op in ops:
+                src = n.inputs[0]
+                prod = [i for i, m in enumerate(g.nodes) if src in m.outputs][0]
+                g.output_nodes[k] = prod
+                g.nodes.pop(ni)
+                g.input_nodes = [i - (i > ni) for i in g.input_nodes]
+                g.output_nodes = [i - (i > ni) for i in g.output_nodes]
+                changed = True
+                break
+    return g
+
+
+def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
+    """`device_only`: strip the tail ops the HIP device leaves to the CPU subgraph (Softmax)."""
     gf = BUILDERS[name](batch=1, **kw)
     if dtype == "fp32":
-        return set_batch(gf, batch)
-    if dtype == "int8":
+        g = set_batch(gf, batch)
+    elif dtype == "int8":
         table = calib_table(name, gf) if not kw else None
-        return set_batch(quantize_int8(gf, table=table), batch)
-    raise NotImplementedError(dtype)
+        g = set_batch(quantize_int8(gf, table=table), batch)
+    else:
+        raise NotImplementedError(dtype)
+    return strip_tail(g) if device_only else g

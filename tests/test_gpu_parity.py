@@ -158,3 +158,25 @@ def test_real_reference_side_by_side_if_present():
     want = ref_capi.run_model(b, x, ref_capi.MODE_INT8, 2)[0]
     got = run_hip(g, x)[0]
     assert np.array_equal(want, got.reshape(want.shape))
+
+
+def test_resnet50_int8_batch2_bit_exact():
+    """BASELINE configs[2] topology (ResNet-50 int8: 3x3 implicit GEMM up to K=4608, 7x7 stem, 1x1 stride 2,
+    eltwise+relu fusion, max pool, global avg pool, FC) at a batch the oracle finishes in seconds."""
+    g = models.build("resnet50", "int8", 2, device_only=True)
+    x = models.synth_input(g, 5)
+    want = oracle.run_graph(g, x, keep_all=True)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0]
+    out_t = g.nodes[g.output_nodes[0]].outputs[0]
+    if not np.array_equal(got.reshape(want[out_t].shape), want[out_t]):
+        for n in g.nodes:                      # pinpoint the first differing layer
+            if n.op in ("Const", "InputOp"):
+                continue
+            t = n.outputs[0]
+            if t in want and not (n.op == "Eltwise"):      # eltwise outputs are fused into the following relu
+                dev = gr.read_tensor(t)
+                assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
+        raise AssertionError("output differs")
+    gr.close()

@@ -86,3 +86,14 @@ def test_mobilenet_v1_int8_whole_model(ref):
     assert np.abs(got.astype(int)).max() > 60
     # thread-count independence of the reference int8 path (SURVEY §8c determinism)
     assert np.array_equal(want, ref.run_model(b, x, ref.MODE_INT8, 1)[0])
+
+
+def test_resnet50_int8_whole_model(ref):
+    """53 conv (1x1, 1x1 s2, 3x3, 7x7 s2) + 16 eltwise + 16 relu + max/avg pool + fc (+ softmax left to the
+    reference): oracle == real reference on the device-side part of the graph."""
+    g = models.build("resnet50", "int8", 1, device_only=True)
+    x = models.synth_input(g, 5)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 8)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want.reshape(got.shape), got)
+    assert np.abs(got.astype(int)).max() > 40
