@@ -72,6 +72,7 @@ struct tamd_graph {
     std::vector<tamd::Step> in_steps;   // input layout launches (after H2D)
     std::vector<tamd::Step> out_steps;  // output layout launches (before D2H)
     std::vector<void*> dev_allocs;
+    void* zero_page = nullptr;          // 256 zero bytes (out-of-image taps of the LDS-DMA conv kernel)
     hipStream_t stream = nullptr;
     hipGraph_t hgraph = nullptr;
     hipGraphExec_t hexec = nullptr;

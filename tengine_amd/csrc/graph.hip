@@ -362,6 +362,8 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         a.ldc = y.cs; a.c_off = y.c_off; a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
         a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.cin = cin; a.ktot = ktot; a.kpad = kpad;
+        if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
+        a.zeros = (const int8_t*)g->zero_page;
         a.M = y.n * y.h * y.w; a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         if (gemm_direct_applicable(a)) {
             st.kernel = "gemm_direct_i8";
@@ -369,6 +371,9 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         } else if (pw_stream_applicable(a)) {
             st.kernel = "pw_stream_i8";
             st.fn = [a](hipStream_t s) { return launch_pw_stream(a, s); };
+        } else if (conv_igemm2_applicable(a)) {
+            st.kernel = conv_igemm2_kernel_name(a);
+            st.fn = [a](hipStream_t s) { return launch_conv_igemm2(a, s); };
         } else {
             st.kernel = conv_igemm_kernel_name(a);
             st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };

@@ -27,6 +27,8 @@ struct ConvArgs {
     int kpad;              // weight row stride (multiple of the K tile)
     int M;                 // N*OH*OW
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
+    const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
+    int dbg;               // perf experiments only (TAMD_IGEMM2_DBG), 0 in production
 };
 
 struct DwArgs {
@@ -94,6 +96,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvArgs& a);   // tile shape the launcher will pick
 hipError_t launch_gemm_direct(const ConvArgs& a, hipStream_t s);   // 1x1, small-M / latency-bound shapes
 bool gemm_direct_applicable(const ConvArgs& a);
+hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t s);  // LDS-DMA 3-stage ring, large problems
+bool conv_igemm2_applicable(const ConvArgs& a);
+const char* conv_igemm2_kernel_name(const ConvArgs& a);
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
 bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);

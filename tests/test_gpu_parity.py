@@ -83,6 +83,22 @@ def test_conv_cases(case):
     check(g, x, str(case))
 
 
+BIG_CASES = [   # large enough for the LDS-DMA 3-stage kernel (conv_igemm2.hip)
+    (8, 64, 56, 56, 64, 3, 1, 1, 1, 0, True, 1),      # ResNet res2 3x3, 128x64 tile
+    (4, 128, 56, 56, 256, 1, 1, 0, 1, -1, True, 1),   # wide 1x1, 128x128 tile, no activation
+    (32, 128, 28, 28, 128, 3, 1, 1, 1, 0, True, 1),   # K = 1152
+    (24, 64, 40, 40, 128, 3, 2, 1, 1, 6, False, 1),   # stride 2, relu6, no bias, ragged M tail
+    (9, 80, 33, 31, 96, 3, 1, 2, 1, 0, True, 2),      # dilation 2, cin/cout not multiples of 32/128
+]
+
+
+@pytest.mark.parametrize("case", BIG_CASES, ids=[str(c) for c in BIG_CASES])
+def test_conv_big_cases(case):
+    n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
+    g, x = conv_graph(17 + cin + cout, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
+    check(g, x, str(case))
+
+
 def test_extreme_values_saturate_like_reference():
     """all-127 inputs x all-(-127) weights: accumulators at their extremes, outputs clamp to -127."""
     g, x = conv_graph(1, 1, 64, 8, 8, 64, 3, 1, 1, act=-1)
