@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
     ap.add_argument("--model", default="mobilenet_v1")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent batch-1 graph instances (1 = sequential, tm_benchmark semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -78,37 +79,46 @@ def main():
         tm_bytes = tdist.broadcast_tmfile(tm_bytes if rank == 0 else None, dist, "cuda")
     g = tm2.read_tm2(tm_bytes)
 
-    gr = capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank)
+    # S graph instances on S HIP streams: independent batch-1 requests in flight concurrently (serving mode).
+    # Default S=1 == tm_benchmark's semantics (one blocking run_graph after the other).
+    S = max(1, args.streams)
+    grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank) for _ in range(S)]
+    gr = grs[0]
     x = models.synth_input(g, 1000 + rank)       # each rank owns its own shard of images
-    gr.set_input(x)
-    gr.upload()                                  # inputs resident in HBM before the timed region
-    gr.sync()
+    for q in grs:
+        q.set_input(x)
+        q.upload()                               # inputs resident in HBM before the timed region
+        q.sync()
 
-    ext = torch.cuda.ExternalStream(gr.stream(), device=torch.device("cuda", local_rank))
-    out_ptr, out_bytes = gr.output_device(0)
-    out_view = torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda")
-    slots, gathered, works = None, None, [None, None]
+    exts = [torch.cuda.ExternalStream(q.stream(), device=torch.device("cuda", local_rank)) for q in grs]
+    views = []
+    for q in grs:
+        out_ptr, out_bytes = q.output_device(0)
+        views.append(torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda"))
+    slots, gathered, works = None, None, {}
     if world > 1:
-        slots = [torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        gathered = [torch.empty(out_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        slots = [[torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
+        gathered = [[torch.empty(out_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
 
     def step(k):
-        gr.launch()
+        i = k % S
+        grs[i].launch()
         if world > 1:
-            s = k & 1
-            with torch.cuda.stream(ext):
-                if works[s] is not None:
-                    works[s].wait()              # slot s free again (gather of step k-2 done)
-                slots[s].copy_(out_view, non_blocking=True)
-                works[s] = dist.all_gather_into_tensor(gathered[s], slots[s], async_op=True)
+            s = (k // S) & 1
+            with torch.cuda.stream(exts[i]):
+                if works.get((i, s)) is not None:
+                    works[(i, s)].wait()         # slot free again (gather issued two rounds ago is done)
+                slots[i][s].copy_(views[i], non_blocking=True)
+                works[(i, s)] = dist.all_gather_into_tensor(gathered[i][s], slots[i][s], async_op=True)
 
     def drain():
         if world > 1:
-            with torch.cuda.stream(ext):
-                for w in works:
-                    if w is not None:
+            for (i, s), w in works.items():
+                if w is not None:
+                    with torch.cuda.stream(exts[i]):
                         w.wait()
-        gr.sync()
+        for q in grs:
+            q.sync()
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
@@ -159,7 +169,8 @@ def main():
         cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds)
 
     out = gr.download()[0]
-    gr.close()
+    for q in grs:
+        q.close()
     if rank == 0:
         value = world * args.batch * args.steps / el
         line = {
@@ -167,7 +178,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "%s int8 224x224 batch=%d per GPU (BASELINE configs[1]), weights = seeded synthetic "
-                                   "tmfile, input resident in HBM, hipGraph replay" % (args.model, args.batch),
+                                   "tmfile, input resident in HBM, hipGraph replay, %d stream(s)" % (args.model, args.batch, S),
+                       "streams": S,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if world > 1 else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
