@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--model", default="mobilenet_v1")
     ap.add_argument("--streams", type=int, default=1, help="concurrent batch-1 graph instances (1 = sequential, tm_benchmark semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path with world_size 1 (test)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -59,13 +60,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus and world > 1:  # noqa
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    use_dist = world > 1 or args.force_dist   # --force-dist exercises the RCCL path on a single GPU (testing)
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -73,7 +76,7 @@ def main():
     if rank == 0:
         g = models.build(args.model, "int8", args.batch)
         tm_bytes = tm2.write_tm2(g)
-    if world > 1:
+    if use_dist:
         from tengine_amd import dist as tdist
         # RCCL over xGMI, once, outside the timed loop (tengine_amd/dist.py; gloo-tested on CPU)
         tm_bytes = tdist.broadcast_tmfile(tm_bytes if rank == 0 else None, dist, "cuda")
@@ -96,14 +99,14 @@ def main():
         out_ptr, out_bytes = q.output_device(0)
         views.append(torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda"))
     slots, gathered, works = None, None, {}
-    if world > 1:
+    if use_dist:
         slots = [[torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
         gathered = [[torch.empty(out_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
 
     def step(k):
         i = k % S
         grs[i].launch()
-        if world > 1:
+        if use_dist:
             s = (k // S) & 1
             with torch.cuda.stream(exts[i]):
                 if works.get((i, s)) is not None:
@@ -112,7 +115,7 @@ def main():
                 works[(i, s)] = dist.all_gather_into_tensor(gathered[i][s], slots[i][s], async_op=True)
 
     def drain():
-        if world > 1:
+        if use_dist:
             for (i, s), w in works.items():
                 if w is not None:
                     with torch.cuda.stream(exts[i]):
@@ -124,18 +127,18 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -165,7 +168,7 @@ def main():
 
     # ---- CPU baseline: the real reference backend on this host's cores (rank 0, N=1 only) ----------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and (world == 1 and not args.force_dist) and not args.no_cpu_baseline:
         cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds)
 
     out = gr.download()[0]
@@ -181,14 +184,14 @@ def main():
                                    "tmfile, input resident in HBM, hipGraph replay, %d stream(s)" % (args.model, args.batch, S),
                        "streams": S,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if world > 1 else "none"},
+                       "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
             "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
         }
         if cpu:
             line["speedup_vs_cpu_reference"] = value / cpu["value"] if cpu["value"] else None
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
