@@ -164,12 +164,95 @@ def eltwise_int8(a, b, etype, sa, sb, out_scale):
     return y
 
 
-def run_graph(g, x, keep_all=False):
-    """Execute a tm2.Graph on the oracle. Returns ({tensor idx: ndarray} if keep_all else list of outputs)."""
+# ---- uint8 (per-tensor asymmetric; the reference simulates it in fp32) -----------------------------------
+def conv2d_uint8(x, w, bias, p, in_q, w_q, out_q, variant=None):
+    """*_q = (scale, zero_point).  variant None -> the reference's selection: group 1 -> hcl, else ref
+    (conv_dw_hcl_x86.c:533 rejects uint8, so depthwise always lands on conv_ref)."""
+    x = np.ascontiguousarray(x, np.uint8)
+    w = np.ascontiguousarray(w, np.uint8)
+    n, cin, h, wd = x.shape
+    od = conv_out_dims(x.shape, w.shape, p)
+    if variant is None:
+        variant = CONV_HCL if p.get("group", 1) == 1 else CONV_REF
+    y = np.empty(od, np.uint8)
+    b = None if bias is None else np.ascontiguousarray(bias, np.int32)
+    rc = lib().orc_conv2d_uint8(_p(x), _p(w), _p(b), _p(y), n, cin, h, wd, od[1], od[2], od[3], p["kernel_h"],
+                                p["kernel_w"], p["stride_h"], p["stride_w"], p.get("pad_h0", 0), p.get("pad_w0", 0),
+                                p.get("dilation_h", 1), p.get("dilation_w", 1), p.get("group", 1),
+                                p.get("activation", -1), C.c_float(in_q[0]), int(in_q[1]), C.c_float(w_q[0]),
+                                int(w_q[1]), C.c_float(out_q[0]), int(out_q[1]), variant)
+    assert rc == 0
+    return y
+
+
+def fc_uint8(x, w, bias, in_q, w_q, bias_scale, out_q):
+    x = np.ascontiguousarray(x, np.uint8).reshape(x.shape[0], -1)
+    w = np.ascontiguousarray(w, np.uint8)
+    y = np.empty((x.shape[0], w.shape[0]), np.uint8)
+    b = None if bias is None else np.ascontiguousarray(bias, np.int32)
+    lib().orc_fc_uint8(_p(x), _p(w), _p(b), _p(y), x.shape[0], x.shape[1], w.shape[0], C.c_float(in_q[0]), int(in_q[1]),
+                       C.c_float(w_q[0]), int(w_q[1]), C.c_float(bias_scale), C.c_float(out_q[0]), int(out_q[1]))
+    return y
+
+
+def pool_uint8(x, p, in_q, out_q):
+    x = np.ascontiguousarray(x, np.uint8)
+    n, c, h, w = x.shape
+    oh, ow, kh, kw, sh, sw, ph0, pw0 = pool_resolve(x.shape, p)
+    y = np.empty((n, c, oh, ow), np.uint8)
+    rc = lib().orc_pool_uint8(_p(x), _p(y), n, c, h, w, oh, ow, kh, kw, sh, sw, ph0, pw0, p["alg"],
+                              p.get("caffe_flavor", 0), C.c_float(in_q[0]), int(in_q[1]), C.c_float(out_q[0]),
+                              int(out_q[1]))
+    assert rc == 0
+    return y
+
+
+def relu_uint8(x, slope, in_q, out_q):
+    x = np.ascontiguousarray(x, np.uint8)
+    y = np.empty_like(x)
+    lib().orc_relu_uint8(_p(x), _p(y), C.c_size_t(x.size), C.c_float(slope), C.c_float(in_q[0]), int(in_q[1]),
+                         C.c_float(out_q[0]), int(out_q[1]))
+    return y
+
+
+def requant_copy_uint8(x, in_q, out_q):
+    x = np.ascontiguousarray(x, np.uint8)
+    y = np.empty_like(x)
+    lib().orc_requant_copy_uint8(_p(x), _p(y), C.c_size_t(x.size), C.c_float(in_q[0]), int(in_q[1]),
+                                 C.c_float(out_q[0]), int(out_q[1]))
+    return y
+
+
+def upsample_uint8(x, scale, in_q, out_q):
+    x = np.ascontiguousarray(x, np.uint8)
+    n, c, h, w = x.shape
+    y = np.empty((n, c, h * scale, w * scale), np.uint8)
+    lib().orc_upsample_uint8(_p(x), _p(y), n, c, h, w, scale, C.c_float(in_q[0]), int(in_q[1]), C.c_float(out_q[0]),
+                             int(out_q[1]))
+    return y
+
+
+def eltwise_uint8(a, b, etype, qa, qb, out_q):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    assert a.shape == b.shape
+    y = np.empty_like(a)
+    rc = lib().orc_eltwise_uint8(_p(a), _p(b), _p(y), C.c_size_t(a.size), etype, C.c_float(qa[0]), int(qa[1]),
+                                 C.c_float(qb[0]), int(qb[1]), C.c_float(out_q[0]), int(out_q[1]))
+    assert rc == 0
+    return y
+
+
+def run_graph(g, x, keep_all=False, teacher=None, report=None):
+    """Execute a tm2.Graph on the oracle. Returns ({tensor idx: ndarray} if keep_all else list of outputs).
+    `teacher` = {tensor idx: ndarray} (e.g. the real reference's intermediate tensors): every node output found
+    there is compared (|diff| histogram appended to `report` as (node name, n, n_bad, max)) and then REPLACED by
+    the teacher's value, so each node is checked in isolation on exactly the inputs the teacher saw."""
     from tengine_amd import tm2
     T = g.tensors
     vals = {i: t.data for i, t in enumerate(T) if t.ttype == tm2.TT_CONST}
     sc = lambda i: np.float32(T[i].scales[0])
+    qp = lambda i: (np.float32(T[i].scales[0]), int(T[i].zero_points[0]) if T[i].zero_points else 0)
     for n in g.nodes:
         op, p = n.op, n.params
         if op == "Const":
@@ -187,17 +270,28 @@ def run_graph(g, x, keep_all=False):
                 y = conv2d_int8(a, w, b, p, sc(i0), T[n.inputs[1]].scales, sc(o0))
             elif dt == DT_FP32:
                 y = conv2d_fp32(a, w, b, p)
+            elif dt == DT_UINT8:
+                y = conv2d_uint8(a, w, b, p, qp(i0), qp(n.inputs[1]), qp(o0))
             else:
                 raise NotImplementedError("oracle conv dtype %d" % dt)
         elif op == "FullyConnected":
             w = vals[n.inputs[1]]
             b = vals[n.inputs[2]] if len(n.inputs) > 2 else None
-            y = fc_int8(a, w, b, sc(i0), T[n.inputs[1]].scales, sc(o0)) if dt == DT_INT8 else fc_fp32(a, w, b)
+            if dt == DT_UINT8:
+                bs = sc(n.inputs[2]) if b is not None else np.float32(0)
+                y = fc_uint8(a, w, b, qp(i0), qp(n.inputs[1]), bs, qp(o0))
+            else:
+                y = fc_int8(a, w, b, sc(i0), T[n.inputs[1]].scales, sc(o0)) if dt == DT_INT8 else fc_fp32(a, w, b)
         elif op == "Pooling":
-            y = pool_int8(a, p, sc(i0), sc(o0)) if dt == DT_INT8 else pool_fp32(a, p)
+            if dt == DT_UINT8:
+                y = pool_uint8(a, p, qp(i0), qp(o0))
+            else:
+                y = pool_int8(a, p, sc(i0), sc(o0)) if dt == DT_INT8 else pool_fp32(a, p)
         elif op == "ReLU":
             if dt == DT_INT8:
                 y = relu_int8(a, p.get("negative_slope", 0.0), sc(i0), sc(o0))
+            elif dt == DT_UINT8:
+                y = relu_uint8(a, p.get("negative_slope", 0.0), qp(i0), qp(o0))
             else:
                 s = np.float32(p.get("negative_slope", 0.0))
                 y = np.where(a < 0, a * s, a).astype(np.float32)
@@ -205,16 +299,30 @@ def run_graph(g, x, keep_all=False):
             b2 = vals[n.inputs[1]]
             if dt == DT_INT8:
                 y = eltwise_int8(a, b2, p["type"], sc(i0), sc(n.inputs[1]), sc(o0))
+            elif dt == DT_UINT8:
+                y = eltwise_uint8(a, b2, p["type"], qp(i0), qp(n.inputs[1]), qp(o0))
             else:
                 y = {tm2.ELT_SUM: a + b2, tm2.ELT_PROD: a * b2, tm2.ELT_SUB: a - b2, tm2.ELT_MAX: np.maximum(a, b2)}[p["type"]]
         elif op == "Dropout":
             y = a
+        elif op == "Concat" and dt == DT_UINT8:
+            y = np.concatenate([requant_copy_uint8(vals[i], qp(i), qp(o0)) for i in n.inputs], axis=p.get("axis", 1))
+        elif op == "Concat" and dt == DT_FP32:
+            y = np.concatenate([vals[i] for i in n.inputs], axis=p.get("axis", 1))
+        elif op == "Upsample" and dt == DT_UINT8:
+            y = upsample_uint8(a, int(p.get("scale", 2)), qp(i0), qp(o0))
         elif op == "Softmax" and dt == DT_FP32:
             ax = p.get("axis", 1)
             e = np.exp(a - a.max(axis=ax, keepdims=True))
             y = (e / e.sum(axis=ax, keepdims=True)).astype(np.float32)
         else:
             raise NotImplementedError("oracle op %s dtype %d" % (op, dt))
+        if teacher is not None and o0 in teacher:
+            tv = np.asarray(teacher[o0]).reshape(y.shape)
+            if report is not None:
+                d = np.abs(tv.astype(np.int64) - y.astype(np.int64)) if y.dtype != np.float32 else np.abs(tv - y)
+                report.append((n.name, int(y.size), int(np.count_nonzero(d)), float(d.max())))
+            y = tv
         vals[o0] = y
     if keep_all:
         return vals

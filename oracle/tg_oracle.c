@@ -333,3 +333,284 @@ ORC_API int orc_pool_fp32(const float* x, float* y, int n, int c, int h, int w, 
         }
     return 0;
 }
+
+/* ================================================================================================
+ * uint8 (per-tensor asymmetric) -- the reference SIMULATES uint8 in fp32.
+ * The reference is built -O3 -std=gnu99 -mfma, i.e. with GCC's default -ffp-contract=fast: every
+ * `a*b + c` in its C source is ONE fused multiply-add.  This file is built -ffp-contract=off, so each fusion
+ * the reference gets is written out as fmaf() here and nothing else is fused.
+ * ============================================================================================== */
+static inline uint8_t sat_u8(int v)
+{
+    if (v > 255) v = 255;
+    if (v < 0) v = 0;
+    return (uint8_t)v;
+}
+
+/* The fp32 GEMM the reference simulates uint8 convolution with: conv/x86/conv_kernel_x86.c:322-960 (sgemm_fp,
+ * __AVX__ branch -- oracle/build_ref.py compiles the reference with -mfma, which implies AVX, like the
+ * reference's own x86 build).  Per output element (row m of M = cout, column j of N = out_h*out_w of ONE image)
+ * the summation ORDER depends on where the element sits in the 8x8 register tiling; restated exactly:
+ *   j <  N&~7                     : one fused chain  s = fma(col[k], w[k], s), k = 0..K-1          (:349-520,651-762,
+ *                                                                                                    :838-877)
+ *   j >= N&~7, m in an 8- or 4-row block : four interleaved fused chains s_r over k = r (mod 4), k < K&~3, then
+ *                                   s = ((0 + (s0+s1)) + (s2+s3)), then the fused chain over the K%4 tail (:531-583,
+ *                                   :769-811)
+ *   j >= N&~7, m in the last M%4 rows    : the same four lane chains (mul+add, contracted to fma by the compiler),
+ *                                   s = ((s0+s1)+s2)+s3, then the fused tail chain (:905-935)
+ * col[] is the im2col column in (c, ky, kx) order with 0.0f at out-of-image taps (:126-185).                 */
+static float sgemm_fp_element(const float* col, const float* w, int K, int full_col, int blocked_row)
+{
+    float s = 0.f;
+    int k = 0;
+    if (full_col)
+    {
+        for (; k < K; k++) s = fmaf(col[k], w[k], s);
+        return s;
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; k + 3 < K; k += 4)
+    {
+        s0 = fmaf(w[k], col[k], s0);
+        s1 = fmaf(w[k + 1], col[k + 1], s1);
+        s2 = fmaf(w[k + 2], col[k + 2], s2);
+        s3 = fmaf(w[k + 3], col[k + 3], s3);
+    }
+    if (blocked_row)
+    {
+        s0 = s0 + s1;
+        s2 = s2 + s3;
+        s = s + s0;
+        s = s + s2;
+    }
+    else
+    {
+        s = s0 + s1;
+        s = s + s2;
+        s = s + s3;
+    }
+    for (; k < K; k++) s = fmaf(w[k], col[k], s);
+    return s;
+}
+
+/* uint8 convolution.
+ * variant ORC_CONV_REF -- conv/conv_kernel_ref_uint8.c:42-195, bit-exact restatement: operands dequantised to
+ *   fp32 (:74-95), ONE sequential fused chain total = fma(x, w, total) in kc->kh->kw order over in-image taps
+ *   (:125-152), + bias_fp32 = (float)b*in_s*k_s (:88-95,155), activation as the naive ref (:157-175),
+ *   round(total/out_s) + out_zp, clamp [0,255] (:177-182).  Used by the reference for every depthwise /
+ *   grouped uint8 conv (conv_dw_hcl_x86.c:533 rejects uint8).
+ * variant ORC_CONV_HCL -- conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8 -> fp32),
+ *   sgemm_fp in its exact summation order (sgemm_fp_element above), then :1703-1794: s = fma((float)bias,
+ *   in_s*k_s, s), relu / relu6 for ANY positive activation code, (int)(round(s/out_s) + out_zp), clamp [0,255]. */
+ORC_API int orc_conv2d_uint8(const uint8_t* x, const uint8_t* w, const int32_t* bias, uint8_t* y, int n, int cin, int h,
+                             int wd, int cout, int oh, int ow, int kh, int kw, int sh, int sw, int ph0, int pw0, int dh,
+                             int dw, int group, int act, float in_scale, int in_zp, float w_scale, int w_zp,
+                             float out_scale, int out_zp, int variant)
+{
+    int cin_g = cin / group, cout_g = cout / group;
+    int K = cin_g * kh * kw, N = oh * ow;
+    float* wf = (float*)malloc(sizeof(float) * (size_t)cout * K);
+    for (size_t i = 0; i < (size_t)cout * K; i++) wf[i] = ((float)w[i] - (float)w_zp) * w_scale;
+    int m_blocked = (cout_g >> 3 << 3) + (((cout_g - (cout_g >> 3 << 3)) >> 2) << 2);
+#pragma omp parallel
+    {
+        float* col = (float*)malloc(sizeof(float) * (size_t)K);
+#pragma omp for collapse(2)
+        for (int b = 0; b < n; b++)
+            for (int j = 0; j < N; j++)
+            {
+                int oy = j / ow, ox = j % ow;
+                for (int g = 0; g < group; g++)
+                {
+                    int kk = 0;
+                    for (int kc = 0; kc < cin_g; kc++)
+                    {
+                        const uint8_t* xc = x + ((size_t)b * cin + (size_t)g * cin_g + kc) * h * wd;
+                        for (int ky = 0; ky < kh; ky++)
+                            for (int kx = 0; kx < kw; kx++, kk++)
+                            {
+                                int iy = oy * sh - ph0 + ky * dh, ix = ox * sw - pw0 + kx * dw;
+                                col[kk] = (iy < 0 || iy >= h || ix < 0 || ix >= wd)
+                                              ? 0.f
+                                              : ((float)xc[iy * wd + ix] - (float)in_zp) * in_scale;
+                            }
+                    }
+                    for (int m = 0; m < cout_g; m++)
+                    {
+                        int oc = g * cout_g + m;
+                        const float* wk = wf + (size_t)oc * K;
+                        float total;
+                        if (variant == ORC_CONV_REF)
+                        {
+                            total = 0.f;
+                            /* out-of-image taps are skipped there; fma(0, w, t) == t, so keeping them is identical */
+                            for (int k = 0; k < K; k++) total = fmaf(col[k], wk[k], total);
+                            if (bias)
+                            {
+                                float bf = (float)bias[oc] * in_scale;
+                                bf = bf * w_scale;
+                                total = total + bf;
+                            }
+                            if (act >= 0)
+                            {
+                                if (total < 0 && act != 1) total = 0;
+                                if (total > 1 && act == 1) total = 1;
+                                if (total > 6 && act == 6) total = 6;
+                                if (total < -1 && act == 1) total = -1;
+                            }
+                        }
+                        else
+                        {
+                            total = sgemm_fp_element(col, wk, K, j < (N & ~7), m < m_blocked);
+                            if (bias) total = fmaf((float)bias[oc], in_scale * w_scale, total);
+                            if (act == 0 && total < 0) total = 0;
+                            if (act > 0)
+                            {
+                                if (total < 0) total = 0;
+                                if (total > 6) total = 6;
+                            }
+                        }
+                        int out = (int)(round((double)(total / out_scale)) + out_zp);
+                        y[(((size_t)b * cout + oc) * oh + oy) * ow + ox] = sat_u8(out);
+                    }
+                }
+            }
+        free(col);
+    }
+    free(wf);
+    return 0;
+}
+
+/* fc uint8 -- fc/fc_ref.c:121-207: data = (float)bias*bias_scale; data = fma(xf, wf, data) j ascending;
+ * round(data/out_s) + out_zp, clamp [0,255].  bias_scale == bias_tensor->scale.                            */
+ORC_API int orc_fc_uint8(const uint8_t* x, const uint8_t* w, const int32_t* bias, uint8_t* y, int batch, int hidden,
+                         int nout, float in_scale, int in_zp, float w_scale, int w_zp, float bias_scale, float out_scale,
+                         int out_zp)
+{
+#pragma omp parallel for
+    for (int o = 0; o < nout; o++)
+        for (int b = 0; b < batch; b++)
+        {
+            float data = bias ? (float)bias[o] * bias_scale : 0.f;
+            for (int j = 0; j < hidden; j++)
+            {
+                float xf = ((float)x[(size_t)b * hidden + j] - (float)in_zp) * in_scale;
+                float wf = ((float)w[(size_t)o * hidden + j] - (float)w_zp) * w_scale;
+                data = fmaf(xf, wf, data);
+            }
+            y[(size_t)b * nout + o] = sat_u8((int)round((double)(data / out_scale)) + out_zp);
+        }
+    return 0;
+}
+
+/* pooling uint8 -- pooling/pooling_kernel_ref_uint8.c:91-200: dequantise all, fp32 max / sequential fp32 sum
+ * (rows then columns) / pool_size, then round(f/out_s) + out_zp with ONLY the upper clamp (:193-196; a negative
+ * value wraps through the uint8 store).                                                                    */
+ORC_API int orc_pool_uint8(const uint8_t* x, uint8_t* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw,
+                           int sh, int sw, int ph0, int pw0, int method, int caffe_flavor, float in_scale, int in_zp,
+                           float out_scale, int out_zp)
+{
+    for (int b = 0; b < n; b++)
+        for (int ch = 0; ch < c; ch++)
+        {
+            const uint8_t* xc = x + ((size_t)b * c + ch) * h * w;
+            for (int py = 0; py < oh; py++)
+                for (int px = 0; px < ow; px++)
+                {
+                    int hs = py * sh - ph0, he = hs + kh;
+                    if (he > h + ph0) he = h + ph0;
+                    int ws = px * sw - pw0, we = ws + kw;
+                    if (we > w + pw0) we = w + pw0;
+                    int pool_size = 1;
+                    if (caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    if (hs < 0) hs = 0;
+                    if (ws < 0) ws = 0;
+                    if (he > h) he = h;
+                    if (we > w) we = w;
+                    if (!caffe_flavor) pool_size = (he - hs) * (we - ws);
+                    float f;
+                    if (method == 0)
+                    {
+                        f = (float)((int)xc[hs * w + ws] - in_zp) * in_scale;
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++)
+                            {
+                                float v = (float)((int)xc[iy * w + ix] - in_zp) * in_scale;
+                                f = f > v ? f : v;
+                            }
+                    }
+                    else
+                    {
+                        float s = 0.f;
+                        for (int iy = hs; iy < he; iy++)
+                            for (int ix = ws; ix < we; ix++) s += (float)((int)xc[iy * w + ix] - in_zp) * in_scale;
+                        f = s / pool_size;
+                    }
+                    int od = (int)round((double)(f / out_scale)) + out_zp;
+                    y[(((size_t)b * c + ch) * oh + py) * ow + px] = (uint8_t)(od > 255 ? 255 : od);
+                }
+        }
+    return 0;
+}
+
+/* relu / leaky uint8 -- relu/relu_kernel_ref_uint8.c:48-95: f=((float)u-zp_in)*in_s; f<0 -> f*slope (or 0);
+ * y = round(f/out_s + out_zp) (zero point added INSIDE the round), clamp [0,255]                           */
+ORC_API int orc_relu_uint8(const uint8_t* x, uint8_t* y, size_t count, float slope, float in_scale, int in_zp,
+                           float out_scale, int out_zp)
+{
+    for (size_t i = 0; i < count; i++)
+    {
+        float f = ((float)x[i] - (float)in_zp) * in_scale;
+        if (f < 0) f = (slope == 0) ? 0 : f * slope;
+        y[i] = sat_u8((int)round((double)(f / out_scale + (float)out_zp)));
+    }
+    return 0;
+}
+
+/* concat uint8, one input slice -- concat/concat_kernel_ref_uint8.c:309-352:
+ * y = roundf(fma((float)(u - zp_in), in_s/out_s, (float)out_zp)), clamp [0,255]                            */
+ORC_API int orc_requant_copy_uint8(const uint8_t* x, uint8_t* y, size_t count, float in_scale, int in_zp,
+                                   float out_scale, int out_zp)
+{
+    float rescale = in_scale / out_scale;
+    for (size_t i = 0; i < count; i++)
+        y[i] = sat_u8((int)roundf(fmaf((float)((int)x[i] - in_zp), rescale, (float)out_zp)));
+    return 0;
+}
+
+/* nearest upsample uint8 -- upsample/upsample_ref.c:74-130: dequantise, replicate (in = out / scale),
+ * y = round(f/out_s + out_zp), clamp [0,255]                                                               */
+ORC_API int orc_upsample_uint8(const uint8_t* x, uint8_t* y, int n, int c, int h, int w, int scale, float in_scale,
+                               int in_zp, float out_scale, int out_zp)
+{
+    int oh = h * scale, ow = w * scale;
+    for (int b = 0; b < n * c; b++)
+        for (int oy = 0; oy < oh; oy++)
+            for (int ox = 0; ox < ow; ox++)
+            {
+                float f = ((float)x[((size_t)b * h + oy / scale) * w + ox / scale] - (float)in_zp) * in_scale;
+                y[((size_t)b * oh + oy) * ow + ox] = sat_u8((int)round((double)(f / out_scale + (float)out_zp)));
+            }
+    return 0;
+}
+
+/* eltwise uint8 (same-shape operands) -- eltwise/eltwise_ref.c:311-585: a=(float)(u0-zp0)*s0, b likewise,
+ * fp32 op, round(r/out_s) + out_zp, clamp [0,255].  type = enum (eltwise_param.h): 0 prod, 2 sum, 4 sub, 6 max.       */
+ORC_API int orc_eltwise_uint8(const uint8_t* a, const uint8_t* b, uint8_t* y, size_t count, int type, float sa, int za,
+                              float sb, int zb, float out_scale, int out_zp)
+{
+    for (size_t i = 0; i < count; i++)
+    {
+        float fa = (float)((int)a[i] - za) * sa, fb = (float)((int)b[i] - zb) * sb, r;
+        switch (type)
+        {
+        case 0: r = fa * fb; break;
+        case 2: r = fa + fb; break;
+        case 4: r = fa - fb; break;
+        case 6: r = fa > fb ? fa : fb; break;
+        default: return -1;
+        }
+        y[i] = sat_u8((int)round((double)(r / out_scale)) + out_zp);
+    }
+    return 0;
+}

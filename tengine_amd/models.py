@@ -417,6 +417,95 @@ def quantize_int8(gf: Graph, calib_q: np.ndarray = None, in_scale=1.0 / 127.0, t
     return g
 
 
+U8_IN_SCALE, U8_IN_ZP = 2.0 / 255.0, 127      # synthetic uint8 input covers [-1, 1)
+
+
+def calibrate_minmax(gf: Graph, calib_q: np.ndarray = None):
+    """min-max calibration for the uint8 flow: {tensor name: [min, max]} of one fp32 forward."""
+    if calib_q is None:
+        calib_q = synth_input(gf, 1234, DT_UINT8)
+    xin = (calib_q.astype(np.float32) - np.float32(U8_IN_ZP)) * np.float32(U8_IN_SCALE)
+    acts = fp32_forward(gf, xin)
+    return {t.name: [float(acts[ti].min()), float(acts[ti].max())] for ti, t in enumerate(gf.tensors)
+            if t.ttype == tm2.TT_VAR}
+
+
+def _u8_qparams(lo, hi):
+    """tools/quantize/quant_tool_uint8.cpp:405-428 (min-max): scale, zero point of an activation."""
+    lo, hi = np.float32(lo), np.float32(hi)
+    if hi < 0:
+        s = (np.float32(0) - lo) / np.float32(255)
+        return s, int(-lo / s)
+    if lo > 0:
+        return hi / np.float32(255), 0
+    s = (hi - lo) / np.float32(255)
+    if s == 0:
+        return np.float32(1e-6), 0
+    return s, int(-lo / s)
+
+
+def quantize_uint8(gf: Graph, table=None) -> Graph:
+    """fp32 IR -> per-tensor asymmetric uint8 IR following save_graph_u8_perlayer
+    (tools/quantize/quant_save_graph.cpp:82-353): activations scale=(max-min)/255, zp=int(-min/scale);
+    relu(slope 0) / max-pool / reshape-like outputs hand their (scale, zp) back to a single-consumer input
+    (:136-202); weights per TENSOR scale=(max-min)/255, zp=int(-min/scale), q=round(w/scale+zp) clip [0,255]
+    (:228-275); bias int32 = roundf(b/(in_s*w_s)) (:277-304)."""
+    if table is None:
+        table = calibrate_minmax(gf)
+    g = Graph(name=gf.name + "_uint8")
+    g.input_nodes, g.output_nodes = list(gf.input_nodes), list(gf.output_nodes)
+    qp = {}
+    for ti, t in enumerate(gf.tensors):
+        if t.ttype == tm2.TT_CONST:
+            continue
+        if t.ttype == tm2.TT_INPUT:
+            qp[ti] = (np.float32(U8_IN_SCALE), U8_IN_ZP)
+        else:
+            qp[ti] = _u8_qparams(*table[t.name])
+    used = {}
+    for n in gf.nodes:
+        for i in n.inputs:
+            used[i] = used.get(i, 0) + 1
+    for n in reversed(gf.nodes):
+        share = n.op in PASS_THROUGH or (n.op == "ReLU" and n.params.get("negative_slope", 0.0) == 0.0) \
+            or (n.op == "Pooling" and n.params["alg"] == 0)
+        if share and gf.tensors[n.inputs[0]].ttype == tm2.TT_VAR and used.get(n.inputs[0], 0) == 1:
+            qp[n.inputs[0]] = qp[n.outputs[0]]
+    for n in gf.nodes:          # run-time pass-through ops never requantise: output carries the input's params
+        if n.op in PASS_THROUGH:
+            qp[n.outputs[0]] = qp[n.inputs[0]]
+    wq = {}
+    for n in gf.nodes:
+        if n.op in ("Convolution", "FullyConnected"):
+            w = np.asarray(gf.tensors[n.inputs[1]].data, dtype=np.float32)
+            wmax, wmin = np.float32(w.max()), np.float32(w.min())
+            ws = np.float32((wmax - wmin) / np.float32(255))
+            if ws == 0:
+                ws = np.float32(1e-8)
+            wz = int(-wmin / ws)
+            q = np.clip(np.round(w / ws + np.float32(wz)), 0, 255).astype(np.uint8)
+            wq[n.inputs[1]] = (q, ws, wz)
+            if len(n.inputs) > 2:
+                bf = np.asarray(gf.tensors[n.inputs[2]].data, dtype=np.float32)
+                bs = np.float32(qp[n.inputs[0]][0] * ws)
+                bq = np.round(bf / bs).astype(np.int64).clip(-2 ** 31 + 1, 2 ** 31 - 1).astype(np.int32)
+                wq[n.inputs[2]] = (bq, bs, 0)
+    for ti, t in enumerate(gf.tensors):
+        if t.ttype == tm2.TT_CONST:
+            if ti in wq:
+                q, s, z = wq[ti]
+                dt = DT_INT32 if q.dtype == np.int32 else DT_UINT8
+                g.tensors.append(tm2.Tensor(t.name, list(t.dims), dt, tm2.TT_CONST, q, [float(s)], [int(z)]))
+            else:
+                g.tensors.append(tm2.Tensor(t.name, list(t.dims), t.dtype, t.ttype, t.data))
+        else:
+            s, z = qp[ti]
+            g.tensors.append(tm2.Tensor(t.name, list(t.dims), DT_UINT8, t.ttype, None, [float(s)], [int(z)]))
+    for n in gf.nodes:
+        g.nodes.append(tm2.Node(n.name, n.op, list(n.inputs), list(n.outputs), dict(n.params)))
+    return g
+
+
 def set_batch(g: Graph, batch: int) -> Graph:
     """Re-shape every var/input tensor to a new batch (== set_tensor_shape + infer_shape)."""
     for t in g.tensors:
@@ -436,13 +525,14 @@ BUILDERS = {
 CALIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "calib")
 
 
-def calib_table(name, gf=None, write=False):
-    """Committed calibration tables (tengine_amd/calib/<model>_int8.json == the quant tool's scale
-    table): make the synthetic int8 models bit-identical on every host."""
-    path = os.path.join(CALIB_DIR, "%s_int8.json" % name)
+def calib_table(name, gf=None, write=False, dtype="int8"):
+    """Committed calibration tables (tengine_amd/calib/<model>_<dtype>.json == the quant tool's scale
+    table): make the synthetic quantised models bit-identical on every host."""
+    path = os.path.join(CALIB_DIR, "%s_%s.json" % (name, dtype))
     if os.path.exists(path) and not write:
         return json.load(open(path))
-    table = calibrate_absmax(gf if gf is not None else BUILDERS[name]())
+    gf = gf if gf is not None else BUILDERS[name]()
+    table = calibrate_absmax(gf) if dtype == "int8" else calibrate_minmax(gf)
     if write:
         os.makedirs(CALIB_DIR, exist_ok=True)
         json.dump(table, open(path, "w"), indent=0, sort_keys=True)
@@ -477,6 +567,9 @@ def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
     elif dtype == "int8":
         table = calib_table(name, gf) if not kw else None
         g = set_batch(quantize_int8(gf, table=table), batch)
+    elif dtype == "uint8":
+        table = calib_table(name, gf, dtype="uint8") if not kw else None
+        g = set_batch(quantize_uint8(gf, table=table), batch)
     else:
         raise NotImplementedError(dtype)
     return strip_tail(g) if device_only else g

@@ -98,3 +98,117 @@ def eltwise_relu_graph(seed, n, c, h, w, with_relu=True, etype=tm2.ELT_SUM):
         ni = g.add_node("relu", "ReLU", [e], [r], negative_slope=0.0)
     g.output_nodes = [ni]
     return g, xin
+
+
+# ---- uint8 (per-tensor asymmetric) single-op graphs --------------------------------------------------------
+from tengine_amd.tm2 import DT_UINT8  # noqa: E402
+
+
+def _u8q(rng, lo=0.01, hi=0.05):
+    # zero points near mid-range keep the accumulators centred (a random zp pair saturates every output);
+    # extreme zero points are exercised through the explicit in_zp / w_zp / out_zp arguments
+    return float(np.float32(rng.uniform(lo, hi))), int(rng.integers(112, 144))
+
+
+def u8_conv_graph(seed, n, cin, h, w, cout, k, s=1, p=0, group=1, act=0, bias=True, dil=1, in_zp=None, w_zp=None,
+                  out_zp=None):
+    rng = np.random.default_rng(seed)
+    g = Graph(name="u8conv_case")
+    xs, xz = _u8q(rng)
+    if in_zp is not None:
+        xz = in_zp
+    x = g.add_input("data", [n, cin, h, w], DT_UINT8, [xs], [xz])
+    wq = rng.integers(0, 256, size=(cout, cin // group, k, k)).astype(np.uint8)
+    ws, wz = _u8q(rng, 0.002, 0.02)
+    if w_zp is not None:
+        wz = w_zp
+    ins = [x, g.add_const("w", wq, DT_UINT8, [ws], [wz])]
+    if bias:
+        bq = rng.integers(-4000, 4000, size=(cout,)).astype(np.int32)
+        ins.append(g.add_const("b", bq, DT_INT32, [float(np.float32(xs) * np.float32(ws))], [0]))
+    oh = (h - dil * (k - 1) - 1 + 2 * p) // s + 1
+    ow = (w - dil * (k - 1) - 1 + 2 * p) // s + 1
+    fan = (cin // group) * k * k
+    os_ = float(np.float32(xs * ws * 73.0 * np.sqrt(fan) * 73.0 / 40.0))
+    oz = int(rng.integers(0, 256)) if out_zp is None else out_zp
+    if act >= 0 and out_zp is None:
+        oz = int(rng.integers(0, 40))
+    if act > 0:
+        os_ = min(os_, float(np.float32(6.3 / (255 - oz))))
+    y = g.add_tensor("out", [n, cout, oh, ow], DT_UINT8, tm2.TT_VAR, None, [os_], [oz])
+    ni = g.add_node("conv", "Convolution", ins, [y], kernel_h=k, kernel_w=k, stride_h=s, stride_w=s,
+                    dilation_h=dil, dilation_w=dil, input_channel=cin, output_channel=cout, group=group,
+                    activation=act, pad_h0=p, pad_w0=p, pad_h1=p, pad_w1=p)
+    g.output_nodes = [ni]
+    return g, rng.integers(0, 256, size=(n, cin, h, w)).astype(np.uint8)
+
+
+def u8_unary_graph(seed, op, dims, out_dims=None, same_q=False, **params):
+    rng = np.random.default_rng(seed)
+    g = Graph(name="u8_%s_case" % op)
+    xs, xz = _u8q(rng)
+    x = g.add_input("data", list(dims), DT_UINT8, [xs], [xz])
+    if same_q:
+        os_, oz = xs, xz
+    else:
+        os_, oz = float(np.float32(xs * rng.uniform(0.5, 1.4))), int(rng.integers(0, 256))
+    y = g.add_tensor("out", list(out_dims or dims), DT_UINT8, tm2.TT_VAR, None, [os_], [oz])
+    ni = g.add_node(op.lower(), op, [x], [y], **params)
+    g.output_nodes = [ni]
+    return g, rng.integers(0, 256, size=dims).astype(np.uint8)
+
+
+def u8_pool_graph(seed, n, c, h, w, alg, k, s, p=0, glob=0, caffe=0, same_q=False):
+    from tengine_amd.models import pool_out
+    if glob:
+        oh = ow = 1
+    else:
+        oh, _, _ = pool_out(h, k, s, p, caffe)
+        ow, _, _ = pool_out(w, k, s, p, caffe)
+    return u8_unary_graph(seed, "Pooling", [n, c, h, w], [n, c, oh, ow], same_q, alg=alg, kernel_h=k, kernel_w=k,
+                          stride_h=s, stride_w=s, **{"global": glob}, caffe_flavor=caffe, pad_h0=p, pad_w0=p,
+                          pad_h1=p, pad_w1=p)
+
+
+def u8_fc_graph(seed, n, hidden_dims, nout, bias=True):
+    rng = np.random.default_rng(seed)
+    g = Graph(name="u8fc_case")
+    xs, xz = _u8q(rng)
+    x = g.add_input("data", [n] + list(hidden_dims), DT_UINT8, [xs], [xz])
+    hidden = int(np.prod(hidden_dims))
+    wq = rng.integers(0, 256, size=(nout, hidden)).astype(np.uint8)
+    ws, wz = _u8q(rng, 0.002, 0.02)
+    ins = [x, g.add_const("w", wq, DT_UINT8, [ws], [wz])]
+    if bias:
+        ins.append(g.add_const("b", rng.integers(-4000, 4000, size=(nout,)).astype(np.int32), DT_INT32,
+                               [float(np.float32(xs) * np.float32(ws))], [0]))
+    os_ = float(np.float32(xs * ws * 73.0 * np.sqrt(hidden) * 73.0 / 40.0))
+    y = g.add_tensor("out", [n, nout], DT_UINT8, tm2.TT_VAR, None, [os_], [int(rng.integers(0, 256))])
+    ni = g.add_node("fc", "FullyConnected", ins, [y], num_output=nout)
+    g.output_nodes = [ni]
+    return g, rng.integers(0, 256, size=[n] + list(hidden_dims)).astype(np.uint8)
+
+
+def u8_route_graph(seed, n, c, h, w):
+    """conv -> leaky -> (upsample x2 ; maxpool) mixed through a concat with per-input rescale, like the
+    YOLOv3-tiny route: data -> leaky -> upsample --\\
+                        data2(=maxpool of a 2x larger leaky) ----> concat -> leaky"""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="u8route_case")
+    xs, xz = _u8q(rng)
+    x = g.add_input("data", [n, c, 2 * h, 2 * w], DT_UINT8, [xs], [xz])
+
+    def var(name, dims, scale_mul):
+        return g.add_tensor(name, dims, DT_UINT8, tm2.TT_VAR, None, [float(np.float32(xs * scale_mul))],
+                            [int(rng.integers(0, 256))])
+    lk = var("lk", [n, c, 2 * h, 2 * w], 0.8)
+    g.add_node("leaky", "ReLU", [x], [lk], negative_slope=0.1)
+    mp = var("mp", [n, c, h, w], 0.9)
+    g.add_node("maxpool", "Pooling", [lk], [mp], alg=0, kernel_h=2, kernel_w=2, stride_h=2, stride_w=2,
+               **{"global": 0}, caffe_flavor=0, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    up = var("up", [n, c, 2 * h, 2 * w], 1.1)
+    g.add_node("upsample", "Upsample", [mp], [up], scale=2)
+    cc = var("cat", [n, 2 * c, 2 * h, 2 * w], 1.2)
+    ni = g.add_node("route", "Concat", [up, lk], [cc], axis=1)
+    g.output_nodes = [ni]
+    return g, rng.integers(0, 256, size=(n, c, 2 * h, 2 * w)).astype(np.uint8)
