@@ -62,7 +62,18 @@ struct IOBind {
     void* pinned = nullptr;          // pinned host bounce buffer
 };
 
+struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
+
 }  // namespace tamd
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            tamd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                            \
+        }                                                                                         \
+    } while (0)
 
 struct tamd_graph {
     std::vector<tamd::HTensor> tensors;
@@ -80,3 +91,24 @@ struct tamd_graph {
     bool prepared = false;
     int gpu = 0;
 };
+
+namespace tamd {
+
+// planner helpers shared by graph.hip (int8, NHWC) and graph_u8.hip (uint8, NCHW)
+PoolGeom pool_geom(const tamd_pool_param& p, int h, int w);
+int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
+void nhwc_geom(HTensor& t);
+int count_consumers(const tamd_graph* g, int tensor);
+int plan_u8(tamd_graph* g);        // graph_u8.hip: every activation tensor is uint8
+
+template <typename T>
+int upload(tamd_graph* g, const std::vector<T>& host, T** dev)
+{
+    void* p = nullptr;
+    if (dev_alloc(g, &p, host.size() * sizeof(T), false)) return -1;
+    HIPCHK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (T*)p;
+    return 0;
+}
+
+}  // namespace tamd

@@ -30,15 +30,6 @@ void set_error(const char* fmt, ...)
     if (getenv("TAMD_VERBOSE")) fprintf(stderr, "tengine_amd: %s\n", g_err);
 }
 
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return -1;                                                                            \
-        }                                                                                         \
-    } while (0)
-
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 static inline int esize(int dt) { return (dt == TAMD_DT_FP32 || dt == TAMD_DT_INT32) ? 4 : (dt == TAMD_DT_FP16 ? 2 : 1); }
 static int cdiv_c(int a, int b) { return a / b; }  // C semantics (truncation), as the reference
@@ -71,9 +62,8 @@ static void pool_real_pads(int out, int in, int kernel, int stride, int pad_org,
     else { *pad0 = pad_org; *pad1 = pad_num - pad_org; }
 }
 
-struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
 // pooling.c:36-100
-static PoolGeom pool_geom(const tamd_pool_param& p, int h, int w)
+PoolGeom pool_geom(const tamd_pool_param& p, int h, int w)
 {
     PoolGeom g{};
     int glob = p.global;
@@ -171,7 +161,7 @@ static int infer_shapes(tamd_graph* g)
 // ---------------------------------------------------------------------------------------------
 // planner
 // ---------------------------------------------------------------------------------------------
-static int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
+int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
 {
     if (bytes == 0) bytes = 16;
     HIPCHK(hipMalloc(p, bytes));
@@ -180,24 +170,14 @@ static int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
     return 0;
 }
 
-template <typename T>
-static int upload(tamd_graph* g, const std::vector<T>& host, T** dev)
-{
-    void* p = nullptr;
-    if (dev_alloc(g, &p, host.size() * sizeof(T), false)) return -1;
-    HIPCHK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    *dev = (T*)p;
-    return 0;
-}
-
-static void nhwc_geom(HTensor& t)
+void nhwc_geom(HTensor& t)
 {
     if (t.dims.size() == 4) { t.n = t.dims[0]; t.c = t.dims[1]; t.h = t.dims[2]; t.w = t.dims[3]; }
     else if (t.dims.size() == 2) { t.n = t.dims[0]; t.c = t.dims[1]; t.h = t.w = 1; }
     else { t.n = 1; t.c = (int)t.elems(); t.h = t.w = 1; }
 }
 
-static int count_consumers(const tamd_graph* g, int tensor)
+int count_consumers(const tamd_graph* g, int tensor)
 {
     int c = 0;
     for (auto& n : g->nodes)
@@ -599,7 +579,8 @@ const char* tamd_version(void) { return "tengine_amd 0.1 (gfx950)"; }
 
 int tamd_op_supported(int op, int dtype)
 {
-    if (dtype != TAMD_DT_INT8) return 0;
+    if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8) return 0;
+    if (op == TAMD_OP_UPSAMPLE) return dtype == TAMD_DT_UINT8;     // nearest upsample: uint8 graphs only so far
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
     case TAMD_OP_ELTWISE: case TAMD_OP_CONCAT: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
@@ -695,7 +676,12 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
     g->gpu = o.gpu_index;
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     if (infer_shapes(g)) return -1;
-    if (plan(g)) return -1;
+    // one quantisation scheme per device graph (the reference's splitter hands over homogeneous subgraphs)
+    bool any_u8 = false, any_other = false;
+    for (auto& t : g->tensors)
+        if (t.ttype != TAMD_TT_CONST) (t.dtype == TAMD_DT_UINT8 ? any_u8 : any_other) = true;
+    if (any_u8 && any_other) { set_error("mixed uint8 / non-uint8 activations in one device graph"); return -1; }
+    if (any_u8 ? plan_u8(g) : plan(g)) return -1;
     HIPCHK(hipDeviceSynchronize());
     if (o.use_hip_graph) {
         // one warm eager pass (module load), then capture compute + output layout launches

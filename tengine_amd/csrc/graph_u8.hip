@@ -1,0 +1,250 @@
+// Planner for uint8 (per-tensor asymmetric) device graphs.
+//
+// The reference simulates uint8 in fp32 (see u8_kernels.hip); the device keeps every activation as a dense
+// NCHW byte tensor -- the reference's own order, so graph inputs/outputs need no layout pass -- and prepares, once
+// at prerun, exactly the fp32 operands the reference prepares:
+//   conv (group 1)  weights -> fp32 as conv_kernel_x86.c:68-80 (interleave_uint8), transposed to [K][cout_pad];
+//                   k -> (c,ky,kx) offsets of im2col_uint8 (:126-185) as a lookup table
+//   conv (grouped)  weights -> fp32 as conv_kernel_ref_uint8.c:82-86, OIHW kept
+//   fc              weights -> fp32 as fc_ref.c:150-160, transposed to [hidden][nout_pad]
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "graph.h"
+
+namespace tamd {
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+static int q_of(const HTensor& t, U8Q* q, const char* what)
+{
+    if (t.scales.empty()) { set_error("%s %s has no quantisation parameters", what, t.name.c_str()); return -1; }
+    q->scale = t.scales[0];
+    q->zp = t.zps.empty() ? 0 : t.zps[0];
+    return 0;
+}
+
+static int plan_conv_u8(tamd_graph* g, HNode& n)
+{
+    HTensor& x = g->tensors[n.in[0]];
+    HTensor& w = g->tensors[n.in[1]];
+    HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+    HTensor& y = g->tensors[n.out[0]];
+    const tamd_conv_param& p = n.p.conv;
+    if (w.dtype != TAMD_DT_UINT8 || (b && b->dtype != TAMD_DT_INT32)) { set_error("conv %s: uint8 weights / int32 bias expected", n.name.c_str()); return -1; }
+    U8Q qx, qw, qy;
+    if (q_of(x, &qx, "tensor") || q_of(w, &qw, "weight") || q_of(y, &qy, "tensor")) return -1;
+    const int cin_g = x.c / p.group, K = cin_g * p.kernel_h * p.kernel_w, cout = y.c;
+    if ((size_t)cout * K != w.data.size()) { set_error("conv %s: weight size mismatch", n.name.c_str()); return -1; }
+    const int32_t* dbias = nullptr;
+    if (b) {
+        std::vector<int32_t> hb((const int32_t*)b->data.data(), (const int32_t*)b->data.data() + cout);
+        int32_t* d = nullptr;
+        if (upload(g, hb, &d)) return -1;
+        dbias = d;
+    }
+    Step st; st.node = n.name;
+    st.macs = (double)y.n * y.h * y.w * cout * K;
+    st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 4.0 * cout * K;
+    if (p.group == 1) {
+        const int Kpad = rup(K, 16), cout_pad = rup(cout, 64);
+        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);
+        for (int co = 0; co < cout; co++)
+            for (int k = 0; k < K; k++)
+                wf[(size_t)k * cout_pad + co] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+        std::vector<int2> lut(Kpad);
+        for (int k = 0; k < Kpad; k++) {
+            if (k >= K) { lut[k] = make_int2(0, 0x4000 << 16); continue; }     // row >= 16384: never inside an image
+            const int kx = k % p.kernel_w, ky = (k / p.kernel_w) % p.kernel_h, c = k / (p.kernel_w * p.kernel_h);
+            lut[k] = make_int2(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w,
+                               ((ky * p.dilation_h) << 16) | (kx * p.dilation_w));
+        }
+        if (x.h >= 0x4000 || p.kernel_h * p.dilation_h >= 0x4000) { set_error("conv %s: image too tall for the tap table", n.name.c_str()); return -1; }
+        float* dwf = nullptr; int2* dlut = nullptr;
+        if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
+        U8ConvArgs a{};
+        a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.klut = dlut; a.bias = dbias; a.y = (uint8_t*)y.dptr;
+        a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;
+        a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
+        a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
+        a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
+        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
+        st.kernel = conv_u8_gemm_kernel_name(a);
+        st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
+    } else {
+        std::vector<float> wf((size_t)cout * K);
+        for (size_t i = 0; i < wf.size(); i++) wf[i] = ((float)w.data[i] - (float)qw.zp) * qw.scale;
+        float* dwf = nullptr;
+        if (upload(g, wf, &dwf)) return -1;
+        U8DirectArgs a{};
+        a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.bias = dbias; a.y = (uint8_t*)y.dptr;
+        a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout;
+        a.KH = p.kernel_h; a.KW = p.kernel_w; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = p.group;
+        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.in_scale = qx.scale; a.in_zp = (float)qx.zp; a.w_scale = qw.scale;
+        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
+        st.kernel = "conv_u8_direct";
+        st.fn = [a](hipStream_t s) { return launch_conv_u8_direct(a, s); };
+    }
+    g->steps.push_back(st);
+    return 0;
+}
+
+static int plan_fc_u8(tamd_graph* g, HNode& n)
+{
+    HTensor& x = g->tensors[n.in[0]];
+    HTensor& w = g->tensors[n.in[1]];
+    HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+    HTensor& y = g->tensors[n.out[0]];
+    U8Q qx, qw, qy;
+    if (q_of(x, &qx, "tensor") || q_of(w, &qw, "weight") || q_of(y, &qy, "tensor")) return -1;
+    const int batch = x.dims[0], hidden = (int)(x.elems() / batch), nout = y.c, nout_pad = rup(nout, 64);
+    if (w.dtype != TAMD_DT_UINT8 || (size_t)hidden * nout != w.data.size()) { set_error("fc %s: weight mismatch", n.name.c_str()); return -1; }
+    if (hidden * 4 > 60000) { set_error("fc %s: hidden %d too large for the LDS row", n.name.c_str(), hidden); return -1; }
+    std::vector<float> wf((size_t)hidden * nout_pad, 0.f);
+    for (int o = 0; o < nout; o++)
+        for (int j = 0; j < hidden; j++)
+            wf[(size_t)j * nout_pad + o] = ((float)w.data[(size_t)o * hidden + j] - (float)qw.zp) * qw.scale;
+    float* dwf = nullptr;
+    if (upload(g, wf, &dwf)) return -1;
+    U8FcArgs a{};
+    a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.y = (uint8_t*)y.dptr;
+    if (b) {
+        std::vector<int32_t> hb((const int32_t*)b->data.data(), (const int32_t*)b->data.data() + nout);
+        int32_t* d = nullptr;
+        if (upload(g, hb, &d)) return -1;
+        a.bias = d;
+        a.bias_scale = b->scales.empty() ? 0.f : b->scales[0];      // fc_ref.c:146 bias_tensor->scale
+    }
+    a.batch = batch; a.hidden = hidden; a.nout = nout; a.nout_pad = nout_pad;
+    a.in_scale = qx.scale; a.in_zp = (float)qx.zp; a.out_scale = qy.scale; a.out_zp = qy.zp;
+    Step st; st.node = n.name; st.kernel = "fc_u8";
+    st.macs = (double)batch * hidden * nout; st.bytes = 4.0 * hidden * nout + batch * (hidden + nout);
+    st.fn = [a](hipStream_t s) { return launch_fc_u8(a, s); };
+    g->steps.push_back(st);
+    return 0;
+}
+
+int plan_u8(tamd_graph* g)
+{
+    for (auto& t : g->tensors) {
+        if (t.ttype == TAMD_TT_CONST) continue;
+        nhwc_geom(t);
+        t.nchw_raw = true;      // dense NCHW bytes: read_tensor / IO copy them as they are
+        t.cs = 0; t.c_off = 0;
+    }
+    std::vector<int> alias_of(g->tensors.size(), -1);
+    for (auto& n : g->nodes)
+        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) alias_of[n.out[0]] = n.in[0];
+    for (auto& io : g->inputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems();
+        if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        t.dptr = io.stage;
+    }
+    for (size_t i = 0; i < g->tensors.size(); i++) {
+        HTensor& t = g->tensors[i];
+        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0) continue;
+        if (dev_alloc(g, &t.dptr, t.elems(), true)) return -1;
+    }
+    for (int pass = 0; pass < 4; pass++)
+        for (size_t i = 0; i < g->tensors.size(); i++)
+            if (alias_of[i] >= 0) g->tensors[i].dptr = g->tensors[alias_of[i]].dptr;
+
+    for (auto& n : g->nodes) {
+        switch (n.op) {
+        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
+            break;
+        case TAMD_OP_CONV:
+            if (plan_conv_u8(g, n)) return -1;
+            break;
+        case TAMD_OP_FC:
+            if (plan_fc_u8(g, n)) return -1;
+            break;
+        case TAMD_OP_POOL: {
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            PoolGeom pg = pool_geom(n.p.pool, x.h, x.w);
+            U8PoolArgs a{};
+            a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
+            a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w;
+            a.KH = pg.kh; a.KW = pg.kw; a.SH = pg.sh; a.SW = pg.sw; a.PH = pg.ph0; a.PW = pg.pw0;
+            a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
+            if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
+            Step st; st.node = n.name; st.kernel = "pool_u8";
+            st.bytes = (double)x.elems() + (double)y.elems();
+            st.fn = [a](hipStream_t s) { return launch_pool_u8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_RELU: case TAMD_OP_UPSAMPLE: {
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            U8MapArgs a{};
+            a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
+            a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w;
+            a.scale = n.op == TAMD_OP_UPSAMPLE ? (int)n.p.ups.scale : 1;
+            a.out_img = y.c * y.h * y.w; a.out_c0 = 0;
+            a.slope = n.op == TAMD_OP_RELU ? n.p.relu.negative_slope : 0.f;
+            if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
+            const bool up = n.op == TAMD_OP_UPSAMPLE;
+            Step st; st.node = n.name; st.kernel = up ? "upsample_u8" : "relu_u8";
+            st.bytes = (double)x.elems() + (double)y.elems();
+            st.fn = [a, up](hipStream_t s) { return up ? launch_upsample_u8(a, s) : launch_relu_u8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_CONCAT: {
+            HTensor& y = g->tensors[n.out[0]];
+            int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+            if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+            int off = 0;
+            for (int i : n.in) {
+                HTensor& x = g->tensors[i];
+                U8MapArgs a{};
+                a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
+                a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.scale = 1;
+                a.out_img = y.c * y.h * y.w; a.out_c0 = off;
+                if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
+                Step st; st.node = n.name; st.kernel = "concat_u8"; st.bytes = 2.0 * x.elems();
+                st.fn = [a](hipStream_t s) { return launch_requant_copy_u8(a, s); };
+                g->steps.push_back(st);
+                off += x.c;
+            }
+            break;
+        }
+        case TAMD_OP_ELTWISE: {
+            HTensor& xa = g->tensors[n.in[0]];
+            HTensor& xb = g->tensors[n.in[1]];
+            HTensor& y = g->tensors[n.out[0]];
+            if (xa.dims != xb.dims) { set_error("eltwise %s: broadcast not supported", n.name.c_str()); return -1; }
+            U8EltArgs a{};
+            a.a = (const uint8_t*)xa.dptr; a.b = (const uint8_t*)xb.dptr; a.y = (uint8_t*)y.dptr;
+            a.count = xa.elems(); a.type = n.p.elt.type;
+            if (a.type != 0 && a.type != 2 && a.type != 4 && a.type != 6) { set_error("eltwise %s: type %d unsupported", n.name.c_str(), a.type); return -1; }
+            if (q_of(xa, &a.qa, "tensor") || q_of(xb, &a.qb, "tensor") || q_of(y, &a.out, "tensor")) return -1;
+            Step st; st.node = n.name; st.kernel = "eltwise_u8"; st.bytes = 3.0 * xa.elems();
+            st.fn = [a](hipStream_t s) { return launch_eltwise_u8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        default:
+            set_error("op %d (%s) is not supported on the device for uint8", n.op, n.name.c_str());
+            return -1;
+        }
+    }
+    for (auto& io : g->outputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems();
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        io.stage = t.dptr;
+    }
+    return 0;
+}
+
+}  // namespace tamd

@@ -110,4 +110,75 @@ hipError_t launch_relu(const ReluArgs& a, hipStream_t s);
 hipError_t launch_nchw_to_nhwc(const LayoutArgs& a, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);
 
+// ---- uint8 (per-tensor asymmetric) ---------------------------------------------------------------------------
+// The reference SIMULATES uint8 in fp32: operands are dequantised, the convolution is an fp32 GEMM
+// whose per-element summation order is fixed by the reference's register tiling, and only the result is
+// requantised.  Byte-identical outputs therefore need the same fp32 operations in the same order, so this path
+// runs on the fp32 vector FMA pipes (one fused chain per output element, chains spread over lanes), not on MFMA.
+// uint8 activations stay in the reference's dense NCHW order on the device (u8_kernels.hip).
+struct U8Q { float scale; int zp; };
+
+struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
+    const uint8_t* x;          // NCHW
+    const float* wf;           // [Kpad][cout_pad] dequantised weights, k = (c*KH+ky)*KW+kx, zero padded
+    const int2* klut;          // [Kpad] {c*H*W + ky*DH*W + kx*DW, (ky*DH) << 16 | kx*DW}; padding rows are out of image
+    const int32_t* bias;       // may be null
+    uint8_t* y;                // NCHW, image stride out_img bytes, first channel at out_c0
+    int N, C, H, W, OH, OW, cout, cout_pad, K, Kpad;
+    int SH, SW, PH, PW;
+    int out_img, out_c0;       // bytes per output image / channel offset (concat outputs are written in place)
+    int m_blocked;             // rows below this sit in an 8- or 4-row block of the reference's sgemm_fp
+    float in_scale, in_zp;     // zero point as float (exact)
+    float bias_scale;          // in_scale * w_scale
+    int act;
+    float out_scale; int out_zp;
+};
+
+struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
+    const uint8_t* x; const float* wf;   // wf: [cout][cin_g*KH*KW] dequantised weights, OIHW order
+    const int32_t* bias; uint8_t* y;
+    int N, C, H, W, OH, OW, cout, KH, KW, SH, SW, PH, PW, DH, DW, group;
+    int out_img, out_c0;
+    float in_scale, in_zp, w_scale;
+    int act;
+    float out_scale; int out_zp;
+};
+
+struct U8FcArgs {              // fc_ref.c:121-207
+    const uint8_t* x; const float* wf;   // wf: [hidden][nout_pad] dequantised, zero padded
+    const int32_t* bias; uint8_t* y;
+    int batch, hidden, nout, nout_pad;
+    float in_scale, in_zp, bias_scale, out_scale; int out_zp;
+};
+
+struct U8PoolArgs {
+    const uint8_t* x; uint8_t* y;
+    int N, C, H, W, OH, OW, KH, KW, SH, SW, PH, PW, method, caffe_flavor;
+    U8Q in, out;
+};
+
+struct U8MapArgs {             // relu / leaky, concat slice copy, nearest upsample: one output byte per input byte
+    const uint8_t* x; uint8_t* y;
+    int N, C, H, W;            // INPUT geometry
+    int out_img, out_c0;       // output image stride (bytes) / channel offset (concat)
+    int scale;                 // upsample factor (1 otherwise)
+    float slope;               // relu
+    U8Q in, out;
+};
+
+struct U8EltArgs {
+    const uint8_t* a; const uint8_t* b; uint8_t* y; size_t count; int type;
+    U8Q qa, qb, out;
+};
+
+hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
+const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);
+hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s);
+hipError_t launch_fc_u8(const U8FcArgs& a, hipStream_t s);
+hipError_t launch_pool_u8(const U8PoolArgs& a, hipStream_t s);
+hipError_t launch_relu_u8(const U8MapArgs& a, hipStream_t s);
+hipError_t launch_requant_copy_u8(const U8MapArgs& a, hipStream_t s);
+hipError_t launch_upsample_u8(const U8MapArgs& a, hipStream_t s);
+hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s);
+
 }  // namespace tamd

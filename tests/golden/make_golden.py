@@ -24,6 +24,13 @@ def main():
         path = os.path.join(HERE, "%s_int8_seed%d.npy" % (name, seed))
         np.save(path, out)
         print(path, out.shape, out.dtype, "absmax", np.abs(out.astype(int)).max())
+    # uint8: YOLOv3-tiny 416x416, both heads
+    g = models.build("yolov3_tiny", "uint8", 1)
+    x = models.synth_input(g, 3, tm2.DT_UINT8)
+    outs = ref_capi.run_model(tm2.write_tm2(g), x, ref_capi.MODE_UINT8, os.cpu_count())
+    path = os.path.join(HERE, "yolov3_tiny_uint8_416_seed3.npz")
+    np.savez_compressed(path, **{"out%d" % i: o for i, o in enumerate(outs)})
+    print(path, [o.shape for o in outs], [len(np.unique(o)) for o in outs])
 
 
 if __name__ == "__main__":

@@ -1,0 +1,131 @@
+"""GPU parity, uint8: the HIP backend through the C ABI against the CPU oracle, which
+tests/test_uint8_oracle.py pins BIT-EXACTLY to the real reference (including the summation order of its AVX
+sgemm).  Bar: byte-identical -- the device performs the reference's fp32 operations in the reference's order."""
+import numpy as np
+import pytest
+
+from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_unary_graph)
+from oracle import oracle
+from tengine_amd import capi, models, tm2
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(g, x):
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    out = gr.run()
+    gr.close()
+    return out
+
+
+def check(g, x, tag=""):
+    want = oracle.run_graph(g, x)
+    got = run_hip(g, x)
+    assert len(want) == len(got)
+    for w, o in zip(want, got):
+        o = o.reshape(w.shape)
+        assert o.dtype == np.uint8
+        bad = np.count_nonzero(w != o)
+        assert bad == 0, "%s: %d / %d bytes differ (max |d| %d)" % (
+            tag, bad, w.size, np.abs(w.astype(int) - o.astype(int)).max())
+        assert len(np.unique(w)) > 3, "degenerate case"
+
+
+U8_CONV = [
+    # n, cin, h, w, cout, k, s, p, group, act, bias, dil
+    (1, 3, 64, 64, 16, 3, 1, 1, 1, -1, True, 1),       # YOLO conv0 shape class (cout 16 -> 256x16 tiles)
+    (1, 16, 40, 40, 32, 3, 1, 1, 1, -1, True, 1),      # 128x32 tiles
+    (1, 64, 20, 20, 128, 3, 1, 1, 1, 0, True, 1),
+    (2, 128, 13, 13, 255, 1, 1, 0, 1, -1, True, 1),    # 169 px: 1 tail pixel; cout 255: 3 rows outside the 8/4 blocks
+    (1, 256, 13, 13, 512, 3, 1, 1, 1, 6, True, 1),     # K = 2304, relu6
+    (1, 30, 26, 26, 70, 3, 2, 1, 1, 0, False, 1),      # stride 2, no bias, K % 4 == 2, cout % 4 == 2, 169 px
+    (3, 7, 9, 11, 13, 3, 1, 1, 1, 1, True, 1),         # odd everything, K = 63 (K % 4 == 3), act code 1 == relu6
+    (1, 32, 12, 12, 16, 3, 1, 2, 1, 0, True, 2),       # dilation 2
+    (1, 64, 1, 1, 10, 1, 1, 0, 1, -1, True, 1),        # 1x1 map: every pixel is a "tail" pixel
+    (1, 512, 7, 7, 64, 3, 1, 1, 1, 0, True, 1),        # K = 4608, 49 px
+    (1, 32, 12, 12, 32, 3, 1, 1, 32, 0, True, 1),      # depthwise -> naive-ref formula
+    (2, 24, 13, 13, 24, 3, 2, 1, 24, 6, True, 1),      # depthwise stride 2, relu6, batch 2
+    (1, 16, 9, 9, 32, 3, 1, 1, 4, 1, True, 1),         # grouped, relu1 clamp
+]
+
+
+@pytest.mark.parametrize("case", U8_CONV, ids=[str(c) for c in U8_CONV])
+def test_conv_u8(case):
+    n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
+    g, x = u8_conv_graph(31 + cin + cout, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
+    check(g, x, str(case))
+
+
+@pytest.mark.parametrize("zps", [(0, 0, 0), (255, 255, 255), (0, 255, 128), (255, 0, 7)])
+def test_conv_u8_extreme_zero_points(zps):
+    g, x = u8_conv_graph(5, 1, 32, 10, 10, 48, 3, 1, 1, act=-1, in_zp=zps[0], w_zp=zps[1], out_zp=zps[2])
+    want = oracle.run_graph(g, x)[0]
+    got = run_hip(g, x)[0].reshape(want.shape)
+    assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("case", [(3, (64,), 10), (2, (32, 4, 4), 100), (4, (2048,), 1000)])
+def test_fc_u8(case):
+    n, hd, nout = case
+    g, x = u8_fc_graph(8, n, hd, nout)
+    check(g, x, "fc")
+
+
+@pytest.mark.parametrize("case", [(1, 16, 14, 14, 0, 2, 2, 0, 0, 0), (1, 16, 13, 13, 0, 2, 1, -1, 0, 0),
+                                  (2, 8, 12, 12, 1, 3, 2, 1, 0, 0), (2, 8, 12, 12, 1, 3, 2, 1, 0, 1),
+                                  (2, 64, 7, 7, 1, 7, 1, 0, 1, 0), (1, 24, 15, 15, 0, 3, 2, 0, 0, 1)])
+def test_pool_u8(case):
+    n, c, h, w, alg, k, s, p, glob, caffe = case
+    g, x = u8_pool_graph(9, n, c, h, w, alg, k, s, p, glob, caffe)
+    check(g, x, "pool")
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.1])
+def test_relu_u8(slope):
+    g, x = u8_unary_graph(13, "ReLU", [2, 8, 19, 9], negative_slope=slope)
+    check(g, x, "relu")
+
+
+def test_upsample_u8():
+    g, x = u8_unary_graph(15, "Upsample", [2, 8, 5, 7], [2, 8, 10, 14], scale=2)
+    check(g, x, "upsample")
+
+
+def test_route_u8():
+    g, x = u8_route_graph(16, 2, 8, 6, 6)
+    check(g, x, "route")
+
+
+def test_yolov3_tiny_uint8_bit_exact():
+    """BASELINE configs[3] class: YOLOv3-tiny uint8 (13 convs up to K = 4608, leaky ReLU, max pools incl. the
+    stride-1 'same' pool, upsample, concat with per-input rescale), whole graph on the device, layer by layer."""
+    g = models.build("yolov3_tiny", "uint8", 1, res=160)
+    x = models.synth_input(g, 3, tm2.DT_UINT8)
+    want = oracle.run_graph(g, x, keep_all=True)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    outs = gr.run()
+    for n in g.nodes:
+        if n.op in ("Const", "InputOp"):
+            continue
+        t = n.outputs[0]
+        dev = gr.read_tensor(t)
+        assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
+    for ni, o in zip(g.output_nodes, outs):
+        w = want[g.nodes[ni].outputs[0]]
+        assert np.array_equal(o.reshape(w.shape), w)
+    gr.close()
+
+
+def test_yolov3_tiny_uint8_416_matches_golden_of_real_reference():
+    import os
+    golden = os.path.join(os.path.dirname(__file__), "golden", "yolov3_tiny_uint8_416_seed3.npz")
+    if not os.path.exists(golden):
+        pytest.skip("golden file not generated")
+    g = models.build("yolov3_tiny", "uint8", 1)
+    x = models.synth_input(g, 3, tm2.DT_UINT8)
+    outs = run_hip(g, x)
+    ref = np.load(golden)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.ravel(), ref["out%d" % i].ravel())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timing table of a config model on the device (HIP events around every launch, the
-TG_DEBUG_TIME analogue of source/device/cpu/cpu_dump.c:607-697).  usage: profile_layers.py [model] [batch] [iters]"""
+TG_DEBUG_TIME analogue of source/device/cpu/cpu_dump.c:607-697).  usage: profile_layers.py [model] [batch] [iters] [int8|uint8]"""
 import os
 import sys
 
@@ -12,9 +12,10 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "mobilenet_v1"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-    g = models.build(name, "int8", batch, device_only=True)
+    dtype = sys.argv[4] if len(sys.argv) > 4 else "int8"
+    g = models.build(name, dtype, batch, device_only=True)
     gr = capi.Graph(tm2.write_tm2(g), batch=batch)
-    gr.set_input(models.synth_input(g, 3))
+    gr.set_input(models.synth_input(g, 3, tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8))
     gr.run()
     prof = gr.profile(iters)
     tot = sum(k["ms"] for k in prof)
