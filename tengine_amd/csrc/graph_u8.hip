@@ -48,11 +48,16 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     st.macs = (double)y.n * y.h * y.w * cout * K;
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 4.0 * cout * K;
     if (p.group == 1) {
-        const int Kpad = rup(K, 16), cout_pad = rup(cout, 64);
-        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);
+        const int Kpad = rup(K, 16), cout_pad = rup(cout, 128);
+        U8ConvArgs a{};
+        a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;
+        a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.cfg = conv_u8_gemm_pick(a);
+        const int TC = conv_u8_gemm_tc(a.cfg);
+        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);        // [cout_pad/TC][Kpad][TC]
         for (int co = 0; co < cout; co++)
             for (int k = 0; k < K; k++)
-                wf[(size_t)k * cout_pad + co] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+                wf[((size_t)(co / TC) * Kpad + k) * TC + co % TC] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
         std::vector<int2> lut(Kpad);
         for (int k = 0; k < Kpad; k++) {
             if (k >= K) { lut[k] = make_int2(0, 0x4000 << 16); continue; }     // row >= 16384: never inside an image
@@ -63,10 +68,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         if (x.h >= 0x4000 || p.kernel_h * p.dilation_h >= 0x4000) { set_error("conv %s: image too tall for the tap table", n.name.c_str()); return -1; }
         float* dwf = nullptr; int2* dlut = nullptr;
         if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
-        U8ConvArgs a{};
         a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.klut = dlut; a.bias = dbias; a.y = (uint8_t*)y.dptr;
-        a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;
-        a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.out_img = cout * y.h * y.w; a.out_c0 = 0;
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;

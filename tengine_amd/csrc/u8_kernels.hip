@@ -47,176 +47,169 @@ __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { ret
 //   pixel j >= (OH*OW)&~7 : four fused chains over k = r (mod 4), k < K&~3, combined
 //                           ((0+(s0+s1))+(s2+s3)) for rows in an 8-/4-row block, ((s0+s1)+s2)+s3 for the last
 //                           cout%4 rows, then the fused chain over the K%4 tail    -> "tail" blocks (same launch)
-// Block = 256 threads = TXN x TYN, thread tile TP pixels x TC channels; K staged 16 at a time through LDS
-// (double buffered, register prefetch).  Padded k rows carry w = 0 and an out-of-image lut entry: fma(0,0,s) == s.
+//
+// Mapping (CDNA4): lane = output pixel (64 consecutive pixels of one image per block), wave = TC output channels.
+//   * the weights of a wave are wave-uniform -> fetched with SCALAR loads (s_load_dwordxN through the constant
+//     address space) and fed to v_fma / v_pk_fma as the SGPR operand: no LDS or VGPR traffic for them at all;
+//   * the dequantised im2col column of each pixel is staged once per block in LDS (k-major, 16 k per stage,
+//     double buffered, conflict-free b32 both ways) and shared by the block's NW waves; the k -> (c,ky,kx) tap
+//     table entry of a staging wave is wave-uniform too (scalar load);
+//   * TC independent fused chains per lane, NW*TC channels per block; TC/NW are picked per layer so that the launch
+//     has enough waves for 1024 SIMDs (a chain of K dependent FMAs is the critical path, K*4 clocks).
+// Padded k rows carry w = 0 and an out-of-image lut entry: fma(0, 0, s) == s.
 // =================================================================================================================
-template <int TXN, int TYN, int TP, int TC, bool TAIL>
-__device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float (&xs)[2][16][TXN * TP],
-                                             float (&ws)[2][16][TYN * TC], int n, int jbase, int jlimit, int co0)
-{
-    constexpr int TPX = TXN * TP, TCX = TYN * TC, KC = 16, NT = 256;
-    constexpr int XE = KC * TPX / NT, WE = KC * TCX / NT, NCH = TAIL ? 4 : 1;
-    const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
-    const int K4 = a.K & ~3;
+typedef const __attribute__((address_space(4))) float* cfloatp;     // constant address space => s_load
+typedef const __attribute__((address_space(4))) int32_t* cint32p;
 
-    // staging role of this thread: one pixel column of the x tile, XE rows of k
-    const int sp = tid % TPX, klb = tid / TPX;
-    const int sj = jbase + sp;
-    const bool svalid = sj < jlimit;
-    const int soy = svalid ? sj / a.OW : 0, sox = svalid ? sj - soy * a.OW : 0;
-    const int iy0 = soy * a.SH - a.PH, ix0 = sox * a.SW - a.PW;
+template <int NW, int TC, bool TAIL>
+__device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float (&xs)[2][16][64], int n, int jbase, int jlimit,
+                                             int co0)
+{
+    constexpr int KC = 16, XE = KC / NW, NCH = TAIL ? 4 : 1, IB = TC * KC <= 32 ? KC : 32 / TC;
+    static_assert(KC % NW == 0, "NW divides 16");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co_w = co0 + wv * TC;
+    const int K4 = a.K & ~3;
+    const cfloatp wc = (cfloatp)(uintptr_t)a.wf;
+    const cfloatp wrow = wc + (size_t)(co_w / TC) * a.Kpad * TC;      // [cout_pad/TC][Kpad][TC]
+    const cint32p lutc = (cint32p)(uintptr_t)a.klut;      // {offset, dy << 16 | dx} pairs
+
+    const int pj = jbase + lane;
+    const bool valid = pj < jlimit;
+    const int oy = valid ? pj / a.OW : 0, ox = valid ? pj - oy * a.OW : 0;
+    const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int pbase = iy0 * a.W + ix0;
 
-    float xr[XE], wr[WE];
+    unsigned xr[XE], xok = 0;      // raw bytes of the next stage; bit i of xok: tap i is inside the image
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < XE; i++) {
-            const int2 e = a.klut[k0 + klb + i * (NT / TPX)];
-            const int iy = iy0 + (e.y >> 16), ix = ix0 + (e.y & 0xffff);
-            const bool ok = svalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            float v = 0.f;
-            if (ok) v = dequant(xin[pbase + e.x], a.in_zp, a.in_scale);
-            xr[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WE; i++) {
-            const int e = tid + NT * i, kl = e / TCX, c = e % TCX, k = k0 + kl;
-            float w = a.wf[(size_t)k * a.cout_pad + co0 + c];
-            if (TAIL && k >= K4) w = 0.f;      // the K%4 remainder is chained after the combine
-            wr[i] = w;
+            const int ex = lutc[2 * (k0 + wv + i * NW)], ey = lutc[2 * (k0 + wv + i * NW) + 1];
+            const int iy = iy0 + (ey >> 16), ix = ix0 + (ey & 0xffff);
+            const bool ok = valid & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);   // branch-free
+            // unconditional load from a safe address: the wait for it can then sink below the FMA block
+            xr[i] = xin[ok ? pbase + ex : 0];
+            xok = ok ? (xok | (1u << i)) : (xok & ~(1u << i));
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < XE; i++) xs[buf][klb + i * (NT / TPX)][sp] = xr[i];
-#pragma unroll
-        for (int i = 0; i < WE; i++) {
-            const int e = tid + NT * i;
-            ws[buf][e / TCX][e % TCX] = wr[i];
-        }
+        for (int i = 0; i < XE; i++)
+            xs[buf][wv + i * NW][lane] = (xok >> i & 1u) ? dequant((uint8_t)xr[i], a.in_zp, a.in_scale) : 0.f;
     };
 
-    float acc[NCH][TP][TC];
+    float acc[NCH][TC];
 #pragma unroll
     for (int r = 0; r < NCH; r++)
 #pragma unroll
-        for (int i = 0; i < TP; i++)
-#pragma unroll
-            for (int j = 0; j < TC; j++) acc[r][i][j] = 0.f;
+        for (int j = 0; j < TC; j++) acc[r][j] = 0.f;
 
     const int nchunk = a.Kpad / KC;
     gload(0);
     sstore(0);
     __syncthreads();
     for (int ch = 0; ch < nchunk; ch++) {
-        const int cur = ch & 1;
-        if (ch + 1 < nchunk) gload((ch + 1) * KC);
+        const int cur = ch & 1, k0 = ch * KC;
+        if (ch + 1 < nchunk) gload(k0 + KC);
+        // the wave's weights of this stage are one contiguous run of KC*TC floats ([cout/TC][Kpad][TC] packing):
+        // scalar loads with immediate offsets, no address arithmetic in the loop
+        const cfloatp wk = wrow + (size_t)k0 * TC;
+#pragma unroll 1
+        for (int h = 0; h < KC; h += IB) {          // IB k per inner block bounds the live SGPRs to IB*TC <= 32
 #pragma unroll
-        for (int kl = 0; kl < KC; kl++) {
-            float xv[TP], wv[TC];
-#pragma unroll
-            for (int i = 0; i < TP; i++) xv[i] = xs[cur][kl][tx * TP + i];
-#pragma unroll
-            for (int j = 0; j < TC; j++) wv[j] = ws[cur][kl][ty * TC + j];
-#pragma unroll
-            for (int i = 0; i < TP; i++)
+            for (int kk = 0; kk < IB; kk++) {
+                const int kl = h + kk;
+                const float xv = xs[cur][kl][lane];
+                const bool live = !TAIL || (k0 + kl) < K4;      // the K%4 remainder is chained after the combine
 #pragma unroll
                 for (int j = 0; j < TC; j++) {
-                    float& s = acc[TAIL ? (kl & 3) : 0][i][j];
-                    s = __builtin_fmaf(xv[i], wv[j], s);
+                    float w = wk[kl * TC + j];
+                    if (TAIL) w = __uint_as_float(__float_as_uint(w) & (live ? 0xffffffffu : 0u));     // scalar ALU
+                    float& s = acc[TAIL ? (kk & 3) : 0][j];
+                    s = __builtin_fmaf(xv, w, s);
                 }
+            }
         }
         if (ch + 1 < nchunk) sstore(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------
+    // ---- epilogue: this lane's pixel, the wave's TC channels ----------------------------------------------
+    if (!valid) return;
     const int OHW = a.OH * a.OW;
 #pragma unroll
     for (int j = 0; j < TC; j++) {
-        const int co = co0 + ty * TC + j;
+        const int co = co_w + j;
         if (co >= a.cout) continue;
-        float bf = 0.f;
-        if (a.bias) bf = (float)a.bias[co];
-#pragma unroll
-        for (int i = 0; i < TP; i++) {
-            const int pj = jbase + tx * TP + i;
-            if (pj >= jlimit) continue;
-            float s;
-            if constexpr (TAIL) {
-                const float s0 = acc[0][i][j], s1 = acc[1][i][j], s2 = acc[2][i][j], s3 = acc[3][i][j];
-                if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
-                else s = ((s0 + s1) + s2) + s3;
-                const int oy = pj / a.OW, ox = pj - oy * a.OW;
-                for (int k = K4; k < a.K; k++) {
-                    const int2 e = a.klut[k];
-                    const int iy = oy * a.SH - a.PH + (e.y >> 16), ix = ox * a.SW - a.PW + (e.y & 0xffff);
-                    float v = 0.f;
-                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        v = dequant(xin[(oy * a.SH - a.PH) * a.W + ox * a.SW - a.PW + e.x], a.in_zp, a.in_scale);
-                    s = __builtin_fmaf(a.wf[(size_t)k * a.cout_pad + co], v, s);
-                }
-            } else
-                s = acc[0][i][j];
-            if (a.bias) s = __builtin_fmaf(bf, a.bias_scale, s);
-            if (a.act == 0) s = s < 0.f ? 0.f : s;
-            if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-            a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
-        }
+        float s;
+        if constexpr (TAIL) {
+            const float s0 = acc[0][j], s1 = acc[1][j], s2 = acc[2][j], s3 = acc[3][j];
+            if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
+            else s = ((s0 + s1) + s2) + s3;
+            for (int k = K4; k < a.K; k++) {
+                const int ex = lutc[2 * k], ey = lutc[2 * k + 1];
+                const int iy = iy0 + (ey >> 16), ix = ix0 + (ey & 0xffff);
+                float v = 0.f;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = dequant(xin[pbase + ex], a.in_zp, a.in_scale);
+                s = __builtin_fmaf(wrow[(size_t)k * TC + j], v, s);
+            }
+        } else
+            s = acc[0][j];
+        if (a.bias) s = __builtin_fmaf((float)((cint32p)(uintptr_t)a.bias)[co], a.bias_scale, s);
+        if (a.act == 0) s = s < 0.f ? 0.f : s;
+        if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+        a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
     }
 }
 
-template <int TXN, int TYN, int TP, int TC>
-__global__ __launch_bounds__(256) void conv_u8_gemm_k(const U8ConvArgs a)
+template <int NW, int TC>
+__global__ __launch_bounds__(NW * 64) void conv_u8_gemm_k(const U8ConvArgs a)
 {
-    constexpr int TPX = TXN * TP, TCX = TYN * TC;
-    static_assert(TXN * TYN == 256, "256 threads");
-    __shared__ __attribute__((aligned(16))) float xs[2][16][TPX];
-    __shared__ __attribute__((aligned(16))) float ws[2][16][TCX];
+    __shared__ float xs[2][16][64];
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    const int tiles = (N8 + TPX - 1) / TPX;
-    const int n = blockIdx.z, co0 = blockIdx.y * TCX;
-    if ((int)blockIdx.x < tiles) conv_u8_body<TXN, TYN, TP, TC, false>(a, xs, ws, n, blockIdx.x * TPX, N8, co0);
-    else conv_u8_body<TXN, TYN, TP, TC, true>(a, xs, ws, n, N8, OHW, co0);
+    const int tiles = (N8 + 63) / 64;
+    const int n = blockIdx.z, co0 = blockIdx.y * (NW * TC);
+    if ((int)blockIdx.x < tiles) conv_u8_body<NW, TC, false>(a, xs, n, blockIdx.x * 64, N8, co0);
+    else conv_u8_body<NW, TC, true>(a, xs, n, N8, OHW, co0);
 }
 
-// tile choice: enough blocks to occupy 256 CUs first, then the largest register tile
-static int u8_cfg(const U8ConvArgs& a)
+// tile choice: the widest channel tile per wave that still leaves >= ~2 waves for each of the 1024 SIMDs.
+// The planner calls this once (geometry only), packs the weights for the chosen TC and stores the index in a.cfg.
+static const struct { int nw, tc; const char* name; } U8_CFGS[] = {
+    {4, 4, "conv_u8_px_w4x4"}, {8, 4, "conv_u8_px_w8x4"}, {16, 2, "conv_u8_px_w16x2"}, {16, 4, "conv_u8_px_w16x4"},
+    {16, 8, "conv_u8_px_w16x8"}};
+
+int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
     static const char* e = getenv("TAMD_U8_CFG");
-    if (e && *e) return atoi(e);
+    if (e && *e) return atoi(e) % 5;
     const int N8 = (a.OH * a.OW) & ~7;
-    auto blocks = [&](int tpx, int tcx) { return (long)((N8 + tpx - 1) / tpx) * ((a.cout + tcx - 1) / tcx) * a.N; };
-    if (a.cout <= 16 && blocks(256, 16) >= 256) return 1;
-    if (a.cout <= 32 && blocks(128, 32) >= 256) return 2;
-    if (blocks(64, 64) >= 384) return 0;
-    if (blocks(32, 32) >= 256) return 3;
-    return 4;
+    const long ptiles = (long)((N8 + 63) / 64 + ((a.OH * a.OW) & 7 ? 1 : 0)) * a.N;
+    auto waves = [&](int nw, int tc) { return ptiles * ((a.cout + nw * tc - 1) / (nw * tc)) * nw; };
+    if (a.cout <= 16) return 0;
+    if (a.cout <= 32) return 1;
+    if (waves(16, 8) >= 2048) return 4;
+    if (waves(16, 4) >= 2048) return 3;
+    return 2;
 }
-
-const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a)
-{
-    static const char* names[] = {"conv_u8_gemm_64x64", "conv_u8_gemm_256x16", "conv_u8_gemm_128x32", "conv_u8_gemm_32x32",
-                                  "conv_u8_gemm_16x32"};
-    return names[u8_cfg(a)];
-}
+int conv_u8_gemm_tc(int cfg) { return U8_CFGS[cfg].tc; }
+const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a) { return U8_CFGS[a.cfg].name; }
 
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
-    auto go = [&](auto kern, int tpx, int tcx) {
-        dim3 grid((N8 + tpx - 1) / tpx + (ntail ? 1 : 0), (a.cout + tcx - 1) / tcx, a.N);
-        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
-        return hipGetLastError();
-    };
-    switch (u8_cfg(a)) {
-    case 1: return go(conv_u8_gemm_k<64, 4, 4, 4>, 256, 16);
-    case 2: return go(conv_u8_gemm_k<32, 8, 4, 4>, 128, 32);
-    case 3: return go(conv_u8_gemm_k<16, 16, 2, 2>, 32, 32);
-    case 4: return go(conv_u8_gemm_k<16, 16, 1, 2>, 16, 32);
-    default: return go(conv_u8_gemm_k<16, 16, 4, 4>, 64, 64);
+    const int nw = U8_CFGS[a.cfg].nw, tc = U8_CFGS[a.cfg].tc;
+    dim3 grid((N8 + 63) / 64 + (ntail ? 1 : 0), (a.cout + nw * tc - 1) / (nw * tc), a.N);
+    switch (a.cfg) {
+    case 0: hipLaunchKernelGGL((conv_u8_gemm_k<4, 4>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((conv_u8_gemm_k<8, 4>), grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((conv_u8_gemm_k<16, 4>), grid, dim3(1024), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((conv_u8_gemm_k<16, 8>), grid, dim3(1024), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_u8_gemm_k<16, 2>), grid, dim3(1024), 0, s, a); break;
     }
+    return hipGetLastError();
 }
 
 // =================================================================================================================
