@@ -48,25 +48,28 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     st.macs = (double)y.n * y.h * y.w * cout * K;
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 4.0 * cout * K;
     if (p.group == 1) {
-        const int Kpad = rup(K, 16), cout_pad = rup(cout, 128);
+        const int Kpad = rup(K, 32), cout_pad = rup(cout, 64);
         U8ConvArgs a{};
         a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;
         a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.cfg = conv_u8_gemm_pick(a);
-        const int TC = conv_u8_gemm_tc(a.cfg);
-        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);        // [cout_pad/TC][Kpad][TC]
+        if ((p.kernel_h - 1) * p.dilation_h > 15 || (p.kernel_w - 1) * p.dilation_w > 15 || (size_t)x.c * x.h * x.w >= (1u << 24)
+            || conv_u8_gemm_lds(a) > 64 * 1024) {
+            set_error("conv %s: kernel extent / image size / K = %d outside the packed tap table of the uint8 GEMM kernel", n.name.c_str(), K);
+            return -1;
+        }
+        // [cout_pad][Kpad], every 32-k chunk class-major: slot (k%4)*8 + (k%32)/4 (u8_kernels.hip)
+        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);
         for (int co = 0; co < cout; co++)
             for (int k = 0; k < K; k++)
-                wf[((size_t)(co / TC) * Kpad + k) * TC + co % TC] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
-        std::vector<int2> lut(Kpad);
-        for (int k = 0; k < Kpad; k++) {
-            if (k >= K) { lut[k] = make_int2(0, 0x4000 << 16); continue; }     // row >= 16384: never inside an image
+                wf[(size_t)co * Kpad + (k & ~31) + (k & 3) * 8 + ((k & 31) >> 2)] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+        std::vector<unsigned> lut(Kpad, 0u);
+        for (int k = 0; k < K; k++) {
             const int kx = k % p.kernel_w, ky = (k / p.kernel_w) % p.kernel_h, c = k / (p.kernel_w * p.kernel_h);
-            lut[k] = make_int2(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w,
-                               ((ky * p.dilation_h) << 16) | (kx * p.dilation_w));
+            lut[k] = (unsigned)(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w) | (unsigned)(kx * p.dilation_w) << 24
+                     | (unsigned)(ky * p.dilation_h) << 28;
         }
-        if (x.h >= 0x4000 || p.kernel_h * p.dilation_h >= 0x4000) { set_error("conv %s: image too tall for the tap table", n.name.c_str()); return -1; }
-        float* dwf = nullptr; int2* dlut = nullptr;
+        float* dwf = nullptr; unsigned* dlut = nullptr;
         if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
         a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.klut = dlut; a.bias = dbias; a.y = (uint8_t*)y.dptr;
         a.out_img = cout * y.h * y.w; a.out_c0 = 0;

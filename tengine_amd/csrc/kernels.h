@@ -120,15 +120,16 @@ struct U8Q { float scale; int zp; };
 
 struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
     const uint8_t* x;          // NCHW
-    const float* wf;           // [cout_pad/TC][Kpad][TC] dequantised weights, k = (c*KH+ky)*KW+kx, zero padded;
-                               // TC = conv_u8_gemm_tc(cfg): one wave's operands of a K stage are contiguous
-    const int2* klut;          // [Kpad] {c*H*W + ky*DH*W + kx*DW, (ky*DH) << 16 | kx*DW}; padding rows are out of image
+    const float* wf;           // [cout_pad][Kpad] dequantised weights, k = (c*KH+ky)*KW+kx, zero padded; inside every
+                               // 32-k chunk the order is class-major: slot (k%4)*8 + (k%32)/4
+    const unsigned* klut;      // [Kpad] packed tap table: (c*H*W + ky*DH*W + kx*DW) | kx*DW << 24 | ky*DH << 28
+                               // (padding rows: 0 -- their weights are 0 and fma(x, 0, s) == s for finite x)
     const int32_t* bias;       // may be null
     uint8_t* y;                // NCHW, image stride out_img bytes, first channel at out_c0
     int N, C, H, W, OH, OW, cout, cout_pad, K, Kpad;
     int SH, SW, PH, PW;
     int out_img, out_c0;       // bytes per output image / channel offset (concat outputs are written in place)
-    int cfg;                   // conv_u8_gemm_pick(): waves per block x channels per wave
+    int cfg;                   // conv_u8_gemm_pick(): block tile (channels x pixels)
     int m_blocked;             // rows below this sit in an 8- or 4-row block of the reference's sgemm_fp
     float in_scale, in_zp;     // zero point as float (exact)
     float bias_scale;          // in_scale * w_scale
@@ -174,7 +175,7 @@ struct U8EltArgs {
 };
 
 int conv_u8_gemm_pick(const U8ConvArgs& a);        // geometry fields only
-int conv_u8_gemm_tc(int cfg);
+size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the chosen configuration
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s);

@@ -48,166 +48,246 @@ __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { ret
 //                           ((0+(s0+s1))+(s2+s3)) for rows in an 8-/4-row block, ((s0+s1)+s2)+s3 for the last
 //                           cout%4 rows, then the fused chain over the K%4 tail    -> "tail" blocks (same launch)
 //
-// Mapping (CDNA4): lane = output pixel (64 consecutive pixels of one image per block), wave = TC output channels.
-//   * the weights of a wave are wave-uniform -> fetched with SCALAR loads (s_load_dwordxN through the constant
-//     address space) and fed to v_fma / v_pk_fma as the SGPR operand: no LDS or VGPR traffic for them at all;
-//   * the dequantised im2col column of each pixel is staged once per block in LDS (k-major, 16 k per stage,
-//     double buffered, conflict-free b32 both ways) and shared by the block's NW waves; the k -> (c,ky,kx) tap
-//     table entry of a staging wave is wave-uniform too (scalar load);
-//   * TC independent fused chains per lane, NW*TC channels per block; TC/NW are picked per layer so that the launch
-//     has enough waves for 1024 SIMDs (a chain of K dependent FMAs is the critical path, K*4 clocks).
-// Padded k rows carry w = 0 and an out-of-image lut entry: fma(0, 0, s) == s.
+// The chains run on the MATRIX cores: v_mfma_f32_16x16x4f32 accumulates D = C + a0*b0 + a1*b1 + a2*b2 + a3*b3 as
+// four IEEE fused multiply-adds in ascending k -- measured bit for bit against fmaf() chains of 4608 steps,
+// profiles/r01_mfma_f32_is_sequential_fma_chain.txt (tools/exp/mfma_f32_exact.hip) -- so issuing the MFMAs of
+// one accumulator tile in ascending k IS the reference's chain.  A = weights (rows = channels), B = dequantised
+// im2col columns (cols = pixels): D lanes run along pixels, i.e. along the NCHW output rows.
+//   * K is staged 32 at a time through LDS (double buffered, one barrier per stage) from a 3-deep REGISTER ring of
+//     global loads (raw bytes + packed weights), so three stages of HBM/L2 latency are always in flight per block;
+//   * inside a stage the 32 k are stored class-major (k%4, then k/4; rows padded to 36 floats: conflict-free
+//     b128): main tiles feed MFMA i with (class kq = lane/16, position i) = k0+4i+kq; tail tiles feed chain r
+//     with (class r, position 4j+kq) = k0+r+4(4j+kq): same data, same MFMA count, four accumulators;
+//   * the k -> (c,ky,kx) tap table (one packed dword per k) lives in LDS for the whole kernel.
+// Padded k rows carry w = 0 and an out-of-image tap: fma(0, 0, s) == s.
 // =================================================================================================================
-typedef const __attribute__((address_space(4))) float* cfloatp;     // constant address space => s_load
-typedef const __attribute__((address_space(4))) int32_t* cint32p;
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int NW, int TC, bool TAIL>
-__device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float (&xs)[2][16][64], int n, int jbase, int jlimit,
-                                             int co0)
+template <int WM, int WN, int TM, int TN, bool TAIL>
+__device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restrict__ ws, float* __restrict__ xs,
+                                             const unsigned* __restrict__ lut, int n, int jbase, int jlimit, int co0)
 {
-    constexpr int KC = 16, XE = KC / NW, NCH = TAIL ? 4 : 1, IB = TC * KC <= 32 ? KC : 32 / TC;
-    static_assert(KC % NW == 0, "NW divides 16");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co_w = co0 + wv * TC;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, KC = 32, LD = 36, NT = 256, D = 3;
+    constexpr int XQ = BN / 32;                          // x quads (4 k of one class, one pixel) per thread per stage
+    constexpr int WQ = (BM * 8 + NT - 1) / NT;           // weight quads (float4) per thread per stage
+    constexpr int NCH = TAIL ? 4 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM, l15 = lane & 15, kq = lane >> 4;
     const int K4 = a.K & ~3;
-    const cfloatp wc = (cfloatp)(uintptr_t)a.wf;
-    const cfloatp wrow = wc + (size_t)(co_w / TC) * a.Kpad * TC;      // [cout_pad/TC][Kpad][TC]
-    const cint32p lutc = (cint32p)(uintptr_t)a.klut;      // {offset, dy << 16 | dx} pairs
 
-    const int pj = jbase + lane;
-    const bool valid = pj < jlimit;
-    const int oy = valid ? pj / a.OW : 0, ox = valid ? pj - oy * a.OW : 0;
-    const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
+    // staging role: pixel column sp of the x tile, quads su*XQ .. su*XQ+XQ-1 (quad qd: class qd/2, positions 4*(qd%2)..+3)
+    const int sp = tid % BN, su = tid / BN;
+    const int sj = jbase + sp;
+    const bool svalid = sj < jlimit;
+    const int soy = svalid ? sj / a.OW : 0, sox = svalid ? sj - soy * a.OW : 0;
+    const int iy0 = soy * a.SH - a.PH, ix0 = sox * a.SW - a.PW;
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int pbase = iy0 * a.W + ix0;
 
-    unsigned xr[XE], xok = 0;      // raw bytes of the next stage; bit i of xok: tap i is inside the image
-    auto gload = [&](int k0) {
+    unsigned xr[D][XQ];          // 4 raw bytes per quad
+    unsigned xok[D];             // bit (4*i + e): element e of quad i is inside the image
+    float4 wr[D][WQ];
+    auto gload = [&](int d, int k0) {
+        xok[d] = 0;
 #pragma unroll
-        for (int i = 0; i < XE; i++) {
-            const int ex = lutc[2 * (k0 + wv + i * NW)], ey = lutc[2 * (k0 + wv + i * NW) + 1];
-            const int iy = iy0 + (ey >> 16), ix = ix0 + (ey & 0xffff);
-            const bool ok = valid & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);   // branch-free
-            // unconditional load from a safe address: the wait for it can then sink below the FMA block
-            xr[i] = xin[ok ? pbase + ex : 0];
-            xok = ok ? (xok | (1u << i)) : (xok & ~(1u << i));
+        for (int i = 0; i < XQ; i++) {
+            const int qd = su * XQ + i, c = qd >> 1, pos0 = (qd & 1) * 4;
+            unsigned pack = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const unsigned t = lut[k0 + c + 4 * (pos0 + e)];            // off | dx << 24 | dy << 28
+                const int iy = iy0 + (int)(t >> 28), ix = ix0 + (int)((t >> 24) & 15);
+                const bool ok = svalid & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+                const unsigned u = xin[ok ? pbase + (int)(t & 0xffffffu) : 0];
+                pack |= u << (8 * e);
+                xok[d] |= ok ? 1u << (4 * i + e) : 0u;
+            }
+            xr[d][i] = pack;
+        }
+#pragma unroll
+        for (int i = 0; i < WQ; i++) {
+            const int idx = tid + NT * i, row = idx >> 3, qd = idx & 7;
+            if (BM * 8 % NT == 0 || idx < BM * 8) {
+                float4 w = *reinterpret_cast<const float4*>(a.wf + (size_t)(co0 + row) * a.Kpad + k0 + qd * 4);
+                if (TAIL) {                                  // the K%4 remainder is chained after the combine
+                    const int kb = k0 + (qd >> 1) + 16 * (qd & 1);
+                    if (kb >= K4) w.x = 0.f;
+                    if (kb + 4 >= K4) w.y = 0.f;
+                    if (kb + 8 >= K4) w.z = 0.f;
+                    if (kb + 12 >= K4) w.w = 0.f;
+                }
+                wr[d][i] = w;
+            }
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int d, int buf) {
 #pragma unroll
-        for (int i = 0; i < XE; i++)
-            xs[buf][wv + i * NW][lane] = (xok >> i & 1u) ? dequant((uint8_t)xr[i], a.in_zp, a.in_scale) : 0.f;
+        for (int i = 0; i < XQ; i++) {
+            const int qd = su * XQ + i;
+            float4 v;
+            v.x = (xok[d] >> (4 * i + 0) & 1u) ? dequant((uint8_t)(xr[d][i]), a.in_zp, a.in_scale) : 0.f;
+            v.y = (xok[d] >> (4 * i + 1) & 1u) ? dequant((uint8_t)(xr[d][i] >> 8), a.in_zp, a.in_scale) : 0.f;
+            v.z = (xok[d] >> (4 * i + 2) & 1u) ? dequant((uint8_t)(xr[d][i] >> 16), a.in_zp, a.in_scale) : 0.f;
+            v.w = (xok[d] >> (4 * i + 3) & 1u) ? dequant((uint8_t)(xr[d][i] >> 24), a.in_zp, a.in_scale) : 0.f;
+            *reinterpret_cast<float4*>(xs + (buf * BN + sp) * LD + qd * 4) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WQ; i++) {
+            const int idx = tid + NT * i, row = idx >> 3, qd = idx & 7;
+            if (BM * 8 % NT == 0 || idx < BM * 8) *reinterpret_cast<float4*>(ws + (buf * BM + row) * LD + qd * 4) = wr[d][i];
+        }
     };
 
-    float acc[NCH][TC];
+    v4f acc[NCH][TM][TN];
 #pragma unroll
     for (int r = 0; r < NCH; r++)
 #pragma unroll
-        for (int j = 0; j < TC; j++) acc[r][j] = 0.f;
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[r][i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int nchunk = a.Kpad / KC;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ch++) {
-        const int cur = ch & 1, k0 = ch * KC;
-        if (ch + 1 < nchunk) gload(k0 + KC);
-        // the wave's weights of this stage are one contiguous run of KC*TC floats ([cout/TC][Kpad][TC] packing):
-        // scalar loads with immediate offsets, no address arithmetic in the loop
-        const cfloatp wk = wrow + (size_t)k0 * TC;
-#pragma unroll 1
-        for (int h = 0; h < KC; h += IB) {          // IB k per inner block bounds the live SGPRs to IB*TC <= 32
 #pragma unroll
-            for (int kk = 0; kk < IB; kk++) {
-                const int kl = h + kk;
-                const float xv = xs[cur][kl][lane];
-                const bool live = !TAIL || (k0 + kl) < K4;      // the K%4 remainder is chained after the combine
+    for (int d = 0; d < D; d++)
+        if (d < nchunk) gload(d, d * KC);
+    for (int ch0 = 0; ch0 < nchunk; ch0 += D) {
 #pragma unroll
-                for (int j = 0; j < TC; j++) {
-                    float w = wk[kl * TC + j];
-                    if (TAIL) w = __uint_as_float(__float_as_uint(w) & (live ? 0xffffffffu : 0u));     // scalar ALU
-                    float& s = acc[TAIL ? (kk & 3) : 0][j];
-                    s = __builtin_fmaf(xv, w, s);
+        for (int d = 0; d < D; d++) {
+            const int ch = ch0 + d;
+            if (ch >= nchunk) break;
+            const int cur = ch & 1;
+            sstore(d, cur);                                       // waits for stage ch's loads only
+            if (ch + D < nchunk) gload(d, (ch + D) * KC);         // refill the ring slot
+            __syncthreads();
+            const float* wsb = ws + cur * BM * LD;
+            const float* xsb = xs + cur * BN * LD;
+            if constexpr (!TAIL) {
+                float af[TM][8], bf[TN][8];
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const float* q = wsb + ((wm * TM + i) * 16 + l15) * LD + kq * 8;
+                    const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+                    af[i][0] = lo.x; af[i][1] = lo.y; af[i][2] = lo.z; af[i][3] = lo.w;
+                    af[i][4] = hi.x; af[i][5] = hi.y; af[i][6] = hi.z; af[i][7] = hi.w;
                 }
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const float* q = xsb + ((wn * TN + j) * 16 + l15) * LD + kq * 8;
+                    const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+                    bf[j][0] = lo.x; bf[j][1] = lo.y; bf[j][2] = lo.z; bf[j][3] = lo.w;
+                    bf[j][4] = hi.x; bf[j][5] = hi.y; bf[j][6] = hi.z; bf[j][7] = hi.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[0][i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+#pragma unroll
+                            for (int j = 0; j < TN; j++) {
+                                const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * 8 + 4 * s + kq];
+                                const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * 8 + 4 * s + kq];
+                                acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][i][j], 0, 0, 0);
+                            }
             }
         }
-        if (ch + 1 < nchunk) sstore(cur ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: this lane's pixel, the wave's TC channels ----------------------------------------------
-    if (!valid) return;
+    // ---- epilogue: D[row = 4*kq + e][col = l15] of each 16x16 tile ------------------------------------------
     const int OHW = a.OH * a.OW;
 #pragma unroll
-    for (int j = 0; j < TC; j++) {
-        const int co = co_w + j;
-        if (co >= a.cout) continue;
-        float s;
-        if constexpr (TAIL) {
-            const float s0 = acc[0][j], s1 = acc[1][j], s2 = acc[2][j], s3 = acc[3][j];
-            if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
-            else s = ((s0 + s1) + s2) + s3;
-            for (int k = K4; k < a.K; k++) {
-                const int ex = lutc[2 * k], ey = lutc[2 * k + 1];
-                const int iy = iy0 + (ey >> 16), ix = ix0 + (ey & 0xffff);
-                float v = 0.f;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = dequant(xin[pbase + ex], a.in_zp, a.in_scale);
-                s = __builtin_fmaf(wrow[(size_t)k * TC + j], v, s);
+    for (int j = 0; j < TN; j++) {
+        const int pj = jbase + (wn * TN + j) * 16 + l15;
+        if (pj >= jlimit) continue;
+        const int oy = pj / a.OW, ox = pj - oy * a.OW;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int co = co0 + (wm * TM + i) * 16 + 4 * kq + e;
+                if (co >= a.cout) continue;
+                float s;
+                if constexpr (TAIL) {
+                    const float s0 = acc[0][i][j][e], s1 = acc[1][i][j][e], s2 = acc[2][i][j][e], s3 = acc[3][i][j][e];
+                    if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
+                    else s = ((s0 + s1) + s2) + s3;
+                    for (int k = K4; k < a.K; k++) {
+                        const unsigned t = lut[k];
+                        const int iy = oy * a.SH - a.PH + (int)(t >> 28), ix = ox * a.SW - a.PW + (int)((t >> 24) & 15);
+                        float v = 0.f;
+                        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                            v = dequant(xin[(oy * a.SH - a.PH) * a.W + ox * a.SW - a.PW + (int)(t & 0xffffffu)], a.in_zp, a.in_scale);
+                        // packed position of k inside its 32-chunk: class k%4, position (k%32)/4
+                        const int kl = k & 31;
+                        s = __builtin_fmaf(a.wf[(size_t)co * a.Kpad + (k & ~31) + (kl & 3) * 8 + (kl >> 2)], v, s);
+                    }
+                } else
+                    s = acc[0][i][j][e];
+                if (a.bias) s = __builtin_fmaf((float)a.bias[co], a.bias_scale, s);
+                if (a.act == 0) s = s < 0.f ? 0.f : s;
+                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
             }
-        } else
-            s = acc[0][j];
-        if (a.bias) s = __builtin_fmaf((float)((cint32p)(uintptr_t)a.bias)[co], a.bias_scale, s);
-        if (a.act == 0) s = s < 0.f ? 0.f : s;
-        if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-        a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
     }
 }
 
-template <int NW, int TC>
-__global__ __launch_bounds__(NW * 64) void conv_u8_gemm_k(const U8ConvArgs a)
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_u8_gemm_k(const U8ConvArgs a)
 {
-    __shared__ float xs[2][16][64];
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ws = smem;                               // [2][BM][36]
+    float* xs = smem + 2 * BM * 36;                 // [2][BN][36]
+    unsigned* lut = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * 36);   // [Kpad]
+    for (int k = threadIdx.x; k < a.Kpad; k += 256) lut[k] = a.klut[k];
+    __syncthreads();
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    const int tiles = (N8 + 63) / 64;
-    const int n = blockIdx.z, co0 = blockIdx.y * (NW * TC);
-    if ((int)blockIdx.x < tiles) conv_u8_body<NW, TC, false>(a, xs, n, blockIdx.x * 64, N8, co0);
-    else conv_u8_body<NW, TC, true>(a, xs, n, N8, OHW, co0);
+    const int tiles = (N8 + BN - 1) / BN;
+    const int n = blockIdx.z, co0 = blockIdx.y * BM;
+    if ((int)blockIdx.x < tiles) conv_u8_body<WM, WN, TM, TN, false>(a, ws, xs, lut, n, blockIdx.x * BN, N8, co0);
+    else conv_u8_body<WM, WN, TM, TN, true>(a, ws, xs, lut, n, N8, OHW, co0);
 }
 
-// tile choice: the widest channel tile per wave that still leaves >= ~2 waves for each of the 1024 SIMDs.
-// The planner calls this once (geometry only), packs the weights for the chosen TC and stores the index in a.cfg.
-static const struct { int nw, tc; const char* name; } U8_CFGS[] = {
-    {4, 4, "conv_u8_px_w4x4"}, {8, 4, "conv_u8_px_w8x4"}, {16, 2, "conv_u8_px_w16x2"}, {16, 4, "conv_u8_px_w16x4"},
-    {16, 8, "conv_u8_px_w16x8"}};
+// tile choice: the largest block tile that still gives every CU at least two blocks (geometry only; the planner
+// stores the index in a.cfg)
+static const struct { int bm, bn; const char* name; } U8_CFGS[] = {
+    {16, 64, "conv_u8_mfma_16x64"}, {32, 32, "conv_u8_mfma_32x32"}, {64, 64, "conv_u8_mfma_64x64"}, {32, 64, "conv_u8_mfma_32x64"}};
 
 int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
     static const char* e = getenv("TAMD_U8_CFG");
-    if (e && *e) return atoi(e) % 5;
-    const int N8 = (a.OH * a.OW) & ~7;
-    const long ptiles = (long)((N8 + 63) / 64 + ((a.OH * a.OW) & 7 ? 1 : 0)) * a.N;
-    auto waves = [&](int nw, int tc) { return ptiles * ((a.cout + nw * tc - 1) / (nw * tc)) * nw; };
+    if (e && *e) return atoi(e) % 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
     if (a.cout <= 16) return 0;
-    if (a.cout <= 32) return 1;
-    if (waves(16, 8) >= 2048) return 4;
-    if (waves(16, 4) >= 2048) return 3;
-    return 2;
+    if (a.cout <= 32) return 3;
+    if (blocks(64, 64) >= 512) return 2;
+    if (blocks(32, 64) >= 384) return 3;
+    return 1;
 }
-int conv_u8_gemm_tc(int cfg) { return U8_CFGS[cfg].tc; }
+size_t conv_u8_gemm_lds(const U8ConvArgs& a) { return (size_t)(2 * (U8_CFGS[a.cfg].bm + U8_CFGS[a.cfg].bn) * 36 + a.Kpad) * 4; }
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a) { return U8_CFGS[a.cfg].name; }
 
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
-    const int nw = U8_CFGS[a.cfg].nw, tc = U8_CFGS[a.cfg].tc;
-    dim3 grid((N8 + 63) / 64 + (ntail ? 1 : 0), (a.cout + nw * tc - 1) / (nw * tc), a.N);
+    const int bm = U8_CFGS[a.cfg].bm, bn = U8_CFGS[a.cfg].bn;
+    const dim3 grid((N8 + bn - 1) / bn + (ntail ? 1 : 0), (a.cout + bm - 1) / bm, a.N);
+    const size_t lds = conv_u8_gemm_lds(a);
     switch (a.cfg) {
-    case 0: hipLaunchKernelGGL((conv_u8_gemm_k<4, 4>), grid, dim3(256), 0, s, a); break;
-    case 1: hipLaunchKernelGGL((conv_u8_gemm_k<8, 4>), grid, dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((conv_u8_gemm_k<16, 4>), grid, dim3(1024), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_u8_gemm_k<16, 8>), grid, dim3(1024), 0, s, a); break;
-    default: hipLaunchKernelGGL((conv_u8_gemm_k<16, 2>), grid, dim3(1024), 0, s, a); break;
+    case 0: hipLaunchKernelGGL((conv_u8_gemm_k<1, 4, 1, 1>), grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 2, 2>), grid, dim3(256), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 2>), grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 1>), grid, dim3(256), lds, s, a); break;
     }
     return hipGetLastError();
 }
