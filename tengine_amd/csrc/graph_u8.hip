@@ -46,7 +46,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     }
     Step st; st.node = n.name;
     st.macs = (double)y.n * y.h * y.w * cout * K;
-    st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 4.0 * cout * K;
+    st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 1.0 * cout * K;
     if (p.group == 1) {
         const int Kpad = rup(K, 32), cout_pad = rup(cout, 64);
         U8ConvArgs a{};
@@ -58,20 +58,21 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             set_error("conv %s: kernel extent / image size / K = %d outside the packed tap table of the uint8 GEMM kernel", n.name.c_str(), K);
             return -1;
         }
-        // [cout_pad][Kpad], every 32-k chunk class-major: slot (k%4)*8 + (k%32)/4 (u8_kernels.hip)
-        std::vector<float> wf((size_t)Kpad * cout_pad, 0.f);
+        // raw bytes, [cout tile][stage][row][32 slots], slot (k%4)*8 + (k%32)/4; padding = weight zero point
+        const int BM = conv_u8_gemm_bm(a.cfg), ntile = (cout + BM - 1) / BM, nstage = Kpad / 32;
+        std::vector<uint8_t> wq((size_t)ntile * nstage * BM * 32, (uint8_t)qw.zp);
         for (int co = 0; co < cout; co++)
             for (int k = 0; k < K; k++)
-                wf[(size_t)co * Kpad + (k & ~31) + (k & 3) * 8 + ((k & 31) >> 2)] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+                wq[(((size_t)(co / BM) * nstage + (k >> 5)) * BM + co % BM) * 32 + (k & 3) * 8 + ((k & 31) >> 2)] = w.data[(size_t)co * K + k];
         std::vector<unsigned> lut(Kpad, 0u);
         for (int k = 0; k < K; k++) {
             const int kx = k % p.kernel_w, ky = (k / p.kernel_w) % p.kernel_h, c = k / (p.kernel_w * p.kernel_h);
             lut[k] = (unsigned)(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w) | (unsigned)(kx * p.dilation_w) << 24
                      | (unsigned)(ky * p.dilation_h) << 28;
         }
-        float* dwf = nullptr; unsigned* dlut = nullptr;
-        if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
-        a.x = (const uint8_t*)x.dptr; a.wf = dwf; a.klut = dlut; a.bias = dbias; a.y = (uint8_t*)y.dptr;
+        uint8_t* dwq = nullptr; unsigned* dlut = nullptr;
+        if (upload(g, wq, &dwq) || upload(g, lut, &dlut)) return -1;
+        a.x = (const uint8_t*)x.dptr; a.wq = dwq; a.klut = dlut; a.w_scale = qw.scale; a.w_zp = (float)qw.zp; a.bias = dbias; a.y = (uint8_t*)y.dptr;
         a.out_img = cout * y.h * y.w; a.out_c0 = 0;
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;

@@ -120,8 +120,9 @@ struct U8Q { float scale; int zp; };
 
 struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
     const uint8_t* x;          // NCHW
-    const float* wf;           // [cout_pad][Kpad] dequantised weights, k = (c*KH+ky)*KW+kx, zero padded; inside every
-                               // 32-k chunk the order is class-major: slot (k%4)*8 + (k%32)/4
+    const uint8_t* wq;         // raw uint8 weights, [cout tile of BM][stage of 32 k][BM rows][32 slots]; BM =
+                               // conv_u8_gemm_bm(cfg); slot of k inside its stage: (k%4)*8 + (k%32)/4 (class-major);
+                               // padding holds the weight zero point (dequantises to exactly 0)
     const unsigned* klut;      // [Kpad] packed tap table: (c*H*W + ky*DH*W + kx*DW) | kx*DW << 24 | ky*DH << 28
                                // (padding rows: 0 -- their weights are 0 and fma(x, 0, s) == s for finite x)
     const int32_t* bias;       // may be null
@@ -132,6 +133,7 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int cfg;                   // conv_u8_gemm_pick(): block tile (channels x pixels)
     int m_blocked;             // rows below this sit in an 8- or 4-row block of the reference's sgemm_fp
     float in_scale, in_zp;     // zero point as float (exact)
+    float w_scale, w_zp;
     float bias_scale;          // in_scale * w_scale
     int act;
     float out_scale; int out_zp;
@@ -175,6 +177,7 @@ struct U8EltArgs {
 };
 
 int conv_u8_gemm_pick(const U8ConvArgs& a);        // geometry fields only
+int conv_u8_gemm_bm(int cfg);                      // channel rows per block tile (weight packing unit)
 size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the chosen configuration
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);

@@ -67,8 +67,8 @@ template <int WM, int WN, int TM, int TN, bool TAIL>
 __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restrict__ ws, float* __restrict__ xs,
                                              const unsigned* __restrict__ lut, int n, int jbase, int jlimit, int co0)
 {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, KC = 32, LD = 36, NT = 256, D = 3;
-    constexpr int XQ = BN / 32;                          // x quads (4 k of one class, one pixel) per thread per stage
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, KC = 32, LD = 36, NT = WM * WN * 64, D = 3;
+    constexpr int XQ = BN * 8 / NT;                      // x quads (4 k of one class, one pixel) per thread per stage
     constexpr int WQ = (BM * 8 + NT - 1) / NT;           // weight quads (float4) per thread per stage
     constexpr int NCH = TAIL ? 4 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,40 +84,31 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int pbase = iy0 * a.W + ix0;
 
-    unsigned xr[D][XQ];          // 4 raw bytes per quad
+    unsigned xr[D][XQ][4];       // raw bytes, one register each: packing here would make the loads wait at once
     unsigned xok[D];             // bit (4*i + e): element e of quad i is inside the image
-    float4 wr[D][WQ];
+    int k0s[D];                  // first k of the stage held in the slot
+    const unsigned* wtile = reinterpret_cast<const unsigned*>(a.wq) + (size_t)(co0 / BM) * (a.Kpad / KC) * (BM * 8);
+    unsigned wr[D][WQ];          // 4 raw weight bytes of one quad
     auto gload = [&](int d, int k0) {
         xok[d] = 0;
+        k0s[d] = k0;
 #pragma unroll
         for (int i = 0; i < XQ; i++) {
             const int qd = su * XQ + i, c = qd >> 1, pos0 = (qd & 1) * 4;
-            unsigned pack = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const unsigned t = lut[k0 + c + 4 * (pos0 + e)];            // off | dx << 24 | dy << 28
                 const int iy = iy0 + (int)(t >> 28), ix = ix0 + (int)((t >> 24) & 15);
                 const bool ok = svalid & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-                const unsigned u = xin[ok ? pbase + (int)(t & 0xffffffu) : 0];
-                pack |= u << (8 * e);
+                xr[d][i][e] = xin[ok ? pbase + (int)(t & 0xffffffu) : 0];
                 xok[d] |= ok ? 1u << (4 * i + e) : 0u;
             }
-            xr[d][i] = pack;
         }
 #pragma unroll
         for (int i = 0; i < WQ; i++) {
-            const int idx = tid + NT * i, row = idx >> 3, qd = idx & 7;
-            if (BM * 8 % NT == 0 || idx < BM * 8) {
-                float4 w = *reinterpret_cast<const float4*>(a.wf + (size_t)(co0 + row) * a.Kpad + k0 + qd * 4);
-                if (TAIL) {                                  // the K%4 remainder is chained after the combine
-                    const int kb = k0 + (qd >> 1) + 16 * (qd & 1);
-                    if (kb >= K4) w.x = 0.f;
-                    if (kb + 4 >= K4) w.y = 0.f;
-                    if (kb + 8 >= K4) w.z = 0.f;
-                    if (kb + 12 >= K4) w.w = 0.f;
-                }
-                wr[d][i] = w;
-            }
+            const int idx = tid + NT * i;
+            // the block's weight tile of a stage is BM*32 contiguous bytes ([cout tile][stage][row][32 slots])
+            if (BM * 8 % NT == 0 || idx < BM * 8) wr[d][i] = wtile[(size_t)(k0 / KC) * (BM * 8) + idx];
         }
     };
     auto sstore = [&](int d, int buf) {
@@ -125,16 +116,31 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
         for (int i = 0; i < XQ; i++) {
             const int qd = su * XQ + i;
             float4 v;
-            v.x = (xok[d] >> (4 * i + 0) & 1u) ? dequant((uint8_t)(xr[d][i]), a.in_zp, a.in_scale) : 0.f;
-            v.y = (xok[d] >> (4 * i + 1) & 1u) ? dequant((uint8_t)(xr[d][i] >> 8), a.in_zp, a.in_scale) : 0.f;
-            v.z = (xok[d] >> (4 * i + 2) & 1u) ? dequant((uint8_t)(xr[d][i] >> 16), a.in_zp, a.in_scale) : 0.f;
-            v.w = (xok[d] >> (4 * i + 3) & 1u) ? dequant((uint8_t)(xr[d][i] >> 24), a.in_zp, a.in_scale) : 0.f;
+            v.x = (xok[d] >> (4 * i + 0) & 1u) ? dequant((uint8_t)xr[d][i][0], a.in_zp, a.in_scale) : 0.f;
+            v.y = (xok[d] >> (4 * i + 1) & 1u) ? dequant((uint8_t)xr[d][i][1], a.in_zp, a.in_scale) : 0.f;
+            v.z = (xok[d] >> (4 * i + 2) & 1u) ? dequant((uint8_t)xr[d][i][2], a.in_zp, a.in_scale) : 0.f;
+            v.w = (xok[d] >> (4 * i + 3) & 1u) ? dequant((uint8_t)xr[d][i][3], a.in_zp, a.in_scale) : 0.f;
             *reinterpret_cast<float4*>(xs + (buf * BN + sp) * LD + qd * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < WQ; i++) {
             const int idx = tid + NT * i, row = idx >> 3, qd = idx & 7;
-            if (BM * 8 % NT == 0 || idx < BM * 8) *reinterpret_cast<float4*>(ws + (buf * BM + row) * LD + qd * 4) = wr[d][i];
+            if (BM * 8 % NT == 0 || idx < BM * 8) {
+                // conv_kernel_x86.c:68-80: w_fp32 = ((float)w - (float)zp) * scale
+                float4 w;
+                w.x = dequant((uint8_t)wr[d][i], a.w_zp, a.w_scale);
+                w.y = dequant((uint8_t)(wr[d][i] >> 8), a.w_zp, a.w_scale);
+                w.z = dequant((uint8_t)(wr[d][i] >> 16), a.w_zp, a.w_scale);
+                w.w = dequant((uint8_t)(wr[d][i] >> 24), a.w_zp, a.w_scale);
+                if (TAIL) {                                  // the K%4 remainder is chained after the combine
+                    const int kb = k0s[d] + (qd >> 1) + 16 * (qd & 1);
+                    if (kb >= K4) w.x = 0.f;
+                    if (kb + 4 >= K4) w.y = 0.f;
+                    if (kb + 8 >= K4) w.z = 0.f;
+                    if (kb + 12 >= K4) w.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(ws + (buf * BM + row) * LD + qd * 4) = w;
+            }
         }
     };
 
@@ -150,55 +156,64 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
 #pragma unroll
     for (int d = 0; d < D; d++)
         if (d < nchunk) gload(d, d * KC);
-    for (int ch0 = 0; ch0 < nchunk; ch0 += D) {
+    // one K stage: ring slot d -> LDS buffer ch&1, refill the slot with stage ch+D, barrier, MFMAs
+    auto stage = [&](int ch, int d, bool refill) {
+        const int cur = ch & 1;
+        __builtin_amdgcn_sched_barrier(0);                    // keep the scheduler from hoisting younger stages' unpacking
+        sstore(d, cur);                                       // (and with it their s_waitcnt) above this stage's MFMAs
+        if (refill) gload(d, (ch + D) * KC);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        const float* wsb = ws + cur * BM * LD;
+        const float* xsb = xs + cur * BN * LD;
+        if constexpr (!TAIL) {
+            float af[TM][8], bf[TN][8];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int ch = ch0 + d;
-            if (ch >= nchunk) break;
-            const int cur = ch & 1;
-            sstore(d, cur);                                       // waits for stage ch's loads only
-            if (ch + D < nchunk) gload(d, (ch + D) * KC);         // refill the ring slot
-            __syncthreads();
-            const float* wsb = ws + cur * BM * LD;
-            const float* xsb = xs + cur * BN * LD;
-            if constexpr (!TAIL) {
-                float af[TM][8], bf[TN][8];
+            for (int i = 0; i < TM; i++) {
+                const float* q = wsb + ((wm * TM + i) * 16 + l15) * LD + kq * 8;
+                const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+                af[i][0] = lo.x; af[i][1] = lo.y; af[i][2] = lo.z; af[i][3] = lo.w;
+                af[i][4] = hi.x; af[i][5] = hi.y; af[i][6] = hi.z; af[i][7] = hi.w;
+            }
 #pragma unroll
-                for (int i = 0; i < TM; i++) {
-                    const float* q = wsb + ((wm * TM + i) * 16 + l15) * LD + kq * 8;
-                    const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
-                    af[i][0] = lo.x; af[i][1] = lo.y; af[i][2] = lo.z; af[i][3] = lo.w;
-                    af[i][4] = hi.x; af[i][5] = hi.y; af[i][6] = hi.z; af[i][7] = hi.w;
-                }
+            for (int j = 0; j < TN; j++) {
+                const float* q = xsb + ((wn * TN + j) * 16 + l15) * LD + kq * 8;
+                const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+                bf[j][0] = lo.x; bf[j][1] = lo.y; bf[j][2] = lo.z; bf[j][3] = lo.w;
+                bf[j][4] = hi.x; bf[j][5] = hi.y; bf[j][6] = hi.z; bf[j][7] = hi.w;
+            }
 #pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    const float* q = xsb + ((wn * TN + j) * 16 + l15) * LD + kq * 8;
-                    const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
-                    bf[j][0] = lo.x; bf[j][1] = lo.y; bf[j][2] = lo.z; bf[j][3] = lo.w;
-                    bf[j][4] = hi.x; bf[j][5] = hi.y; bf[j][6] = hi.z; bf[j][7] = hi.w;
-                }
+            for (int s = 0; s < 8; s++)
 #pragma unroll
-                for (int s = 0; s < 8; s++)
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[0][i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int s = 0; s < 2; s++)
 #pragma unroll
                     for (int i = 0; i < TM; i++)
 #pragma unroll
-                        for (int j = 0; j < TN; j++)
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[0][i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int s = 0; s < 2; s++)
-#pragma unroll
-                        for (int i = 0; i < TM; i++)
-#pragma unroll
-                            for (int j = 0; j < TN; j++) {
-                                const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * 8 + 4 * s + kq];
-                                const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * 8 + 4 * s + kq];
-                                acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][i][j], 0, 0, 0);
-                            }
-            }
+                        for (int j = 0; j < TN; j++) {
+                            const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * 8 + 4 * s + kq];
+                            const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * 8 + 4 * s + kq];
+                            acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][i][j], 0, 0, 0);
+                        }
         }
+    };
+    int ch = 0;
+    // steady state: every refill is in range, the body is branch-free so the load counters stay exact
+    for (; ch + 2 * D <= nchunk; ch += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) stage(ch + d, d, true);
+    }
+    for (; ch < nchunk; ch += D) {                            // drain: at most 2*D-1 stages
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (ch + d < nchunk) stage(ch + d, d, ch + d + D < nchunk);
     }
 
     // ---- epilogue: D[row = 4*kq + e][col = l15] of each 16x16 tile ------------------------------------------
@@ -227,7 +242,8 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                             v = dequant(xin[(oy * a.SH - a.PH) * a.W + ox * a.SW - a.PW + (int)(t & 0xffffffu)], a.in_zp, a.in_scale);
                         // packed position of k inside its 32-chunk: class k%4, position (k%32)/4
                         const int kl = k & 31;
-                        s = __builtin_fmaf(a.wf[(size_t)co * a.Kpad + (k & ~31) + (kl & 3) * 8 + (kl >> 2)], v, s);
+                        const uint8_t wb = a.wq[((size_t)(co0 / BM) * (a.Kpad / KC) + (k >> 5)) * (BM * 32) + (co - co0) * 32 + (kl & 3) * 8 + (kl >> 2)];
+                        s = __builtin_fmaf(dequant(wb, a.w_zp, a.w_scale), v, s);
                     }
                 } else
                     s = acc[0][i][j][e];
@@ -240,53 +256,57 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
 }
 
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_u8_gemm_k(const U8ConvArgs a)
+__global__ __launch_bounds__(WM * WN * 64) void conv_u8_gemm_k(const U8ConvArgs a)
 {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ws = smem;                               // [2][BM][36]
     float* xs = smem + 2 * BM * 36;                 // [2][BN][36]
     unsigned* lut = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * 36);   // [Kpad]
-    for (int k = threadIdx.x; k < a.Kpad; k += 256) lut[k] = a.klut[k];
+    for (int k = threadIdx.x; k < a.Kpad; k += WM * WN * 64) lut[k] = a.klut[k];
     __syncthreads();
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    const int tiles = (N8 + BN - 1) / BN;
-    const int n = blockIdx.z, co0 = blockIdx.y * BM;
-    if ((int)blockIdx.x < tiles) conv_u8_body<WM, WN, TM, TN, false>(a, ws, xs, lut, n, blockIdx.x * BN, N8, co0);
+    const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
+    // x = (image, pixel tile): blocks that stream the same weight tile are neighbours in launch order (L2 reuse)
+    const int n = blockIdx.x / tpi, tile = blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
+    if (tile < tiles) conv_u8_body<WM, WN, TM, TN, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
     else conv_u8_body<WM, WN, TM, TN, true>(a, ws, xs, lut, n, N8, OHW, co0);
 }
 
 // tile choice: the largest block tile that still gives every CU at least two blocks (geometry only; the planner
 // stores the index in a.cfg)
 static const struct { int bm, bn; const char* name; } U8_CFGS[] = {
-    {16, 64, "conv_u8_mfma_16x64"}, {32, 32, "conv_u8_mfma_32x32"}, {64, 64, "conv_u8_mfma_64x64"}, {32, 64, "conv_u8_mfma_32x64"}};
+    {16, 64, "conv_u8_mfma_16x64"}, {32, 32, "conv_u8_mfma_32x32"}, {64, 64, "conv_u8_mfma_64x64"}, {32, 64, "conv_u8_mfma_32x64"},
+    {16, 16, "conv_u8_mfma_16x16"}};
 
 int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
     static const char* e = getenv("TAMD_U8_CFG");
-    if (e && *e) return atoi(e) % 4;
+    if (e && *e) return atoi(e) % 5;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
     if (a.cout <= 16) return 0;
     if (a.cout <= 32) return 3;
     if (blocks(64, 64) >= 512) return 2;
     if (blocks(32, 64) >= 384) return 3;
-    return 1;
+    if (blocks(32, 32) >= 512) return 1;
+    return 4;                                          // one wave per block: the most blocks (latency-bound layers)
 }
 size_t conv_u8_gemm_lds(const U8ConvArgs& a) { return (size_t)(2 * (U8_CFGS[a.cfg].bm + U8_CFGS[a.cfg].bn) * 36 + a.Kpad) * 4; }
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a) { return U8_CFGS[a.cfg].name; }
+int conv_u8_gemm_bm(int cfg) { return U8_CFGS[cfg].bm; }
 
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
     const int bm = U8_CFGS[a.cfg].bm, bn = U8_CFGS[a.cfg].bn;
-    const dim3 grid((N8 + bn - 1) / bn + (ntail ? 1 : 0), (a.cout + bm - 1) / bm, a.N);
+    const dim3 grid(((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
     const size_t lds = conv_u8_gemm_lds(a);
     switch (a.cfg) {
     case 0: hipLaunchKernelGGL((conv_u8_gemm_k<1, 4, 1, 1>), grid, dim3(256), lds, s, a); break;
     case 2: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 2, 2>), grid, dim3(256), lds, s, a); break;
     case 3: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 2>), grid, dim3(256), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((conv_u8_gemm_k<1, 1, 1, 1>), grid, dim3(64), lds, s, a); break;
     default: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 1>), grid, dim3(256), lds, s, a); break;
     }
     return hipGetLastError();
