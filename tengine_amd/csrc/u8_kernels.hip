@@ -42,7 +42,7 @@ __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { ret
 // group == 1 convolution: conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8, k = (c,ky,kx),
 // 0.0f at out-of-image taps), :322-960 sgemm_fp, :1703-1794 bias / activation / requantise.
 // Per image the GEMM is [cout] x [OH*OW] x [K]; an element's summation order depends on its place in the
-// reference's tiling (oracle/tg_oracle.c sgemm_fp_element restates it):
+// reference's tiling:
 //   pixel j <  (OH*OW)&~7 : one fused chain over k = 0..K-1                       -> "main" blocks
 //   pixel j >= (OH*OW)&~7 : four fused chains over k = r (mod 4), k < K&~3, combined
 //                           ((0+(s0+s1))+(s2+s3)) for rows in an 8-/4-row block, ((s0+s1)+s2)+s3 for the last

@@ -41,6 +41,7 @@ extern "C" {
 #include "fc_param.h"
 #include "pooling_param.h"
 #include "relu_param.h"
+#include "upsample_param.h"
 }
 
 #include "tengine_amd.h"
@@ -67,11 +68,12 @@ int map_op(int op)
     case OP_ELTWISE: return TAMD_OP_ELTWISE;
     case OP_CONCAT: return TAMD_OP_CONCAT;
     case OP_DROPOUT: return TAMD_OP_DROPOUT;
+    case OP_UPSAMPLE: return TAMD_OP_UPSAMPLE;
     default: return -1;
     }
 }
 
-const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT};
+const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT, OP_UPSAMPLE};
 
 bool op_supported(int op)
 {
@@ -142,6 +144,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
         tamd_relu_param rp;
         tamd_eltwise_param ep;
         tamd_concat_param ccp;
+        tamd_upsample_param up;
         const void* param = nullptr;
         switch (op) {
         case TAMD_OP_CONV: {
@@ -171,6 +174,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
             break;
         }
         case TAMD_OP_CONCAT: ccp.axis = ((const struct concat_param*)n->op.param_mem)->axis; param = &ccp; break;
+        case TAMD_OP_UPSAMPLE: up.scale = ((const struct upsample_param*)n->op.param_mem)->scale; param = &up; break;
         default: break;
         }
         tamd_node_desc nd;
@@ -288,6 +292,8 @@ int hip_describe(struct device* device, struct vector* allowed_ops, struct vecto
         if (!op_supported(i)) push_vector_data(blocked_ops, &i);
     int p = TENGINE_DT_INT8;
     push_vector_data(precision, &p);
+    p = TENGINE_DT_UINT8;
+    push_vector_data(precision, &p);
     return 0;
 }
 
@@ -322,7 +328,8 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
         if (!op_supported(n->op.type)) return false;
         for (int k = 0; k < n->output_num; k++) {
             struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
-            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8) return false;
+            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8) return false;
+            if (t->tensor_type != TENSOR_TYPE_CONST && !tamd_op_supported(map_op(n->op.type), t->data_type)) return false;
             if (t->tensor_type != TENSOR_TYPE_CONST && t->quant_param_num != 1) return false;
         }
         if (n->op.type == OP_ELTWISE) {

@@ -93,3 +93,26 @@ def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
     got = rg.outputs()[0]
     rg.close()
     assert np.array_equal(want, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["route", "yolov3_tiny"])
+def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
+    """uint8 through the reference's own API: device "HIP" == CPU device, byte for byte."""
+    from helpers import u8_route_graph
+    _load_plugin(ref)
+    if case == "route":
+        g, x = u8_route_graph(16, 2, 8, 6, 6)
+    else:
+        g = models.build("yolov3_tiny", "uint8", 1)
+        x = models.synth_input(g, 3, tm2.DT_UINT8)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_UINT8, 8)
+    rg = ref.RefGraph(b, ref.MODE_UINT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()
+    rg.close()
+    assert len(want) == len(got)
+    for w, o in zip(want, got):
+        assert np.array_equal(w, o)
