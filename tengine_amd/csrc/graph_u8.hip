@@ -9,6 +9,7 @@
 //   fc              weights -> fp32 as fc_ref.c:150-160, transposed to [hidden][nout_pad]
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "graph.h"
@@ -47,7 +48,60 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     Step st; st.node = n.name;
     st.macs = (double)y.n * y.h * y.w * cout * K;
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 1.0 * cout * K;
-    if (p.group == 1) {
+    static const char* dma_env = getenv("TAMD_U8_DMA");
+    const bool use_dma = dma_env && atoi(dma_env) != 0;      // measured no faster than the register-staged kernel
+    if (p.group == 1 && use_dma && (p.kernel_h - 1) * p.dilation_h <= 15 && (p.kernel_w - 1) * p.dilation_w <= 15
+        && (size_t)x.c * x.h * x.w < (1u << 24)) {
+        // ---- asynchronous fp32 MFMA kernel (conv_f32_mfma.hip): fp32 copy of the input + fp32 packed weights ----
+        const int Kpad = rup(K, 32), nstage = Kpad / 32;
+        F32ConvArgs a{};
+        a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout;
+        a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.cfg = conv_f32_mfma_pick(a);
+        const int BM = conv_f32_mfma_bm(a.cfg), ntile = (cout + BM - 1) / BM;
+        const int G = 64 / BM, NIg = 32 / G;                   // k rows per 64-float group, groups per stage
+        // w_fp32 = ((float)w - (float)zp) * scale (conv_kernel_x86.c:68-80); [tile][stage][group][ (k%G)*BM + c ]
+        std::vector<float> wf((size_t)ntile * nstage * 32 * BM, 0.f);
+        for (int co = 0; co < cout; co++)
+            for (int k = 0; k < K; k++) {
+                const int r = k & 31;
+                wf[(((size_t)(co / BM) * nstage + (k >> 5)) * NIg + r / G) * 64 + (r % G) * BM + co % BM] =
+                    ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+            }
+        std::vector<unsigned> lut(Kpad, 0u);
+        for (int k = 0; k < K; k++) {
+            const int kx = k % p.kernel_w, ky = (k / p.kernel_w) % p.kernel_h, c = k / (p.kernel_w * p.kernel_h);
+            lut[k] = (unsigned)(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w) | (unsigned)(kx * p.dilation_w) << 24
+                     | (unsigned)(ky * p.dilation_h) << 28;
+        }
+        float* dwf = nullptr; unsigned* dlut = nullptr;
+        if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
+        // the fp32 copy of the input tensor (shared by every conv that reads it; refreshed once per run)
+        float* xf = nullptr;
+        auto it = g->f32_copy.find(n.in[0]);
+        if (it == g->f32_copy.end()) {
+            void* pxf = nullptr;
+            if (dev_alloc(g, &pxf, x.elems() * sizeof(float), true)) return -1;
+            xf = (float*)pxf;
+            g->f32_copy[n.in[0]] = xf;
+            const uint8_t* src = (const uint8_t*)x.dptr;
+            const size_t cnt = x.elems();
+            const float zp = (float)qx.zp, sc = qx.scale;
+            Step dq; dq.node = x.name; dq.kernel = "dequant_u8_f32"; dq.bytes = 5.0 * cnt;
+            dq.fn = [src, xf, cnt, zp, sc](hipStream_t s) { return launch_dequant_u8_f32(src, xf, cnt, zp, sc, s); };
+            g->steps.push_back(dq);
+        } else
+            xf = it->second;
+        if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
+        a.x = xf; a.w = dwf; a.klut = dlut; a.zeros = (const float*)g->zero_page; a.bias = dbias; a.y = (uint8_t*)y.dptr;
+        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
+        a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
+        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
+        st.kernel = conv_f32_mfma_kernel_name(a);
+        st.bytes = 4.0 * x.elems() + (double)y.elems() + 4.0 * cout * K;
+        st.fn = [a](hipStream_t s) { return launch_conv_f32_mfma(a, s); };
+    } else if (p.group == 1) {
         const int Kpad = rup(K, 32), cout_pad = rup(cout, 64);
         U8ConvArgs a{};
         a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;

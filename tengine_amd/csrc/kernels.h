@@ -182,6 +182,32 @@ size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the c
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s);
+
+// group == 1 convolution as an fp32 GEMM on the matrix cores, operands streamed with LDS-DMA (conv_f32_mfma.hip).
+// Serves uint8 models (x = dequantised copy of the byte tensor, uint8 epilogue) and fp32 models (fp32 epilogue).
+struct F32ConvArgs {
+    const float* x;            // NCHW fp32
+    const float* w;            // packed fp32 weights: [cout tile of BM][stage of 32 k][row group][64], see graph_u8.hip
+    const unsigned* klut;      // [Kpad] packed tap table (as U8ConvArgs::klut)
+    const float* zeros;        // >= 4 zero bytes: source of out-of-image taps
+    const int32_t* bias;       // uint8 models (may be null)
+    const float* bias_f32;     // fp32 models (may be null)
+    uint8_t* y;                // uint8 output (NCHW) ...
+    float* out_f32;            // ... or fp32 output when non-null
+    int N, C, H, W, OH, OW, cout, K, Kpad;
+    int SH, SW, PH, PW;
+    int out_img, out_c0;       // elements per output image / channel offset
+    int cfg, m_blocked;
+    float bias_scale;
+    int act;
+    float out_scale; int out_zp;
+};
+int conv_f32_mfma_pick(const F32ConvArgs& a);      // geometry fields only
+int conv_f32_mfma_bm(int cfg);
+size_t conv_f32_mfma_lds(int cfg);
+const char* conv_f32_mfma_kernel_name(const F32ConvArgs& a);
+hipError_t launch_conv_f32_mfma(const F32ConvArgs& a, hipStream_t s);
+hipError_t launch_dequant_u8_f32(const uint8_t* x, float* y, size_t n, float zp, float scale, hipStream_t s);
 hipError_t launch_fc_u8(const U8FcArgs& a, hipStream_t s);
 hipError_t launch_pool_u8(const U8PoolArgs& a, hipStream_t s);
 hipError_t launch_relu_u8(const U8MapArgs& a, hipStream_t s);

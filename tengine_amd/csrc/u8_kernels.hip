@@ -198,6 +198,7 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                     for (int i = 0; i < TM; i++)
 #pragma unroll
                         for (int j = 0; j < TN; j++) {
+                            if (jbase + (wn * TN + j) * 16 >= jlimit) continue;      // no tail pixel in this 16-pixel column
                             const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * 8 + 4 * s + kq];
                             const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * 8 + 4 * s + kq];
                             acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][i][j], 0, 0, 0);
