@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 MFMA peak (2x bf16 2.5 PF)
+MFMA_F32_PEAK_TOPS = 157.3   # fp32 MFMA peak (the uint8 configs are fp32-simulated: u8_kernels.hip)
 
 
 class _CAI:
@@ -46,6 +47,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
     ap.add_argument("--model", default="mobilenet_v1")
+    ap.add_argument("--dtype", default="int8", choices=["int8", "uint8"],
+                    help="int8 = BASELINE metric; uint8 = the fp32-simulated configs (yolov3_tiny ...), side lines only")
     ap.add_argument("--streams", type=int, default=1, help="concurrent batch-1 graph instances (1 = sequential, tm_benchmark semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path with world_size 1 (test)")
@@ -74,7 +77,7 @@ def main():
 
     # ---- model: rank 0 synthesises the int8 tmfile, RCCL broadcast of the raw bytes ----------------
     if rank == 0:
-        g = models.build(args.model, "int8", args.batch)
+        g = models.build(args.model, args.dtype, args.batch, device_only=(args.model != "mobilenet_v1"))
         tm_bytes = tm2.write_tm2(g)
     if use_dist:
         from tengine_amd import dist as tdist
@@ -87,7 +90,8 @@ def main():
     S = max(1, args.streams)
     grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank) for _ in range(S)]
     gr = grs[0]
-    x = models.synth_input(g, 1000 + rank)       # each rank owns its own shard of images
+    u8 = args.dtype == "uint8"
+    x = models.synth_input(g, 1000 + rank, tm2.DT_UINT8 if u8 else tm2.DT_INT8)   # each rank owns its own shard of images
     for q in grs:
         q.set_input(x)
         q.upload()                               # inputs resident in HBM before the timed region
@@ -154,13 +158,14 @@ def main():
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
         t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
-        t_mfma = 2.0 * d["macs"] / (MFMA_I8_PEAK_TOPS * 1e12)
+        mfma_peak = MFMA_F32_PEAK_TOPS if u8 else MFMA_I8_PEAK_TOPS
+        t_mfma = 2.0 * d["macs"] / (mfma_peak * 1e12)
         if t_hbm >= t_mfma:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
         else:
             ach = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": ach / MFMA_I8_PEAK_TOPS}
+            roofline = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TOP/s", "frac": ach / mfma_peak}
         roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "traffic": None,
                          "kernel_time_share": d["ms"] / max(sum(f["ms"] for f in fam.values()), 1e-12),
@@ -169,7 +174,7 @@ def main():
     # ---- CPU baseline: the real reference backend on this host's cores (rank 0, N=1 only) ----------
     cpu = None
     if rank == 0 and (world == 1 and not args.force_dist) and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds)
+        cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds, u8)
 
     out = gr.download()[0]
     for q in grs:
@@ -177,11 +182,14 @@ def main():
     if rank == 0:
         value = world * args.batch * args.steps / el
         line = {
-            "metric": "images/sec int8 MobileNet-v1 224x224", "value": value, "unit": "images/s", "n_gpus": world,
+            "metric": "images/sec int8 MobileNet-v1 224x224" if (args.model, args.dtype) == ("mobilenet_v1", "int8")
+            else "images/sec %s %s" % (args.dtype, args.model), "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "%s int8 224x224 batch=%d per GPU (BASELINE configs[1]), weights = seeded synthetic "
-                                   "tmfile, input resident in HBM, hipGraph replay, %d stream(s)" % (args.model, args.batch, S),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (uint8 simulated in fp32, as the reference)" if u8 else "int8",
+            "data": "synthetic",
+            "config": {"workload": "%s %s batch=%d per GPU%s, weights = seeded synthetic tmfile, input resident in HBM, "
+                                   "hipGraph replay, %d stream(s)" % (args.model, args.dtype, args.batch,
+                                                                      " (BASELINE configs[1])" if (args.model, args.dtype, args.batch) == ("mobilenet_v1", "int8", 1) else "", S),
                        "streams": S,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if use_dist else "none"},
@@ -195,7 +203,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(tm_bytes, g, x, batch, budget_s):
+def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
     """Reference `source/device/cpu` path through create_graph/prerun/run_graph on the host cores."""
     import numpy as np
     threads = os.cpu_count() or 1
@@ -203,7 +211,7 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s):
         from oracle import ref_capi
         if not ref_capi.available():
             raise FileNotFoundError
-        rg = ref_capi.RefGraph(tm_bytes, ref_capi.MODE_INT8, threads)
+        rg = ref_capi.RefGraph(tm_bytes, ref_capi.MODE_UINT8 if u8 else ref_capi.MODE_INT8, threads)
         rg.set_input(x)
         rg.run()                                   # warm-up (weight packing, pool alloc)
         ts, t_end = [], time.perf_counter() + budget_s

@@ -31,6 +31,14 @@ def main():
     path = os.path.join(HERE, "yolov3_tiny_uint8_416_seed3.npz")
     np.savez_compressed(path, **{"out%d" % i: o for i, o in enumerate(outs)})
     print(path, [o.shape for o in outs], [len(np.unique(o)) for o in outs])
+    # uint8 classification nets: MobileNet-v1 (13 depthwise layers -> conv_ref formula) and ResNet-50 (eltwise, fc)
+    for name, dev_only in [("mobilenet_v1", False), ("resnet50", True)]:
+        g = models.build(name, "uint8", 1, device_only=dev_only)
+        x = models.synth_input(g, 5, tm2.DT_UINT8)
+        out = ref_capi.run_model(tm2.write_tm2(g), x, ref_capi.MODE_UINT8, os.cpu_count())[0]
+        path = os.path.join(HERE, "%s_uint8_seed5.npy" % name)
+        np.save(path, out)
+        print(path, out.shape, len(np.unique(out)))
 
 
 if __name__ == "__main__":

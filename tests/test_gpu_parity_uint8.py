@@ -129,3 +129,18 @@ def test_yolov3_tiny_uint8_416_matches_golden_of_real_reference():
     ref = np.load(golden)
     for i, o in enumerate(outs):
         assert np.array_equal(o.ravel(), ref["out%d" % i].ravel())
+
+
+@pytest.mark.parametrize("name,dev_only,batch", [("mobilenet_v1", False, 1), ("resnet50", True, 1), ("mobilenet_v1", False, 3)])
+def test_uint8_classifiers_bit_exact(name, dev_only, batch):
+    """MobileNet-v1 uint8 (depthwise -> conv_ref order, 1x1-map classifier) and ResNet-50 uint8 (eltwise, pools, fc)."""
+    import os
+    g = models.build(name, "uint8", batch, device_only=dev_only)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    got = run_hip(g, x)[0]
+    if batch == 1:
+        golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "%s_uint8_seed5.npy" % name))
+        assert np.array_equal(got.ravel(), golden.ravel())      # bytes of the REAL reference
+    else:
+        want = oracle.run_graph(g, x)[0]
+        assert np.array_equal(got.reshape(want.shape), want)

@@ -111,3 +111,14 @@ def test_uint8_quantizer_restatement():
     g2 = tm2.read_tm2(tm2.write_tm2(g))
     assert [t.zero_points for t in g2.tensors if t.dtype == tm2.DT_UINT8] == \
            [t.zero_points for t in g.tensors if t.dtype == tm2.DT_UINT8]
+
+
+@pytest.mark.parametrize("name,dev_only", [("mobilenet_v1", False), ("resnet50", True)])
+def test_uint8_classifiers_oracle_matches_golden_of_real_reference(name, dev_only):
+    """MobileNet-v1 uint8 (13 depthwise convs on the conv_ref formula, classifier = 1x1 conv on a 1x1 map, i.e. only
+    'tail' pixels) and ResNet-50 uint8 (eltwise, max/avg pool, fc): oracle == bytes of the real reference."""
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "%s_uint8_seed5.npy" % name))
+    g = models.build(name, "uint8", 1, device_only=dev_only)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    out = oracle.run_graph(g, x)[0]
+    assert np.array_equal(out.ravel(), golden.ravel())
