@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_k(const F32ConvArgs a)
     // ONE LDS object, nothing else read from LDS or global memory by vector loads inside the K loop: hipcc drains
     // vmcnt in front of any such read it cannot disambiguate from the in-flight LDS-DMA
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    const int OHW = a.OH * a.OW, N8 = a.tail_split ? (OHW & ~7) : OHW;
     const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
     const int PT = tpi * a.N, CT = (a.cout + BM - 1) / BM;
     // block -> (channel tile, pixel tile).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b%8) and
@@ -259,8 +259,8 @@ int conv_f32_mfma_pick(const F32ConvArgs& a)
 {
     static const char* e = getenv("TAMD_F32_CFG");
     if (e && *e) return atoi(e) % 5;
-    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
+    const int OHW = a.OH * a.OW, N8 = a.tail_split ? (OHW & ~7) : OHW;
+    auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW != N8 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
     if (OHW <= 16 && a.cout > 32) return 4;            // 1x1 .. 4x4 maps: 64 channels x 16 pixels
     if (a.cout <= 16) return 0;
     if (a.cout <= 32) return 3;
@@ -274,7 +274,7 @@ const char* conv_f32_mfma_kernel_name(const F32ConvArgs& a) { return F32_CFGS[a.
 
 hipError_t launch_conv_f32_mfma(const F32ConvArgs& a, hipStream_t s)
 {
-    const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
+    const int OHW = a.OH * a.OW, N8 = a.tail_split ? (OHW & ~7) : OHW, ntail = OHW - N8;
     const int bm = F32_CFGS[a.cfg].bm, bn = F32_CFGS[a.cfg].bn;
     const int PT = ((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, CT = (a.cout + bm - 1) / bm;
     const dim3 grid(CT >= 8 ? 8 * ((CT + 7) / 8) * PT : CT * PT, 1, 1);

@@ -102,6 +102,7 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
 void nhwc_geom(HTensor& t);
 int count_consumers(const tamd_graph* g, int tensor);
 int plan_u8(tamd_graph* g);        // graph_u8.hip: every activation tensor is uint8
+int plan_f32(tamd_graph* g);       // graph_f32.hip: every activation tensor is fp32
 
 template <typename T>
 int upload(tamd_graph* g, const std::vector<T>& host, T** dev)

@@ -579,8 +579,9 @@ const char* tamd_version(void) { return "tengine_amd 0.1 (gfx950)"; }
 
 int tamd_op_supported(int op, int dtype)
 {
-    if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8) return 0;
-    if (op == TAMD_OP_UPSAMPLE) return dtype == TAMD_DT_UINT8;     // nearest upsample: uint8 graphs only so far
+    if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
+    if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
+    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
     case TAMD_OP_ELTWISE: case TAMD_OP_CONCAT: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
@@ -677,11 +678,11 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     if (infer_shapes(g)) return -1;
     // one quantisation scheme per device graph (the reference's splitter hands over homogeneous subgraphs)
-    bool any_u8 = false, any_other = false;
+    bool any_u8 = false, any_f32 = false, any_i8 = false;
     for (auto& t : g->tensors)
-        if (t.ttype != TAMD_TT_CONST) (t.dtype == TAMD_DT_UINT8 ? any_u8 : any_other) = true;
-    if (any_u8 && any_other) { set_error("mixed uint8 / non-uint8 activations in one device graph"); return -1; }
-    if (any_u8 ? plan_u8(g) : plan(g)) return -1;
+        if (t.ttype != TAMD_TT_CONST) (t.dtype == TAMD_DT_UINT8 ? any_u8 : t.dtype == TAMD_DT_FP32 ? any_f32 : any_i8) = true;
+    if ((int)any_u8 + (int)any_f32 + (int)any_i8 > 1) { set_error("mixed int8 / uint8 / fp32 activations in one device graph"); return -1; }
+    if (any_u8 ? plan_u8(g) : any_f32 ? plan_f32(g) : plan(g)) return -1;
     HIPCHK(hipDeviceSynchronize());
     if (o.use_hip_graph) {
         // one warm eager pass (module load), then capture compute + output layout launches

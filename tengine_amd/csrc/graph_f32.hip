@@ -1,0 +1,205 @@
+// Planner for fp32 device graphs (config #1 plumbing, parity bar 1e-4, order-free).
+// Dense NCHW fp32 tensors -- the reference's own order, no layout pass at the graph edges.  group == 1 convolutions
+// and FC run on the matrix cores (conv_f32_mfma.hip, LDS-DMA operand ring); the reference's Winograd F(4,3) path
+// (wino_conv_kernel_x86.c) is a CPU speed-up with the same mathematical result, so it has no device counterpart.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "graph.h"
+
+namespace tamd {
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// conv (group 1) or FC as [cout] x [pixels] x [K] GEMM on the matrix cores
+static int plan_gemm_f32(tamd_graph* g, HNode& n, const float* xdev, int N, int C, int H, int W, int OH, int OW, int cout,
+                         int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW, int act, float* ydev)
+{
+    HTensor& w = g->tensors[n.in[1]];
+    HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+    const int K = C * KH * KW, Kpad = rup(K, 32), nstage = Kpad / 32;
+    if (w.dtype != TAMD_DT_FP32 || (size_t)cout * K * 4 != w.data.size()) { set_error("%s: fp32 weight size mismatch", n.name.c_str()); return -1; }
+    if ((KH - 1) * DH > 15 || (KW - 1) * DW > 15 || (size_t)C * H * W >= (1u << 24)) { set_error("%s: kernel extent / image size outside the packed tap table", n.name.c_str()); return -1; }
+    F32ConvArgs a{};
+    a.N = N; a.C = C; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.cout = cout; a.K = K; a.Kpad = Kpad;
+    a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW;
+    a.tail_split = 0;
+    a.cfg = conv_f32_mfma_pick(a);
+    const int BM = conv_f32_mfma_bm(a.cfg), ntile = (cout + BM - 1) / BM, G = 64 / BM, NIg = 32 / G;
+    const float* wsrc = (const float*)w.data.data();
+    std::vector<float> wf((size_t)ntile * nstage * 32 * BM, 0.f);
+    for (int co = 0; co < cout; co++)
+        for (int k = 0; k < K; k++) {
+            const int r = k & 31;
+            wf[(((size_t)(co / BM) * nstage + (k >> 5)) * NIg + r / G) * 64 + (r % G) * BM + co % BM] = wsrc[(size_t)co * K + k];
+        }
+    std::vector<unsigned> lut(Kpad, 0u);
+    for (int k = 0; k < K; k++) {
+        const int kx = k % KW, ky = (k / KW) % KH, c = k / (KW * KH);
+        lut[k] = (unsigned)(c * H * W + ky * DH * W + kx * DW) | (unsigned)(kx * DW) << 24 | (unsigned)(ky * DH) << 28;
+    }
+    float* dwf = nullptr; unsigned* dlut = nullptr;
+    if (upload(g, wf, &dwf) || upload(g, lut, &dlut)) return -1;
+    if (b) {
+        if (b->dtype != TAMD_DT_FP32) { set_error("%s: fp32 bias expected", n.name.c_str()); return -1; }
+        std::vector<float> hb((const float*)b->data.data(), (const float*)b->data.data() + cout);
+        float* d = nullptr;
+        if (upload(g, hb, &d)) return -1;
+        a.bias_f32 = d;
+    }
+    if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
+    a.x = xdev; a.w = dwf; a.klut = dlut; a.zeros = (const float*)g->zero_page; a.out_f32 = ydev;
+    a.out_img = cout * OH * OW; a.out_c0 = 0; a.act = act; a.out_scale = 1.f;
+    Step st; st.node = n.name; st.kernel = conv_f32_mfma_kernel_name(a);
+    st.macs = (double)N * OH * OW * cout * K;
+    st.bytes = 4.0 * ((double)N * C * H * W + (double)N * cout * OH * OW + (double)cout * K);
+    st.fn = [a](hipStream_t s) { return launch_conv_f32_mfma(a, s); };
+    g->steps.push_back(st);
+    return 0;
+}
+
+int plan_f32(tamd_graph* g)
+{
+    for (auto& t : g->tensors) {
+        if (t.ttype == TAMD_TT_CONST) continue;
+        nhwc_geom(t);
+        t.nchw_raw = true;
+        t.cs = 0; t.c_off = 0;
+    }
+    std::vector<int> alias_of(g->tensors.size(), -1);
+    for (auto& n : g->nodes)
+        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) alias_of[n.out[0]] = n.in[0];
+    for (auto& io : g->inputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems() * 4;
+        if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        t.dptr = io.stage;
+    }
+    for (size_t i = 0; i < g->tensors.size(); i++) {
+        HTensor& t = g->tensors[i];
+        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0) continue;
+        if (dev_alloc(g, &t.dptr, t.elems() * 4, true)) return -1;
+    }
+    for (int pass = 0; pass < 4; pass++)
+        for (size_t i = 0; i < g->tensors.size(); i++)
+            if (alias_of[i] >= 0) g->tensors[i].dptr = g->tensors[alias_of[i]].dptr;
+
+    for (auto& n : g->nodes) {
+        if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST || n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) continue;
+        HTensor& x = g->tensors[n.in[0]];
+        HTensor& y = g->tensors[n.out[0]];
+        switch (n.op) {
+        case TAMD_OP_CONV: {
+            const tamd_conv_param& p = n.p.conv;
+            if (p.group == 1) {
+                if (plan_gemm_f32(g, n, (const float*)x.dptr, x.n, x.c, x.h, x.w, y.h, y.w, y.c, p.kernel_h, p.kernel_w, p.stride_h,
+                                  p.stride_w, p.pad_h0, p.pad_w0, p.dilation_h, p.dilation_w, p.activation, (float*)y.dptr)) return -1;
+            } else {
+                HTensor& w = g->tensors[n.in[1]];
+                HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+                std::vector<float> hw((const float*)w.data.data(), (const float*)w.data.data() + w.data.size() / 4);
+                float* dw = nullptr; float* db = nullptr;
+                if (upload(g, hw, &dw)) return -1;
+                if (b) {
+                    std::vector<float> hb((const float*)b->data.data(), (const float*)b->data.data() + y.c);
+                    if (upload(g, hb, &db)) return -1;
+                }
+                F32DirectArgs a{};
+                a.x = (const float*)x.dptr; a.w = dw; a.bias = db; a.y = (float*)y.dptr;
+                a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = y.c;
+                a.KH = p.kernel_h; a.KW = p.kernel_w; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+                a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = p.group;
+                a.out_img = y.c * y.h * y.w; a.out_c0 = 0; a.act = p.activation;
+                Step st; st.node = n.name; st.kernel = "conv_f32_direct";
+                st.macs = (double)y.elems() * (x.c / p.group) * p.kernel_h * p.kernel_w;
+                st.bytes = 4.0 * ((double)x.elems() + (double)y.elems());
+                st.fn = [a](hipStream_t s) { return launch_conv_f32_direct(a, s); };
+                g->steps.push_back(st);
+            }
+            break;
+        }
+        case TAMD_OP_FC: {
+            const int batch = x.dims[0], hidden = (int)(x.elems() / batch);
+            if (plan_gemm_f32(g, n, (const float*)x.dptr, batch, hidden, 1, 1, 1, 1, y.c, 1, 1, 1, 1, 0, 0, 1, 1, -1, (float*)y.dptr)) return -1;
+            break;
+        }
+        case TAMD_OP_POOL: {
+            PoolGeom pg = pool_geom(n.p.pool, x.h, x.w);
+            F32PoolArgs a{};
+            a.x = (const float*)x.dptr; a.y = (float*)y.dptr;
+            a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w;
+            a.KH = pg.kh; a.KW = pg.kw; a.SH = pg.sh; a.SW = pg.sw; a.PH = pg.ph0; a.PW = pg.pw0;
+            a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
+            Step st; st.node = n.name; st.kernel = "pool_f32"; st.bytes = 4.0 * ((double)x.elems() + (double)y.elems());
+            st.fn = [a](hipStream_t s) { return launch_pool_f32(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_RELU: case TAMD_OP_RELU6: case TAMD_OP_UPSAMPLE: {
+            F32MapArgs a{};
+            a.x = (const float*)x.dptr; a.y = (float*)y.dptr;
+            a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w;
+            a.scale = n.op == TAMD_OP_UPSAMPLE ? (int)n.p.ups.scale : 1;
+            a.out_img = y.c * y.h * y.w; a.out_c0 = 0;
+            a.slope = n.op == TAMD_OP_RELU ? n.p.relu.negative_slope : 0.f;
+            const int mode = n.op == TAMD_OP_RELU ? 0 : (n.op == TAMD_OP_UPSAMPLE ? 2 : 3);
+            Step st; st.node = n.name; st.kernel = mode == 2 ? "upsample_f32" : "relu_f32"; st.bytes = 4.0 * ((double)x.elems() + (double)y.elems());
+            st.fn = [a, mode](hipStream_t s) { return launch_map_f32(a, mode, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_CONCAT: {
+            int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+            if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+            int off = 0;
+            for (int i : n.in) {
+                HTensor& xi = g->tensors[i];
+                F32MapArgs a{};
+                a.x = (const float*)xi.dptr; a.y = (float*)y.dptr;
+                a.N = xi.n; a.C = xi.c; a.H = xi.h; a.W = xi.w; a.scale = 1;
+                a.out_img = y.c * y.h * y.w; a.out_c0 = off;
+                Step st; st.node = n.name; st.kernel = "concat_f32"; st.bytes = 8.0 * xi.elems();
+                st.fn = [a](hipStream_t s) { return launch_map_f32(a, 1, s); };
+                g->steps.push_back(st);
+                off += xi.c;
+            }
+            break;
+        }
+        case TAMD_OP_ELTWISE: {
+            HTensor& xb = g->tensors[n.in[1]];
+            const int type = n.p.elt.type;
+            if (x.dims != xb.dims || (type != 0 && type != 2 && type != 4 && type != 6)) { set_error("eltwise %s: broadcast / type %d unsupported", n.name.c_str(), type); return -1; }
+            const float* pa = (const float*)x.dptr; const float* pb = (const float*)xb.dptr; float* py = (float*)y.dptr;
+            const size_t cnt = x.elems();
+            Step st; st.node = n.name; st.kernel = "eltwise_f32"; st.bytes = 12.0 * cnt;
+            st.fn = [pa, pb, py, cnt, type](hipStream_t s) { return launch_eltwise_f32(pa, pb, py, cnt, type, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_SOFTMAX: {
+            // softmax_param.axis is 1 (channels) in every config graph; the ABI carries no other axis
+            const float* px = (const float*)x.dptr; float* py = (float*)y.dptr;
+            const int N = x.dims[0], C = x.dims.size() > 1 ? x.dims[1] : 1;
+            const int inner = (int)(x.elems() / ((size_t)N * C));
+            Step st; st.node = n.name; st.kernel = "softmax_f32"; st.bytes = 8.0 * x.elems();
+            st.fn = [px, py, N, C, inner](hipStream_t s) { return launch_softmax_f32(px, py, N, C, inner, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        default:
+            set_error("op %d (%s) is not supported on the device for fp32", n.op, n.name.c_str());
+            return -1;
+        }
+    }
+    for (auto& io : g->outputs) {
+        HTensor& t = g->tensors[io.tensor];
+        io.bytes = t.elems() * 4;
+        HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        io.stage = t.dptr;
+    }
+    return 0;
+}
+
+}  // namespace tamd

@@ -57,6 +57,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         F32ConvArgs a{};
         a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout;
         a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
+        a.tail_split = 1;
         a.cfg = conv_f32_mfma_pick(a);
         const int BM = conv_f32_mfma_bm(a.cfg), ntile = (cout + BM - 1) / BM;
         const int G = 64 / BM, NIg = 32 / G;                   // k rows per 64-float group, groups per stage

@@ -198,6 +198,7 @@ struct F32ConvArgs {
     int SH, SW, PH, PW;
     int out_img, out_c0;       // elements per output image / channel offset
     int cfg, m_blocked;
+    int tail_split;            // 1: uint8 models (the reference's tail-pixel summation order); 0: fp32 models (order-free)
     float bias_scale;
     int act;
     float out_scale; int out_zp;
@@ -208,6 +209,28 @@ size_t conv_f32_mfma_lds(int cfg);
 const char* conv_f32_mfma_kernel_name(const F32ConvArgs& a);
 hipError_t launch_conv_f32_mfma(const F32ConvArgs& a, hipStream_t s);
 hipError_t launch_dequant_u8_f32(const uint8_t* x, float* y, size_t n, float zp, float scale, hipStream_t s);
+
+// ---- fp32 models (f32_kernels.hip): dense NCHW fp32 ------------------------------------------------------------------
+struct F32DirectArgs {         // grouped / depthwise convolution
+    const float* x; const float* w; const float* bias; float* y;
+    int N, C, H, W, OH, OW, cout, KH, KW, SH, SW, PH, PW, DH, DW, group;
+    int out_img, out_c0, act;
+};
+struct F32PoolArgs {
+    const float* x; float* y;
+    int N, C, H, W, OH, OW, KH, KW, SH, SW, PH, PW, method, caffe_flavor;
+};
+struct F32MapArgs {            // relu / leaky / relu6, concat slice copy, nearest upsample
+    const float* x; float* y;
+    int N, C, H, W;            // INPUT geometry
+    int out_img, out_c0, scale;
+    float slope;
+};
+hipError_t launch_conv_f32_direct(const F32DirectArgs& a, hipStream_t s);
+hipError_t launch_pool_f32(const F32PoolArgs& a, hipStream_t s);
+hipError_t launch_map_f32(const F32MapArgs& a, int mode, hipStream_t s);   // 0 relu/leaky, 1 concat copy, 2 upsample, 3 relu6
+hipError_t launch_eltwise_f32(const float* a, const float* b, float* y, size_t count, int type, hipStream_t s);
+hipError_t launch_softmax_f32(const float* x, float* y, int N, int C, int inner, hipStream_t s);
 hipError_t launch_fc_u8(const U8FcArgs& a, hipStream_t s);
 hipError_t launch_pool_u8(const U8PoolArgs& a, hipStream_t s);
 hipError_t launch_relu_u8(const U8MapArgs& a, hipStream_t s);

@@ -1,0 +1,74 @@
+"""GPU parity, fp32: the HIP backend through the C ABI against the CPU oracle (double-accumulated
+restatement, itself within 1e-5 of the real reference: tests/test_fp32_oracle.py).  Tolerance 1e-4, written here:
+|device - oracle| <= 1e-4 + 1e-4 * |oracle|."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tengine_amd import capi, models, tm2
+from tengine_amd.tm2 import DT_FP32, Graph
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def run_hip(g, x):
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    out = gr.run()
+    gr.close()
+    return out
+
+
+def conv_graph_f32(seed, n, cin, h, w, cout, k, s=1, p=0, group=1, act=0, bias=True, dil=1):
+    rng = np.random.default_rng(seed)
+    g = Graph(name="conv_f32_case")
+    x = g.add_input("data", [n, cin, h, w], DT_FP32, None, None)
+    fan = (cin // group) * k * k
+    ins = [x, g.add_const("w", rng.normal(0, np.sqrt(2.0 / fan), size=(cout, cin // group, k, k)).astype(np.float32), DT_FP32, None, None)]
+    if bias:
+        ins.append(g.add_const("b", rng.uniform(-0.1, 0.1, size=(cout,)).astype(np.float32), DT_FP32, None, None))
+    oh = (h - dil * (k - 1) - 1 + 2 * p) // s + 1
+    ow = (w - dil * (k - 1) - 1 + 2 * p) // s + 1
+    y = g.add_tensor("out", [n, cout, oh, ow], DT_FP32, tm2.TT_VAR, None, None, None)
+    ni = g.add_node("conv", "Convolution", ins, [y], kernel_h=k, kernel_w=k, stride_h=s, stride_w=s, dilation_h=dil,
+                    dilation_w=dil, input_channel=cin, output_channel=cout, group=group, activation=act, pad_h0=p,
+                    pad_w0=p, pad_h1=p, pad_w1=p)
+    g.output_nodes = [ni]
+    return g, rng.normal(0, 1, size=(n, cin, h, w)).astype(np.float32)
+
+
+F32_CONV = [
+    (1, 3, 64, 64, 16, 3, 2, 1, 1, 0, True, 1),
+    (2, 64, 20, 20, 128, 3, 1, 1, 1, 0, True, 1),
+    (1, 128, 13, 13, 255, 1, 1, 0, 1, -1, True, 1),
+    (1, 256, 13, 13, 512, 3, 1, 1, 1, 6, False, 1),
+    (3, 7, 9, 11, 13, 3, 1, 1, 1, -1, True, 1),
+    (1, 32, 12, 12, 16, 3, 1, 2, 1, 0, True, 2),
+    (4, 64, 1, 1, 10, 1, 1, 0, 1, -1, True, 1),
+    (1, 32, 12, 12, 32, 3, 1, 1, 32, 0, True, 1),
+    (2, 24, 13, 13, 24, 3, 2, 1, 24, 6, True, 1),
+]
+
+
+@pytest.mark.parametrize("case", F32_CONV, ids=[str(c) for c in F32_CONV])
+def test_conv_f32(case):
+    n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
+    g, x = conv_graph_f32(3 + cin + cout, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
+    want = oracle.run_graph(g, x)[0]
+    got = run_hip(g, x)[0].reshape(want.shape)
+    assert got.dtype == np.float32
+    assert np.allclose(got, want, **TOL), "max |d| %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("name,batch", [("squeezenet_v1.1", 1), ("squeezenet_v1.1", 4), ("mobilenet_v1", 2)])
+def test_fp32_models(name, batch):
+    """BASELINE configs[0] (SqueezeNet-v1.1 fp32 227x227: conv / fire concat / max+avg pool / dropout / softmax) and
+    MobileNet-v1 fp32 (depthwise)."""
+    g = models.build(name, "fp32", batch)
+    x = models.synth_input(g, 5, DT_FP32)
+    want = oracle.run_graph(g, x)
+    got = run_hip(g, x)
+    for w, o in zip(want, got):
+        assert np.allclose(o.reshape(w.shape), w, **TOL), "max |d| %g" % np.abs(o.reshape(w.shape) - w).max()
+        assert np.abs(w).max() > 1e-3
