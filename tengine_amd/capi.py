@@ -151,6 +151,10 @@ class Graph:
     def stream(self):
         return lib().tamd_graph_stream(self._h)
 
+    def kernel_num(self):
+        """number of compute launches of one forward pass"""
+        return lib().tamd_graph_kernel_num(self._h)
+
     def profile(self, iters=10):
         n = lib().tamd_graph_kernel_num(self._h)
         arr = (KernelInfo * n)()

@@ -859,6 +859,12 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
     size_t need = t.elems() * esize(t.dtype);
     if (bytes != need) { set_error("read_tensor: %zu bytes given, %zu needed", bytes, need); return -1; }
     HIPCHK(hipStreamSynchronize(g->stream));
+    if (t.nchw_raw && t.is_view) {      // NCHW channel slice of a concat buffer (uint8 / fp32 planners): one row per image
+        const size_t es = esize(t.dtype), img = (size_t)t.c * t.h * t.w * es;
+        HIPCHK(hipMemcpy2D(host, img, (const char*)t.dptr + (size_t)t.c_off * t.h * t.w * es, (size_t)t.cs * t.h * t.w * es, img,
+                           (size_t)t.n, hipMemcpyDeviceToHost));
+        return 0;
+    }
     if (t.nchw_raw) { HIPCHK(hipMemcpy(host, t.dptr, need, hipMemcpyDeviceToHost)); return 0; }
     void* tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, need));

@@ -14,7 +14,7 @@ static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // conv (group 1) or FC as [cout] x [pixels] x [K] GEMM on the matrix cores
 static int plan_gemm_f32(tamd_graph* g, HNode& n, const float* xdev, int N, int C, int H, int W, int OH, int OW, int cout,
-                         int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW, int act, float* ydev)
+                         int KH, int KW, int SH, int SW, int PH, int PW, int DH, int DW, int act, float* ydev, int oimg, int oc0)
 {
     HTensor& w = g->tensors[n.in[1]];
     HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
@@ -50,7 +50,7 @@ static int plan_gemm_f32(tamd_graph* g, HNode& n, const float* xdev, int N, int 
     }
     if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
     a.x = xdev; a.w = dwf; a.klut = dlut; a.zeros = (const float*)g->zero_page; a.out_f32 = ydev;
-    a.out_img = cout * OH * OW; a.out_c0 = 0; a.act = act; a.out_scale = 1.f;
+    a.out_img = oimg; a.out_c0 = oc0; a.act = act; a.out_scale = 1.f;
     Step st; st.node = n.name; st.kernel = conv_f32_mfma_kernel_name(a);
     st.macs = (double)N * OH * OW * cout * K;
     st.bytes = 4.0 * ((double)N * C * H * W + (double)N * cout * OH * OW + (double)cout * K);
@@ -77,14 +77,44 @@ int plan_f32(tamd_graph* g)
         HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
         t.dptr = io.stage;
     }
+    // concat-by-offset: a conv / relu / upsample whose only consumer is a channel concat writes its
+    // channels straight into the concat output (kernel arguments out_img / out_c0); the concat launch disappears
+    std::vector<int> view_of(g->tensors.size(), -1), view_off(g->tensors.size(), 0);
+    for (auto& n : g->nodes) {
+        if (n.op != TAMD_OP_CONCAT) continue;
+        HTensor& y = g->tensors[n.out[0]];
+        const int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+        int off = 0;
+        for (int i : n.in) {
+            HTensor& xi = g->tensors[i];
+            bool ok = ax == 1 && xi.ttype == TAMD_TT_VAR && count_consumers(g, i) == 1 && alias_of[i] < 0 && view_of[i] < 0;
+            if (ok) {
+                ok = false;
+                for (auto& pn : g->nodes)
+                    if (!pn.out.empty() && pn.out[0] == i)
+                        ok = pn.op == TAMD_OP_CONV || pn.op == TAMD_OP_RELU || pn.op == TAMD_OP_RELU6 || pn.op == TAMD_OP_UPSAMPLE;
+            }
+            if (ok) { view_of[i] = n.out[0]; view_off[i] = off; }
+            off += xi.c;
+        }
+    }
     for (size_t i = 0; i < g->tensors.size(); i++) {
         HTensor& t = g->tensors[i];
-        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0) continue;
+        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0 || view_of[i] >= 0) continue;
         if (dev_alloc(g, &t.dptr, t.elems() * 4, true)) return -1;
     }
+    for (size_t i = 0; i < g->tensors.size(); i++)
+        if (view_of[i] >= 0) {
+            HTensor& t = g->tensors[i];
+            HTensor& o = g->tensors[view_of[i]];
+            if (!o.dptr) { set_error("concat of concat views is not supported"); return -1; }
+            t.dptr = o.dptr; t.is_view = true; t.c_off = view_off[i]; t.cs = o.c;      // cs: channels of the enclosing buffer
+        }
     for (int pass = 0; pass < 4; pass++)
         for (size_t i = 0; i < g->tensors.size(); i++)
             if (alias_of[i] >= 0) g->tensors[i].dptr = g->tensors[alias_of[i]].dptr;
+    // output placement of a tensor: elements per image of the buffer it lives in, first channel
+    auto out_img = [](const HTensor& t) { return (t.is_view ? t.cs : t.c) * t.h * t.w; };
 
     for (auto& n : g->nodes) {
         if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST || n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) continue;
@@ -95,7 +125,7 @@ int plan_f32(tamd_graph* g)
             const tamd_conv_param& p = n.p.conv;
             if (p.group == 1) {
                 if (plan_gemm_f32(g, n, (const float*)x.dptr, x.n, x.c, x.h, x.w, y.h, y.w, y.c, p.kernel_h, p.kernel_w, p.stride_h,
-                                  p.stride_w, p.pad_h0, p.pad_w0, p.dilation_h, p.dilation_w, p.activation, (float*)y.dptr)) return -1;
+                                  p.stride_w, p.pad_h0, p.pad_w0, p.dilation_h, p.dilation_w, p.activation, (float*)y.dptr, out_img(y), y.c_off)) return -1;
             } else {
                 HTensor& w = g->tensors[n.in[1]];
                 HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
@@ -111,7 +141,7 @@ int plan_f32(tamd_graph* g)
                 a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = y.c;
                 a.KH = p.kernel_h; a.KW = p.kernel_w; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
                 a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = p.group;
-                a.out_img = y.c * y.h * y.w; a.out_c0 = 0; a.act = p.activation;
+                a.out_img = out_img(y); a.out_c0 = y.c_off; a.act = p.activation;
                 Step st; st.node = n.name; st.kernel = "conv_f32_direct";
                 st.macs = (double)y.elems() * (x.c / p.group) * p.kernel_h * p.kernel_w;
                 st.bytes = 4.0 * ((double)x.elems() + (double)y.elems());
@@ -122,7 +152,7 @@ int plan_f32(tamd_graph* g)
         }
         case TAMD_OP_FC: {
             const int batch = x.dims[0], hidden = (int)(x.elems() / batch);
-            if (plan_gemm_f32(g, n, (const float*)x.dptr, batch, hidden, 1, 1, 1, 1, y.c, 1, 1, 1, 1, 0, 0, 1, 1, -1, (float*)y.dptr)) return -1;
+            if (plan_gemm_f32(g, n, (const float*)x.dptr, batch, hidden, 1, 1, 1, 1, y.c, 1, 1, 1, 1, 0, 0, 1, 1, -1, (float*)y.dptr, y.c, 0)) return -1;
             break;
         }
         case TAMD_OP_POOL: {
@@ -142,7 +172,7 @@ int plan_f32(tamd_graph* g)
             a.x = (const float*)x.dptr; a.y = (float*)y.dptr;
             a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w;
             a.scale = n.op == TAMD_OP_UPSAMPLE ? (int)n.p.ups.scale : 1;
-            a.out_img = y.c * y.h * y.w; a.out_c0 = 0;
+            a.out_img = out_img(y); a.out_c0 = y.c_off;
             a.slope = n.op == TAMD_OP_RELU ? n.p.relu.negative_slope : 0.f;
             const int mode = n.op == TAMD_OP_RELU ? 0 : (n.op == TAMD_OP_UPSAMPLE ? 2 : 3);
             Step st; st.node = n.name; st.kernel = mode == 2 ? "upsample_f32" : "relu_f32"; st.bytes = 4.0 * ((double)x.elems() + (double)y.elems());
@@ -156,6 +186,7 @@ int plan_f32(tamd_graph* g)
             int off = 0;
             for (int i : n.in) {
                 HTensor& xi = g->tensors[i];
+                if (xi.is_view && xi.dptr == y.dptr) { off += xi.c; continue; }      // written in place by its producer
                 F32MapArgs a{};
                 a.x = (const float*)xi.dptr; a.y = (float*)y.dptr;
                 a.N = xi.n; a.C = xi.c; a.H = xi.h; a.W = xi.w; a.scale = 1;

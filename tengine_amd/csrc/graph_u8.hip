@@ -95,7 +95,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             xf = it->second;
         if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
         a.x = xf; a.w = dwf; a.klut = dlut; a.zeros = (const float*)g->zero_page; a.bias = dbias; a.y = (uint8_t*)y.dptr;
-        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.out_img = (y.is_view ? y.cs : cout) * y.h * y.w; a.out_c0 = y.c_off;
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
         a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
@@ -128,7 +128,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         uint8_t* dwq = nullptr; unsigned* dlut = nullptr;
         if (upload(g, wq, &dwq) || upload(g, lut, &dlut)) return -1;
         a.x = (const uint8_t*)x.dptr; a.wq = dwq; a.klut = dlut; a.w_scale = qw.scale; a.w_zp = (float)qw.zp; a.bias = dbias; a.y = (uint8_t*)y.dptr;
-        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.out_img = (y.is_view ? y.cs : cout) * y.h * y.w; a.out_c0 = y.c_off;
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
@@ -145,7 +145,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout;
         a.KH = p.kernel_h; a.KW = p.kernel_w; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = p.group;
-        a.out_img = cout * y.h * y.w; a.out_c0 = 0;
+        a.out_img = (y.is_view ? y.cs : cout) * y.h * y.w; a.out_c0 = y.c_off;
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp; a.w_scale = qw.scale;
         a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
         st.kernel = "conv_u8_direct";
@@ -208,11 +208,41 @@ int plan_u8(tamd_graph* g)
         HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
         t.dptr = io.stage;
     }
+    // concat-by-offset: when an input carries the concat output's (scale, zero point) the reference's
+    // per-element rescale roundf((u - zp) * 1 + zp) is the identity (concat_kernel_ref_uint8.c:309-352), so a conv /
+    // relu / upsample whose only consumer is that concat writes its channels straight into the concat output
+    std::vector<int> view_of(g->tensors.size(), -1), view_off(g->tensors.size(), 0);
+    for (auto& n : g->nodes) {
+        if (n.op != TAMD_OP_CONCAT) continue;
+        HTensor& y = g->tensors[n.out[0]];
+        const int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+        int off = 0;
+        for (int i : n.in) {
+            HTensor& xi = g->tensors[i];
+            bool ok = ax == 1 && xi.ttype == TAMD_TT_VAR && count_consumers(g, i) == 1 && alias_of[i] < 0 && view_of[i] < 0
+                      && !xi.scales.empty() && !y.scales.empty() && xi.scales[0] == y.scales[0]
+                      && (xi.zps.empty() ? 0 : xi.zps[0]) == (y.zps.empty() ? 0 : y.zps[0]);
+            if (ok) {
+                ok = false;
+                for (auto& pn : g->nodes)
+                    if (!pn.out.empty() && pn.out[0] == i) ok = pn.op == TAMD_OP_CONV || pn.op == TAMD_OP_RELU || pn.op == TAMD_OP_UPSAMPLE;
+            }
+            if (ok) { view_of[i] = n.out[0]; view_off[i] = off; }
+            off += xi.c;
+        }
+    }
     for (size_t i = 0; i < g->tensors.size(); i++) {
         HTensor& t = g->tensors[i];
-        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0) continue;
+        if (t.ttype == TAMD_TT_CONST || t.dptr || alias_of[i] >= 0 || view_of[i] >= 0) continue;
         if (dev_alloc(g, &t.dptr, t.elems(), true)) return -1;
     }
+    for (size_t i = 0; i < g->tensors.size(); i++)
+        if (view_of[i] >= 0) {
+            HTensor& t = g->tensors[i];
+            HTensor& o = g->tensors[view_of[i]];
+            if (!o.dptr) { set_error("concat of concat views is not supported"); return -1; }
+            t.dptr = o.dptr; t.is_view = true; t.c_off = view_off[i]; t.cs = o.c;      // cs: channels of the enclosing buffer
+        }
     for (int pass = 0; pass < 4; pass++)
         for (size_t i = 0; i < g->tensors.size(); i++)
             if (alias_of[i] >= 0) g->tensors[i].dptr = g->tensors[alias_of[i]].dptr;
@@ -250,7 +280,7 @@ int plan_u8(tamd_graph* g)
             a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
             a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w;
             a.scale = n.op == TAMD_OP_UPSAMPLE ? (int)n.p.ups.scale : 1;
-            a.out_img = y.c * y.h * y.w; a.out_c0 = 0;
+            a.out_img = (y.is_view ? y.cs : y.c) * y.h * y.w; a.out_c0 = y.c_off;
             a.slope = n.op == TAMD_OP_RELU ? n.p.relu.negative_slope : 0.f;
             if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
             const bool up = n.op == TAMD_OP_UPSAMPLE;
@@ -267,6 +297,7 @@ int plan_u8(tamd_graph* g)
             int off = 0;
             for (int i : n.in) {
                 HTensor& x = g->tensors[i];
+                if (x.is_view && x.dptr == y.dptr) { off += x.c; continue; }       // written in place by its producer
                 U8MapArgs a{};
                 a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
                 a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.scale = 1;

@@ -97,6 +97,36 @@ def test_route_u8():
     check(g, x, "route")
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_concat_by_offset_u8(batch):
+    """two convs whose outputs carry the concat's own (scale, zp): the planner lets them write into the concat
+    buffer directly (the reference's per-element rescale is then the identity) -- result must not change."""
+    g, x = u8_conv_graph(21, batch, 16, 11, 11, 24, 1, act=0)
+    g.output_nodes = []
+    xin = g.nodes[g.input_nodes[0]].outputs[0]
+    a = g.nodes[-1].outputs[0]
+    rng = np.random.default_rng(4)
+    q = (g.tensors[a].scales[0], g.tensors[a].zero_points[0])
+    w2 = g.add_const("w2", rng.integers(0, 256, size=(40, 16, 3, 3)).astype(np.uint8), tm2.DT_UINT8, [0.004], [121])
+    b = g.add_tensor("out2", [batch, 40, 11, 11], tm2.DT_UINT8, tm2.TT_VAR, None, [q[0]], [q[1]])
+    g.add_node("conv2", "Convolution", [xin, w2], [b], kernel_h=3, kernel_w=3, stride_h=1, stride_w=1, dilation_h=1,
+               dilation_w=1, input_channel=16, output_channel=40, group=1, activation=0, pad_h0=1, pad_w0=1, pad_h1=1, pad_w1=1)
+    c = g.add_tensor("cat", [batch, 64, 11, 11], tm2.DT_UINT8, tm2.TT_VAR, None, [q[0]], [q[1]])
+    ni = g.add_node("cat", "Concat", [a, b], [c], axis=1)
+    r = g.add_tensor("lk", [batch, 64, 11, 11], tm2.DT_UINT8, tm2.TT_VAR, None, [q[0] * 0.7], [9])
+    ni = g.add_node("lk", "ReLU", [c], [r], negative_slope=0.1)
+    g.output_nodes = [ni]
+    want = oracle.run_graph(g, x, keep_all=True)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0]
+    assert gr.kernel_num() == 3, "the concat launches should be gone"
+    for t in (a, b, c, r):
+        assert np.array_equal(gr.read_tensor(t).reshape(want[t].shape), want[t])
+    assert np.array_equal(got.reshape(want[r].shape), want[r])
+    gr.close()
+
+
 def test_yolov3_tiny_uint8_bit_exact():
     """BASELINE configs[3] class: YOLOv3-tiny uint8 (13 convs up to K = 4608, leaky ReLU, max pools incl. the
     stride-1 'same' pool, upsample, concat with per-input rescale), whole graph on the device, layer by layer."""

@@ -15,7 +15,7 @@ def main():
     dtype = sys.argv[4] if len(sys.argv) > 4 else "int8"
     g = models.build(name, dtype, batch, device_only=True)
     gr = capi.Graph(tm2.write_tm2(g), batch=batch)
-    gr.set_input(models.synth_input(g, 3, tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8))
+    gr.set_input(models.synth_input(g, 3, {"uint8": tm2.DT_UINT8, "fp32": tm2.DT_FP32}.get(dtype, tm2.DT_INT8)))
     gr.run()
     prof = gr.profile(iters)
     tot = sum(k["ms"] for k in prof)
