@@ -167,7 +167,8 @@ def main():
             ach = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TOP/s", "frac": ach / mfma_peak}
         roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
-                         "traffic": None,
+                         "traffic": pmc_traffic(args.model, args.dtype, args.batch, dom),
+                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                          "kernel_time_share": d["ms"] / max(sum(f["ms"] for f in fam.values()), 1e-12),
                          "sum_kernel_ms_per_step": sum(f["ms"] for f in fam.values())})
 
@@ -201,6 +202,23 @@ def main():
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic(model, dtype, batch, family):
+    """HBM bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC summary of this workload
+    (profiles/r01_traffic_<model>_<dtype>_b<batch>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
+    same-session streaming-copy calibration -- tools/collect_profiles.sh, tools/traffic_summary.py); None when this
+    workload has no PMC pass (counters cannot be collected from inside the timed process)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_%s_%s_b%d.json" % (model, dtype, batch))
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot, n = 0.0, 0
+    for name, v in ks.items():
+        if family in name and v["hbm_read_bytes_per_launch"] is not None:
+            tot += (v["hbm_read_bytes_per_launch"] + (v["hbm_write_bytes_per_launch"] or 0.0)) * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
 
 
 def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
