@@ -41,6 +41,7 @@ extern "C" {
 #include "fc_param.h"
 #include "pooling_param.h"
 #include "relu_param.h"
+#include "softmax_param.h"
 #include "upsample_param.h"
 }
 
@@ -69,11 +70,15 @@ int map_op(int op)
     case OP_CONCAT: return TAMD_OP_CONCAT;
     case OP_DROPOUT: return TAMD_OP_DROPOUT;
     case OP_UPSAMPLE: return TAMD_OP_UPSAMPLE;
+    case OP_SOFTMAX: return TAMD_OP_SOFTMAX;
+    case OP_RELU6: return TAMD_OP_RELU6;
+    case OP_FLATTEN: return TAMD_OP_FLATTEN;
     default: return -1;
     }
 }
 
-const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT, OP_UPSAMPLE};
+const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT, OP_UPSAMPLE,
+                             OP_SOFTMAX, OP_RELU6};
 
 bool op_supported(int op)
 {
@@ -294,6 +299,8 @@ int hip_describe(struct device* device, struct vector* allowed_ops, struct vecto
     push_vector_data(precision, &p);
     p = TENGINE_DT_UINT8;
     push_vector_data(precision, &p);
+    p = TENGINE_DT_FP32;
+    push_vector_data(precision, &p);
     return 0;
 }
 
@@ -328,15 +335,17 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
         if (!op_supported(n->op.type)) return false;
         for (int k = 0; k < n->output_num; k++) {
             struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
-            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8) return false;
+            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8
+                && t->data_type != TENGINE_DT_FP32) return false;
             if (t->tensor_type != TENSOR_TYPE_CONST && !tamd_op_supported(map_op(n->op.type), t->data_type)) return false;
-            if (t->tensor_type != TENSOR_TYPE_CONST && t->quant_param_num != 1) return false;
+            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_FP32 && t->quant_param_num != 1) return false;
         }
         if (n->op.type == OP_ELTWISE) {
             int ty = ((const struct eltwise_param*)n->op.param_mem)->type;
             if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
         }
         if (n->op.type == OP_CONCAT && ((const struct concat_param*)n->op.param_mem)->axis != 1) return false;
+        if (n->op.type == OP_SOFTMAX && ((const struct softmax_param*)n->op.param_mem)->axis != 1) return false;
     }
     return true;
 }

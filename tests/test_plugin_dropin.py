@@ -96,6 +96,24 @@ def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
 
 
 @pytest.mark.gpu
+def test_hip_device_fp32_matches_reference_cpu_device(ref):
+    """fp32: SqueezeNet-v1.1 through the reference's API on device "HIP" vs its CPU device
+    (im2col+sgemm / Winograd there, fp32 MFMA here): 1e-4."""
+    _load_plugin(ref)
+    g = models.build("squeezenet_v1.1", "fp32", 1)
+    x = models.synth_input(g, 5, tm2.DT_FP32)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_FP32, 8)[0]
+    rg = ref.RefGraph(b, ref.MODE_FP32, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()[0]
+    rg.close()
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
+    assert abs(float(got.sum()) - 1.0) < 1e-3          # softmax ran (on the device)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["route", "yolov3_tiny"])
 def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     """uint8 through the reference's own API: device "HIP" == CPU device, byte for byte."""
