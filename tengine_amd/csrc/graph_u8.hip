@@ -49,7 +49,10 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     st.macs = (double)y.n * y.h * y.w * cout * K;
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 1.0 * cout * K;
     static const char* dma_env = getenv("TAMD_U8_DMA");
-    const bool use_dma = dma_env && atoi(dma_env) != 0;      // measured no faster than the register-staged kernel
+    bool use_dma = dma_env && atoi(dma_env) != 0;            // measured no faster than the register-staged kernel
+    // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~11k taps (e.g. 7x7x512) it does not
+    // fit next to the operand tiles, the DMA kernel (table read with scalar loads) takes over
+    if (p.group == 1 && (size_t)(rup(K, 32) + 2 * (64 + 64) * 36) * 4 > 64 * 1024) use_dma = true;
     if (p.group == 1 && use_dma && (p.kernel_h - 1) * p.dilation_h <= 15 && (p.kernel_w - 1) * p.dilation_w <= 15
         && (size_t)x.c * x.h * x.w < (1u << 24)) {
         // ---- asynchronous fp32 MFMA kernel (conv_f32_mfma.hip): fp32 copy of the input + fp32 packed weights ----

@@ -120,7 +120,7 @@ def test_concat_by_offset_u8(batch):
     gr = capi.Graph(tm2.write_tm2(g))
     gr.set_input(x)
     got = gr.run()[0]
-    assert gr.kernel_num() == 3, "the concat launches should be gone"
+    assert not [k for k in gr.profile(1) if "concat" in k["kernel"]], "the concat launches should be gone"
     for t in (a, b, c, r):
         assert np.array_equal(gr.read_tensor(t).reshape(want[t].shape), want[t])
     assert np.array_equal(got.reshape(want[r].shape), want[r])
