@@ -233,6 +233,7 @@ static int pick_cfg(const ConvArgs& a)
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
     if (forced >= 0 && forced <= 4) return forced;
+    if (a.cfg >= 0 && a.cfg <= 4) return a.cfg;            // plan-time autotune result
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.cout + bn - 1) / bn); };
     // biggest tile that still gives every CU a block; small problems fall to the small tiles
     if (a.cout <= 32) return a.M > 64 ? 1 : 3;

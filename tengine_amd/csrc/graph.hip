@@ -345,19 +345,49 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
         a.zeros = (const int8_t*)g->zero_page;
         a.M = y.n * y.h * y.w; a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
-        if (gemm_direct_applicable(a)) {
-            st.kernel = "gemm_direct_i8";
-            st.fn = [a](hipStream_t s) { return launch_gemm_direct(a, s); };
-        } else if (pw_stream_applicable(a)) {
-            st.kernel = "pw_stream_i8";
-            st.fn = [a](hipStream_t s) { return launch_pw_stream(a, s); };
-        } else if (conv_igemm2_applicable(a)) {
-            st.kernel = conv_igemm2_kernel_name(a);
-            st.fn = [a](hipStream_t s) { return launch_conv_igemm2(a, s); };
-        } else {
-            st.kernel = conv_igemm_kernel_name(a);
-            st.fn = [a](hipStream_t s) { return launch_conv_igemm(a, s); };
+        a.cfg = -1;
+        // candidates: every kernel of the family computes the same bytes (exact integer GEMM + the same epilogue), so
+        // the choice is purely a matter of speed
+        struct Cand { std::string name; std::function<hipError_t(hipStream_t)> fn; };
+        std::vector<Cand> cands;
+        if (gemm_direct_applicable(a)) cands.push_back({"gemm_direct_i8", [a](hipStream_t s) { return launch_gemm_direct(a, s); }});
+        if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
+        if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
+        const bool heuristic_done = !cands.empty();
+        static const char* at_env = getenv("TAMD_AUTOTUNE");
+        const bool autotune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6;
+        if (!heuristic_done || autotune) {
+            if (autotune) {
+                for (int c = 0; c < 5; c++) {
+                    if ((c == 1 || c == 3) && cout > 256 && a.M > 4096) continue;       // slivers: never competitive there
+                    ConvArgs ac = a; ac.cfg = c;
+                    cands.push_back({conv_igemm_kernel_name(ac), [ac](hipStream_t s) { return launch_conv_igemm(ac, s); }});
+                }
+            } else
+                cands.push_back({conv_igemm_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm(a, s); }});
         }
+        size_t best = 0;
+        if (autotune && cands.size() > 1) {
+            // plan-time autotune: a few timed launches of each candidate on the real buffers (outputs are overwritten
+            // again by the first real run); the heuristics above remain the fallback (TAMD_AUTOTUNE=0)
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            float best_ms = 1e30f;
+            for (size_t c = 0; c < cands.size(); c++) {
+                hipError_t err = cands[c].fn(g->stream);
+                if (err == hipSuccess) err = cands[c].fn(g->stream);
+                if (err != hipSuccess) { (void)hipGetLastError(); continue; }
+                HIPCHK(hipEventRecord(e0, g->stream));
+                for (int it = 0; it < 5; it++) (void)cands[c].fn(g->stream);
+                HIPCHK(hipEventRecord(e1, g->stream));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) { best_ms = ms; best = c; }
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+        st.kernel = cands[best].name;
+        st.fn = cands[best].fn;
     }
     g->steps.push_back(st);
     return 0;

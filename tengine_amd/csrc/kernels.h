@@ -29,6 +29,7 @@ struct ConvArgs {
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
     int dbg;               // perf experiments only (TAMD_IGEMM2_DBG), 0 in production
+    int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
 };
 
 struct DwArgs {
