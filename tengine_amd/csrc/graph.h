@@ -109,7 +109,8 @@ int upload(tamd_graph* g, const std::vector<T>& host, T** dev)
 {
     void* p = nullptr;
     if (dev_alloc(g, &p, host.size() * sizeof(T), false)) return -1;
-    HIPCHK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));   // own stream only
+    HIPCHK(hipStreamSynchronize(g->stream));
     *dev = (T*)p;
     return 0;
 }

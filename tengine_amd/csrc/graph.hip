@@ -15,10 +15,16 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 
 #include "epilogue.h"
 
 namespace tamd {
+
+// prerun (plan + hipGraph capture) and the device-synchronous frees are serialised process-wide: HIP rejects legacy-
+// stream / synchronous operations of one host thread while another one captures (seen as "operation would make the
+// legacy stream depend on a capturing blocking stream" under tools/exp/stress_threads.py).  run/launch are not affected.
+static std::mutex g_capture_mutex;
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...)
@@ -166,7 +172,7 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
     if (bytes == 0) bytes = 16;
     HIPCHK(hipMalloc(p, bytes));
     g->dev_allocs.push_back(*p);
-    if (zero) HIPCHK(hipMemset(*p, 0, bytes));
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, g->stream));    // never the legacy stream: it would collide with another thread's capture
     return 0;
 }
 
@@ -365,6 +371,17 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
                 }
             } else
                 cands.push_back({conv_igemm_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm(a, s); }});
+        }
+        if (const char* force = getenv("TAMD_FORCE_GEMM")) {     // tests: pin one member of the family (read at every prerun)
+            const std::string want = force;
+            std::vector<Cand> only;
+            for (int c = 0; c < 5; c++) {
+                ConvArgs ac = a; ac.cfg = c;
+                if (want == "igemm" + std::to_string(c)) only.push_back({conv_igemm_kernel_name(ac), [ac](hipStream_t s) { return launch_conv_igemm(ac, s); }});
+            }
+            for (auto& c : cands)
+                if (c.name.find(want) == 0) only.push_back(c);
+            if (!only.empty()) cands = only;
         }
         size_t best = 0;
         if (autotune && cands.size() > 1) {
@@ -699,6 +716,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
 {
     if (!g) return -1;
     if (g->prepared) return 0;
+    std::lock_guard<std::mutex> lk(g_capture_mutex);
     tamd_options o{};
     o.dev_name = "HIP"; o.gpu_index = 0; o.use_hip_graph = 1; o.profile = 0;
     if (opt) o = *opt;     // options may be NULL (scheduler.c:49-59)
@@ -891,19 +909,24 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
     HIPCHK(hipStreamSynchronize(g->stream));
     if (t.nchw_raw && t.is_view) {      // NCHW channel slice of a concat buffer (uint8 / fp32 planners): one row per image
         const size_t es = esize(t.dtype), img = (size_t)t.c * t.h * t.w * es;
-        HIPCHK(hipMemcpy2D(host, img, (const char*)t.dptr + (size_t)t.c_off * t.h * t.w * es, (size_t)t.cs * t.h * t.w * es, img,
-                           (size_t)t.n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2DAsync(host, img, (const char*)t.dptr + (size_t)t.c_off * t.h * t.w * es, (size_t)t.cs * t.h * t.w * es, img,
+                                (size_t)t.n, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
         return 0;
     }
-    if (t.nchw_raw) { HIPCHK(hipMemcpy(host, t.dptr, need, hipMemcpyDeviceToHost)); return 0; }
+    if (t.nchw_raw) {
+        HIPCHK(hipMemcpyAsync(host, t.dptr, need, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        return 0;
+    }
     void* tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, need));
     LayoutArgs a{(const int8_t*)t.dptr + t.c_off, tmp, t.n, t.c, t.h, t.w, t.cs, esize(t.dtype)};
     hipError_t e = launch_nhwc_to_nchw(a, g->stream);
     if (e != hipSuccess) { hipFree(tmp); set_error("layout launch failed"); return -1; }
+    HIPCHK(hipMemcpyAsync(host, tmp, need, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    HIPCHK(hipMemcpy(host, tmp, need, hipMemcpyDeviceToHost));
-    hipFree(tmp);
+    { std::lock_guard<std::mutex> lk(g_capture_mutex); hipFree(tmp); }
     return 0;
 }
 
@@ -911,6 +934,7 @@ void tamd_graph_destroy(tamd_graph* g)
 {
     if (!g) return;
     if (g->stream) hipStreamSynchronize(g->stream);
+    std::lock_guard<std::mutex> lk(g_capture_mutex);      // hipFree is device-synchronous: not while another thread captures
     if (g->hexec) hipGraphExecDestroy(g->hexec);
     if (g->hgraph) hipGraphDestroy(g->hgraph);
     for (void* p : g->dev_allocs) hipFree(p);

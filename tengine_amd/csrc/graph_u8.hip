@@ -117,25 +117,59 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             return -1;
         }
         // raw bytes, [cout tile][stage][row][32 slots], slot (k%4)*8 + (k%32)/4; padding = weight zero point
-        const int BM = conv_u8_gemm_bm(a.cfg), ntile = (cout + BM - 1) / BM, nstage = Kpad / 32;
-        std::vector<uint8_t> wq((size_t)ntile * nstage * BM * 32, (uint8_t)qw.zp);
-        for (int co = 0; co < cout; co++)
-            for (int k = 0; k < K; k++)
-                wq[(((size_t)(co / BM) * nstage + (k >> 5)) * BM + co % BM) * 32 + (k & 3) * 8 + ((k & 31) >> 2)] = w.data[(size_t)co * K + k];
+        const int nstage = Kpad / 32;
+        std::map<int, uint8_t*> packed;            // BM -> device copy of the weights packed for that tile height
+        auto pack_for = [&](int BM) -> uint8_t* {
+            auto it = packed.find(BM);
+            if (it != packed.end()) return it->second;
+            const int ntile = (cout + BM - 1) / BM;
+            std::vector<uint8_t> wq((size_t)ntile * nstage * BM * 32, (uint8_t)qw.zp);
+            for (int co = 0; co < cout; co++)
+                for (int k = 0; k < K; k++)
+                    wq[(((size_t)(co / BM) * nstage + (k >> 5)) * BM + co % BM) * 32 + (k & 3) * 8 + ((k & 31) >> 2)] = w.data[(size_t)co * K + k];
+            uint8_t* d = nullptr;
+            if (upload(g, wq, &d)) return nullptr;
+            packed[BM] = d;
+            return d;
+        };
         std::vector<unsigned> lut(Kpad, 0u);
         for (int k = 0; k < K; k++) {
             const int kx = k % p.kernel_w, ky = (k / p.kernel_w) % p.kernel_h, c = k / (p.kernel_w * p.kernel_h);
             lut[k] = (unsigned)(c * x.h * x.w + ky * p.dilation_h * x.w + kx * p.dilation_w) | (unsigned)(kx * p.dilation_w) << 24
                      | (unsigned)(ky * p.dilation_h) << 28;
         }
-        uint8_t* dwq = nullptr; unsigned* dlut = nullptr;
-        if (upload(g, wq, &dwq) || upload(g, lut, &dlut)) return -1;
-        a.x = (const uint8_t*)x.dptr; a.wq = dwq; a.klut = dlut; a.w_scale = qw.scale; a.w_zp = (float)qw.zp; a.bias = dbias; a.y = (uint8_t*)y.dptr;
+        unsigned* dlut = nullptr;
+        if (upload(g, lut, &dlut)) return -1;
+        a.x = (const uint8_t*)x.dptr; a.klut = dlut; a.w_scale = qw.scale; a.w_zp = (float)qw.zp; a.bias = dbias; a.y = (uint8_t*)y.dptr;
         a.out_img = (y.is_view ? y.cs : cout) * y.h * y.w; a.out_c0 = y.c_off;
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
         a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
+        // plan-time autotune over the tile configurations (every one produces the same bytes: the chain order of an
+        // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
+        static const char* at_env = getenv("TAMD_AUTOTUNE");
+        if (!(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG")) {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            float best_ms = 1e30f;
+            int best_cfg = a.cfg;
+            for (int c = 0; c < 5; c++) {
+                U8ConvArgs ac = a; ac.cfg = c;
+                if (conv_u8_gemm_lds(ac) > 64 * 1024) continue;
+                if ((ac.wq = pack_for(conv_u8_gemm_bm(c))) == nullptr) return -1;
+                if (launch_conv_u8_gemm(ac, g->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+                HIPCHK(hipEventRecord(e0, g->stream));
+                for (int it = 0; it < 3; it++) (void)launch_conv_u8_gemm(ac, g->stream);
+                HIPCHK(hipEventRecord(e1, g->stream));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) { best_ms = ms; best_cfg = c; }
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            a.cfg = best_cfg;
+        }
+        if ((a.wq = pack_for(conv_u8_gemm_bm(a.cfg))) == nullptr) return -1;
         st.kernel = conv_u8_gemm_kernel_name(a);
         st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
     } else {
