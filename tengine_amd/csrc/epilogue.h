@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels.h"
+
 namespace tamd {
 
 __device__ __forceinline__ int sat127(int v) { return v > 127 ? 127 : (v < -127 ? -127 : v); }
@@ -141,6 +143,39 @@ __device__ __forceinline__ void half_wave_regroup(unsigned (&p)[4])
     sw(p[2], p[3]);      // lower: p2=16-19 p3=20-23 | upper: p2=24-27 p3=28-31
     sw(p[0], p[2]);      // lower: p2=8-11           | upper: p0=16-19
     sw(p[1], p[3]);      // lower: p3=12-15          | upper: p1=20-23
+}
+
+// ---- conv + eltwise (+ ReLU) fused in the conv epilogue --------------------------------------------
+// The conv result is still rounded to int8 exactly as the stand-alone conv would store it (q_c); the eltwise node
+// (eltwise_ref.c:589-640,833-837: f = op(q_a*s_a, q_b*s_b), y = sat(round(f/out_s))) and the optional ReLU node
+// (relu_kernel_ref_int8.c:40-94 on y) are then applied to q_c and the residual byte in registers -- the same float
+// operations on the same int8 values, so the bytes cannot differ from the three-launch sequence.
+// (struct EltFuse lives in kernels.h next to ConvArgs)
+__device__ __forceinline__ int sx8(unsigned v, int b) { return (int)(v << (24 - 8 * b)) >> 24; }
+
+__device__ __forceinline__ unsigned fuse_elt4(unsigned pc, unsigned pr, const EltFuse& e, float inv_out, float inv_relu)
+{
+    int q[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const float fc = __fmul_rn((float)sx8(pc, b), e.s_conv), fr = __fmul_rn((float)sx8(pr, b), e.s_res);
+        const float fa = e.conv_is_first ? fc : fr, fb = e.conv_is_first ? fr : fc;
+        float f;
+        switch (e.type) {
+        case 0: f = __fmul_rn(fa, fb); break;
+        case 2: f = __fadd_rn(fa, fb); break;
+        case 4: f = __fsub_rn(fa, fb); break;
+        default: f = fa > fb ? fa : fb; break;
+        }
+        int y = round_div_sat(f, e.out_scale, inv_out);
+        if (e.relu) {
+            float f2 = __fmul_rn((float)y, e.out_scale);
+            f2 = f2 < 0.f ? 0.f : f2;
+            y = round_div_sat(f2, e.relu_out_scale, inv_relu);
+        }
+        q[b] = y;
+    }
+    return pack4(q[0], q[1], q[2], q[3]);
 }
 
 }  // namespace tamd

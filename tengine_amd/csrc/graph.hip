@@ -207,7 +207,15 @@ static int conv_mode(const tamd_conv_param& p, int batch, int cin, int cout)
     return RQ_CONV_REF;
 }
 
-static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
+struct FusedElt {            // an eltwise (+ReLU) node folded into the epilogue of the conv that produces its later operand
+    int res_tensor;          // the other eltwise operand
+    int elt_tensor;          // the eltwise node's own output (its scale)
+    int out_tensor;          // where the result is stored: elt_tensor, or the ReLU's output when one follows
+    int type;
+    bool conv_is_first, relu;
+};
+
+static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = nullptr)
 {
     HTensor& x = g->tensors[n.in[0]];
     HTensor& w = g->tensors[n.in[1]];
@@ -352,12 +360,25 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
         a.zeros = (const int8_t*)g->zero_page;
         a.M = y.n * y.h * y.w; a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         a.cfg = -1;
+        if (fz) {      // conv -> eltwise (-> relu) in one launch: the conv's own int8 rounding is kept, see epilogue.h
+            HTensor& r = g->tensors[fz->res_tensor];
+            HTensor& o = g->tensors[fz->out_tensor];
+            a.elt.res = (const int8_t*)r.dptr; a.elt.res_ldc = r.cs; a.elt.res_c_off = r.c_off;
+            a.elt.type = fz->type; a.elt.conv_is_first = fz->conv_is_first ? 1 : 0;
+            a.elt.s_conv = y.scales[0]; a.elt.s_res = r.scales[0];
+            a.elt.out_scale = g->tensors[fz->elt_tensor].scales[0];
+            a.elt.relu = fz->relu ? 1 : 0; a.elt.relu_out_scale = o.scales[0];
+            a.y = (int8_t*)o.dptr; a.ldc = o.cs; a.c_off = o.c_off;
+            a.c_limit = o.is_view ? cout : std::min(rup(cout, 16), o.cs - o.c_off);
+            st.bytes += (double)r.n * r.h * r.w * r.c;
+        }
         // candidates: every kernel of the family computes the same bytes (exact integer GEMM + the same epilogue), so
         // the choice is purely a matter of speed
         struct Cand { std::string name; std::function<hipError_t(hipStream_t)> fn; };
         std::vector<Cand> cands;
-        if (gemm_direct_applicable(a)) cands.push_back({"gemm_direct_i8", [a](hipStream_t s) { return launch_gemm_direct(a, s); }});
-        if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
+        // (the fused eltwise tail lives in the conv_igemm / conv_igemm2 epilogues only)
+        if (!fz && gemm_direct_applicable(a)) cands.push_back({"gemm_direct_i8", [a](hipStream_t s) { return launch_gemm_direct(a, s); }});
+        if (!fz && pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
         if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
         const bool heuristic_done = !cands.empty();
         static const char* at_env = getenv("TAMD_AUTOTUNE");
@@ -403,7 +424,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc)
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
-        st.kernel = cands[best].name;
+        st.kernel = cands[best].name + (fz ? (fz->relu ? "+eltwise+relu" : "+eltwise") : "");
         st.fn = cands[best].fn;
     }
     g->steps.push_back(st);
@@ -496,6 +517,42 @@ static int plan(tamd_graph* g)
     }
     // ---- 2. compile nodes ---------------------------------------------------------------------
     std::vector<char> fused(g->nodes.size(), 0);
+    // conv -> eltwise (-> relu) fusion (ResNet: branch2c / branch1 + residual add + relu): the eltwise is
+    // folded into the LATER of its two producers when that one is a group-1 GEMM conv whose output feeds nothing else
+    std::vector<FusedElt> fuse_at(g->nodes.size());
+    std::vector<char> has_fuse(g->nodes.size(), 0);
+    static const char* fuse_env = getenv("TAMD_FUSE_ELTWISE");
+    auto producer = [&](int t) { for (size_t i = 0; i < g->nodes.size(); i++) if (!g->nodes[i].out.empty() && g->nodes[i].out[0] == t) return (int)i; return -1; };
+    for (size_t ei = 0; ei < g->nodes.size() && !(fuse_env && atoi(fuse_env) == 0); ei++) {
+        HNode& e = g->nodes[ei];
+        if (e.op != TAMD_OP_ELTWISE || e.in.size() != 2) continue;
+        const int ty = e.p.elt.type;
+        if (ty != 0 && ty != 2 && ty != 4 && ty != 6) continue;
+        HTensor& ta = g->tensors[e.in[0]];
+        HTensor& tb = g->tensors[e.in[1]];
+        HTensor& te = g->tensors[e.out[0]];
+        if (ta.dims != tb.dims || ta.is_view || tb.is_view || te.is_view || ta.ttype == TAMD_TT_CONST || tb.ttype == TAMD_TT_CONST) continue;
+        const int pa = producer(e.in[0]), pb = producer(e.in[1]);
+        const int later = std::max(pa, pb), conv_in = later == pa ? 0 : 1;
+        if (later < 0 || later >= (int)ei) continue;
+        HNode& c = g->nodes[later];
+        if (c.op != TAMD_OP_CONV || c.p.conv.group != 1 || g->tensors[c.in[0]].nchw_raw || has_fuse[later]) continue;
+        if (c.p.conv.kernel_h * c.p.conv.kernel_w > 128 || count_consumers(g, e.in[conv_in]) != 1) continue;
+        FusedElt fz{};
+        fz.res_tensor = e.in[1 - conv_in]; fz.elt_tensor = e.out[0]; fz.out_tensor = e.out[0]; fz.type = ty;
+        fz.conv_is_first = conv_in == 0; fz.relu = false;
+        size_t relu_node = 0;
+        if (count_consumers(g, e.out[0]) == 1)
+            for (size_t nj = ei + 1; nj < g->nodes.size(); nj++) {
+                HNode& r = g->nodes[nj];
+                if (r.op == TAMD_OP_RELU && r.in[0] == e.out[0] && r.p.relu.negative_slope == 0.f && !g->tensors[r.out[0]].is_view) {
+                    fz.relu = true; fz.out_tensor = r.out[0]; relu_node = nj;
+                    break;
+                }
+            }
+        fuse_at[later] = fz; has_fuse[later] = 1; fused[ei] = 1;
+        if (fz.relu) fused[relu_node] = 1;
+    }
     for (size_t ni = 0; ni < g->nodes.size(); ni++) {
         HNode& n = g->nodes[ni];
         if (fused[ni]) continue;
@@ -503,7 +560,7 @@ static int plan(tamd_graph* g)
         case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_CONCAT:
             break;
         case TAMD_OP_CONV:
-            if (plan_conv(g, n, false)) return -1;
+            if (plan_conv(g, n, false, has_fuse[ni] ? &fuse_at[ni] : nullptr)) return -1;
             break;
         case TAMD_OP_FC:
             if (plan_conv(g, n, true)) return -1;

@@ -8,6 +8,17 @@
 
 namespace tamd {
 
+struct EltFuse {              // eltwise (+ReLU) node applied in the conv epilogue (epilogue.h: fuse_elt4)
+    const int8_t* res;        // the other eltwise operand (NHWC, same pixels); nullptr: no fusion
+    int res_ldc, res_c_off;   // its channel stride / offset
+    int type;                 // ELT_* (0 prod, 2 sum, 4 sub, 6 max)
+    int conv_is_first;        // the conv output is eltwise input 0 (matters for sub)
+    float s_conv, s_res;      // scales of the conv output tensor and of the residual tensor
+    float out_scale;          // eltwise output scale
+    int relu;                 // a ReLU (slope 0) node follows
+    float relu_out_scale;
+};
+
 struct ConvArgs {
     const int8_t* x;       // NHWC input, channel stride cs_in
     const int8_t* w;       // packed weights [cout_pad][kpad]
@@ -30,6 +41,7 @@ struct ConvArgs {
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
     int dbg;               // perf experiments only (TAMD_IGEMM2_DBG), 0 in production
     int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
+    EltFuse elt;           // fused eltwise(+relu) tail (conv_igemm / conv_igemm2 only); y/ldc/c_off then describe ITS output
 };
 
 struct DwArgs {
@@ -114,9 +126,10 @@ hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);
 // ---- uint8 (per-tensor asymmetric) ---------------------------------------------------------------------------
 // The reference SIMULATES uint8 in fp32: operands are dequantised, the convolution is an fp32 GEMM
 // whose per-element summation order is fixed by the reference's register tiling, and only the result is
-// requantised.  Byte-identical outputs therefore need the same fp32 operations in the same order, so this path
-// runs on the fp32 vector FMA pipes (one fused chain per output element, chains spread over lanes), not on MFMA.
-// uint8 activations stay in the reference's dense NCHW order on the device (u8_kernels.hip).
+// requantised.  Byte-identical outputs therefore need the same fp32 operations in the same order: one fused
+// multiply-add chain per output element -- which is exactly how v_mfma_f32_16x16x4f32 accumulates (measured,
+// profiles/r01_mfma_f32_is_sequential_fma_chain.txt), so the path runs on the matrix cores (u8_kernels.hip).
+// uint8 activations stay in the reference's dense NCHW order on the device.
 struct U8Q { float scale; int zp; };
 
 struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
