@@ -169,6 +169,10 @@ def main():
         roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                          "traffic": pmc_traffic(args.model, args.dtype, args.batch, dom),
                          "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                         # whole-step matrix-core utilisation (BASELINE metric's second half): all MACs of the step
+                         # over the summed kernel time, against the dense MFMA peak of the compute dtype
+                         "mfma_util_pct": 100.0 * 2.0 * sum(f["macs"] for f in fam.values())
+                         / (max(sum(f["ms"] for f in fam.values()), 1e-12) * 1e-3) / (mfma_peak * 1e12),
                          "kernel_time_share": d["ms"] / max(sum(f["ms"] for f in fam.values()), 1e-12),
                          "sum_kernel_ms_per_step": sum(f["ms"] for f in fam.values())})
 

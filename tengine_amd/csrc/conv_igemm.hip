@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void conv_igemm_i8_kernel(ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
 
-    const int nk = a.kpad / BK;
+    // ceil: a stage may run past kpad -- the activation operand is zero there (k >= ktot / tap >= ntaps) and the
+    // weight rows are followed by readable memory (next row, or the planner's 256-byte tail), so it adds exact zeros
+    const int nk = (a.kpad + BK - 1) / BK;
     gload(0);
     lstore(0);
     __syncthreads();
@@ -234,6 +236,15 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool is1x1)
     const int tiles_m = (a.M + BM - 1) / BM;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const size_t lds = 2 * (size_t)(BM + BN) * (BK + 16);
+    if (lds > 64 * 1024) {       // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup needs the opt-in
+        static bool set1 = false, set0 = false;
+        bool& done = is1x1 ? set1 : set0;
+        if (!done) {
+            if (is1x1) (void)hipFuncSetAttribute((const void*)conv_igemm_i8_kernel<BM, BN, BK, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            else (void)hipFuncSetAttribute((const void*)conv_igemm_i8_kernel<BM, BN, BK, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done = true;
+        }
+    }
     if (is1x1)
         hipLaunchKernelGGL((conv_igemm_i8_kernel<BM, BN, BK, WM, WN, true>), dim3(grid), dim3(256), lds, s, a);
     else
@@ -247,8 +258,8 @@ static int pick_cfg(const ConvArgs& a)
 {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
-    if (forced >= 0 && forced <= 4) return forced;
-    if (a.cfg >= 0 && a.cfg <= 4) return a.cfg;            // plan-time autotune result
+    if (forced >= 0 && forced <= 7) return forced;
+    if (a.cfg >= 0 && a.cfg <= 7) return a.cfg;            // plan-time autotune result
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.cout + bn - 1) / bn); };
     // biggest tile that still gives every CU a block; small problems fall to the small tiles
     if (a.cout <= 32) return a.M > 64 ? 1 : 3;
@@ -261,9 +272,14 @@ static int pick_cfg(const ConvArgs& a)
 const char* conv_igemm_kernel_name(const ConvArgs& a)
 {
     static const char* names[] = {"conv_igemm_i8<128x128x64>", "conv_igemm_i8<128x32x64>", "conv_igemm_i8<64x64x64>",
-                                  "conv_igemm_i8<32x128x64>", "conv_igemm_i8<128x64x64>"};
+                                  "conv_igemm_i8<32x128x64>", "conv_igemm_i8<128x64x64>",
+                                  // deep-K stages (autotune only): 4x the MFMA work per barrier / per exposed latency, for
+                                  // the K >= 512 layers (ResNet 3x3) whose 64-deep stages are shorter than a memory round trip
+                                  "conv_igemm_i8<128x128x256>", "conv_igemm_i8<128x64x256>", "conv_igemm_i8<64x64x256>"};
     return names[pick_cfg(a)];
 }
+int conv_igemm_num_cfgs() { return 8; }
+bool conv_igemm_cfg_ok(const ConvArgs& a, int cfg) { return cfg < 5 || a.kpad >= 512; }
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s)
 {
@@ -273,6 +289,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s)
     case 1: return launch_cfg<128, 32, 64, 4, 1>(a, s, is1x1);
     case 2: return launch_cfg<64, 64, 64, 2, 2>(a, s, is1x1);
     case 4: return launch_cfg<128, 64, 64, 2, 2>(a, s, is1x1);
+    case 5: return launch_cfg<128, 128, 256, 2, 2>(a, s, is1x1);
+    case 6: return launch_cfg<128, 64, 256, 2, 2>(a, s, is1x1);
+    case 7: return launch_cfg<64, 64, 256, 2, 2>(a, s, is1x1);
     default: return launch_cfg<32, 128, 64, 1, 4>(a, s, is1x1);
     }
 }

@@ -339,7 +339,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         const int kpad = rup(ktot, 64);
         const int cout_pad = rup(cout, 128);
         if (KH * KW > 128) { set_error("conv %s: kernel %dx%d too large", n.name.c_str(), KH, KW); return -1; }
-        std::vector<int8_t> wp((size_t)cout_pad * kpad, 0);
+        std::vector<int8_t> wp((size_t)cout_pad * kpad + 256, 0);      // + tail: deep-K stages may read past the last row
         for (int co = 0; co < cout; co++)
             for (int ci = 0; ci < cin; ci++)
                 for (int ky = 0; ky < KH; ky++)
@@ -385,8 +385,9 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         const bool autotune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6;
         if (!heuristic_done || autotune) {
             if (autotune) {
-                for (int c = 0; c < 5; c++) {
+                for (int c = 0; c < conv_igemm_num_cfgs(); c++) {
                     if ((c == 1 || c == 3) && cout > 256 && a.M > 4096) continue;       // slivers: never competitive there
+                    if (!conv_igemm_cfg_ok(a, c)) continue;
                     ConvArgs ac = a; ac.cfg = c;
                     cands.push_back({conv_igemm_kernel_name(ac), [ac](hipStream_t s) { return launch_conv_igemm(ac, s); }});
                 }
@@ -396,9 +397,9 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if (const char* force = getenv("TAMD_FORCE_GEMM")) {     // tests: pin one member of the family (read at every prerun)
             const std::string want = force;
             std::vector<Cand> only;
-            for (int c = 0; c < 5; c++) {
+            for (int c = 0; c < conv_igemm_num_cfgs(); c++) {
                 ConvArgs ac = a; ac.cfg = c;
-                if (want == "igemm" + std::to_string(c)) only.push_back({conv_igemm_kernel_name(ac), [ac](hipStream_t s) { return launch_conv_igemm(ac, s); }});
+                if (want == "igemm" + std::to_string(c) && conv_igemm_cfg_ok(a, c)) only.push_back({conv_igemm_kernel_name(ac), [ac](hipStream_t s) { return launch_conv_igemm(ac, s); }});
             }
             for (auto& c : cands)
                 if (c.name.find(want) == 0) only.push_back(c);

@@ -107,6 +107,8 @@ struct LayoutArgs {        // NCHW <-> NHWC(cs) int8 / generic element size
 // launchers (return hipError_t of the launch)
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 const char* conv_igemm_kernel_name(const ConvArgs& a);   // tile shape the launcher will pick
+int conv_igemm_num_cfgs();                               // ConvArgs::cfg values the autotuner may try
+bool conv_igemm_cfg_ok(const ConvArgs& a, int cfg);
 hipError_t launch_gemm_direct(const ConvArgs& a, hipStream_t s);   // 1x1, small-M / latency-bound shapes
 bool gemm_direct_applicable(const ConvArgs& a);
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t s);  // LDS-DMA 3-stage ring, large problems
