@@ -258,8 +258,8 @@ static int pick_cfg(const ConvArgs& a)
 {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
-    if (forced >= 0 && forced <= 7) return forced;
-    if (a.cfg >= 0 && a.cfg <= 7) return a.cfg;            // plan-time autotune result
+    if (forced >= 0 && forced <= 9) return forced;
+    if (a.cfg >= 0 && a.cfg <= 9) return a.cfg;            // plan-time autotune result
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.cout + bn - 1) / bn); };
     // biggest tile that still gives every CU a block; small problems fall to the small tiles
     if (a.cout <= 32) return a.M > 64 ? 1 : 3;
@@ -275,11 +275,12 @@ const char* conv_igemm_kernel_name(const ConvArgs& a)
                                   "conv_igemm_i8<32x128x64>", "conv_igemm_i8<128x64x64>",
                                   // deep-K stages (autotune only): 4x the MFMA work per barrier / per exposed latency, for
                                   // the K >= 512 layers (ResNet 3x3) whose 64-deep stages are shorter than a memory round trip
-                                  "conv_igemm_i8<128x128x256>", "conv_igemm_i8<128x64x256>", "conv_igemm_i8<64x64x256>"};
+                                  "conv_igemm_i8<128x128x256>", "conv_igemm_i8<128x64x256>", "conv_igemm_i8<64x64x256>",
+                                  "conv_igemm_i8<64x64x128>", "conv_igemm_i8<128x64x128>"};
     return names[pick_cfg(a)];
 }
-int conv_igemm_num_cfgs() { return 8; }
-bool conv_igemm_cfg_ok(const ConvArgs& a, int cfg) { return cfg < 5 || a.kpad >= 512; }
+int conv_igemm_num_cfgs() { return 10; }
+bool conv_igemm_cfg_ok(const ConvArgs& a, int cfg) { return cfg < 5 || (cfg < 8 ? a.kpad >= 512 : a.kpad >= 256); }
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s)
 {
@@ -292,6 +293,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s)
     case 5: return launch_cfg<128, 128, 256, 2, 2>(a, s, is1x1);
     case 6: return launch_cfg<128, 64, 256, 2, 2>(a, s, is1x1);
     case 7: return launch_cfg<64, 64, 256, 2, 2>(a, s, is1x1);
+    case 8: return launch_cfg<64, 64, 128, 2, 2>(a, s, is1x1);
+    case 9: return launch_cfg<128, 64, 128, 2, 2>(a, s, is1x1);
     default: return launch_cfg<32, 128, 64, 1, 4>(a, s, is1x1);
     }
 }

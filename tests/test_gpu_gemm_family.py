@@ -28,7 +28,7 @@ SHAPES = [
     (9, 80, 33, 31, 96, 3, 1, 2, 1, 0, True, 2),
     (1, 512, 7, 7, 512, 3, 1, 1, 1, 0, True, 1),
 ]
-MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "gemm_direct", "pw_stream",
+MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct", "pw_stream",
            "conv_igemm2"]
 
 
