@@ -50,9 +50,9 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 1.0 * cout * K;
     static const char* dma_env = getenv("TAMD_U8_DMA");
     bool use_dma = dma_env && atoi(dma_env) != 0;            // measured no faster than the register-staged kernel
-    // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~11k taps (e.g. 7x7x512) it does not
-    // fit next to the operand tiles, the DMA kernel (table read with scalar loads) takes over
-    if (p.group == 1 && (size_t)(rup(K, 32) + 2 * (64 + 64) * 36) * 4 > 64 * 1024) use_dma = true;
+    // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~28k taps it does not fit next to the
+    // operand tiles (160 KB per CU) and the DMA kernel (table read with scalar loads) takes over
+    if (p.group == 1 && (size_t)(rup(K, 64) + 2 * (64 + 64) * 36) * 4 > 150 * 1024) use_dma = true;
     if (p.group == 1 && use_dma && (p.kernel_h - 1) * p.dilation_h <= 15 && (p.kernel_w - 1) * p.dilation_w <= 15
         && (size_t)x.c * x.h * x.w < (1u << 24)) {
         // ---- asynchronous fp32 MFMA kernel (conv_f32_mfma.hip): fp32 copy of the input + fp32 packed weights ----
@@ -106,30 +106,32 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         st.bytes = 4.0 * x.elems() + (double)y.elems() + 4.0 * cout * K;
         st.fn = [a](hipStream_t s) { return launch_conv_f32_mfma(a, s); };
     } else if (p.group == 1) {
-        const int Kpad = rup(K, 32), cout_pad = rup(cout, 64);
+        const int Kpad = rup(K, 64), cout_pad = rup(cout, 64);     // 64: the deepest K stage of the kernel family
         U8ConvArgs a{};
         a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.cout_pad = cout_pad;
         a.K = K; a.Kpad = Kpad; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
         a.cfg = conv_u8_gemm_pick(a);
         if ((p.kernel_h - 1) * p.dilation_h > 15 || (p.kernel_w - 1) * p.dilation_w > 15 || (size_t)x.c * x.h * x.w >= (1u << 24)
-            || conv_u8_gemm_lds(a) > 64 * 1024) {
+            || conv_u8_gemm_lds(a) > 150 * 1024) {
             set_error("conv %s: kernel extent / image size / K = %d outside the packed tap table of the uint8 GEMM kernel", n.name.c_str(), K);
             return -1;
         }
         // raw bytes, [cout tile][stage][row][32 slots], slot (k%4)*8 + (k%32)/4; padding = weight zero point
-        const int nstage = Kpad / 32;
-        std::map<int, uint8_t*> packed;            // BM -> device copy of the weights packed for that tile height
-        auto pack_for = [&](int BM) -> uint8_t* {
-            auto it = packed.find(BM);
+        std::map<int, uint8_t*> packed;            // (BM, KC) -> device copy of the weights packed for that tile shape
+        auto pack_for = [&](int cfg) -> uint8_t* {
+            const int BM = conv_u8_gemm_bm(cfg), KC = conv_u8_gemm_kc(cfg), NPOS = KC / 4, nstage = Kpad / KC;
+            auto it = packed.find(BM * 1000 + KC);
             if (it != packed.end()) return it->second;
             const int ntile = (cout + BM - 1) / BM;
-            std::vector<uint8_t> wq((size_t)ntile * nstage * BM * 32, (uint8_t)qw.zp);
+            std::vector<uint8_t> wq((size_t)ntile * nstage * BM * KC, (uint8_t)qw.zp);
             for (int co = 0; co < cout; co++)
-                for (int k = 0; k < K; k++)
-                    wq[(((size_t)(co / BM) * nstage + (k >> 5)) * BM + co % BM) * 32 + (k & 3) * 8 + ((k & 31) >> 2)] = w.data[(size_t)co * K + k];
+                for (int k = 0; k < K; k++) {
+                    const int kl = k % KC;
+                    wq[(((size_t)(co / BM) * nstage + k / KC) * BM + co % BM) * KC + (kl & 3) * NPOS + (kl >> 2)] = w.data[(size_t)co * K + k];
+                }
             uint8_t* d = nullptr;
             if (upload(g, wq, &d)) return nullptr;
-            packed[BM] = d;
+            packed[BM * 1000 + KC] = d;
             return d;
         };
         std::vector<unsigned> lut(Kpad, 0u);
@@ -154,10 +156,10 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             float best_ms = 1e30f;
             int best_cfg = a.cfg;
-            for (int c = 0; c < 5; c++) {
+            for (int c = 0; c < conv_u8_gemm_num_cfgs(); c++) {
                 U8ConvArgs ac = a; ac.cfg = c;
-                if (conv_u8_gemm_lds(ac) > 64 * 1024) continue;
-                if ((ac.wq = pack_for(conv_u8_gemm_bm(c))) == nullptr) return -1;
+                if (conv_u8_gemm_lds(ac) > 150 * 1024) continue;
+                if ((ac.wq = pack_for(c)) == nullptr) return -1;
                 if (launch_conv_u8_gemm(ac, g->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
                 HIPCHK(hipEventRecord(e0, g->stream));
                 for (int it = 0; it < 3; it++) (void)launch_conv_u8_gemm(ac, g->stream);
@@ -169,7 +171,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;
         }
-        if ((a.wq = pack_for(conv_u8_gemm_bm(a.cfg))) == nullptr) return -1;
+        if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
         st.kernel = conv_u8_gemm_kernel_name(a);
         st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
     } else {

@@ -194,6 +194,8 @@ struct U8EltArgs {
 
 int conv_u8_gemm_pick(const U8ConvArgs& a);        // geometry fields only
 int conv_u8_gemm_bm(int cfg);                      // channel rows per block tile (weight packing unit)
+int conv_u8_gemm_kc(int cfg);                      // K stage depth (weight packing unit)
+int conv_u8_gemm_num_cfgs();
 size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the chosen configuration
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);

@@ -63,13 +63,16 @@ __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { ret
 // =================================================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int WM, int WN, int TM, int TN, bool TAIL>
+template <int WM, int WN, int TM, int TN, int KC, bool TAIL>
 __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restrict__ ws, float* __restrict__ xs,
                                              const unsigned* __restrict__ lut, int n, int jbase, int jlimit, int co0)
 {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, KC = 32, LD = 36, NT = WM * WN * 64, D = 3;
-    constexpr int XQ = BN * 8 / NT;                      // x quads (4 k of one class, one pixel) per thread per stage
-    constexpr int WQ = (BM * 8 + NT - 1) / NT;           // weight quads (float4) per thread per stage
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LD = KC + 4, NT = WM * WN * 64, D = 3;
+    constexpr int NPOS = KC / 4;                         // slots per class (k%4) in a row == quads (float4) per row
+    constexpr int QPC = NPOS / 4;                        // quads per class
+    constexpr int XQ = BN * NPOS / NT;                   // x quads (4 k of one class, one pixel) per thread per stage
+    constexpr int WQ = (BM * NPOS + NT - 1) / NT;        // weight quads (float4) per thread per stage
+    static_assert(KC == 32 || KC == 64, "stage depth");
     constexpr int NCH = TAIL ? 4 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM, l15 = lane & 15, kq = lane >> 4;
@@ -87,14 +90,14 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
     unsigned xr[D][XQ][4];       // raw bytes, one register each: packing here would make the loads wait at once
     unsigned xok[D];             // bit (4*i + e): element e of quad i is inside the image
     int k0s[D];                  // first k of the stage held in the slot
-    const unsigned* wtile = reinterpret_cast<const unsigned*>(a.wq) + (size_t)(co0 / BM) * (a.Kpad / KC) * (BM * 8);
+    const unsigned* wtile = reinterpret_cast<const unsigned*>(a.wq) + (size_t)(co0 / BM) * (a.Kpad / KC) * (BM * NPOS);
     unsigned wr[D][WQ];          // 4 raw weight bytes of one quad
     auto gload = [&](int d, int k0) {
         xok[d] = 0;
         k0s[d] = k0;
 #pragma unroll
         for (int i = 0; i < XQ; i++) {
-            const int qd = su * XQ + i, c = qd >> 1, pos0 = (qd & 1) * 4;
+            const int qd = su * XQ + i, c = qd / QPC, pos0 = (qd % QPC) * 4;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const unsigned t = lut[k0 + c + 4 * (pos0 + e)];            // off | dx << 24 | dy << 28
@@ -107,8 +110,8 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
 #pragma unroll
         for (int i = 0; i < WQ; i++) {
             const int idx = tid + NT * i;
-            // the block's weight tile of a stage is BM*32 contiguous bytes ([cout tile][stage][row][32 slots])
-            if (BM * 8 % NT == 0 || idx < BM * 8) wr[d][i] = wtile[(size_t)(k0 / KC) * (BM * 8) + idx];
+            // the block's weight tile of a stage is BM*KC contiguous bytes ([cout tile][stage][row][KC slots])
+            if (BM * NPOS % NT == 0 || idx < BM * NPOS) wr[d][i] = wtile[(size_t)(k0 / KC) * (BM * NPOS) + idx];
         }
     };
     auto sstore = [&](int d, int buf) {
@@ -124,8 +127,8 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
         }
 #pragma unroll
         for (int i = 0; i < WQ; i++) {
-            const int idx = tid + NT * i, row = idx >> 3, qd = idx & 7;
-            if (BM * 8 % NT == 0 || idx < BM * 8) {
+            const int idx = tid + NT * i, row = idx / NPOS, qd = idx % NPOS;
+            if (BM * NPOS % NT == 0 || idx < BM * NPOS) {
                 // conv_kernel_x86.c:68-80: w_fp32 = ((float)w - (float)zp) * scale
                 float4 w;
                 w.x = dequant((uint8_t)wr[d][i], a.w_zp, a.w_scale);
@@ -133,7 +136,7 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                 w.z = dequant((uint8_t)(wr[d][i] >> 16), a.w_zp, a.w_scale);
                 w.w = dequant((uint8_t)(wr[d][i] >> 24), a.w_zp, a.w_scale);
                 if (TAIL) {                                  // the K%4 remainder is chained after the combine
-                    const int kb = k0s[d] + (qd >> 1) + 16 * (qd & 1);
+                    const int kb = k0s[d] + qd / QPC + 16 * (qd % QPC);
                     if (kb >= K4) w.x = 0.f;
                     if (kb + 4 >= K4) w.y = 0.f;
                     if (kb + 8 >= K4) w.z = 0.f;
@@ -167,23 +170,27 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
         const float* wsb = ws + cur * BM * LD;
         const float* xsb = xs + cur * BN * LD;
         if constexpr (!TAIL) {
-            float af[TM][8], bf[TN][8];
+            float af[TM][NPOS], bf[TN][NPOS];
 #pragma unroll
             for (int i = 0; i < TM; i++) {
-                const float* q = wsb + ((wm * TM + i) * 16 + l15) * LD + kq * 8;
-                const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
-                af[i][0] = lo.x; af[i][1] = lo.y; af[i][2] = lo.z; af[i][3] = lo.w;
-                af[i][4] = hi.x; af[i][5] = hi.y; af[i][6] = hi.z; af[i][7] = hi.w;
+                const float* q = wsb + ((wm * TM + i) * 16 + l15) * LD + kq * NPOS;
+#pragma unroll
+                for (int v = 0; v < QPC; v++) {
+                    const float4 f = *reinterpret_cast<const float4*>(q + 4 * v);
+                    af[i][4 * v] = f.x; af[i][4 * v + 1] = f.y; af[i][4 * v + 2] = f.z; af[i][4 * v + 3] = f.w;
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
-                const float* q = xsb + ((wn * TN + j) * 16 + l15) * LD + kq * 8;
-                const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
-                bf[j][0] = lo.x; bf[j][1] = lo.y; bf[j][2] = lo.z; bf[j][3] = lo.w;
-                bf[j][4] = hi.x; bf[j][5] = hi.y; bf[j][6] = hi.z; bf[j][7] = hi.w;
+                const float* q = xsb + ((wn * TN + j) * 16 + l15) * LD + kq * NPOS;
+#pragma unroll
+                for (int v = 0; v < QPC; v++) {
+                    const float4 f = *reinterpret_cast<const float4*>(q + 4 * v);
+                    bf[j][4 * v] = f.x; bf[j][4 * v + 1] = f.y; bf[j][4 * v + 2] = f.z; bf[j][4 * v + 3] = f.w;
+                }
             }
 #pragma unroll
-            for (int s = 0; s < 8; s++)
+            for (int s = 0; s < NPOS; s++)
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -193,14 +200,14 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int s = 0; s < 2; s++)
+                for (int s = 0; s < QPC; s++)
 #pragma unroll
                     for (int i = 0; i < TM; i++)
 #pragma unroll
                         for (int j = 0; j < TN; j++) {
                             if (jbase + (wn * TN + j) * 16 >= jlimit) continue;      // no tail pixel in this 16-pixel column
-                            const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * 8 + 4 * s + kq];
-                            const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * 8 + 4 * s + kq];
+                            const float av = wsb[((wm * TM + i) * 16 + l15) * LD + r * NPOS + 4 * s + kq];
+                            const float bv = xsb[((wn * TN + j) * 16 + l15) * LD + r * NPOS + 4 * s + kq];
                             acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][i][j], 0, 0, 0);
                         }
         }
@@ -242,8 +249,8 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                             v = dequant(xin[(oy * a.SH - a.PH) * a.W + ox * a.SW - a.PW + (int)(t & 0xffffffu)], a.in_zp, a.in_scale);
                         // packed position of k inside its 32-chunk: class k%4, position (k%32)/4
-                        const int kl = k & 31;
-                        const uint8_t wb = a.wq[((size_t)(co0 / BM) * (a.Kpad / KC) + (k >> 5)) * (BM * 32) + (co - co0) * 32 + (kl & 3) * 8 + (kl >> 2)];
+                        const int kl = k % KC;
+                        const uint8_t wb = a.wq[((size_t)(co0 / BM) * (a.Kpad / KC) + k / KC) * (BM * KC) + (co - co0) * KC + (kl & 3) * NPOS + (kl >> 2)];
                         s = __builtin_fmaf(dequant(wb, a.w_zp, a.w_scale), v, s);
                     }
                 } else
@@ -256,34 +263,37 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int KC>
 __global__ __launch_bounds__(WM * WN * 64) void conv_u8_gemm_k(const U8ConvArgs a)
 {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LD = KC + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ws = smem;                               // [2][BM][36]
-    float* xs = smem + 2 * BM * 36;                 // [2][BN][36]
-    unsigned* lut = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * 36);   // [Kpad]
+    float* ws = smem;                               // [2][BM][LD]
+    float* xs = smem + 2 * BM * LD;                 // [2][BN][LD]
+    unsigned* lut = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LD);   // [Kpad]
     for (int k = threadIdx.x; k < a.Kpad; k += WM * WN * 64) lut[k] = a.klut[k];
     __syncthreads();
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
     // x = (image, pixel tile): blocks that stream the same weight tile are neighbours in launch order (L2 reuse)
     const int n = blockIdx.x / tpi, tile = blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
-    if (tile < tiles) conv_u8_body<WM, WN, TM, TN, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
-    else conv_u8_body<WM, WN, TM, TN, true>(a, ws, xs, lut, n, N8, OHW, co0);
+    if (tile < tiles) conv_u8_body<WM, WN, TM, TN, KC, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
+    else conv_u8_body<WM, WN, TM, TN, KC, true>(a, ws, xs, lut, n, N8, OHW, co0);
 }
 
-// tile choice: the largest block tile that still gives every CU at least two blocks (geometry only; the planner
-// stores the index in a.cfg)
-static const struct { int bm, bn; const char* name; } U8_CFGS[] = {
-    {16, 64, "conv_u8_mfma_16x64"}, {32, 32, "conv_u8_mfma_32x32"}, {64, 64, "conv_u8_mfma_64x64"}, {32, 64, "conv_u8_mfma_32x64"},
-    {16, 16, "conv_u8_mfma_16x16"}};
+// configurations: block tile (channels x pixels) and K stage depth.  conv_u8_gemm_pick is the geometry heuristic (the
+// largest tile that still gives every CU two blocks); the planner's autotune times all of them and stores the index in
+// a.cfg.  The 64-deep stages halve the barriers / exposed load latencies per K at twice the LDS.
+static const struct { int bm, bn, kc; const char* name; } U8_CFGS[] = {
+    {16, 64, 32, "conv_u8_mfma_16x64"}, {32, 32, 32, "conv_u8_mfma_32x32"}, {64, 64, 32, "conv_u8_mfma_64x64"},
+    {32, 64, 32, "conv_u8_mfma_32x64"}, {16, 16, 32, "conv_u8_mfma_16x16"},
+    {64, 64, 64, "conv_u8_mfma_64x64k64"}, {32, 64, 64, "conv_u8_mfma_32x64k64"}, {32, 32, 64, "conv_u8_mfma_32x32k64"}};
 
+int conv_u8_gemm_num_cfgs() { return 8; }
 int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
     static const char* e = getenv("TAMD_U8_CFG");
-    if (e && *e) return atoi(e) % 5;
+    if (e && *e) return atoi(e) % 8;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
     if (a.cout <= 16) return 0;
@@ -293,9 +303,13 @@ int conv_u8_gemm_pick(const U8ConvArgs& a)
     if (blocks(32, 32) >= 512) return 1;
     return 4;                                          // one wave per block: the most blocks (latency-bound layers)
 }
-size_t conv_u8_gemm_lds(const U8ConvArgs& a) { return (size_t)(2 * (U8_CFGS[a.cfg].bm + U8_CFGS[a.cfg].bn) * 36 + a.Kpad) * 4; }
+size_t conv_u8_gemm_lds(const U8ConvArgs& a)
+{
+    return (size_t)(2 * (U8_CFGS[a.cfg].bm + U8_CFGS[a.cfg].bn) * (U8_CFGS[a.cfg].kc + 4) + a.Kpad) * 4;
+}
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a) { return U8_CFGS[a.cfg].name; }
 int conv_u8_gemm_bm(int cfg) { return U8_CFGS[cfg].bm; }
+int conv_u8_gemm_kc(int cfg) { return U8_CFGS[cfg].kc; }
 
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
@@ -303,14 +317,21 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
     const int bm = U8_CFGS[a.cfg].bm, bn = U8_CFGS[a.cfg].bn;
     const dim3 grid(((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
     const size_t lds = conv_u8_gemm_lds(a);
+    auto go = [&](auto kern, int threads) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, a);
+        return hipGetLastError();
+    };
     switch (a.cfg) {
-    case 0: hipLaunchKernelGGL((conv_u8_gemm_k<1, 4, 1, 1>), grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 2, 2>), grid, dim3(256), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 2>), grid, dim3(256), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_u8_gemm_k<1, 1, 1, 1>), grid, dim3(64), lds, s, a); break;
-    default: hipLaunchKernelGGL((conv_u8_gemm_k<2, 2, 1, 1>), grid, dim3(256), lds, s, a); break;
+    case 0: return go(conv_u8_gemm_k<1, 4, 1, 1, 32>, 256);
+    case 2: return go(conv_u8_gemm_k<2, 2, 2, 2, 32>, 256);
+    case 3: return go(conv_u8_gemm_k<2, 2, 1, 2, 32>, 256);
+    case 4: return go(conv_u8_gemm_k<1, 1, 1, 1, 32>, 64);
+    case 5: return go(conv_u8_gemm_k<2, 2, 2, 2, 64>, 256);
+    case 6: return go(conv_u8_gemm_k<2, 2, 1, 2, 64>, 256);
+    case 7: return go(conv_u8_gemm_k<2, 2, 1, 1, 64>, 256);
+    default: return go(conv_u8_gemm_k<2, 2, 1, 1, 32>, 256);
     }
-    return hipGetLastError();
 }
 
 // =================================================================================================================

@@ -50,7 +50,8 @@ RAGGED_U8 = [
     (1, 16, 17, 5, 24, 3, 3, 1, 1, 6, False, 1),
     (7, 33, 6, 6, 65, 1, 1, 0, 1, 0, True, 1),
     (1, 640, 3, 5, 9, 3, 1, 1, 1, 0, True, 1),        # K = 5760, 15 pixels (8 main + 7 tail), 9 rows (8-block + 1 single)
-    (1, 512, 7, 7, 34, 7, 1, 3, 1, 0, True, 1),       # K = 25088: tap table too big for LDS -> the LDS-DMA kernel
+    (1, 512, 7, 7, 34, 7, 1, 3, 1, 0, True, 1),       # K = 25088: 100 KB tap table in LDS (opt-in above 64 KB)
+    (1, 3600, 3, 3, 8, 3, 1, 1, 1, 0, True, 1),       # K = 32400: tap table too big for LDS -> the LDS-DMA kernel
     (3, 12, 8, 8, 12, 3, 1, 1, 3, 0, True, 1),
 ]
 
