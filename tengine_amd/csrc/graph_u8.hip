@@ -119,7 +119,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         // raw bytes, [cout tile][stage][row][32 slots], slot (k%4)*8 + (k%32)/4; padding = weight zero point
         std::map<int, uint8_t*> packed;            // (BM, KC) -> device copy of the weights packed for that tile shape
         auto pack_for = [&](int cfg) -> uint8_t* {
-            const int BM = conv_u8_gemm_bm(cfg), KC = conv_u8_gemm_kc(cfg), NPOS = KC / 4, nstage = Kpad / KC;
+            const int BM = conv_u8_gemm_bm(cfg), KC = conv_u8_gemm_kc(cfg), NPOS = KC / 4, nstage = rup(K, KC) / KC;
             auto it = packed.find(BM * 1000 + KC);
             if (it != packed.end()) return it->second;
             const int ntile = (cout + BM - 1) / BM;
@@ -157,7 +157,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             float best_ms = 1e30f;
             int best_cfg = a.cfg;
             for (int c = 0; c < conv_u8_gemm_num_cfgs(); c++) {
-                U8ConvArgs ac = a; ac.cfg = c;
+                U8ConvArgs ac = a; ac.cfg = c; ac.Kpad = rup(K, conv_u8_gemm_kc(c));
                 if (conv_u8_gemm_lds(ac) > 150 * 1024) continue;
                 if ((ac.wq = pack_for(c)) == nullptr) return -1;
                 if (launch_conv_u8_gemm(ac, g->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -171,6 +171,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;
         }
+        a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
         st.kernel = conv_u8_gemm_kernel_name(a);
         st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
