@@ -26,16 +26,19 @@ static int q_of(const HTensor& t, U8Q* q, const char* what)
     return 0;
 }
 
-static int plan_conv_u8(tamd_graph* g, HNode& n)
+static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
 {
     HTensor& x = g->tensors[n.in[0]];
     HTensor& w = g->tensors[n.in[1]];
     HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
-    HTensor& y = g->tensors[n.out[0]];
+    HTensor& yc = g->tensors[n.out[0]];                               // the conv's own output: its quantisation parameters
+    HTensor& y = relu ? g->tensors[relu->out[0]] : yc;                // where the bytes go (the fused ReLU's output)
     const tamd_conv_param& p = n.p.conv;
     if (w.dtype != TAMD_DT_UINT8 || (b && b->dtype != TAMD_DT_INT32)) { set_error("conv %s: uint8 weights / int32 bias expected", n.name.c_str()); return -1; }
     U8Q qx, qw, qy;
-    if (q_of(x, &qx, "tensor") || q_of(w, &qw, "weight") || q_of(y, &qy, "tensor")) return -1;
+    if (q_of(x, &qx, "tensor") || q_of(w, &qw, "weight") || q_of(yc, &qy, "tensor")) return -1;
+    U8Relu fr{};
+    if (relu) { fr.on = 1; fr.slope = relu->p.relu.negative_slope; if (q_of(y, &fr.out, "tensor")) return -1; }
     const int cin_g = x.c / p.group, K = cin_g * p.kernel_h * p.kernel_w, cout = y.c;
     if ((size_t)cout * K != w.data.size()) { set_error("conv %s: weight size mismatch", n.name.c_str()); return -1; }
     const int32_t* dbias = nullptr;
@@ -53,6 +56,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
     // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~28k taps it does not fit next to the
     // operand tiles (160 KB per CU) and the DMA kernel (table read with scalar loads) takes over
     if (p.group == 1 && (size_t)(rup(K, 64) + 2 * (64 + 64) * 36) * 4 > 150 * 1024) use_dma = true;
+    if (p.group == 1 && use_dma && relu) return 2;           // the DMA kernel has no fused ReLU tail: plan the two nodes apart
     if (p.group == 1 && use_dma && (p.kernel_h - 1) * p.dilation_h <= 15 && (p.kernel_w - 1) * p.dilation_w <= 15
         && (size_t)x.c * x.h * x.w < (1u << 24)) {
         // ---- asynchronous fp32 MFMA kernel (conv_f32_mfma.hip): fp32 copy of the input + fp32 packed weights ----
@@ -147,7 +151,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         a.m_blocked = (cout >> 3 << 3) + (((cout - (cout >> 3 << 3)) >> 2) << 2);
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
-        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
+        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp; a.relu = fr;
         // plan-time autotune over the tile configurations (every one produces the same bytes: the chain order of an
         // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
         static const char* at_env = getenv("TAMD_AUTOTUNE");
@@ -173,7 +177,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
-        st.kernel = conv_u8_gemm_kernel_name(a);
+        st.kernel = std::string(conv_u8_gemm_kernel_name(a)) + (relu ? "+relu" : "");
         st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
     } else {
         std::vector<float> wf((size_t)cout * K);
@@ -187,8 +191,8 @@ static int plan_conv_u8(tamd_graph* g, HNode& n)
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.group = p.group;
         a.out_img = (y.is_view ? y.cs : cout) * y.h * y.w; a.out_c0 = y.c_off;
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp; a.w_scale = qw.scale;
-        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp;
-        st.kernel = "conv_u8_direct";
+        a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp; a.relu = fr;
+        st.kernel = relu ? "conv_u8_direct+relu" : "conv_u8_direct";
         st.fn = [a](hipStream_t s) { return launch_conv_u8_direct(a, s); };
     }
     g->steps.push_back(st);
@@ -287,13 +291,28 @@ int plan_u8(tamd_graph* g)
         for (size_t i = 0; i < g->tensors.size(); i++)
             if (alias_of[i] >= 0) g->tensors[i].dptr = g->tensors[alias_of[i]].dptr;
 
-    for (auto& n : g->nodes) {
+    // conv -> ReLU / leaky ReLU fusion (YOLOv3-tiny: 11 of them): the ReLU node is applied to the conv's own uint8
+    // result in the conv epilogue when nothing else reads that result
+    const char* fuse_env = getenv("TAMD_FUSE_RELU");          // read at every prerun (tests switch it)
+    std::vector<char> fused(g->nodes.size(), 0);
+    for (size_t ni = 0; ni < g->nodes.size(); ni++) {
+        HNode& n = g->nodes[ni];
+        if (fused[ni]) continue;
         switch (n.op) {
         case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
             break;
-        case TAMD_OP_CONV:
-            if (plan_conv_u8(g, n)) return -1;
+        case TAMD_OP_CONV: {
+            const HNode* relu = nullptr;
+            size_t rj = 0;
+            if (!(fuse_env && atoi(fuse_env) == 0) && count_consumers(g, n.out[0]) == 1)
+                for (size_t nj = ni + 1; nj < g->nodes.size(); nj++)
+                    if (g->nodes[nj].op == TAMD_OP_RELU && g->nodes[nj].in[0] == n.out[0]) { relu = &g->nodes[nj]; rj = nj; break; }
+            int rc = plan_conv_u8(g, n, relu);
+            if (rc == 2) { relu = nullptr; rc = plan_conv_u8(g, n, nullptr); }       // kernel without the fused tail
+            if (rc) return -1;
+            if (relu) fused[rj] = 1;
             break;
+        }
         case TAMD_OP_FC:
             if (plan_fc_u8(g, n)) return -1;
             break;

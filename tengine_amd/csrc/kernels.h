@@ -133,6 +133,9 @@ hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);
 // profiles/r01_mfma_f32_is_sequential_fma_chain.txt), so the path runs on the matrix cores (u8_kernels.hip).
 // uint8 activations stay in the reference's dense NCHW order on the device.
 struct U8Q { float scale; int zp; };
+// a ReLU node folded into the producing conv: applied to the conv's own uint8 result in registers
+// (relu_kernel_ref_uint8.c:48-95 on that byte), so the bytes equal the two-launch sequence
+struct U8Relu { int on; float slope; U8Q out; };
 
 struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
     const uint8_t* x;          // NCHW
@@ -153,6 +156,7 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     float bias_scale;          // in_scale * w_scale
     int act;
     float out_scale; int out_zp;
+    U8Relu relu;               // fused ReLU / leaky ReLU node (y, out_img, out_c0 then describe ITS output)
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
@@ -163,6 +167,7 @@ struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c o
     float in_scale, in_zp, w_scale;
     int act;
     float out_scale; int out_zp;
+    U8Relu relu;
 };
 
 struct U8FcArgs {              // fc_ref.c:121-207

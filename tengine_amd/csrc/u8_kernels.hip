@@ -38,6 +38,14 @@ __device__ __forceinline__ uint8_t quant_round_in(float f, U8Q q)
 }
 __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { return ((float)u - zp) * scale; }
 
+// ReLU / leaky ReLU node applied to a conv's own uint8 result: relu_kernel_ref_uint8.c:48-95 on that byte
+__device__ __forceinline__ uint8_t fused_relu(uint8_t q, float scale, int zp, const U8Relu& r)
+{
+    float f = dequant(q, (float)zp, scale);
+    if (f < 0.f) f = (r.slope == 0.f) ? 0.f : f * r.slope;
+    return quant_round_in(f, r.out);
+}
+
 // =================================================================================================================
 // group == 1 convolution: conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8, k = (c,ky,kx),
 // 0.0f at out-of-image taps), :322-960 sgemm_fp, :1703-1794 bias / activation / requantise.
@@ -258,7 +266,9 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                 if (a.bias) s = __builtin_fmaf((float)a.bias[co], a.bias_scale, s);
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
+                uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
+                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = q;
             }
     }
 }
@@ -372,7 +382,9 @@ __global__ __launch_bounds__(256) void conv_u8_direct_k(const U8DirectArgs a)
         if (total > 6.f && a.act == 6) total = 6.f;
         if (total < -1.f && a.act == 1) total = -1.f;
     }
-    a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + oc) * OHW + pj] = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+    uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + oc) * OHW + pj] = q;
 }
 
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s)

@@ -97,6 +97,23 @@ def test_route_u8():
     check(g, x, "route")
 
 
+@pytest.mark.parametrize("group,slope", [(1, 0.1), (1, 0.0), (24, 0.1)])
+def test_conv_relu_fused_u8(group, slope):
+    """conv -> (leaky) ReLU folded into one launch: the ReLU node works on the conv's own uint8 bytes in registers."""
+    g, x = u8_conv_graph(77, 2, 24, 13, 13, 24 if group > 1 else 40, 3, 1, 1, group=group, act=-1)
+    c = g.nodes[-1].outputs[0]
+    r = g.add_tensor("lk", list(g.tensors[c].dims), tm2.DT_UINT8, tm2.TT_VAR, None, [g.tensors[c].scales[0] * 0.6], [31])
+    ni = g.add_node("lk", "ReLU", [c], [r], negative_slope=slope)
+    g.output_nodes = [ni]
+    want = oracle.run_graph(g, x)[0]
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    assert gr.kernel_num() == 1, "conv and ReLU should be one launch"
+    gr.close()
+    assert np.array_equal(want, got)
+
+
 @pytest.mark.parametrize("batch", [1, 3])
 def test_concat_by_offset_u8(batch):
     """two convs whose outputs carry the concat's own (scale, zp): the planner lets them write into the concat
@@ -130,10 +147,15 @@ def test_concat_by_offset_u8(batch):
 def test_yolov3_tiny_uint8_bit_exact():
     """BASELINE configs[3] class: YOLOv3-tiny uint8 (13 convs up to K = 4608, leaky ReLU, max pools incl. the
     stride-1 'same' pool, upsample, concat with per-input rescale), whole graph on the device, layer by layer."""
+    import os
     g = models.build("yolov3_tiny", "uint8", 1, res=160)
     x = models.synth_input(g, 3, tm2.DT_UINT8)
     want = oracle.run_graph(g, x, keep_all=True)
-    gr = capi.Graph(tm2.write_tm2(g))
+    os.environ["TAMD_FUSE_RELU"] = "0"        # every node in its own launch, so that every tensor exists
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        del os.environ["TAMD_FUSE_RELU"]
     gr.set_input(x)
     outs = gr.run()
     for n in g.nodes:
