@@ -168,7 +168,11 @@ __device__ __forceinline__ unsigned fuse_elt4(unsigned pc, unsigned pr, const El
         default: f = fa > fb ? fa : fb; break;
         }
         int y = round_div_sat(f, e.out_scale, inv_out);
-        if (e.relu) {
+        if (e.relu == 2) {
+            // ReLU whose output scale IS the eltwise output scale (the quantiser shares them): for an integer |y| <= 127,
+            // fl(fl(y*s)/s) is within 2^-22 relative of y, so round() gives y back exactly and the node is max(y, 0)
+            y = y < 0 ? 0 : y;
+        } else if (e.relu) {
             float f2 = __fmul_rn((float)y, e.out_scale);
             f2 = f2 < 0.f ? 0.f : f2;
             y = round_div_sat(f2, e.relu_out_scale, inv_relu);

@@ -367,7 +367,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             a.elt.type = fz->type; a.elt.conv_is_first = fz->conv_is_first ? 1 : 0;
             a.elt.s_conv = y.scales[0]; a.elt.s_res = r.scales[0];
             a.elt.out_scale = g->tensors[fz->elt_tensor].scales[0];
-            a.elt.relu = fz->relu ? 1 : 0; a.elt.relu_out_scale = o.scales[0];
+            a.elt.relu = fz->relu ? (o.scales[0] == a.elt.out_scale ? 2 : 1) : 0; a.elt.relu_out_scale = o.scales[0];
             a.y = (int8_t*)o.dptr; a.ldc = o.cs; a.c_off = o.c_off;
             a.c_limit = o.is_view ? cout : std::min(rup(cout, 16), o.cs - o.c_off);
             st.bytes += (double)r.n * r.h * r.w * r.c;
@@ -611,7 +611,7 @@ static int plan(tamd_graph* g)
                     if (r.op == TAMD_OP_RELU && r.in[0] == n.out[0] && r.p.relu.negative_slope == 0.f) {
                         HTensor& ry = g->tensors[r.out[0]];
                         if (ry.is_view) break;
-                        a.fuse_relu = 1; a.relu_out_scale = ry.scales[0];
+                        a.fuse_relu = ry.scales[0] == a.out_scale ? 2 : 1; a.relu_out_scale = ry.scales[0];
                         y = &ry; fused[nj] = 1; kname = "eltwise_relu_i8";
                         break;
                     }

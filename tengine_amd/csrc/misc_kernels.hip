@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void eltwise_i8_kernel(EltArgs a)
             default: f = fa > fb ? fa : fb; break;
             }
             int y = round_div_sat(f, a.out_scale, inv_out);
-            if (a.fuse_relu) {
+            if (a.fuse_relu == 2) {
+                y = y < 0 ? 0 : y;      // relu_out_scale == out_scale: round(fl(fl(y*s)/s)) == y (epilogue.h fuse_elt4)
+            } else if (a.fuse_relu) {
                 float f2 = __fmul_rn((float)y, a.out_scale);
                 f2 = f2 < 0.f ? 0.f : f2;
                 y = round_div_sat(f2, a.relu_out_scale, inv_relu);

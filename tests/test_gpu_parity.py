@@ -129,6 +129,16 @@ def test_eltwise_relu(with_relu):
     check(g, x, "eltwise")
 
 
+@pytest.mark.parametrize("etype", [tm2.ELT_SUM, tm2.ELT_SUB, tm2.ELT_MAX, tm2.ELT_PROD])
+def test_eltwise_relu_with_its_own_scale(etype):
+    """ReLU output scale != eltwise output scale: the general two-rounding tail (not the max(y,0) shortcut), and the
+    non-commutative SUB with the conv on either side; fused into the later conv's epilogue."""
+    g, x = eltwise_relu_graph(19, 3, 32, 9, 9, True, etype)
+    r = [t for t in g.tensors if t.name == "relu"][0]
+    r.scales = [float(np.float32(r.scales[0] * 0.83))]
+    check(g, x, "eltwise etype %d" % etype)
+
+
 def test_mobilenet_v1_int8_batch1_bit_exact():
     g = models.build("mobilenet_v1", "int8", 1)
     x = models.synth_input(g, 7)
