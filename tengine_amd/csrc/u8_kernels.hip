@@ -387,8 +387,59 @@ __global__ __launch_bounds__(256) void conv_u8_direct_k(const U8DirectArgs a)
     a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + oc) * OHW + pj] = q;
 }
 
+// depthwise 3x3 (every MobileNet dw layer), same arithmetic as conv_u8_direct_k.  Threads run over the flattened
+// (channel, pixel) index of one image so 7x7 and 14x14 maps still fill their wavefronts; the nine taps are loaded up
+// front from clamped addresses -- one memory round trip instead of nine dependent ones -- and an out-of-image tap
+// enters the chain as 0.0f, which leaves `total` unchanged exactly as the reference's `continue` does.
+__global__ __launch_bounds__(256) void conv_u8_dw3_k(const U8DirectArgs a)
+{
+    const int OHW = a.OH * a.OW;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (idx >= a.cout * OHW) return;
+    const int oc = idx / OHW, pj = idx - oc * OHW;
+    const int oy = pj / a.OW, ox = pj - oy * a.OW;
+    const uint8_t* xc = a.x + ((size_t)n * a.C + oc) * a.H * a.W;
+    const float* wk = a.wf + (size_t)oc * 9;
+    unsigned u[9];
+    bool ok[9];
+    float w[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int iy = oy * a.SH - a.PH + (t / 3) * a.DH, ix = ox * a.SW - a.PW + (t % 3) * a.DW;
+        ok[t] = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        u[t] = xc[ok[t] ? iy * a.W + ix : 0];
+        w[t] = wk[t];
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const float xf = ok[t] ? dequant((uint8_t)u[t], a.in_zp, a.in_scale) : 0.f;
+        total = __builtin_fmaf(xf, w[t], total);
+    }
+    if (a.bias) {
+        float bf = (float)a.bias[oc] * a.in_scale;
+        bf = bf * a.w_scale;
+        total = total + bf;
+    }
+    if (a.act >= 0) {
+        if (total < 0.f && a.act != 1) total = 0.f;
+        if (total > 1.f && a.act == 1) total = 1.f;
+        if (total > 6.f && a.act == 6) total = 6.f;
+        if (total < -1.f && a.act == 1) total = -1.f;
+    }
+    uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    a.y[(size_t)n * a.out_img + (size_t)a.out_c0 * OHW + idx] = q;
+}
+
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s)
 {
+    if (a.group == a.C && a.cout == a.C && a.KH == 3 && a.KW == 3) {
+        dim3 grid((a.cout * a.OH * a.OW + 255) / 256, a.N);
+        hipLaunchKernelGGL(conv_u8_dw3_k, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     dim3 grid((a.OH * a.OW + 255) / 256, a.cout, a.N);
     hipLaunchKernelGGL(conv_u8_direct_k, grid, dim3(256), 0, s, a);
     return hipGetLastError();
