@@ -305,6 +305,10 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
                 y = {tm2.ELT_SUM: a + b2, tm2.ELT_PROD: a * b2, tm2.ELT_SUB: a - b2, tm2.ELT_MAX: np.maximum(a, b2)}[p["type"]]
         elif op == "Dropout":
             y = a
+        elif op == "Permute":       # permute/permute_ref.c:203-296: a byte copy in the new order, no requantisation
+            y = np.ascontiguousarray(np.transpose(a, p["order"]))
+        elif op == "Flatten":       # flatten/flatten_ref.c:53-77: element copy; shape [n, prod(rest)] (flatten.c:34-61)
+            y = a.reshape(a.shape[0], -1)
         elif op == "Concat" and dt == DT_UINT8:
             y = np.concatenate([requant_copy_uint8(vals[i], qp(i), qp(o0)) for i in n.inputs], axis=p.get("axis", 1))
         elif op == "Concat" and dt == DT_FP32:

@@ -400,8 +400,8 @@ static float sgemm_fp_element(const float* col, const float* w, int K, int full_
  *   round(total/out_s) + out_zp, clamp [0,255] (:177-182).  Used by the reference for every depthwise /
  *   grouped uint8 conv (conv_dw_hcl_x86.c:533 rejects uint8).
  * variant ORC_CONV_HCL -- conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8 -> fp32),
- *   sgemm_fp in its exact summation order (sgemm_fp_element above), then :1703-1794: s = fma((float)bias,
- *   in_s*k_s, s), relu / relu6 for ANY positive activation code, (int)(round(s/out_s) + out_zp), clamp [0,255]. */
+ *   sgemm_fp in its exact summation order (sgemm_fp_element above), then :1703-1794: s = s + (float)bias *
+ *   (in_s*k_s) (product rounded first), relu / relu6 for ANY positive activation code, (int)(round(s/out_s) + out_zp), clamp [0,255]. */
 ORC_API int orc_conv2d_uint8(const uint8_t* x, const uint8_t* w, const int32_t* bias, uint8_t* y, int n, int cin, int h,
                              int wd, int cout, int oh, int ow, int kh, int kw, int sh, int sw, int ph0, int pw0, int dh,
                              int dw, int group, int act, float in_scale, int in_zp, float w_scale, int w_zp,
@@ -462,7 +462,10 @@ ORC_API int orc_conv2d_uint8(const uint8_t* x, const uint8_t* w, const int32_t* 
                         else
                         {
                             total = sgemm_fp_element(col, wk, K, j < (N & ~7), m < m_blocked);
-                            if (bias) total = fmaf((float)bias[oc], in_scale * w_scale, total);
+                            /* :1733-1743 -- the loop-invariant product (float)bias * bias_scale is hoisted out of the
+                             * pixel loop by the compiler and ADDED (vmulss once, then vaddps): two roundings, not an fma.
+                             * Read off the reference object's disassembly; an fma here differs once per ~2e5 outputs. */
+                            if (bias) total = total + (float)bias[oc] * (in_scale * w_scale);
                             if (act == 0 && total < 0) total = 0;
                             if (act > 0)
                             {

@@ -208,7 +208,7 @@ __device__ __forceinline__ void conv_f32_body(const F32ConvArgs& a, float* smem,
                     a.out_f32[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = sum;
                 } else {
                     // uint8 model: conv_kernel_x86.c:1703-1794
-                    if (a.bias) sum = __builtin_fmaf((float)a.bias[co], a.bias_scale, sum);
+                    if (a.bias) sum = sum + (float)a.bias[co] * a.bias_scale;      // rounded product, then add (see u8_kernels.hip)
                     if (a.act == 0) sum = sum < 0.f ? 0.f : sum;
                     if (a.act > 0) { sum = sum < 0.f ? 0.f : sum; sum = sum > 6.f ? 6.f : sum; }
                     const int q = quant_round_div_i(sum, a.out_scale, a.out_zp);

@@ -7,9 +7,10 @@
 //   * every `a*b + c` the reference's compiler contracts (-O3 -mfma, default -ffp-contract=fast) is one
 //     __builtin_fmaf here; nothing else is fused (this TU is built -ffp-contract=off);
 //   * divisions are correctly rounded (__fdiv_rn), round() is round-half-away (roundf).
-// A sequential fp32 chain per output element cannot use MFMA (its internal accumulation order is not the
-// reference's) nor split K; the parallelism is across output elements: lanes = pixels x channels, operands staged
-// through LDS, register tiles of independent chains per thread.  Bound: fp32 vector FMA issue, not HBM.
+//   * where the reference's compiler did NOT fuse (a loop-invariant product it hoisted, e.g. the conv bias term) the
+//     product is rounded first -- read off the reference object's disassembly, not guessed from the C text.
+// A sequential chain per output element cannot split K; the parallelism is across output elements, and the fp32
+// MFMA instructions happen to accumulate in exactly that sequential fused order (see below).
 // Activations stay in the reference's dense NCHW order (lanes along pixels read consecutive bytes).
 #include <hip/hip_runtime.h>
 
@@ -263,7 +264,9 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                     }
                 } else
                     s = acc[0][i][j][e];
-                if (a.bias) s = __builtin_fmaf((float)a.bias[co], a.bias_scale, s);
+                // the compiled reference hoists (float)bias * bias_scale out of its pixel loop and ADDS the rounded product
+                // (conv_kernel_x86.c:1733-1743: vmulss, then vaddps -- not an fma)
+                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
                 uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));

@@ -115,6 +115,18 @@ class _B:
         self.g.add_node(name, "Upsample", [x], [y], scale=float(scale))
         return y
 
+    def permute(self, name, x, order=(0, 2, 3, 1)):
+        d = self.dims(x)
+        y = self.g.add_tensor(name + "/0", [d[i] for i in order], DT_FP32)
+        self.g.add_node(name, "Permute", [x], [y], flag=0, order=list(order))
+        return y
+
+    def flatten(self, name, x):
+        d = self.dims(x)
+        y = self.g.add_tensor(name + "/0", [d[0], int(np.prod(d[1:]))], DT_FP32)
+        self.g.add_node(name, "Flatten", [x], [y], axis=1, end_axis=3)
+        return y
+
     def finish(self, outs):
         for o in outs:
             for ni, n in enumerate(self.g.nodes):
@@ -253,6 +265,39 @@ def yolov3_tiny_fp32(batch=1, res=416, nout=255):
     return b.finish([head2, head1])
 
 
+def mssd_fp32(batch=1, res=300, classes=21):
+    """MobileNet-v1-SSD 300x300 (benchmark/models/mssd_benchmark.tmfile, the BASELINE "MobileNet-SSD" stand-in,
+    SURVEY §8d): 47 convs = conv0 + 13 (dw, pw) pairs + 4 (1x1, 3x3 s2) extra pairs + 6 loc and 6 conf 1x1 heads on
+    conv11 (19x19, 3 priors), conv13 (10x10), conv14_2 (5x5), conv15_2 (3x3), conv16_2 (2x2), conv17_2 (1x1) (6 priors
+    each); every head goes Permute(0,2,3,1) -> Flatten -> Concat(axis 1).  Outputs: mbox_loc [N, 1917*4] and
+    mbox_conf [N, 1917*classes]; the Reshape/Softmax/PriorBox/DetectionOutput tail of the tmfile is host-side
+    post-processing the splitter leaves on the CPU device."""
+    b = _B("mssd", [batch, 3, res, res])
+    x = b.conv("conv0", b.cur, 32, 3, 2, 1, act=0)
+    cfg = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1),
+           (1024, 2), (1024, 1)]
+    feats = []
+    for i, (c, s) in enumerate(cfg):
+        cin = b.dims(x)[1]
+        x = b.conv("conv%d/dw" % (i + 1), x, cin, 3, s, 1, group=cin, act=0)
+        x = b.conv("conv%d" % (i + 1), x, c, 1, act=0)
+        if i + 1 in (11, 13):
+            feats.append(("conv%d" % (i + 1), x, 3 if i + 1 == 11 else 6))
+    for i, (c1, c2) in enumerate([(256, 512), (128, 256), (128, 256), (64, 128)]):
+        x = b.conv("conv%d_1" % (14 + i), x, c1, 1, act=0)
+        x = b.conv("conv%d_2" % (14 + i), x, c2, 3, 2, 1, act=0)
+        feats.append(("conv%d_2" % (14 + i), x, 6))
+    outs = []
+    for kind, per in (("loc", 4), ("conf", classes)):
+        flats = []
+        for name, f, priors in feats:
+            h = b.conv("%s_mbox_%s" % (name, kind), f, priors * per, 1, act=-1)
+            h = b.permute("%s_mbox_%s_perm" % (name, kind), h)
+            flats.append(b.flatten("%s_mbox_%s_flat" % (name, kind), h))
+        outs.append(b.concat("mbox_%s" % kind, flats, axis=1))
+    return b.finish(outs)
+
+
 # --------------------------------------------------------------------------------------
 # fp32 forward (calibration only)
 # --------------------------------------------------------------------------------------
@@ -323,6 +368,8 @@ def fp32_forward(g: Graph, x: np.ndarray):
             y = a.repeat_interleave(s, dim=2).repeat_interleave(s, dim=3)
         elif op == "Flatten":
             y = a.reshape(a.shape[0], -1)
+        elif op == "Permute":
+            y = a.permute(*p["order"]).contiguous()
         else:
             raise NotImplementedError(op)
         vals[n.outputs[0]] = y
@@ -519,6 +566,7 @@ BUILDERS = {
     "resnet50": resnet50_fp32,
     "squeezenet_v1.1": squeezenet_v11_fp32,
     "yolov3_tiny": yolov3_tiny_fp32,
+    "mssd": mssd_fp32,
 }
 
 
