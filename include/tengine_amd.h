@@ -58,6 +58,7 @@ enum {
     TAMD_OP_RELU6 = 10,
     TAMD_OP_FLATTEN = 11,
     TAMD_OP_SOFTMAX = 12, /* fp32 only */
+    TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 graphs, order (0,2,3,1) -- the SSD head permute */
     TAMD_OP_NUM
 };
 
@@ -84,6 +85,7 @@ typedef struct tamd_relu_param { float negative_slope; } tamd_relu_param;   /* r
 typedef struct tamd_eltwise_param { int type; int caffe_flavor; float shift, power, scale; } tamd_eltwise_param;
 typedef struct tamd_concat_param { int axis; } tamd_concat_param;
 typedef struct tamd_upsample_param { float scale; } tamd_upsample_param;
+typedef struct tamd_permute_param { int order[4]; } tamd_permute_param;      /* permute_param.h: order0..order3 */
 
 /* == the quantisation-relevant part of struct tensor (source/graph/tensor.h:43-102) */
 typedef struct tamd_tensor_desc {

@@ -39,6 +39,7 @@ union NodeParam {
     tamd_eltwise_param elt;
     tamd_concat_param concat;
     tamd_upsample_param ups;
+    tamd_permute_param perm;
 };
 
 struct HNode {

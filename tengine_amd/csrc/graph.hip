@@ -150,6 +150,16 @@ static int infer_shapes(tamd_graph* g)
             y.dims = {x.dims[0], x.dims[1], x.dims[2] * sc, x.dims[3] * sc};
             break;
         }
+        case TAMD_OP_PERMUTE: {           // permute.c infer_shape: out.dims[i] = in.dims[order[i]]
+            if (x.dims.size() != 4) { set_error("permute %s: only 4-D tensors", n.name.c_str()); return -1; }
+            y.dims.resize(4);
+            for (int i = 0; i < 4; i++) {
+                const int o = n.p.perm.order[i];
+                if (o < 0 || o > 3) { set_error("permute %s: bad order", n.name.c_str()); return -1; }
+                y.dims[i] = x.dims[o];
+            }
+            break;
+        }
         case TAMD_OP_FLATTEN: {
             int f = 1;
             for (size_t i = 1; i < x.dims.size(); i++) f *= x.dims[i];
@@ -696,6 +706,7 @@ int tamd_op_supported(int op, int dtype)
     if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
     if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
     if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
+    if (op == TAMD_OP_PERMUTE) return dtype == TAMD_DT_UINT8;      // SSD heads (Permute -> Flatten -> Concat), uint8 graphs
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
     case TAMD_OP_ELTWISE: case TAMD_OP_CONCAT: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
@@ -751,6 +762,7 @@ int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* d)
         case TAMD_OP_ELTWISE: n.p.elt = *(const tamd_eltwise_param*)d->param; break;
         case TAMD_OP_CONCAT: n.p.concat = *(const tamd_concat_param*)d->param; break;
         case TAMD_OP_UPSAMPLE: n.p.ups = *(const tamd_upsample_param*)d->param; break;
+        case TAMD_OP_PERMUTE: n.p.perm = *(const tamd_permute_param*)d->param; break;
         default: break;
         }
     }

@@ -293,6 +293,33 @@ int plan_u8(tamd_graph* g)
 
     // conv -> ReLU / leaky ReLU fusion (YOLOv3-tiny: 11 of them): the ReLU node is applied to the conv's own uint8
     // result in the conv epilogue when nothing else reads that result
+    // SSD heads (MobileNet-SSD: 12 of them): conv -> Permute(0,2,3,1) -> Flatten -> Concat.  The permute and the
+    // flatten only re-index bytes, so the concat reads the conv result in permuted order itself: perm_src[flatten
+    // output] = the permute's input, and the permute launch disappears (TAMD_FUSE_PERMUTE=0 keeps it)
+    std::vector<int> perm_src(g->tensors.size(), -1);
+    std::vector<char> skip_perm(g->nodes.size(), 0);
+    {
+        const char* pe = getenv("TAMD_FUSE_PERMUTE");
+        if (!(pe && atoi(pe) == 0))
+            for (size_t pi = 0; pi < g->nodes.size(); pi++) {
+                const HNode& pn = g->nodes[pi];
+                const int* o = pn.p.perm.order;
+                if (pn.op != TAMD_OP_PERMUTE || !(o[0] == 0 && o[1] == 2 && o[2] == 3 && o[3] == 1)) continue;
+                if (count_consumers(g, pn.out[0]) != 1) continue;
+                const HNode* fl = nullptr;
+                for (auto& m : g->nodes)
+                    if (m.op == TAMD_OP_FLATTEN && m.in[0] == pn.out[0]) fl = &m;
+                if (!fl || count_consumers(g, fl->out[0]) != 1) continue;
+                bool to_concat = false;
+                for (auto& m : g->nodes)
+                    if (m.op == TAMD_OP_CONCAT)
+                        for (int i : m.in) to_concat |= (i == fl->out[0]);
+                if (!to_concat) continue;
+                perm_src[fl->out[0]] = pn.in[0];
+                skip_perm[pi] = 1;
+            }
+    }
+
     const char* fuse_env = getenv("TAMD_FUSE_RELU");          // read at every prerun (tests switch it)
     std::vector<char> fused(g->nodes.size(), 0);
     for (size_t ni = 0; ni < g->nodes.size(); ni++) {
@@ -349,23 +376,50 @@ int plan_u8(tamd_graph* g)
             g->steps.push_back(st);
             break;
         }
+        case TAMD_OP_PERMUTE: {
+            if (skip_perm[ni]) break;                 // folded into the concat that reads it (below)
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            const int* o = n.p.perm.order;
+            if (!(o[0] == 0 && o[1] == 2 && o[2] == 3 && o[3] == 1)) { set_error("permute %s: only order (0,2,3,1) is supported on the device", n.name.c_str()); return -1; }
+            U8CatArgs a{};
+            a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
+            a.N = x.dims[0]; a.in_img = (int)(x.elems() / x.dims[0]);
+            a.perm_c = x.dims[1]; a.perm_p = x.dims[2] * x.dims[3];
+            a.out_img = a.in_img; a.out_off = 0; a.identity = 1;
+            a.in.scale = a.out.scale = 1.f;
+            Step st; st.node = n.name; st.kernel = "permute_u8"; st.bytes = 2.0 * x.elems();
+            st.fn = [a](hipStream_t s) { return launch_flatcat_u8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
         case TAMD_OP_CONCAT: {
             HTensor& y = g->tensors[n.out[0]];
             int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
-            if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+            if (ax != 1) { set_error("concat %s: only axis 1 is supported on the device", n.name.c_str()); return -1; }
+            // axis 1 of [n][c][...]: every input is one contiguous slice of each output image
+            const int out_img = (int)(y.elems() / y.dims[0]);
             int off = 0;
             for (int i : n.in) {
                 HTensor& x = g->tensors[i];
-                if (x.is_view && x.dptr == y.dptr) { off += x.c; continue; }       // written in place by its producer
-                U8MapArgs a{};
+                const int in_img = (int)(x.elems() / x.dims[0]);
+                if (x.is_view && x.dptr == y.dptr) { off += in_img; continue; }       // written in place by its producer
+                U8CatArgs a{};
                 a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
-                a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.scale = 1;
-                a.out_img = y.c * y.h * y.w; a.out_c0 = off;
+                a.N = x.dims[0]; a.in_img = in_img; a.out_img = out_img; a.out_off = off;
                 if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
-                Step st; st.node = n.name; st.kernel = "concat_u8"; st.bytes = 2.0 * x.elems();
-                st.fn = [a](hipStream_t s) { return launch_requant_copy_u8(a, s); };
+                // roundf((u - zp) * 1 + zp) == u: equal parameters make the rescale a copy
+                a.identity = a.in.scale == a.out.scale && a.in.zp == a.out.zp;
+                const char* kname = "concat_u8";
+                if (perm_src[i] >= 0) {                                  // Permute(0,2,3,1) -> Flatten -> this concat
+                    HTensor& s = g->tensors[perm_src[i]];
+                    a.x = (const uint8_t*)s.dptr; a.perm_c = s.dims[1]; a.perm_p = s.dims[2] * s.dims[3];
+                    kname = "permute_concat_u8";
+                }
+                Step st; st.node = n.name; st.kernel = kname; st.bytes = 2.0 * x.elems();
+                st.fn = [a](hipStream_t s) { return launch_flatcat_u8(a, s); };
                 g->steps.push_back(st);
-                off += x.c;
+                off += in_img;
             }
             break;
         }

@@ -192,6 +192,15 @@ struct U8MapArgs {             // relu / leaky, concat slice copy, nearest upsam
     U8Q in, out;
 };
 
+struct U8CatArgs {             // flat per-image slice copy: concat on axis 1 of any rank, Permute(0,2,3,1), or both at once
+    const uint8_t* x; uint8_t* y;
+    int N, in_img;             // images, bytes per input image
+    int perm_c, perm_p;        // 0: source index == j; else source = (j % perm_c) * perm_p + j / perm_c  (NCHW read in NHWC order)
+    int out_img, out_off;      // output image stride / byte offset of this slice inside the output image
+    int identity;              // 1: plain byte copy (permute, or concat input carrying the output's scale and zero point)
+    U8Q in, out;
+};
+
 struct U8EltArgs {
     const uint8_t* a; const uint8_t* b; uint8_t* y; size_t count; int type;
     U8Q qa, qb, out;
@@ -259,6 +268,7 @@ hipError_t launch_pool_u8(const U8PoolArgs& a, hipStream_t s);
 hipError_t launch_relu_u8(const U8MapArgs& a, hipStream_t s);
 hipError_t launch_requant_copy_u8(const U8MapArgs& a, hipStream_t s);
 hipError_t launch_upsample_u8(const U8MapArgs& a, hipStream_t s);
+hipError_t launch_flatcat_u8(const U8CatArgs& a, hipStream_t s);
 hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s);
 
 }  // namespace tamd

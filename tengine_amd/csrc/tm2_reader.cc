@@ -68,6 +68,7 @@ int map_op(uint32_t t)
     case 10: return TAMD_OP_FLATTEN;
     case 11: return TAMD_OP_FC;
     case 12: return TAMD_OP_INPUT;
+    case 15: return TAMD_OP_PERMUTE;
     case 16: return TAMD_OP_POOL;
     case 20: return TAMD_OP_RELU;
     case 21: return TAMD_OP_RELU6;
@@ -165,6 +166,9 @@ extern "C" tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size)
                 break;
             case TAMD_OP_CONCAT: p.concat.axis = r.i32(po); break;
             case TAMD_OP_UPSAMPLE: p.ups.scale = r.f32(po); break;
+            case TAMD_OP_PERMUTE:                              // TM2_PermuteParam {flag, order0..3} (tm2_permute.c)
+                for (int i = 0; i < 4; i++) p.perm.order[i] = r.i32(po + 4 + 4 * i);
+                break;
             default: break;
             }
         }

@@ -436,9 +436,79 @@ __global__ __launch_bounds__(256) void conv_u8_dw3_k(const U8DirectArgs a)
     a.y[(size_t)n * a.out_img + (size_t)a.out_c0 * OHW + idx] = q;
 }
 
+// The same, four horizontally adjacent outputs per thread (pad 1, dilation 1, stride S): the 3 x (3S+3) input bytes
+// they share are loaded once (4.5 resp. 6.75 loads per output instead of 9) and -- what matters more on this
+// latency-bound op -- every thread keeps four outputs' worth of bytes in flight.  Each output still runs its own
+// nine-step chain in (ky, kx) order.
+template <int S>
+__global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
+{
+    constexpr int NC = 3 * S + 3;
+    const int QW = (a.OW + 3) >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (idx >= a.cout * a.OH * QW) return;
+    const int xq = idx % QW, r = idx / QW, oy = r % a.OH, oc = r / a.OH;
+    const int ox0 = xq * 4, iy0 = oy * S - 1, ix0 = ox0 * S - 1;
+    const uint8_t* xc = a.x + ((size_t)n * a.C + oc) * a.H * a.W;
+    const float* wk = a.wf + (size_t)oc * 9;
+    unsigned u[3][NC];
+    unsigned okm = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const int iy = iy0 + ky;
+        const bool rok = (unsigned)iy < (unsigned)a.H;
+        const uint8_t* row = xc + (rok ? iy : 0) * a.W;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int ix = ix0 + c;
+            const bool ok = rok & ((unsigned)ix < (unsigned)a.W);
+            u[ky][c] = row[ok ? ix : 0];
+            okm |= ok ? 1u << (ky * NC + c) : 0u;
+        }
+    }
+    float w[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) w[t] = wk[t];
+    float bf = 0.f;
+    if (a.bias) {
+        bf = (float)a.bias[oc] * a.in_scale;
+        bf = bf * a.w_scale;
+    }
+    float xf[3][NC];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            xf[ky][c] = (okm >> (ky * NC + c) & 1u) ? dequant((uint8_t)u[ky][c], a.in_zp, a.in_scale) : 0.f;
+    uint8_t* yo = a.y + (size_t)n * a.out_img + ((size_t)(a.out_c0 + oc) * a.OH + oy) * a.OW + ox0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float total = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; t++) total = __builtin_fmaf(xf[t / 3][j * S + t % 3], w[t], total);
+        if (a.bias) total = total + bf;
+        if (a.act >= 0) {
+            if (total < 0.f && a.act != 1) total = 0.f;
+            if (total > 1.f && a.act == 1) total = 1.f;
+            if (total > 6.f && a.act == 6) total = 6.f;
+            if (total < -1.f && a.act == 1) total = -1.f;
+        }
+        uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+        if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+        if (ox0 + j < a.OW) yo[j] = q;
+    }
+}
+
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s)
 {
     if (a.group == a.C && a.cout == a.C && a.KH == 3 && a.KW == 3) {
+        const bool quad = a.PH == 1 && a.PW == 1 && a.DH == 1 && a.DW == 1 && a.SH == a.SW && (a.SH == 1 || a.SH == 2) && a.OW >= 4;
+        if (quad) {
+            dim3 grid((a.cout * a.OH * ((a.OW + 3) / 4) + 255) / 256, a.N);
+            if (a.SH == 1) hipLaunchKernelGGL(conv_u8_dw3x4_k<1>, grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(conv_u8_dw3x4_k<2>, grid, dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
         dim3 grid((a.cout * a.OH * a.OW + 255) / 256, a.N);
         hipLaunchKernelGGL(conv_u8_dw3_k, grid, dim3(256), 0, s, a);
         return hipGetLastError();
@@ -563,6 +633,29 @@ static hipError_t launch_map(const U8MapArgs& a, hipStream_t s)
 hipError_t launch_relu_u8(const U8MapArgs& a, hipStream_t s) { return launch_map<0>(a, s); }
 hipError_t launch_requant_copy_u8(const U8MapArgs& a, hipStream_t s) { return launch_map<1>(a, s); }
 hipError_t launch_upsample_u8(const U8MapArgs& a, hipStream_t s) { return launch_map<2>(a, s); }
+
+// SSD head plumbing in one pass: permute/permute_ref.c:203-296 (order 0,2,3,1: out[n][p][c] = in[n][c][p], bytes
+// unchanged), flatten/flatten_ref.c:53-77 (copy) and concat_kernel_ref_uint8.c:127-160 (axis 1 of [n][len] tensors,
+// roundf(fma(u - zp_in, s_in / s_out, zp_out)) per element) collapse into one indexed copy per concat input.
+__global__ __launch_bounds__(256) void flatcat_u8_k(const U8CatArgs a, float rescale)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (j >= a.in_img) return;
+    const int src = a.perm_c ? (j % a.perm_c) * a.perm_p + j / a.perm_c : j;
+    const uint8_t u = a.x[(size_t)n * a.in_img + src];
+    uint8_t q = u;
+    if (!a.identity) {
+        float r = roundf(__builtin_fmaf((float)((int)u - a.in.zp), rescale, (float)a.out.zp));
+        q = sat_u8((int)fminf(fmaxf(r, -65536.f), 65536.f));
+    }
+    a.y[(size_t)n * a.out_img + a.out_off + j] = q;
+}
+
+hipError_t launch_flatcat_u8(const U8CatArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(flatcat_u8_k, dim3((a.in_img + 255) / 256, a.N), dim3(256), 0, s, a, a.in.scale / a.out.scale);
+    return hipGetLastError();
+}
 
 // eltwise (same-shape operands): eltwise/eltwise_ref.c:311-585
 __global__ __launch_bounds__(256) void eltwise_u8_k(const U8EltArgs a)

@@ -39,6 +39,8 @@ extern "C" {
 #include "convolution_param.h"
 #include "eltwise_param.h"
 #include "fc_param.h"
+#include "flatten_param.h"
+#include "permute_param.h"
 #include "pooling_param.h"
 #include "relu_param.h"
 #include "softmax_param.h"
@@ -73,6 +75,7 @@ int map_op(int op)
     case OP_SOFTMAX: return TAMD_OP_SOFTMAX;
     case OP_RELU6: return TAMD_OP_RELU6;
     case OP_FLATTEN: return TAMD_OP_FLATTEN;
+    case OP_PERMUTE: return TAMD_OP_PERMUTE;
     default: return -1;
     }
 }
@@ -80,10 +83,18 @@ int map_op(int op)
 const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT, OP_UPSAMPLE,
                              OP_SOFTMAX, OP_RELU6};
 
-bool op_supported(int op)
+// SSD head plumbing (Permute -> Flatten -> Concat): on the device for uint8 graphs only, so these two are added to
+// the allowed list per graph (hip_split_graph) instead of globally -- an int8 / fp32 graph keeps them on the CPU
+// without dragging the convolutions around them back there
+const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN};
+
+bool op_supported(int op, int dtype)
 {
     for (int o : kSupportedOps)
         if (o == op) return true;
+    if (dtype == TENGINE_DT_UINT8)
+        for (int o : kUint8OnlyOps)
+            if (o == op) return true;
     return false;
 }
 
@@ -150,6 +161,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
         tamd_eltwise_param ep;
         tamd_concat_param ccp;
         tamd_upsample_param up;
+        tamd_permute_param pmp;
         const void* param = nullptr;
         switch (op) {
         case TAMD_OP_CONV: {
@@ -180,6 +192,12 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
         }
         case TAMD_OP_CONCAT: ccp.axis = ((const struct concat_param*)n->op.param_mem)->axis; param = &ccp; break;
         case TAMD_OP_UPSAMPLE: up.scale = ((const struct upsample_param*)n->op.param_mem)->scale; param = &up; break;
+        case TAMD_OP_PERMUTE: {
+            const struct permute_param* p = (const struct permute_param*)n->op.param_mem;
+            pmp = {{p->order0, p->order1, p->order2, p->order3}};
+            param = &pmp;
+            break;
+        }
         default: break;
         }
         tamd_node_desc nd;
@@ -289,12 +307,19 @@ int hip_dev_release(struct device* dev)
     return tamd_shutdown();
 }
 
+// allowed / blocked operator lists for a graph of activation type `dtype` (-1: unknown)
+void fill_op_lists(struct vector* allowed_ops, struct vector* blocked_ops, int dtype)
+{
+    for (int i = 0; i < OP_BUILTIN_LAST; i++) {
+        if (op_supported(i, dtype)) push_vector_data(allowed_ops, &i);
+        else push_vector_data(blocked_ops, &i);
+    }
+}
+
 int hip_describe(struct device* device, struct vector* allowed_ops, struct vector* blocked_ops, struct vector* precision)
 {
     (void)device;
-    for (int op : kSupportedOps) push_vector_data(allowed_ops, &op);
-    for (int i = 0; i < OP_BUILTIN_LAST; i++)
-        if (!op_supported(i)) push_vector_data(blocked_ops, &i);
+    fill_op_lists(allowed_ops, blocked_ops, -1);
     int p = TENGINE_DT_INT8;
     push_vector_data(precision, &p);
     p = TENGINE_DT_UINT8;
@@ -332,7 +357,8 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
 {
     for (int j = 0; j < sg->node_num; j++) {
         struct node* n = get_ir_graph_node(ir, sg->node_list[j]);
-        if (!op_supported(n->op.type)) return false;
+        const int out_dt = n->output_num ? get_ir_graph_tensor(ir, n->output_tensors[0])->data_type : -1;
+        if (!op_supported(n->op.type, out_dt)) return false;
         for (int k = 0; k < n->output_num; k++) {
             struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
             if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8
@@ -346,6 +372,11 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
         }
         if (n->op.type == OP_CONCAT && ((const struct concat_param*)n->op.param_mem)->axis != 1) return false;
         if (n->op.type == OP_SOFTMAX && ((const struct softmax_param*)n->op.param_mem)->axis != 1) return false;
+        if (n->op.type == OP_PERMUTE) {
+            const struct permute_param* p = (const struct permute_param*)n->op.param_mem;
+            if (!(p->order0 == 0 && p->order1 == 2 && p->order2 == 3 && p->order3 == 1)) return false;
+        }
+        if (n->op.type == OP_FLATTEN && ((const struct flatten_param*)n->op.param_mem)->axis != 1) return false;
     }
     return true;
 }
@@ -359,6 +390,18 @@ int hip_split_graph(struct graph* ir_graph)
     struct vector* blocked_ops = create_vector(sizeof(int), nullptr);
     struct vector* precision = create_vector(sizeof(int), nullptr);
     cur_dev->allocator->describe(cur_dev, allowed_ops, blocked_ops, precision);
+    int graph_dt = -1;
+    if (ir_graph->input_num > 0) {
+        struct node* in_node = get_ir_graph_node(ir_graph, ir_graph->input_nodes[0]);
+        if (in_node->output_num > 0) graph_dt = get_ir_graph_tensor(ir_graph, in_node->output_tensors[0])->data_type;
+    }
+    if (graph_dt == TENGINE_DT_UINT8) {          // the uint8-only operators join the allowed list for this graph
+        release_vector(allowed_ops);
+        release_vector(blocked_ops);
+        allowed_ops = create_vector(sizeof(int), nullptr);
+        blocked_ops = create_vector(sizeof(int), nullptr);
+        fill_op_lists(allowed_ops, blocked_ops, graph_dt);
+    }
     split_graph_node_to_sub_graph(ir_graph, allowed_ops, blocked_ops, precision);
     release_vector(allowed_ops);
     release_vector(blocked_ops);

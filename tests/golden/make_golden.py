@@ -39,6 +39,14 @@ def main():
         path = os.path.join(HERE, "%s_uint8_seed5.npy" % name)
         np.save(path, out)
         print(path, out.shape, len(np.unique(out)))
+    # MobileNet-SSD 300x300 uint8 (BASELINE configs[4] stand-in): mbox_loc and mbox_conf after the on-graph
+    # Permute -> Flatten -> Concat plumbing
+    g = models.build("mssd", "uint8", 1)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    outs = ref_capi.run_model(tm2.write_tm2(g), x, ref_capi.MODE_UINT8, os.cpu_count())
+    path = os.path.join(HERE, "mssd_uint8_300_seed5.npz")
+    np.savez_compressed(path, **{"out%d" % i: o for i, o in enumerate(outs)})
+    print(path, [o.shape for o in outs], [len(np.unique(o)) for o in outs])
 
 
 if __name__ == "__main__":

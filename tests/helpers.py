@@ -212,3 +212,47 @@ def u8_route_graph(seed, n, c, h, w):
     ni = g.add_node("route", "Concat", [up, lk], [cc], axis=1)
     g.output_nodes = [ni]
     return g, rng.integers(0, 256, size=(n, c, 2 * h, 2 * w)).astype(np.uint8)
+
+
+def u8_ssd_head_graph(seed, n, c, h, w, priors=(3, 6), per=4, same_q=False, standalone_permute=False):
+    """SSD head plumbing on two feature maps (data at h x w, its 2x2 max-pool): per map a 1x1 conv with priors*per
+    channels -> Permute(0,2,3,1) -> Flatten -> one Concat on axis 1 with per-input rescale (`same_q`: every head
+    carries the concat's scale / zero point, the copy case).  `standalone_permute`: the graph ends at the first
+    head's Permute (its own launch on the device)."""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="u8_ssd_head_case")
+    xs, xz = _u8q(rng)
+    x = g.add_input("data", [n, c, h, w], DT_UINT8, [xs], [xz])
+    mp = g.add_tensor("mp", [n, c, h // 2, w // 2], DT_UINT8, tm2.TT_VAR, None, [xs], [xz])
+    g.add_node("maxpool", "Pooling", [x], [mp], alg=0, kernel_h=2, kernel_w=2, stride_h=2, stride_w=2,
+               **{"global": 0}, caffe_flavor=0, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    cat_s, cat_z = float(np.float32(xs * 9.0)), int(rng.integers(60, 200))
+    flats = []
+    for i, (feat, fh, fw) in enumerate(((x, h, w), (mp, h // 2, w // 2))):
+        cout = priors[i] * per
+        wq = rng.integers(0, 256, size=(cout, c, 1, 1)).astype(np.uint8)
+        ws, wz = _u8q(rng, 0.002, 0.02)
+        bq = rng.integers(-4000, 4000, size=(cout,)).astype(np.int32)
+        ins = [feat, g.add_const("w%d" % i, wq, DT_UINT8, [ws], [wz]),
+               g.add_const("b%d" % i, bq, DT_INT32, [float(np.float32(xs) * np.float32(ws))], [0])]
+        if same_q:
+            os_, oz = cat_s, cat_z
+        else:
+            os_, oz = float(np.float32(xs * ws * 73.0 * np.sqrt(c) * 73.0 / 40.0 * (1.0 + 0.3 * i))), int(rng.integers(60, 200))
+        y = g.add_tensor("head%d" % i, [n, cout, fh, fw], DT_UINT8, tm2.TT_VAR, None, [os_], [oz])
+        g.add_node("head%d" % i, "Convolution", ins, [y], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1,
+                   dilation_w=1, input_channel=c, output_channel=cout, group=1, activation=-1, pad_h0=0, pad_w0=0,
+                   pad_h1=0, pad_w1=0)
+        pm = g.add_tensor("perm%d" % i, [n, fh, fw, cout], DT_UINT8, tm2.TT_VAR, None, [os_], [oz])
+        pi = g.add_node("perm%d" % i, "Permute", [y], [pm], flag=0, order=[0, 2, 3, 1])
+        if standalone_permute:
+            g.output_nodes = [pi]
+            return g, rng.integers(0, 256, size=(n, c, h, w)).astype(np.uint8)
+        fl = g.add_tensor("flat%d" % i, [n, fh * fw * cout], DT_UINT8, tm2.TT_VAR, None, [os_], [oz])
+        g.add_node("flat%d" % i, "Flatten", [pm], [fl], axis=1, end_axis=3)
+        flats.append(fl)
+    total = sum(g.tensors[f].dims[1] for f in flats)
+    cc = g.add_tensor("mbox", [n, total], DT_UINT8, tm2.TT_VAR, None, [cat_s], [cat_z])
+    ni = g.add_node("mbox", "Concat", flats, [cc], axis=1)
+    g.output_nodes = [ni]
+    return g, rng.integers(0, 256, size=(n, c, h, w)).astype(np.uint8)

@@ -4,7 +4,7 @@ sgemm).  Bar: byte-identical -- the device performs the reference's fp32 operati
 import numpy as np
 import pytest
 
-from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_unary_graph)
+from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_ssd_head_graph, u8_unary_graph)
 from oracle import oracle
 from tengine_amd import capi, models, tm2
 
@@ -47,6 +47,13 @@ U8_CONV = [
     (1, 32, 12, 12, 32, 3, 1, 1, 32, 0, True, 1),      # depthwise -> naive-ref formula
     (2, 24, 13, 13, 24, 3, 2, 1, 24, 6, True, 1),      # depthwise stride 2, relu6, batch 2
     (1, 16, 9, 9, 32, 3, 1, 1, 4, 1, True, 1),         # grouped, relu1 clamp
+    (2, 40, 19, 19, 40, 3, 1, 1, 40, 0, True, 1),      # dw, width 19: last quad of a row is ragged (mssd conv7..11/dw)
+    (1, 48, 38, 38, 48, 3, 2, 1, 48, 0, True, 1),      # dw stride 2, 38 -> 19 (mssd conv6/dw)
+    (3, 16, 10, 10, 16, 3, 2, 1, 16, -1, False, 1),    # dw stride 2, 10 -> 5, no bias, no activation
+    (1, 16, 5, 5, 16, 3, 2, 1, 16, 0, True, 1),        # dw, OW = 3 < 4: single-output kernel
+    (1, 16, 12, 12, 16, 3, 1, 0, 16, 0, True, 1),      # dw, pad 0: single-output kernel
+    (1, 16, 12, 12, 16, 3, 1, 2, 16, 1, True, 2),      # dw, dilation 2, relu1
+    (1, 8, 11, 11, 8, 5, 1, 2, 8, 0, True, 1),         # dw 5x5: generic direct kernel
 ]
 
 
@@ -196,3 +203,49 @@ def test_uint8_classifiers_bit_exact(name, dev_only, batch):
     else:
         want = oracle.run_graph(g, x)[0]
         assert np.array_equal(got.reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("same_q", [False, True])
+def test_ssd_head_plumbing_u8(fuse, same_q):
+    """conv -> Permute(0,2,3,1) -> Flatten -> Concat(axis 1): by default the concat reads the conv result in permuted
+    order itself (one launch per head); TAMD_FUSE_PERMUTE=0 keeps the permute launches. Same bytes either way."""
+    import os
+    g, x = u8_ssd_head_graph(31, 3, 24, 10, 6, same_q=same_q)
+    want = oracle.run_graph(g, x)[0]
+    if not fuse:
+        os.environ["TAMD_FUSE_PERMUTE"] = "0"
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        os.environ.pop("TAMD_FUSE_PERMUTE", None)
+    gr.set_input(x)
+    got = gr.run()[0]
+    kernels = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert np.array_equal(got.reshape(want.shape), want)
+    assert len(np.unique(want)) > 3
+    assert ("permute_u8" in kernels) == (not fuse), kernels
+    assert ("permute_concat_u8" in kernels) == fuse, kernels
+
+
+def test_permute_standalone_u8():
+    check(*u8_ssd_head_graph(32, 2, 8, 5, 7, standalone_permute=True), tag="permute")
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_mssd_uint8_300_bit_exact(batch):
+    """BASELINE configs[4] stand-in (MobileNet-SSD 300x300 uint8, mssd_benchmark.tmfile topology): 47 convs incl. 13
+    depthwise (conv_ref order) and the 12 Permute -> Flatten -> Concat heads, whole graph on the device."""
+    import os
+    g = models.build("mssd", "uint8", batch)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    outs = run_hip(g, x)
+    if batch == 1:
+        ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "mssd_uint8_300_seed5.npz"))
+        for i, o in enumerate(outs):
+            assert np.array_equal(o.ravel(), ref["out%d" % i].ravel())      # bytes of the REAL reference
+    else:
+        want = oracle.run_graph(g, x)
+        for w, o in zip(want, outs):
+            assert np.array_equal(o.reshape(w.shape), w)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_unary_graph)
+from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_ssd_head_graph, u8_unary_graph)
 from oracle import oracle, ref_capi
 from tengine_amd import models, tm2
 
@@ -67,6 +67,9 @@ def test_glue_ops_uint8_oracle_is_the_reference():
     both(*u8_unary_graph(14, "ReLU", [2, 8, 9, 9], negative_slope=0.1))
     both(*u8_unary_graph(15, "Upsample", [1, 8, 5, 5], [1, 8, 10, 10], scale=2))
     both(*u8_route_graph(16, 1, 8, 6, 6))
+    both(*u8_ssd_head_graph(17, 2, 16, 6, 6))                       # permute -> flatten -> concat with rescale
+    both(*u8_ssd_head_graph(18, 1, 8, 5, 7, same_q=True))
+    both(*u8_ssd_head_graph(19, 2, 8, 4, 4, standalone_permute=True))
 
 
 @needs_ref
@@ -122,3 +125,15 @@ def test_uint8_classifiers_oracle_matches_golden_of_real_reference(name, dev_onl
     x = models.synth_input(g, 5, tm2.DT_UINT8)
     out = oracle.run_graph(g, x)[0]
     assert np.array_equal(out.ravel(), golden.ravel())
+
+
+def test_mssd_uint8_300_oracle_matches_golden_of_real_reference():
+    """MobileNet-SSD 300x300 uint8: 47 convs (13 depthwise on the conv_ref formula) and the Permute -> Flatten ->
+    Concat head plumbing; this graph is what exposed the unfused bias add of the reference's uint8 GEMM epilogue."""
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "mssd_uint8_300_seed5.npz"))
+    g = models.build("mssd", "uint8", 1)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    outs = oracle.run_graph(g, x)
+    assert [o.shape for o in outs] == [(1, 1917 * 4), (1, 1917 * 21)]
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.ravel(), golden["out%d" % i].ravel())
