@@ -9,8 +9,10 @@ python $R/tools/profile_layers.py mobilenet_v1 64 10 int8 > $O/layers_mobilenet_
 python $R/tools/profile_layers.py resnet50 32 5 int8      > $O/layers_resnet50_int8_b32.txt 2>&1
 python $R/tools/profile_layers.py yolov3_tiny 1 20 uint8  > $O/layers_yolov3_tiny_uint8_b1.txt 2>&1
 python $R/tools/profile_layers.py yolov3_tiny 8 10 uint8  > $O/layers_yolov3_tiny_uint8_b8.txt 2>&1
+python $R/tools/profile_layers.py mssd 16 10 uint8        > $O/layers_mssd_uint8_b16.txt 2>&1
 python $R/tools/profile_layers.py squeezenet_v1.1 1 20 fp32 > $O/layers_squeezenet_fp32_b1.txt 2>&1
 python $R/bench.py --model yolov3_tiny --dtype uint8 --batch 8 --steps 50 --cpu-seconds 8 > $O/bench_yolov3_tiny_uint8_b8.json 2> $O/bench_yolo.err
+python $R/bench.py --model mssd --dtype uint8 --batch 16 --steps 50 --cpu-seconds 8 > $O/bench_mssd_uint8_b16.json 2> $O/bench_mssd.err
 python $R/bench.py --model resnet50 --batch 32 --steps 30 --cpu-seconds 8 > $O/bench_resnet50_int8_b32.json 2> $O/bench_rn.err
 python $R/bench.py --streams 16 --steps 2000 --no-cpu-baseline > $O/bench_mobilenet_b1_16streams.json 2> $O/bench_s16.err
 for f in $O/layers_*.txt; do echo $f; tail -1 $f; done
