@@ -386,9 +386,9 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         // the choice is purely a matter of speed
         struct Cand { std::string name; std::function<hipError_t(hipStream_t)> fn; };
         std::vector<Cand> cands;
-        // (the fused eltwise tail lives in the conv_igemm / conv_igemm2 epilogues only)
+        // (the fused eltwise tail lives in the conv_igemm / conv_igemm2 / pw_stream epilogues)
         if (!fz && gemm_direct_applicable(a)) cands.push_back({"gemm_direct_i8", [a](hipStream_t s) { return launch_gemm_direct(a, s); }});
-        if (!fz && pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
+        if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
         if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
         const bool heuristic_done = !cands.empty();
         static const char* at_env = getenv("TAMD_AUTOTUNE");

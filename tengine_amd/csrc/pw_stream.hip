@@ -18,7 +18,8 @@ namespace tamd {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int S, int NT>
+// ELT: the eltwise (+ReLU) node that consumes this conv is applied in the epilogue (epilogue.h: fuse_elt4), as in conv_igemm
+template <int S, int NT, bool ELT>
 __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) int sbias[NT * 32];
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
     __syncthreads();
 
     const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const float inv_elt = ELT ? __fdiv_rn(1.0f, a.elt.out_scale) : 1.f;
+    const float inv_relu = (ELT && a.elt.relu) ? __fdiv_rn(1.0f, a.elt.relu_out_scale) : 1.f;
     const int tiles_m = (a.M + 31) / 32;
     for (int tile = blockIdx.x * 4 + wave; tile < tiles_m; tile += gridDim.x * 4) {
         const int m = tile * 32 + l31;
@@ -70,8 +73,16 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
             }
             half_wave_regroup(p);
             const int cb = n0 + i * 32 + hi * 16;
-            if (mvalid && cb < a.c_limit)
+            if (mvalid && cb < a.c_limit) {
+                if (ELT) {         // residual operand: the same pixel, the 16 channels this lane now holds
+                    const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + cb);
+                    p[0] = fuse_elt4(p[0], r.x, a.elt, inv_elt, inv_relu);
+                    p[1] = fuse_elt4(p[1], r.y, a.elt, inv_elt, inv_relu);
+                    p[2] = fuse_elt4(p[2], r.z, a.elt, inv_elt, inv_relu);
+                    p[3] = fuse_elt4(p[3], r.w, a.elt, inv_elt, inv_relu);
+                }
                 *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + cb) = make_uint4(p[0], p[1], p[2], p[3]);
+            }
         }
     }
 }
@@ -82,6 +93,7 @@ bool pw_stream_applicable(const ConvArgs& a)
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0);
     const int S = a.kpad / 32;
     // 16-B stores need 16-channel granularity of the destination (always true for non-view outputs)
+    if (a.elt.res && ((a.elt.res_ldc | a.elt.res_c_off) & 15)) return false;      // 16-B reads of the residual operand
     return is1x1 && S <= 4 && a.M >= 2048 && (a.c_limit % 16 == 0) && (a.c_off % 16 == 0) && (a.ldc % 16 == 0);
 }
 
@@ -93,7 +105,8 @@ static hipError_t launch_pw(const ConvArgs& a, hipStream_t s)
     int bx = (tiles_m + 3) / 4;
     const int cap = 2048 / groups > 0 ? 2048 / groups : 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT>), dim3(bx, groups), dim3(256), 0, s, a);
+    if (a.elt.res) hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, true>), dim3(bx, groups), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, false>), dim3(bx, groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

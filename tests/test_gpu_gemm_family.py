@@ -59,3 +59,28 @@ def test_family_member_is_exact_on_every_shape(member, cases):
             assert np.array_equal(got, want), "%s (%s) wrong on %s" % (member, name, c)
     finally:
         del os.environ["TAMD_FORCE_GEMM"]
+
+
+@pytest.mark.parametrize("member", ["pw_stream", "igemm0", "igemm2", "conv_igemm2"])
+@pytest.mark.parametrize("etype,own_relu_scale", [(tm2.ELT_SUM, False), (tm2.ELT_SUB, True)])
+def test_fused_eltwise_tail_is_exact_in_every_member(member, etype, own_relu_scale):
+    """conv -> eltwise -> ReLU folded into the epilogue of each family member that offers it (ResNet block tails);
+    4 x 64 x 28 x 28 makes the streaming pointwise kernel eligible too."""
+    from helpers import eltwise_relu_graph
+    g, x = eltwise_relu_graph(23, 4, 64, 28, 28, True, etype)
+    if own_relu_scale:
+        r = [t for t in g.tensors if t.name == "relu"][0]
+        r.scales = [float(np.float32(r.scales[0] * 0.83))]
+    want = oracle.run_graph(g, x)[0]
+    os.environ["TAMD_FORCE_GEMM"] = member
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        del os.environ["TAMD_FORCE_GEMM"]
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    names = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert np.array_equal(got, want), names
+    assert any("+eltwise" in k for k in names), names
+    assert len(np.unique(want)) > 3
