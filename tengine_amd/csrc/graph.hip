@@ -284,9 +284,15 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
     if (x.nchw_raw && group == 1 && cin <= 4 && cin * KH * KW <= 224 && cout <= 128
         && p.dilation_h * (KH - 1) < 256 && p.dilation_w * (KW - 1) < 256) {
         // ---- first layer from the NCHW graph input on MFMA ----
-        const int kreal = cin * KH * KW, kp = rup(kreal, 32), cpad = rup(cout, 32);
+        const char* rows_env = getenv("TAMD_FIRST_ROWS");                   // 0: always the generic gather kernel (tests; read at every prerun)
+        const int kwp = (rows_env && atoi(rows_env) == 0) ? 0 : conv_first_kwp(cin, KH, KW, p.dilation_w);
+        const int kreal = cin * KH * KW, kp = kwp ? rup(cin * KH * kwp, 32) : rup(kreal, 32), cpad = rup(cout, 32);
         std::vector<int8_t> wp((size_t)cpad * kp, 0);
-        for (int co = 0; co < cout; co++) memcpy(&wp[(size_t)co * kp], wd + (size_t)co * kreal, kreal);   // OIHW row as stored
+        for (int co = 0; co < cout; co++) {
+            if (!kwp) { memcpy(&wp[(size_t)co * kp], wd + (size_t)co * kreal, kreal); continue; }   // OIHW row as stored
+            for (int r = 0; r < cin * KH; r++)                              // kx padded to kwp: a patch row is kwp consecutive bytes
+                memcpy(&wp[(size_t)co * kp + (size_t)r * kwp], wd + (size_t)co * kreal + (size_t)r * KW, KW);
+        }
         std::vector<int32_t> bp(cpad, 0);
         std::vector<float> sp(cpad, 1.f);
         for (int c = 0; c < cout; c++) { bp[c] = bd ? bd[c] : 0; sp[c] = ws[c]; }
@@ -297,7 +303,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         a.N = x.n; a.C = cin; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = cout; a.ldc = y.cs; a.c_off = y.c_off;
         a.c_limit = y.is_view ? cout : std::min(rup(cout, 16), y.cs - y.c_off);
         a.KH = KH; a.KW = KW; a.SH = p.stride_h; a.SW = p.stride_w; a.PH = p.pad_h0; a.PW = p.pad_w0;
-        a.DH = p.dilation_h; a.DW = p.dilation_w; a.kp = kp;
+        a.DH = p.dilation_h; a.DW = p.dilation_w; a.kp = kp; a.kwp = kwp;
         a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         st.kernel = "conv_first_i8";
         st.fn = [a](hipStream_t s) { return launch_conv_first(a, s); };
@@ -487,7 +493,7 @@ static int plan(tamd_graph* g)
     for (auto& io : g->inputs) {
         HTensor& t = g->tensors[io.tensor];
         io.bytes = t.elems() * esize(t.dtype);
-        if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
+        if (dev_alloc(g, &io.stage, io.bytes + 64, true)) return -1;     // slack: the first-layer kernel over-reads the last row by < 8 bytes
         HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
         bool direct = (t.dims.size() == 4 && t.c <= 4 && count_consumers(g, io.tensor) == 1);
         if (direct) {

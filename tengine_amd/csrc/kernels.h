@@ -76,6 +76,7 @@ struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on 
     int N, C, H, W, OH, OW, cout, ldc, c_off, c_limit;
     int KH, KW, SH, SW, PH, PW, DH, DW;
     int kp;                // roundup(C*KH*KW, 32) <= 256
+    int kwp;               // 0: k = OIHW order (gather kernel); 4 / 8: k = (c*KH+ky)*kwp + kx, kp = roundup(C*KH*kwp, 32) <= 192
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
@@ -117,6 +118,7 @@ const char* conv_igemm2_kernel_name(const ConvArgs& a);
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
 bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
+int conv_first_kwp(int C, int KH, int KW, int DW);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);

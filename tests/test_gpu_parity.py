@@ -206,3 +206,41 @@ def test_resnet50_int8_batch2_bit_exact():
                 assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
         raise AssertionError("output differs")
     gr.close()
+
+
+FIRST_LAYER_CASES = [
+    # n, cin, h, w, cout, k, s, p, act  -- first layer straight from the NCHW graph input (conv_first.hip)
+    (2, 3, 37, 41, 32, 7, 2, 3, 0),      # 7x7 s2 p3 (ResNet stem), odd sizes: left/right/top/bottom borders, 2 images
+    (3, 3, 20, 10, 16, 3, 1, 1, 0),      # 3x3 s1 p1, width 10: the 4-byte rows of the last pixels run past the row end
+    (1, 1, 9, 9, 8, 3, 2, 1, -1),        # one input channel
+    (2, 4, 12, 14, 40, 5, 1, 2, 6),      # 4 channels, 5x5 (rows of 8), relu6, cout 40 (two cout tiles, ragged)
+    (1, 3, 16, 16, 64, 7, 1, 3, 0),      # 7x7 s1: three border columns on either side
+    (2, 3, 8, 8, 24, 3, 2, 0, 0),        # no padding
+    (1, 4, 7, 9, 16, 7, 2, 3, 0),        # 4 x 7 rows of 8 = 224 k > 192: generic gather kernel
+    (1, 3, 12, 12, 16, 3, 1, 2, 0, 2),   # dilation 2: generic gather kernel
+]
+
+
+@pytest.mark.parametrize("rows", [True, False])
+@pytest.mark.parametrize("case", FIRST_LAYER_CASES, ids=[str(c) for c in FIRST_LAYER_CASES])
+def test_first_layer_from_nchw(case, rows):
+    """both first-layer kernels (row-granular unaligned loads / generic byte gather, TAMD_FIRST_ROWS=0) on shapes that
+    hit every border case; the graph input is read in NCHW, images are adjacent in memory."""
+    n, cin, h, w, cout, k, s, p, act = case[:9]
+    dil = case[9] if len(case) > 9 else 1
+    g, x = conv_graph(900 + h + w + cout, n, cin, h, w, cout, k, s, p, 1, act, True, dil)
+    x[:] = np.random.default_rng(7).integers(-127, 128, size=x.shape)       # dense non-zero borders
+    want = oracle.run_graph(g, x)[0]
+    if not rows:
+        os.environ["TAMD_FIRST_ROWS"] = "0"
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        os.environ.pop("TAMD_FIRST_ROWS", None)
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    names = [q["kernel"] for q in gr.profile(1)]
+    gr.close()
+    assert names[0].startswith("conv_first"), names
+    assert np.array_equal(got, want), "%d bytes differ" % np.count_nonzero(got != want)
+    assert np.count_nonzero(want) > 0
