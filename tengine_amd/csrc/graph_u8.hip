@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <functional>
+
 #include "graph.h"
 
 namespace tamd {
@@ -160,17 +162,55 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             float best_ms = 1e30f;
             int best_cfg = a.cfg;
-            for (int c = 0; c < conv_u8_gemm_num_cfgs(); c++) {
+            // per-launch time of a candidate: a warm-up launch, then 5 back-to-back launches (25 when that is under 20 us)
+            auto time_of = [&](const std::function<hipError_t()>& launch, float* out) -> int {
+                if (launch() != hipSuccess) { (void)hipGetLastError(); *out = 1e30f; return 0; }
+                int reps = 5;
+                for (int round = 0; round < 2; round++) {
+                    HIPCHK(hipEventRecord(e0, g->stream));
+                    for (int it = 0; it < reps; it++) (void)launch();
+                    HIPCHK(hipEventRecord(e1, g->stream));
+                    HIPCHK(hipEventSynchronize(e1));
+                    HIPCHK(hipEventElapsedTime(out, e0, e1));
+                    *out /= reps;
+                    if (*out > 0.02f) break;
+                    reps = 25;
+                }
+                return 0;
+            };
+            // the heuristic choice is timed first; another shape has to beat it by more than the timing noise
+            std::vector<int> order{a.cfg};
+            for (int c = 0; c < conv_u8_gemm_num_cfgs(); c++)
+                if (c != a.cfg) order.push_back(c);
+            for (int c : order) {
                 U8ConvArgs ac = a; ac.cfg = c; ac.Kpad = rup(K, conv_u8_gemm_kc(c));
                 if (conv_u8_gemm_lds(ac) > 150 * 1024) continue;
                 if ((ac.wq = pack_for(c)) == nullptr) return -1;
-                if (launch_conv_u8_gemm(ac, g->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
-                HIPCHK(hipEventRecord(e0, g->stream));
-                for (int it = 0; it < 3; it++) (void)launch_conv_u8_gemm(ac, g->stream);
-                HIPCHK(hipEventRecord(e1, g->stream));
-                HIPCHK(hipEventSynchronize(e1));
-                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-                if (ms < best_ms) { best_ms = ms; best_cfg = c; }
+                float ms = 0;
+                if (time_of([&]() { return launch_conv_u8_gemm(ac, g->stream); }, &ms)) return -1;
+                if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best_cfg = c; }
+            }
+            // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
+            const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
+            if (conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
+                && !(rgb_env && atoi(rgb_env) == 0)) {
+                U8ConvArgs ac = a;
+                ac.wf_ld = rup(K, 4);
+                std::vector<float> wf((size_t)cout * ac.wf_ld, 0.f);
+                for (int co = 0; co < cout; co++)
+                    for (int k = 0; k < K; k++) wf[(size_t)co * ac.wf_ld + k] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+                float* dwf = nullptr;
+                if (upload(g, wf, &dwf)) return -1;
+                ac.wf = dwf;
+                float ms = 1e30f;
+                if (time_of([&]() { return launch_conv_u8_rgb3x3(ac, g->stream); }, &ms)) return -1;
+                if (ms < best_ms * 0.96f || (rgb_env && atoi(rgb_env) == 1)) {
+                    hipEventDestroy(e0); hipEventDestroy(e1);
+                    st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "");
+                    st.fn = [ac](hipStream_t s) { return launch_conv_u8_rgb3x3(ac, s); };
+                    g->steps.push_back(st);
+                    return 0;
+                }
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;

@@ -159,6 +159,8 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int act;
     float out_scale; int out_zp;
     U8Relu relu;               // fused ReLU / leaky ReLU node (y, out_img, out_c0 then describe ITS output)
+    const float* wf;           // conv_u8_rgb3x3 only: dequantised weights, [cout][wf_ld] rows in OIHW k order
+    int wf_ld;
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
@@ -214,6 +216,8 @@ int conv_u8_gemm_kc(int cfg);                      // K stage depth (weight pack
 int conv_u8_gemm_num_cfgs();
 size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the chosen configuration
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
+bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
+hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s);
 

@@ -348,6 +348,95 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 }
 
 // =================================================================================================================
+// First layers (3x3, <= 4 input channels, dilation 1: YOLOv3-tiny conv0, MobileNet / SSD conv0): K = 9*C is one
+// MFMA stage at most, so the GEMM kernel above is all set-up and epilogue there.  Here a thread owns one pixel, keeps
+// its K dequantised taps in registers and walks the output channels: weights are LDS broadcasts, each
+// output is its own chain in the reference's order -- the single chain for pixels j < (OH*OW)&~7, the four k%4 chains
+// + combine + K%4 remainder for the tail pixels (same rules as conv_u8_body) -- followed by the same epilogue.
+// Stores run along pixels (NCHW rows).  Bound: VALU (27..36 fma + the exact requantisation per output).
+// =================================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
+{
+    constexpr int K = 9 * C, K4 = K & ~3, LD = (K + 3) & ~3;
+    // the dequantised weights live in LDS: every lane reads the same address (broadcast), and unlike global loads they
+    // are not ordered against the byte stores of the channel loop (which the compiler must assume may alias them)
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < a.cout * LD; i += 256) wl[i] = a.wf[i];
+    __syncthreads();
+    const int OHW = a.OH * a.OW;
+    const int pj = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (pj >= OHW) return;
+    const int oy = pj / a.OW, ox = pj - oy * a.OW;
+    const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
+    const uint8_t* xin = a.x + (size_t)n * C * a.H * a.W;
+    unsigned u[K];
+    unsigned long long okm = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        u[k] = xin[ok ? (c * a.H + iy) * a.W + ix : 0];
+        okm |= ok ? 1ull << k : 0ull;
+    }
+    float xf[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) xf[k] = (okm >> k & 1ull) ? dequant((uint8_t)u[k], a.in_zp, a.in_scale) : 0.f;   // im2col zero
+    const bool tail = pj >= (OHW & ~7);
+    uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + pj;
+    for (int co = 0; co < a.cout; co++) {
+        float w[LD];
+#pragma unroll
+        for (int k = 0; k < LD; k += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(wl + co * LD + k);
+            w[k] = f.x; w[k + 1] = f.y; w[k + 2] = f.z; w[k + 3] = f.w;
+        }
+        float s = 0.f;
+        if (!tail) {
+#pragma unroll
+            for (int k = 0; k < K; k++) s = __builtin_fmaf(xf[k], w[k], s);
+        } else {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < K4; k += 4) {
+                s0 = __builtin_fmaf(w[k], xf[k], s0);
+                s1 = __builtin_fmaf(w[k + 1], xf[k + 1], s1);
+                s2 = __builtin_fmaf(w[k + 2], xf[k + 2], s2);
+                s3 = __builtin_fmaf(w[k + 3], xf[k + 3], s3);
+            }
+            if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
+            else s = ((s0 + s1) + s2) + s3;
+#pragma unroll
+            for (int k = K4; k < K; k++) s = __builtin_fmaf(w[k], xf[k], s);
+        }
+        if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+        if (a.act == 0) s = s < 0.f ? 0.f : s;
+        if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+        uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
+        if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+        yo[(size_t)co * OHW] = q;
+    }
+}
+
+bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group)
+{
+    return group == 1 && kh == 3 && kw == 3 && dh == 1 && dw == 1 && (cin == 1 || cin == 3 || cin == 4);
+}
+
+hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s)
+{
+    dim3 grid((a.OH * a.OW + 255) / 256, a.N);
+    switch (a.C) {
+    case 1: hipLaunchKernelGGL(conv_u8_rgb3x3_k<1>, grid, dim3(256), (size_t)a.cout * 12 * 4, s, a); break;
+    case 3: hipLaunchKernelGGL(conv_u8_rgb3x3_k<3>, grid, dim3(256), (size_t)a.cout * 28 * 4, s, a); break;
+    case 4: hipLaunchKernelGGL(conv_u8_rgb3x3_k<4>, grid, dim3(256), (size_t)a.cout * 36 * 4, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// =================================================================================================================
 // grouped / depthwise convolution: conv/conv_kernel_ref_uint8.c:42-195 -- one fused chain in (kc, ky, kx) order over
 // the in-image taps, + bias_fp32 = ((float)b * in_s) * k_s as a separate add, naive-ref activation, requantise.
 // One thread per output element, lanes along the output row (consecutive input bytes for stride 1).

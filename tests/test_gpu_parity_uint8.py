@@ -249,3 +249,42 @@ def test_mssd_uint8_300_bit_exact(batch):
         want = oracle.run_graph(g, x)
         for w, o in zip(want, outs):
             assert np.array_equal(o.reshape(w.shape), w)
+
+
+RGB_CASES = [
+    # n, cin, h, w, cout, s, p, act
+    (2, 3, 80, 80, 16, 1, 1, -1),      # YOLOv3-tiny conv0 class
+    (2, 3, 101, 99, 32, 2, 1, 0),      # MobileNet / SSD conv0 class: stride 2, 50*50 = 2500 px -> 4 tail pixels per image
+    (4, 3, 51, 53, 18, 1, 1, 6),       # 2703 px: 7 tail pixels; cout 18: rows 16, 17 sit outside the 8-/4-row blocks
+    (3, 4, 60, 60, 13, 1, 0, 0),       # 4 channels (K = 36), no padding, 58*58 = 3364 px: 4 tail pixels
+    (4, 1, 150, 150, 24, 2, 1, -1),    # one channel (K = 9: K % 4 == 1 remainder chain on the tail pixels)
+]
+
+
+@pytest.mark.parametrize("case", RGB_CASES, ids=[str(c) for c in RGB_CASES])
+@pytest.mark.parametrize("leaky", [False, True])
+def test_first_layer_u8_valu_kernel(case, leaky):
+    """the per-pixel first-layer kernel (conv_u8_rgb3x3) pinned with TAMD_U8_RGB3X3=1: main and tail pixels, blocked and
+    unblocked rows, fused leaky ReLU -- must equal the oracle (and therefore the MFMA family) byte for byte."""
+    import os
+    n, cin, h, w, cout, s, p, act = case
+    g, x = u8_conv_graph(600 + h + cout, n, cin, h, w, cout, 3, s, p, 1, act, True, 1)
+    if leaky:
+        c = g.nodes[-1].outputs[0]
+        t = g.tensors[c]
+        r = g.add_tensor("lk", list(t.dims), tm2.DT_UINT8, tm2.TT_VAR, None, [float(np.float32(t.scales[0] * 0.8))], [31])
+        ni = g.add_node("lk", "ReLU", [c], [r], negative_slope=0.1)
+        g.output_nodes = [ni]
+    want = oracle.run_graph(g, x)[0]
+    os.environ["TAMD_U8_RGB3X3"] = "1"
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        del os.environ["TAMD_U8_RGB3X3"]
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    names = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert names[0].startswith("conv_u8_rgb3x3"), names
+    assert np.array_equal(got, want), "%d bytes differ" % np.count_nonzero(got != want)
+    assert len(np.unique(want)) > 3
