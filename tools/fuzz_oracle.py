@@ -1,0 +1,85 @@
+"""Randomised oracle-vs-reference campaign (CPU only; needs oracle/_ref, i.e. runs where /root/reference was built).
+
+The hand-picked parity cases pin the semantics; this pins the *rare events*: one fp32 rounding that differs (an fma
+where the reference's compiler emitted mul+add, say) flips one output byte in 1e5..1e6, far below what a few test
+layers can see.  Random single-op graphs (conv incl. depthwise, pooling, fc, relu, eltwise, concat routes, SSD head
+plumbing) are run through the real reference CPU backend and through oracle/tg_oracle.c; every byte must agree.
+
+    python tools/fuzz_oracle.py --dtype uint8 --seconds 150 --seed 1
+
+Round-1 campaign: uint8 7.7e8 outputs / 18001 graphs, int8 3.1e8 outputs / 12086 graphs, 0 mismatches.
+Known reference defect found on the way: its int8 path segfaults for a conv / fc with ONE output channel
+(conv_hcl int8 packing), so those shapes are excluded here (the HIP backend itself handles them)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+from oracle import oracle, ref_capi  # noqa: E402
+from tengine_amd import tm2  # noqa: E402
+
+
+def random_graph(rng, dtype):
+    u8 = dtype == "uint8"
+    seed = int(rng.integers(1 << 30))
+    kind = int(rng.integers(0, 10))
+    if kind < 6:
+        k = int(rng.choice([1, 1, 3, 3, 5]))
+        cin, cout = int(rng.integers(2, 200)), int(rng.integers(2, 130))
+        h, w, n = int(rng.integers(k, 40)), int(rng.integers(k, 40)), int(rng.integers(1, 3))
+        s, p = int(rng.choice([1, 1, 2])), int(rng.integers(0, k // 2 + 1))
+        act, grp = int(rng.choice([-1, 0, 1, 6])), 1
+        if rng.random() < 0.3:
+            grp, cout = cin, cin
+        f = H.u8_conv_graph if u8 else H.conv_graph
+        return f(seed, n, cin, h, w, cout, k, s, p, grp, act, bool(rng.random() < 0.8), 1)
+    if kind == 6:
+        f = H.u8_pool_graph if u8 else H.pool_graph
+        return f(seed, 2, 32, int(rng.integers(6, 40)), int(rng.integers(6, 40)), int(rng.integers(0, 2)),
+                 int(rng.choice([2, 3])), int(rng.choice([1, 2])), int(rng.integers(0, 2)), 0, int(rng.integers(0, 2)))
+    if kind == 7:
+        f = H.u8_fc_graph if u8 else H.fc_graph
+        return f(seed, int(rng.integers(1, 5)), (int(rng.integers(8, 600)),), int(rng.integers(2, 300)))
+    if not u8:
+        et = int(rng.choice([tm2.ELT_SUM, tm2.ELT_SUB, tm2.ELT_MAX, tm2.ELT_PROD]))
+        return H.eltwise_relu_graph(seed, 2, 32, 14, 14, bool(rng.integers(0, 2)), et)
+    if kind == 8:
+        return H.u8_route_graph(seed, 2, 16, 20, 20) if rng.random() < 0.5 else \
+            H.u8_unary_graph(seed, "ReLU", [2, 32, 40, 40], negative_slope=float(rng.choice([0.0, 0.1])))
+    return H.u8_ssd_head_graph(seed, 2, 32, 12, 12, same_q=bool(rng.random() < 0.3))
+
+
+def campaign(dtype, seconds, seed, verbose=True):
+    """returns (graphs, outputs compared, mismatching outputs)"""
+    rng = np.random.default_rng(seed)
+    mode = ref_capi.MODE_UINT8 if dtype == "uint8" else ref_capi.MODE_INT8
+    t0, graphs, tot, bad = time.time(), 0, 0, 0
+    while time.time() - t0 < seconds:
+        g, x = random_graph(rng, dtype)
+        want = ref_capi.run_model(tm2.write_tm2(g), x, mode, 4)
+        got = oracle.run_graph(g, x)
+        graphs += 1
+        for w, o in zip(want, got):
+            d = int(np.count_nonzero(w != o.reshape(w.shape)))
+            tot += w.size
+            bad += d
+            if d and verbose:
+                print("MISMATCH", g.name, [t.dims for t in g.tensors[:3]], g.nodes[-1].params, d, "of", w.size, flush=True)
+    return graphs, tot, bad
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="uint8", choices=["int8", "uint8"])
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    if not ref_capi.available():
+        raise SystemExit("the reference library is not built here (python oracle/build_ref.py)")
+    print("%s: %d graphs, %d outputs, %d mismatches" % ((a.dtype,) + campaign(a.dtype, a.seconds, a.seed)))
