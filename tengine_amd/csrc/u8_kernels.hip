@@ -305,7 +305,7 @@ static const struct { int bm, bn, kc; const char* name; } U8_CFGS[] = {
 int conv_u8_gemm_num_cfgs() { return 8; }
 int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
-    static const char* e = getenv("TAMD_U8_CFG");
+    const char* e = getenv("TAMD_U8_CFG");                 // tests / fuzzing: pin one tile shape (read at every prerun)
     if (e && *e) return atoi(e) % 8;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
