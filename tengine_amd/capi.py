@@ -42,6 +42,10 @@ class TamdError(RuntimeError):
     pass
 
 
+def version():
+    return lib().tamd_version().decode()
+
+
 def lib():
     global _lib
     if _lib is None:
