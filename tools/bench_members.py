@@ -32,7 +32,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     os.environ["TAMD_AUTOTUNE"] = "0"
-    print("%-34s" % "shape (batch %d)" % batch + "".join("%12s" % m for m in MEMBERS))
+    print("%-34s" % "shape (batch %d)" % batch + "".join("%18s" % m for m in MEMBERS))
     for cin, hw, cout, k, s, p in SHAPES[which]:
         g, x = conv_graph(1, batch, cin, hw, hw, cout, k, s, p, 1, 0, True, 1)
         b = tm2.write_tm2(g)
@@ -50,9 +50,10 @@ def main():
             conv = [q for q in prof if q["macs"] > 0][-1]
             gr.close()
             macs = conv["macs"]
-            want = m.replace("igemm", "conv_igemm_i8") if m.startswith("igemm") and m != "igemm" else m
-            pinned = (m in conv["kernel"]) or (m.startswith("igemm") and "conv_igemm_i8" in conv["kernel"])
-            cells.append("%12s" % (("%.1f" % (conv["ms"] * 1e3)) if pinned else "-"))
+            # the cell names the kernel that actually ran: a member that does not apply to the shape falls back to the
+            # planner's default, which shows as a different name in its column
+            kn = conv["kernel"].replace("conv_igemm_i8", "ig").replace("conv_igemm2_i8", "ig2").replace("_i8", "")
+            cells.append("%18s" % ("%.1f %s" % (conv["ms"] * 1e3, kn[:11])))
         print("%-34s" % ("%dx%d^2 -> %d k%d s%d  %.0f MMAC" % (cin, hw, cout, k, s, macs / 1e6)) + "".join(cells))
 
 
