@@ -121,7 +121,8 @@ typedef struct tamd_options {
 
 typedef struct tamd_graph tamd_graph;
 
-/* ---- device -------------------------------------------------------------------------------- */
+/* ---- device: what struct interface.init / release_device and allocator.describe need
+ * (source/device/device.h:40-84; the CUDA backend's equivalents: cuda_device.cc:47-83,212-238) ---- */
 TAMD_API int tamd_device_count(void);
 TAMD_API int tamd_init(int gpu_index);
 TAMD_API int tamd_shutdown(void);
@@ -130,7 +131,9 @@ TAMD_API const char* tamd_version(void);
 /* 1 if (op, dtype) can run on the device -- what allocator.describe publishes */
 TAMD_API int tamd_op_supported(int op, int dtype);
 
-/* ---- graph construction ------------------------------------------------------------------- */
+/* ---- graph construction: the plugin's pre_run walks `struct subgraph` (source/graph/subgraph.h, node.h:46-70,
+ * tensor.h:43-102) and mirrors it through these calls, like CUDAEngine::Build does for its own IR
+ * (source/device/cuda/cuda_executor.cc:72-134) ------------------------------------------------- */
 TAMD_API tamd_graph* tamd_graph_create(void);
 TAMD_API int tamd_graph_add_tensor(tamd_graph* g, const tamd_tensor_desc* desc);  /* -> tensor index or <0 */
 TAMD_API int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* desc);      /* -> node index or <0   */
@@ -141,7 +144,10 @@ TAMD_API tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size);
 /* re-shape the batch dimension of every input (== set_tensor_shape + infer_shape) before prerun */
 TAMD_API int tamd_graph_set_batch(tamd_graph* g, int batch);
 
-/* ---- execution ---------------------------------------------------------------------------- */
+/* ---- execution ----------------------------------------------------------------------------
+ * prerun  <- interface.pre_run   (device.h:46, called from scheduler.c:49-59; options may be NULL)
+ * run     <- interface.run       (device.h:49, scheduler.c:134; must return with outputs complete)
+ * destroy <- interface.post_run / release_graph (device.h:52-58, scheduler.c:201, subgraph.c:53-56) */
 TAMD_API int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt);
 TAMD_API int tamd_graph_input_num(const tamd_graph* g);
 TAMD_API int tamd_graph_output_num(const tamd_graph* g);
@@ -164,7 +170,8 @@ TAMD_API void* tamd_graph_stream(tamd_graph* g);          /* hipStream_t        
 /* time `iters` back-to-back launches with HIP events on the graph's stream -> total ms */
 TAMD_API int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms);
 
-/* ---- introspection / profiling ------------------------------------------------------------ */
+/* ---- introspection / profiling: the TG_DEBUG_TIME / TG_DEBUG_DATA analogues of the CPU device
+ * (source/device/cpu/cpu_define.h:41-43, cpu_dump.c:607-697) ---------------------------------- */
 typedef struct tamd_kernel_info {
     char node[64];        /* graph node name                                     */
     char kernel[48];      /* device kernel family                                */
