@@ -232,6 +232,17 @@ def upsample_uint8(x, scale, in_q, out_q):
     return y
 
 
+def softmax_uint8(x, axis, in_q, out_q):
+    x = np.ascontiguousarray(x, np.uint8)
+    axis = axis % x.ndim
+    outer = int(np.prod(x.shape[:axis])) if axis else 1
+    inner = int(np.prod(x.shape[axis + 1:])) if axis + 1 < x.ndim else 1
+    y = np.empty_like(x)
+    lib().orc_softmax_uint8(_p(x), _p(y), outer, x.shape[axis], inner, C.c_float(in_q[0]), int(in_q[1]),
+                            C.c_float(out_q[0]), int(out_q[1]))
+    return y
+
+
 def eltwise_uint8(a, b, etype, qa, qb, out_q):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
@@ -307,6 +318,10 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
             y = a
         elif op == "Permute":       # permute/permute_ref.c:203-296: a byte copy in the new order, no requantisation
             y = np.ascontiguousarray(np.transpose(a, p["order"]))
+        elif op == "Reshape":       # reshape/reshape_ref.c: element copy into the inferred shape (reshape.c:37-160)
+            y = a.reshape(g.tensors[o0].dims)
+        elif op == "Softmax" and dt == DT_UINT8:
+            y = softmax_uint8(a, p.get("axis", 1), qp(i0), qp(o0))
         elif op == "Flatten":       # flatten/flatten_ref.c:53-77: element copy; shape [n, prod(rest)] (flatten.c:34-61)
             y = a.reshape(a.shape[0], -1)
         elif op == "Concat" and dt == DT_UINT8:

@@ -484,6 +484,44 @@ ORC_API int orc_conv2d_uint8(const uint8_t* x, const uint8_t* w, const int32_t* 
     return 0;
 }
 
+/* uint8 softmax -- softmax/softmax_kernel_ref_uint8.c:40-119 with softmax_kernel_ref.h:35-85: dequantise to fp32,
+ * per (outer, inner) position: max over the axis (:35-50), out = (float)exp((double)(x - max)) -- C `exp`, i.e. the
+ * DOUBLE routine, rounded to float on the store (:67) --, sum accumulated in fp32 in axis order (:68), out / sum
+ * (:72-79), then (int)(round(out / out_scale) + out_zp), clamp [0,255] (:103-113).                              */
+ORC_API int orc_softmax_uint8(const uint8_t* x, uint8_t* y, int out_size, int on_size, int in_size, float in_scale,
+                              int in_zp, float out_scale, int out_zp)
+{
+    float* f = (float*)malloc(sizeof(float) * (size_t)on_size * in_size);
+    float* o = (float*)malloc(sizeof(float) * (size_t)on_size * in_size);
+    float* mx = (float*)malloc(sizeof(float) * (size_t)in_size);
+    float* sm = (float*)malloc(sizeof(float) * (size_t)in_size);
+    for (int i = 0; i < out_size; i++)
+    {
+        const uint8_t* xi = x + (size_t)i * on_size * in_size;
+        uint8_t* yi = y + (size_t)i * on_size * in_size;
+        for (int j = 0; j < on_size * in_size; j++) f[j] = ((float)xi[j] - (float)(uint8_t)in_zp) * in_scale;
+        for (int l = 0; l < in_size; l++) mx[l] = f[l];
+        for (int j = 0; j < on_size; j++)
+            for (int l = 0; l < in_size; l++)
+                if (mx[l] < f[j * in_size + l]) mx[l] = f[j * in_size + l];
+        for (int l = 0; l < in_size; l++) sm[l] = 0.f;
+        for (int j = 0; j < on_size; j++)
+            for (int l = 0; l < in_size; l++)
+            {
+                o[j * in_size + l] = (float)exp((double)(f[j * in_size + l] - mx[l]));
+                sm[l] = sm[l] + o[j * in_size + l];
+            }
+        for (int j = 0; j < on_size * in_size; j++)
+        {
+            float v = o[j] / sm[j % in_size];
+            int u = (int)(round((double)(v / out_scale)) + (double)(uint8_t)out_zp);
+            yi[j] = sat_u8(u);
+        }
+    }
+    free(f); free(o); free(mx); free(sm);
+    return 0;
+}
+
 /* fc uint8 -- fc/fc_ref.c:121-207: data = (float)bias*bias_scale; data = fma(xf, wf, data) j ascending;
  * round(data/out_s) + out_zp, clamp [0,255].  bias_scale == bias_tensor->scale.                            */
 ORC_API int orc_fc_uint8(const uint8_t* x, const uint8_t* w, const int32_t* bias, uint8_t* y, int batch, int hidden,

@@ -127,6 +127,16 @@ class _B:
         self.g.add_node(name, "Flatten", [x], [y], axis=1, end_axis=3)
         return y
 
+    def reshape(self, name, x, re_shape):
+        """reshape.c infer_shape with is_onnx set: 0 copies the input dim, -1 is inferred"""
+        d = self.dims(x)
+        out = [d[i] if v == 0 else v for i, v in enumerate(re_shape)]
+        if -1 in out:
+            out[out.index(-1)] = int(np.prod(d)) // int(-np.prod(out))
+        y = self.g.add_tensor(name + "/0", out, DT_FP32)
+        self.g.add_node(name, "Reshape", [x], [y], is_mxnet=0, reverse=0, is_onnx=1, re_shape=list(re_shape))
+        return y
+
     def finish(self, outs):
         for o in outs:
             for ni, n in enumerate(self.g.nodes):
@@ -265,13 +275,15 @@ def yolov3_tiny_fp32(batch=1, res=416, nout=255):
     return b.finish([head2, head1])
 
 
-def mssd_fp32(batch=1, res=300, classes=21):
+def mssd_fp32(batch=1, res=300, classes=21, tail=False):
     """MobileNet-v1-SSD 300x300 (benchmark/models/mssd_benchmark.tmfile, the BASELINE "MobileNet-SSD" stand-in,
     SURVEY §8d): 47 convs = conv0 + 13 (dw, pw) pairs + 4 (1x1, 3x3 s2) extra pairs + 6 loc and 6 conf 1x1 heads on
     conv11 (19x19, 3 priors), conv13 (10x10), conv14_2 (5x5), conv15_2 (3x3), conv16_2 (2x2), conv17_2 (1x1) (6 priors
     each); every head goes Permute(0,2,3,1) -> Flatten -> Concat(axis 1).  Outputs: mbox_loc [N, 1917*4] and
     mbox_conf [N, 1917*classes]; the Reshape/Softmax/PriorBox/DetectionOutput tail of the tmfile is host-side
-    post-processing the splitter leaves on the CPU device."""
+    post-processing the splitter leaves on the CPU device.  `tail=True` appends the quantised part of that tail --
+    Reshape(0,-1,classes) -> Softmax(axis 2) -> Flatten on mbox_conf -- for oracle-vs-reference tests of the next
+    row; the device graphs are built without it."""
     b = _B("mssd", [batch, 3, res, res])
     x = b.conv("conv0", b.cur, 32, 3, 2, 1, act=0)
     cfg = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1),
@@ -295,6 +307,10 @@ def mssd_fp32(batch=1, res=300, classes=21):
             h = b.permute("%s_mbox_%s_perm" % (name, kind), h)
             flats.append(b.flatten("%s_mbox_%s_flat" % (name, kind), h))
         outs.append(b.concat("mbox_%s" % kind, flats, axis=1))
+    if tail:
+        y = b.reshape("mbox_conf_reshape", outs[1], [0, -1, classes])
+        y = b.softmax("mbox_conf_softmax", y, axis=2)
+        outs[1] = b.flatten("mbox_conf_flatten", y)
     return b.finish(outs)
 
 
@@ -370,6 +386,8 @@ def fp32_forward(g: Graph, x: np.ndarray):
             y = a.reshape(a.shape[0], -1)
         elif op == "Permute":
             y = a.permute(*p["order"]).contiguous()
+        elif op == "Reshape":
+            y = a.reshape(g.tensors[n.outputs[0]].dims)
         else:
             raise NotImplementedError(op)
         vals[n.outputs[0]] = y
@@ -578,7 +596,12 @@ def calib_table(name, gf=None, write=False, dtype="int8"):
     table): make the synthetic quantised models bit-identical on every host."""
     path = os.path.join(CALIB_DIR, "%s_%s.json" % (name, dtype))
     if os.path.exists(path) and not write:
-        return json.load(open(path))
+        table = json.load(open(path))
+        if gf is not None and dtype == "uint8":      # optional tail tensors (mssd tail=True): ranges known a priori
+            for t in gf.tensors:
+                if t.ttype == tm2.TT_VAR and t.name not in table:
+                    table[t.name] = table["mbox_conf/0"] if t.name == "mbox_conf_reshape/0" else [0.0, 1.0]
+        return table
     gf = gf if gf is not None else BUILDERS[name]()
     table = calibrate_absmax(gf) if dtype == "int8" else calibrate_minmax(gf)
     if write:
@@ -616,7 +639,7 @@ def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
         table = calib_table(name, gf) if not kw else None
         g = set_batch(quantize_int8(gf, table=table), batch)
     elif dtype == "uint8":
-        table = calib_table(name, gf, dtype="uint8") if not kw else None
+        table = calib_table(name, gf, dtype="uint8") if (not kw or set(kw) == {"tail"}) else None
         g = set_batch(quantize_uint8(gf, table=table), batch)
     else:
         raise NotImplementedError(dtype)

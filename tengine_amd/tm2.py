@@ -155,6 +155,11 @@ def _unpack_param(op: str, b: bytes, off: int) -> Dict:
     if op == "Permute":
         v = struct.unpack_from("<5i", b, off)
         return {"flag": v[0], "order": list(v[1:])}
+    if op == "Reshape":
+        is_mx, rev, voff, is_onnx = struct.unpack_from("<iiIi", b, off)
+        n = struct.unpack_from("<I", b, voff)[0] if voff else 0
+        return {"is_mxnet": is_mx, "reverse": rev, "is_onnx": is_onnx,
+                "re_shape": list(struct.unpack_from("<%di" % n, b, voff + 4)) if n else []}
     return {}
 
 
@@ -212,7 +217,11 @@ def write_tm2(g: Graph) -> bytes:
     # nodes
     node_offs = []
     for ni, n in enumerate(g.nodes):
-        pb = _pack_param(n.op, n.params)
+        if n.op == "Reshape":    # TM2_ReshapeParam {is_mxnet, reverse, offset_re_shape -> TM2_Vector_dims, is_onnx} (tm2_format.h:565-571)
+            pb = struct.pack("<iiIi", n.params.get("is_mxnet", 0), n.params.get("reverse", 0),
+                             bl.vec_i32(n.params["re_shape"]), n.params.get("is_onnx", 1))
+        else:
+            pb = _pack_param(n.op, n.params)
         po = bl.put(pb) if pb else 0
         op = bl.put(struct.pack("<III", 1, OPTYPE[n.op], po))               # TM2_Operator
         vi = bl.vec_u32(n.inputs) if n.inputs else 0

@@ -137,3 +137,15 @@ def test_mssd_uint8_300_oracle_matches_golden_of_real_reference():
     assert [o.shape for o in outs] == [(1, 1917 * 4), (1, 1917 * 21)]
     for i, o in enumerate(outs):
         assert np.array_equal(o.ravel(), golden["out%d" % i].ravel())
+
+
+@needs_ref
+def test_softmax_and_reshape_uint8_oracle_is_the_reference():
+    """the quantised part of the SSD tail (next row): Softmax (C `exp` on a double, sequential fp32 sum)
+    and Reshape, single ops and behind the whole MobileNet-SSD graph."""
+    both(*u8_unary_graph(41, "Softmax", [2, 21, 5, 7], axis=1))
+    both(*u8_unary_graph(42, "Softmax", [3, 40, 21], axis=2))
+    both(*u8_unary_graph(43, "Softmax", [4, 100], axis=1))
+    g = models.build("mssd", "uint8", 2, tail=True)
+    assert [n.op for n in g.nodes[-3:]] == ["Reshape", "Softmax", "Flatten"]
+    both(g, models.synth_input(g, 5, tm2.DT_UINT8))
