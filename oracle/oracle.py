@@ -232,6 +232,13 @@ def upsample_uint8(x, scale, in_q, out_q):
     return y
 
 
+def requant_copy_int8(x, in_scale, out_scale):
+    x = np.ascontiguousarray(x, np.int8)
+    y = np.empty_like(x)
+    lib().orc_requant_copy_int8(_p(x), _p(y), C.c_size_t(x.size), C.c_float(in_scale), C.c_float(out_scale))
+    return y
+
+
 def softmax_uint8(x, axis, in_q, out_q):
     x = np.ascontiguousarray(x, np.uint8)
     axis = axis % x.ndim
@@ -326,6 +333,8 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
             y = a.reshape(a.shape[0], -1)
         elif op == "Concat" and dt == DT_UINT8:
             y = np.concatenate([requant_copy_uint8(vals[i], qp(i), qp(o0)) for i in n.inputs], axis=p.get("axis", 1))
+        elif op == "Concat" and dt == DT_INT8:
+            y = np.concatenate([requant_copy_int8(vals[i], sc(i), sc(o0)) for i in n.inputs], axis=p.get("axis", 1))
         elif op == "Concat" and dt == DT_FP32:
             y = np.concatenate([vals[i] for i in n.inputs], axis=p.get("axis", 1))
         elif op == "Upsample" and dt == DT_UINT8:

@@ -208,6 +208,23 @@ ORC_API int orc_relu_int8(const int8_t* x, int8_t* y, size_t count, float slope,
     return 0;
 }
 
+/* concat int8, one input slice -- concat/concat_kernel_ref_int8.c:60-95 (same text for every rank / axis):
+ * rescale = in_scale / out_scale ; q = roundf((float)x * rescale) ; q > 127 -> 127 ; and q < -127 -> **+127**: the
+ * reference's lower clamp assigns the wrong sign at all ten sites (:83-84, :113-114, ... :430-431).  "Identical to
+ * the reference" includes that defect, so it is restated, not repaired.                                          */
+ORC_API int orc_requant_copy_int8(const int8_t* x, int8_t* y, size_t count, float in_scale, float out_scale)
+{
+    float rescale = in_scale / out_scale;
+    for (size_t i = 0; i < count; i++)
+    {
+        int q = (int)roundf((float)x[i] * rescale);
+        if (q > 127) q = 127;
+        else if (q < -127) q = 127;
+        y[i] = (int8_t)q;
+    }
+    return 0;
+}
+
 /* int8 eltwise, same-shape operands -- eltwise/eltwise_ref.c:589-640,833-837:
  * a=(float)qa*sa ; b=(float)qb*sb ; f = a (+|*|max|-) b ; y = round(f/out_scale) clamp +-127
  * type codes: eltwise_param.h (0 PROD, 2 SUM, 4 SUB, 6 MAX)                                              */

@@ -256,3 +256,23 @@ def u8_ssd_head_graph(seed, n, c, h, w, priors=(3, 6), per=4, same_q=False, stan
     ni = g.add_node("mbox", "Concat", flats, [cc], axis=1)
     g.output_nodes = [ni]
     return g, rng.integers(0, 256, size=(n, c, h, w)).astype(np.uint8)
+
+
+def i8_concat_graph(seed, n, c, h, w, axis=1, shrink=False):
+    """int8: data -> ReLU (scale s1) and data -> leaky ReLU (scale s2) -> Concat (scale s3) on `axis`.  `shrink`: the
+    output scale is smaller than an input scale, so rescaled values leave [-127, 127] (the reference's clamp path)."""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="i8concat_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, c, h, w], DT_INT8, [xs], [0])
+    a = g.add_tensor("a", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [float(np.float32(xs * 0.9))], [0])
+    g.add_node("relu", "ReLU", [x], [a], negative_slope=0.0)
+    b = g.add_tensor("b", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [float(np.float32(xs * 1.1))], [0])
+    g.add_node("leaky", "ReLU", [x], [b], negative_slope=0.9)
+    d = [n, c, h, w]
+    d[axis] *= 2
+    so = float(np.float32(xs * (0.7 if shrink else 1.3)))
+    y = g.add_tensor("cat", d, DT_INT8, tm2.TT_VAR, None, [so], [0])
+    ni = g.add_node("cat", "Concat", [a, b], [y], axis=axis)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)

@@ -4,7 +4,7 @@ covering every kernel-selection branch of the reference and on w
 import numpy as np
 import pytest
 
-from helpers import conv_graph, eltwise_relu_graph, fc_graph, pool_graph
+from helpers import conv_graph, eltwise_relu_graph, fc_graph, i8_concat_graph, pool_graph
 from oracle import oracle
 from tengine_amd import models, tm2
 
@@ -74,6 +74,18 @@ def test_eltwise_relu_int8_oracle_equals_reference(ref, with_relu):
     want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
     got = oracle.run_graph(g, x)[0]
     assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("axis,shrink", [(1, False), (1, True), (2, True), (3, True), (0, True)])
+def test_concat_int8_oracle_equals_reference(ref, axis, shrink):
+    """int8 concat with per-input rescale (concat_kernel_ref_int8.c), incl. the reference's lower clamp, which writes
+    +127 for values below -127 at every one of its ten sites: restated as it is (`shrink` exercises it)."""
+    g, x = i8_concat_graph(30 + axis, 2, 8, 5, 6, axis, shrink)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want, got.reshape(want.shape))
+    if shrink:
+        assert (want == 127).sum() > 100 and want.min() >= -127      # negative inputs came out as +127
 
 
 def test_mobilenet_v1_int8_whole_model(ref):
