@@ -15,5 +15,7 @@ python $R/bench.py --model yolov3_tiny --dtype uint8 --batch 8 --steps 50 --cpu-
 python $R/bench.py --model mssd --dtype uint8 --batch 16 --steps 50 --cpu-seconds 8 > $O/bench_mssd_uint8_b16.json 2> $O/bench_mssd.err
 python $R/bench.py --model resnet50 --batch 32 --steps 30 --cpu-seconds 8 > $O/bench_resnet50_int8_b32.json 2> $O/bench_rn.err
 python $R/bench.py --streams 16 --steps 2000 --no-cpu-baseline > $O/bench_mobilenet_b1_16streams.json 2> $O/bench_s16.err
+# host-to-host (PCIe-inclusive) figures: tm_benchmark's own loop
+(python $R/tools/tm_benchmark.py -r 100 -s 1 -p int8; python $R/tools/tm_benchmark.py -r 30 -s 5 -p int8 -b 32; python $R/tools/tm_benchmark.py -r 30 -s 8 -p uint8 -b 8) > $O/tm_benchmark_host_to_host.txt 2>&1
 for f in $O/layers_*.txt; do echo $f; tail -1 $f; done
 for f in $O/bench_*.json; do tail -1 $f | cut -c1-260; done
