@@ -52,8 +52,20 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent batch-1 graph instances (1 = sequential, tm_benchmark semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path with world_size 1 (test)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total images per step, sharded over the ranks with shard_range (strong split of one batch, e.g. "
+                         "--model yolov3_tiny --dtype uint8 --global-batch 64); 0 = --batch per GPU (weak scaling)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU/gloo plumbing check of the N-rank path (spawn, tmfile broadcast, sharding, gather of every "
+                         "output); no device work, the JSON line carries value null and dry_run true")
+    ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` run plainly: start the N ranks ourselves (one process per GPU) -- or fail
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
+        return
 
     import numpy as np
     import torch
@@ -63,8 +75,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:  # noqa
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d -- refusing to report a line for the wrong GPU count" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit("bench.py: %d rank(s) on this node but %d HIP device(s) visible" % (world, torch.cuda.device_count()))
     use_dist = world > 1 or args.force_dist   # --force-dist exercises the RCCL path on a single GPU (testing)
     dist = None
     torch.cuda.set_device(local_rank)
@@ -74,13 +90,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from tengine_amd import dist as tdist
+    if args.global_batch:
+        args.batch = tdist.shard_range(args.global_batch, world, rank)[1]       # this rank's contiguous shard
+        if args.batch == 0:
+            raise SystemExit("bench.py: --global-batch %d leaves rank %d without images" % (args.global_batch, rank))
+    total_images = args.global_batch if args.global_batch else world * args.batch
+    max_shard = tdist.shard_range(total_images, world, 0)[1]
 
     # ---- model: rank 0 synthesises the int8 tmfile, RCCL broadcast of the raw bytes ----------------
     if rank == 0:
         g = models.build(args.model, args.dtype, args.batch, device_only=(args.model != "mobilenet_v1"))
         tm_bytes = tm2.write_tm2(g)
     if use_dist:
-        from tengine_amd import dist as tdist
         # RCCL over xGMI, once, outside the timed loop (tengine_amd/dist.py; gloo-tested on CPU)
         tm_bytes = tdist.broadcast_tmfile(tm_bytes if rank == 0 else None, dist, "cuda")
     g = tm2.read_tm2(tm_bytes)
@@ -98,14 +120,27 @@ def main():
         q.sync()
 
     exts = [torch.cuda.ExternalStream(q.stream(), device=torch.device("cuda", local_rank)) for q in grs]
-    views = []
+    # EVERY graph output is gathered (YOLOv3-tiny: two heads = 215 475 B/image; mssd: loc + conf): the outputs of one
+    # step are packed into one slot (each padded to the largest shard, so ragged --global-batch shards gather with one
+    # equal-sized collective) and all-gathered with a single call
+    n_out = gr.output_num()
+    views, out_sizes = [], []
     for q in grs:
-        out_ptr, out_bytes = q.output_device(0)
-        views.append(torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda"))
+        vq = []
+        for oi in range(n_out):
+            out_ptr, out_bytes = q.output_device(oi)
+            vq.append(torch.as_tensor(_CAI(out_ptr, out_bytes), device="cuda"))
+        views.append(vq)
+        out_sizes = [int(v.numel()) for v in vq]
+    per_image = [b // args.batch for b in out_sizes]
+    slot_off, slot_bytes = [], 0
+    for b in per_image:
+        slot_off.append(slot_bytes)
+        slot_bytes += b * max_shard
     slots, gathered, works = None, None, {}
     if use_dist:
-        slots = [[torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
-        gathered = [[torch.empty(out_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
+        slots = [[torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
+        gathered = [[torch.empty(slot_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
 
     def step(k):
         i = k % S
@@ -115,7 +150,8 @@ def main():
             with torch.cuda.stream(exts[i]):
                 if works.get((i, s)) is not None:
                     works[(i, s)].wait()         # slot free again (gather issued two rounds ago is done)
-                slots[i][s].copy_(views[i], non_blocking=True)
+                for oi in range(n_out):
+                    slots[i][s][slot_off[oi]:slot_off[oi] + out_sizes[oi]].copy_(views[i][oi], non_blocking=True)
                 works[(i, s)] = dist.all_gather_into_tensor(gathered[i][s], slots[i][s], async_op=True)
 
     def drain():
@@ -147,13 +183,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # ---- the SURVEY §8(d) metric as tm_benchmark times it (tm_benchmark.cc:118-129): host buffer in -> H2D -> graph
+    # -> D2H -> host buffer out, one blocking run after the other; reported beside `value`, never as `value` ----------
+    host_to_host = None
+    if rank == 0 and not use_dist:
+        n_h2h = max(10, min(args.steps, 300))
+        gr.run_noreturn()
+        ts = []
+        for _ in range(n_h2h):
+            t1 = time.perf_counter()
+            gr.run_noreturn()
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        in_bytes = int(np.asarray(x).nbytes)
+        host_to_host = {"images_per_s_min": args.batch / ts[0], "images_per_s_median": args.batch / ts[len(ts) // 2],
+                        "ms_min": 1e3 * ts[0], "ms_median": 1e3 * ts[len(ts) // 2], "runs": n_h2h,
+                        "what": "tamd_graph_run(): memcpy to pinned + H2D %d B + hipGraph replay + D2H %d B + copy out, blocking, "
+                                "1 stream -- what tm_benchmark times" % (in_bytes, sum(out_sizes))}
+
     # ---- roofline of the dominant kernel (HIP events on the launch stream, same process) -----------
     roofline = None
     if rank == 0:
         prof = gr.profile(20)
         fam = {}
         for k in prof:
-            f = fam.setdefault(k["kernel"], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            # family = the kernel's base name: template variants (tile shapes, K splits) of one kernel count together
+            f = fam.setdefault(k["kernel"].split("<")[0].split("+")[0], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
             f["ms"] += k["ms"]; f["bytes"] += k["bytes"]; f["macs"] += k["macs"]; f["launches"] += 1
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
@@ -185,20 +240,21 @@ def main():
     for q in grs:
         q.close()
     if rank == 0:
-        value = world * args.batch * args.steps / el
+        value = total_images * args.steps / el
         line = {
             "metric": "images/sec int8 MobileNet-v1 224x224" if (args.model, args.dtype) == ("mobilenet_v1", "int8")
             else "images/sec %s %s" % (args.dtype, args.model), "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (uint8 simulated in fp32, as the reference)" if u8 else "int8",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32 (uint8 simulated in fp32, as the reference)" if u8 else "int8",
             "data": "synthetic",
             "config": {"workload": "%s %s batch=%d per GPU%s, weights = seeded synthetic tmfile, input resident in HBM, "
                                    "hipGraph replay, %d stream(s)" % (args.model, args.dtype, args.batch,
                                                                       " (BASELINE configs[1])" if (args.model, args.dtype, args.batch) == ("mobilenet_v1", "int8", 1) else "", S),
                        "streams": S,
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "collectives": "rccl broadcast(tmfile) once + all_gather(outputs) per step" if use_dist else "none"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "global_batch": total_images, "parallelism": "dp%d" % world,
+                       "collectives": "rccl broadcast(tmfile) once + one all_gather of all %d output(s) (%d B/image) per step"
+                                      % (n_out, sum(per_image)) if use_dist else "none"},
+            "roofline": roofline, "cpu_baseline": cpu, "host_to_host": host_to_host,
             "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
         }
         if cpu:
@@ -213,7 +269,7 @@ def pmc_traffic(model, dtype, batch, family):
     (profiles/r01_traffic_<model>_<dtype>_b<batch>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
     same-session streaming-copy calibration -- tools/collect_profiles.sh, tools/traffic_summary.py); None when this
     workload has no PMC pass (counters cannot be collected from inside the timed process)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_%s_%s_b%d.json" % (model, dtype, batch))
+    path = os.path.join(ROOT, "profiles", "r02_traffic_%s_%s_b%d.json" % (model, dtype, batch))
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
@@ -226,26 +282,39 @@ def pmc_traffic(model, dtype, batch, family):
 
 
 def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
-    """Reference `source/device/cpu` path through create_graph/prerun/run_graph on the host cores."""
+    """Reference `source/device/cpu` path through create_graph/prerun/run_graph on the host cores, swept over thread
+    counts {1, 8, 32, physical cores, logical cpus} (SURVEY §8d asks for {1, all physical cores}; 256 OpenMP threads on
+    a 256-way SMT host oversubscribe the small batch-1 layers).  `value` = the BEST point of the sweep, `cores` = the
+    threads of that point, the whole sweep is in `sample`."""
     import numpy as np
-    threads = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    physical = physical_cores() or logical
+    sweep = sorted({t for t in (1, 8, 32, physical, logical) if 1 <= t <= logical})
     try:
         from oracle import ref_capi
         if not ref_capi.available():
             raise FileNotFoundError
-        rg = ref_capi.RefGraph(tm_bytes, ref_capi.MODE_UINT8 if u8 else ref_capi.MODE_INT8, threads)
-        rg.set_input(x)
-        rg.run()                                   # warm-up (weight packing, pool alloc)
-        ts, t_end = [], time.perf_counter() + budget_s
-        while time.perf_counter() < t_end or len(ts) < 3:
-            t0 = time.perf_counter()
-            rg.run()
-            ts.append(time.perf_counter() - t0)
-        rg.close()
-        return {"value": batch / min(ts), "unit": "images/s", "cores": threads, "kind": "reference",
-                "sample": "%d timed run_graph() calls of the same tmfile/input (batch %d), min %.1f ms, mean %.1f ms, "
-                          "reference CPU backend built -O3 -mfma -fopenmp from the unmodified sources"
-                          % (len(ts), batch, 1e3 * min(ts), 1e3 * float(np.mean(ts)))}
+        pts = []
+        per_point = budget_s / len(sweep)
+        for threads in sweep:
+            rg = ref_capi.RefGraph(tm_bytes, ref_capi.MODE_UINT8 if u8 else ref_capi.MODE_INT8, threads)
+            rg.set_input(x)
+            rg.run()                                   # warm-up (weight packing, pool alloc)
+            ts, t_end = [], time.perf_counter() + per_point
+            while time.perf_counter() < t_end or len(ts) < 3:
+                t0 = time.perf_counter()
+                rg.run()
+                ts.append(time.perf_counter() - t0)
+            rg.close()
+            pts.append((threads, min(ts), float(np.mean(ts)), len(ts)))
+        best = min(pts, key=lambda p: p[1])
+        return {"value": batch / best[1], "unit": "images/s", "cores": best[0], "kind": "reference",
+                "physical_cores": physical, "logical_cpus": logical,
+                "sweep": [{"threads": p[0], "min_ms": 1e3 * p[1], "mean_ms": 1e3 * p[2], "runs": p[3]} for p in pts],
+                "sample": "timed run_graph() calls of the same tmfile/input (batch %d) at each thread count of the sweep (%s), "
+                          "%.0f s of CPU work in total; value = best point (%d threads, min %.1f ms); reference CPU backend "
+                          "built -O3 -mfma -fopenmp from the unmodified sources"
+                          % (batch, ", ".join("%d thr: %.1f ms" % (p[0], 1e3 * p[1]) for p in pts), budget_s, best[0], 1e3 * best[1])}
     except (FileNotFoundError, OSError):
         from oracle import oracle
         oracle.run_graph(g, x)
@@ -254,8 +323,102 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
             t0 = time.perf_counter()
             oracle.run_graph(g, x)
             ts.append(time.perf_counter() - t0)
-        return {"value": batch / min(ts), "unit": "images/s", "cores": threads, "kind": "port",
+        return {"value": batch / min(ts), "unit": "images/s", "cores": logical, "kind": "port",
                 "sample": "%d timed oracle passes (batch %d), min %.1f ms" % (len(ts), batch, 1e3 * min(ts))}
+
+
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo; None when it cannot be read"""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        return len(cores) or None
+    except OSError:
+        return None
+
+
+def respawn(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU.  Fails
+    (rc != 0) when the node cannot host N ranks -- never a silent N=1 line."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
+def dry_run(args, rank, world):
+    """CPU/gloo check of the N-rank plumbing (no device, no compute): tmfile broadcast + integrity check, native-format
+    reload on every rank, shard_range over --global-batch (or --batch per rank), ONE all_gather of every graph output
+    padded to the largest shard, trimmed back to the global image order.  The outputs are rank/image tagged bytes, not
+    results; the line says dry_run and carries value null so it can never be read as a measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from tengine_amd import dist as tdist
+    from tengine_amd import models, tm2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = args.global_batch if args.global_batch else world * args.batch
+        start, count = tdist.shard_range(total, world, rank)
+        counts = [tdist.shard_range(total, world, r)[1] for r in range(world)]
+        tm_bytes = None
+        if rank == 0:
+            tm_bytes = tm2.write_tm2(models.build(args.model, args.dtype, 1, device_only=(args.model != "mobilenet_v1")))
+        tm_bytes = tdist.broadcast_tmfile(tm_bytes, dist, "cpu")
+        g = tm2.read_tm2(tm_bytes)
+        outs = [g.tensors[g.nodes[ni].outputs[0]] for ni in g.output_nodes]
+        per_image = [int(np.prod(t.dims[1:])) for t in outs]
+        ok = True
+        for k in range(max(1, min(args.steps, 3))):
+            gathered = []
+            for oi, b in enumerate(per_image):
+                local = torch.empty((count, b), dtype=torch.uint8)
+                for j in range(count):
+                    local[j] = (start + j + 7 * oi + k) % 251           # tag: global image index
+                gathered.append(tdist.all_gather_outputs(local, dist, counts))
+            for oi, gt in enumerate(gathered):
+                want = (torch.arange(total) + 7 * oi + k) % 251
+                ok = ok and gt.shape == (total, per_image[oi]) and bool((gt[:, 0].long() == want).all()) and bool((gt[:, -1].long() == want).all())
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise SystemExit("bench.py --dry-run: gathered outputs are not in global image order")
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec %s %s" % (args.dtype, args.model), "value": None, "unit": "images/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "config": {"workload": "%s %s: gloo plumbing check only, no device work" % (args.model, args.dtype),
+                                         "global_batch": total, "shards": counts, "outputs": len(per_image),
+                                         "gather_bytes_per_image": sum(per_image), "tmfile_bytes": len(tm_bytes),
+                                         "parallelism": "dp%d" % world}}))
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

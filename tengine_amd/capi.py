@@ -129,6 +129,13 @@ class Graph:
         _check(lib().tamd_graph_run(self._h), "run")
         return [o.copy() for o in self._out]
 
+    def run_noreturn(self):
+        """tamd_graph_run() without copying the outputs again (they are in the arrays handed to set_output)"""
+        _check(lib().tamd_graph_run(self._h), "run")
+
+    def output_num(self):
+        return lib().tamd_graph_output_num(self._h)
+
     def upload(self):
         _check(lib().tamd_graph_upload_inputs(self._h), "upload_inputs")
 

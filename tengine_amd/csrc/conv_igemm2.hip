@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_i8_kernel(ConvArgs a)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and so have everyone else's; every wave is also done reading the slot stage s+LA will overwrite
         __builtin_amdgcn_s_barrier();
-        if (s + LA < nk && !(a.dbg & 2)) issue(s + LA);
+        if (s + LA < nk) issue(s + LA);
         const int8_t* base = smem + (s % STAGES) * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_i8_kernel(ConvArgs a)
             for (int i = 0; i < TN; i++)
 #pragma unroll
                 for (int j = 0; j < TM; j++)
-                    if (!(a.dbg & 1)) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -266,9 +266,7 @@ const char* conv_igemm2_kernel_name(const ConvArgs& a) { return use_bn128(a) ? "
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t s)
 {
     static const int stages = env_int("TAMD_IGEMM2_STAGES", 3);
-    static const int dbg = env_int("TAMD_IGEMM2_DBG", 0);      // perf experiments only: 1 = no MFMA, 2 = no refills
-    ConvArgs b = a;
-    b.dbg = dbg;
+    const ConvArgs& b = a;
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0);
     if (use_bn128(a)) {
         if (stages <= 3) return launch2<128, 3>(b, s, is1x1);

@@ -130,12 +130,24 @@ static hipError_t launch_dw(const DwArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// two-fragment strips (6 / 3 outputs per lane) once there is enough work to fill the chip with them
+// and the row is long enough not to waste the strip tail; else the short strips
+static bool dw_wide(const DwArgs& a)
+{
+    const long px = (long)a.N * a.OH * a.OW;
+    return px * (a.cw / 4) >= 6L * 256 * 256 * 4 && a.OW >= 12;
+}
+
+const char* dwconv3x3_kernel_name(const DwArgs& a)
+{
+    const bool wide = dw_wide(a);
+    if (a.S == 1) return wide ? "dwconv3x3_i8<1,2>" : "dwconv3x3_i8<1,1>";
+    return wide ? "dwconv3x3_i8<2,2>" : "dwconv3x3_i8<2,1>";
+}
+
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s)
 {
-    // two-fragment strips (6 / 3 outputs per lane) once there is enough work to fill the chip with them
-    // and the row is long enough not to waste the strip tail; else the short strips
-    const long px = (long)a.N * a.OH * a.OW;
-    const bool wide = px * (a.cw / 4) >= 6L * 256 * 256 * 4 && a.OW >= 12;
+    const bool wide = dw_wide(a);
     if (a.S == 1) return wide ? launch_dw<1, 2>(a, s) : launch_dw<1, 1>(a, s);
     return wide ? launch_dw<2, 2>(a, s) : launch_dw<2, 1>(a, s);
 }

@@ -328,7 +328,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             a.N = x.n; a.H = x.h; a.W = x.w; a.C = cin; a.cs_in = x.cs; a.cw = cw; a.OH = y.h; a.OW = y.w;
             a.ldc = y.cs; a.c_off = y.c_off; a.S = p.stride_h; a.PH = p.pad_h0; a.PW = p.pad_w0;
             a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
-            st.kernel = "dwconv3x3_i8";
+            st.kernel = dwconv3x3_kernel_name(a);
             st.fn = [a](hipStream_t s) { return launch_dwconv3x3(a, s); };
         } else {
             // ---- generic direct (first layer from NCHW, grouped, non-3x3 depthwise) ----

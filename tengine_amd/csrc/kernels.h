@@ -39,7 +39,6 @@ struct ConvArgs {
     int M;                 // N*OH*OW
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
-    int dbg;               // perf experiments only (TAMD_IGEMM2_DBG), 0 in production
     int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
     EltFuse elt;           // fused eltwise(+relu) tail (conv_igemm / conv_igemm2 only); y/ldc/c_off then describe ITS output
 };
@@ -120,6 +119,7 @@ bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
 int conv_first_kwp(int C, int KH, int KW, int DW);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
+const char* dwconv3x3_kernel_name(const DwArgs& a);   // variant <stride, fragments per row> the launcher will pick
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);

@@ -78,3 +78,42 @@ def test_gloo_world2_broadcast_shard_gather(total):
         assert p.exitcode == 0
     ok, nbytes = q.get(timeout=10)
     assert ok and nbytes > 1000
+
+
+# ---- bench.py's own N-rank entry: `python bench.py --gpus N` must start N ranks or fail ------------
+import json  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                          env=e, timeout=300)
+
+
+def test_bench_gpus2_dry_run_spawns_two_ranks_and_gathers_every_output():
+    """plain `python bench.py --gpus 2 ...`: re-exec under torch.distributed.run, gloo plumbing on CPU -- tmfile
+    broadcast, ragged shards of --global-batch 5, ONE gather of both YOLOv3-tiny heads, global image order"""
+    r = _bench("--gpus", "2", "--dry-run", "--model", "yolov3_tiny", "--dtype", "uint8", "--global-batch", "5", "--steps", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["shards"] == [3, 2] and line["config"]["outputs"] == 2
+    assert line["config"]["gather_bytes_per_image"] == 255 * 13 * 13 + 255 * 26 * 26      # SURVEY §8e: 215 475 B / image
+
+
+def test_bench_gpus2_without_two_devices_fails_loudly():
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no JSON line may be printed for the wrong GPU count"
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _bench("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
