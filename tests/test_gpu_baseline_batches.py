@@ -72,9 +72,9 @@ def test_mssd_uint8_300_batch16():
 WIDE_DW = [
     # n, c, hw, stride, expected kernel
     (16, 64, 112, 1, "dwconv3x3_i8<1,2>"),
-    (16, 64, 112, 2, "dwconv3x3_i8<2,2>"),
+    (32, 64, 112, 2, "dwconv3x3_i8<2,2>"),       # 32 x 56^2 outputs x 16 quads: past the wide-kernel threshold
     (24, 128, 57, 1, "dwconv3x3_i8<1,2>"),      # odd width: strip tail of the 6-output strips, ragged rows
-    (40, 128, 57, 2, "dwconv3x3_i8<2,2>"),      # stride 2 on an odd map: last window touches the right border
+    (64, 128, 57, 2, "dwconv3x3_i8<2,2>"),      # stride 2 on an odd map: last window touches the right border
     (1, 64, 112, 1, "dwconv3x3_i8<1,1>"),       # the batch-1 variants, by name
     (1, 64, 112, 2, "dwconv3x3_i8<2,1>"),
 ]
