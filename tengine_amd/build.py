@@ -21,7 +21,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "gemm_direct.hip", "pw_stream.hip", "conv_first.hip", "dwconv.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "conv_f32_mfma.hip", "f32_kernels.hip", "graph.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc"]
+SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "gemm_direct.hip", "pw_stream.hip", "conv_first.hip", "dwconv.hip", "pwdw.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "conv_f32_mfma.hip", "f32_kernels.hip", "graph.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 

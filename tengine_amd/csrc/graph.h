@@ -86,6 +86,7 @@ struct tamd_graph {
     std::vector<tamd::Step> out_steps;  // output layout launches (before D2H)
     std::vector<void*> dev_allocs;
     std::map<int, float*> f32_copy;     // uint8 tensor -> its dequantised fp32 copy (input of the fp32 MFMA conv kernel)
+    std::vector<char> fused_away;       // tensors that only exist inside a fused launch (read_tensor refuses them)
     void* zero_page = nullptr;          // 256 zero bytes (out-of-image taps of the LDS-DMA conv kernel)
     hipStream_t stream = nullptr;
     hipGraph_t hgraph = nullptr;

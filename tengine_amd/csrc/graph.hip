@@ -217,6 +217,65 @@ static int conv_mode(const tamd_conv_param& p, int batch, int cin, int cout)
     return RQ_CONV_REF;
 }
 
+
+// the reference's three requantisation formulas folded into (m1, m2[c], lo, hi, out_scale) -- epilogue.h.
+// Host float arithmetic here is binary32, unfused (-ffp-contract=off), exactly the reference's expressions.
+struct RqFold { float m1, lo, hi, out_scale; std::vector<float> m2; };
+static RqFold fold_requant(int mode, int act, float in_s, float out_s, const HTensor& w, int cout)
+{
+    RqFold r;
+    r.m2.resize(cout);
+    for (int i = 0; i < cout; i++) r.m2[i] = w.scales.size() == (size_t)cout ? w.scales[i] : w.scales[0];
+    r.m1 = in_s; r.out_scale = out_s; r.lo = -FLT_MAX; r.hi = FLT_MAX;
+    if (mode == RQ_CONV_HCL) {
+        if (act == 0) r.lo = 0.f;
+        if (act > 0) { r.lo = 0.f; r.hi = 6.f; }
+    } else if (mode == RQ_CONV_REF) {
+        r.m1 = 1.0f;
+        for (int i = 0; i < cout; i++) { volatile float d = in_s * r.m2[i]; r.m2[i] = d; }
+        if (act == 1) { r.lo = -1.f; r.hi = 1.f; }
+        else if (act >= 0) { r.lo = 0.f; if (act == 6) r.hi = 6.f; }
+    } else {   // RQ_FC
+        r.m1 = 1.0f;
+        for (int i = 0; i < cout; i++) { volatile float d = in_s * r.m2[i]; volatile float q = d / out_s; r.m2[i] = q; }
+        r.out_scale = 1.0f;
+    }
+    return r;
+}
+
+// average duration of one launch of `fn` on the graph's stream, back to back (plan-time autotune)
+static int time_fn(tamd_graph* g, const std::function<hipError_t(hipStream_t)>& fn, float* ms_out)
+{
+    hipEvent_t e0, e1;
+    *ms_out = 1e30f;
+    hipError_t err = fn(g->stream);
+    if (err == hipSuccess) err = fn(g->stream);
+    if (err != hipSuccess) { (void)hipGetLastError(); return 0; }
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float ms = 0;
+    int reps = 5;
+    // short kernels (batch-1 layers are a few microseconds) get more repetitions so that the ranking is stable
+    for (int round = 0; round < 2; round++) {
+        HIPCHK(hipEventRecord(e0, g->stream));
+        for (int it = 0; it < reps; it++) (void)fn(g->stream);
+        HIPCHK(hipEventRecord(e1, g->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        if (ms > 0.02f) break;
+        reps = 40;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = ms;
+    return 0;
+}
+
+static bool autotune_enabled()
+{
+    static const char* at_env = getenv("TAMD_AUTOTUNE");
+    return !(at_env && atoi(at_env) == 0);
+}
+
 struct FusedElt {            // an eltwise (+ReLU) node folded into the epilogue of the conv that produces its later operand
     int res_tensor;          // the other eltwise operand
     int elt_tensor;          // the eltwise node's own output (its scale)
@@ -252,26 +311,9 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
     }
     const int cout = y.c, cin = x.c, group = p.group;
     const int cin_g = cin / group;
-    // fold the reference's three requantisation formulas into (m1, m2[c], lo, hi, out_scale) -- epilogue.h.
-    // Host float arithmetic here is binary32, unfused (-ffp-contract=off), exactly the reference's expressions.
-    const float in_s = x.scales[0], out_s = y.scales[0];
-    std::vector<float> ws(cout);     // becomes m2[c]
-    for (int i = 0; i < cout; i++) ws[i] = w.scales.size() == (size_t)cout ? w.scales[i] : w.scales[0];
-    float in_scale = in_s, out_scale = out_s, rq_lo = -FLT_MAX, rq_hi = FLT_MAX;   // in_scale plays m1
-    const int act = p.activation;
-    if (mode == RQ_CONV_HCL) {
-        if (act == 0) rq_lo = 0.f;
-        if (act > 0) { rq_lo = 0.f; rq_hi = 6.f; }
-    } else if (mode == RQ_CONV_REF) {
-        in_scale = 1.0f;
-        for (int i = 0; i < cout; i++) { volatile float d = in_s * ws[i]; ws[i] = d; }
-        if (act == 1) { rq_lo = -1.f; rq_hi = 1.f; }
-        else if (act >= 0) { rq_lo = 0.f; if (act == 6) rq_hi = 6.f; }
-    } else {   // RQ_FC
-        in_scale = 1.0f;
-        for (int i = 0; i < cout; i++) { volatile float d = in_s * ws[i]; volatile float r = d / out_s; ws[i] = r; }
-        out_scale = 1.0f;
-    }
+    const RqFold rqf = fold_requant(mode, p.activation, x.scales[0], y.scales[0], w, cout);
+    const std::vector<float>& ws = rqf.m2;     // m2[c]
+    const float in_scale = rqf.m1, out_scale = rqf.out_scale, rq_lo = rqf.lo, rq_hi = rqf.hi;
     const int8_t* wd = (const int8_t*)w.data.data();
     const int32_t* bd = b ? (const int32_t*)b->data.data() : nullptr;
     const int KH = p.kernel_h, KW = p.kernel_w;
@@ -397,8 +439,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
         if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
         const bool heuristic_done = !cands.empty();
-        static const char* at_env = getenv("TAMD_AUTOTUNE");
-        const bool autotune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6;
+        const bool autotune = autotune_enabled() && st.macs >= 4e6;
         if (!heuristic_done || autotune) {
             if (autotune) {
                 for (int c = 0; c < conv_igemm_num_cfgs(); c++) {
@@ -425,35 +466,221 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if (autotune && cands.size() > 1) {
             // plan-time autotune: a few timed launches of each candidate on the real buffers (outputs are overwritten
             // again by the first real run); the heuristics above remain the fallback (TAMD_AUTOTUNE=0)
-            hipEvent_t e0, e1;
-            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             float best_ms = 1e30f;
             for (size_t c = 0; c < cands.size(); c++) {
-                hipError_t err = cands[c].fn(g->stream);
-                if (err == hipSuccess) err = cands[c].fn(g->stream);
-                if (err != hipSuccess) { (void)hipGetLastError(); continue; }
-                // short kernels (batch-1 layers are a few microseconds) get more repetitions so that the ranking is stable
-                float ms = 0;
-                int reps = 5;
-                for (int round = 0; round < 2; round++) {
-                    HIPCHK(hipEventRecord(e0, g->stream));
-                    for (int it = 0; it < reps; it++) (void)cands[c].fn(g->stream);
-                    HIPCHK(hipEventRecord(e1, g->stream));
-                    HIPCHK(hipEventSynchronize(e1));
-                    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-                    ms /= reps;
-                    if (ms > 0.02f) break;
-                    reps = 40;
-                }
+                float ms;
+                if (time_fn(g, cands[c].fn, &ms)) return -1;
+                if (ms > 1e29f) continue;
                 // the heuristic candidates come first: a later one has to win by more than the timing noise
                 if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best = c; }
             }
-            hipEventDestroy(e0); hipEventDestroy(e1);
         }
         st.kernel = cands[best].name + (fz ? (fz->relu ? "+eltwise+relu" : "+eltwise") : "");
         st.fn = cands[best].fn;
     }
     g->steps.push_back(st);
+    return 0;
+}
+
+
+static int plan_pool(tamd_graph* g, HNode& n)
+{
+    HTensor& x = g->tensors[n.in[0]];
+    HTensor& y = g->tensors[n.out[0]];
+    PoolGeom pg = pool_geom(n.p.pool, x.h, x.w);
+    PoolArgs a{};
+    a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr;
+    a.N = x.n; a.H = x.h; a.W = x.w; a.C = x.c; a.cs_in = x.cs; a.OH = y.h; a.OW = y.w; a.ldc = y.cs; a.c_off = y.c_off;
+    a.KH = pg.kh; a.KW = pg.kw; a.SH = pg.sh; a.SW = pg.sw; a.PH = pg.ph0; a.PW = pg.pw0;
+    a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
+    a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
+    const PoolArgs av = a;
+    Step st; st.node = n.name; st.kernel = "pool_i8";
+    st.bytes = (double)x.n * x.h * x.w * x.c + (double)y.n * y.h * y.w * y.c;
+    st.fn = [av](hipStream_t s) { return launch_pool(av, s); };
+    g->steps.push_back(st);
+    return 0;
+}
+
+// ---- pointwise conv + its single consumer (depthwise 3x3 | global pooling) in one launch: pwdw.hip ---------------------
+// Which node, if any, can ride in pointwise conv `ni`'s launch.  *tmode: 1 depthwise 3x3, 0 global pooling.
+static int find_pwdw_tail(tamd_graph* g, size_t ni, int* tmode)
+{
+    const HNode& n = g->nodes[ni];
+    if (n.op != TAMD_OP_CONV || n.in.size() < 2) return -1;
+    const tamd_conv_param& p = n.p.conv;
+    const HTensor& x = g->tensors[n.in[0]];
+    const HTensor& y = g->tensors[n.out[0]];
+    if (p.group != 1 || p.kernel_h != 1 || p.kernel_w != 1 || p.stride_h != 1 || p.stride_w != 1 || p.pad_h0 || p.pad_h1 || p.pad_w0
+        || p.pad_w1 || x.nchw_raw || y.is_view || x.dtype != TAMD_DT_INT8 || count_consumers(g, n.out[0]) != 1)
+        return -1;
+    for (auto& o : g->outputs) if (o.tensor == n.out[0]) return -1;
+    for (size_t nj = ni + 1; nj < g->nodes.size(); nj++) {
+        const HNode& c = g->nodes[nj];
+        if (c.in.empty() || c.in[0] != n.out[0]) continue;
+        const HTensor& o = g->tensors[c.out[0]];
+        if (c.op == TAMD_OP_CONV && c.in.size() >= 2) {
+            const tamd_conv_param& q = c.p.conv;
+            const bool dw3 = q.group > 1 && q.group == y.c && o.c == y.c && q.kernel_h == 3 && q.kernel_w == 3 && q.dilation_h == 1
+                             && q.dilation_w == 1 && q.stride_h == q.stride_w && (q.stride_h == 1 || q.stride_h == 2) && q.pad_h0 >= 0
+                             && q.pad_w0 >= 0 && q.pad_h0 <= 2 && q.pad_w0 <= 2;
+            if (!dw3 || o.scales.empty() || g->tensors[c.in[1]].scales.empty()) return -1;
+            *tmode = 1;
+            return (int)nj;
+        }
+        if (c.op == TAMD_OP_POOL) {
+            const PoolGeom pg = pool_geom(c.p.pool, y.h, y.w);
+            const int m = c.p.pool.pool_method;
+            if (pg.oh != 1 || pg.ow != 1 || pg.kh != y.h || pg.kw != y.w || pg.ph0 || pg.pw0 || (m != 0 && m != 1) || y.h * y.w > 1024 || o.scales.empty())
+                return -1;
+            *tmode = 0;
+            return (int)nj;
+        }
+        return -1;
+    }
+    return -1;
+}
+
+// The two nodes were just planned as steps [s0, s0 + 2); build the fused launch, and keep whichever is faster
+// (plan-time measurement; without autotune: fuse the small-map cases where launches, not bytes, are the cost).
+// TAMD_FUSE_PWDW=0 never fuses, =2 always fuses; TAMD_PWDW_CFG="TH,TW,threads" pins the tile configuration (tests).
+static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
+{
+    const char* fenv = getenv("TAMD_FUSE_PWDW");                 // read at every prerun
+    const int fmode = fenv ? atoi(fenv) : 1;
+    if (fmode == 0) return 0;
+    HTensor& x = g->tensors[pw.in[0]];
+    HTensor& w = g->tensors[pw.in[1]];
+    HTensor* b = pw.in.size() > 2 ? &g->tensors[pw.in[2]] : nullptr;
+    HTensor& mid = g->tensors[pw.out[0]];
+    HTensor& y = g->tensors[tl.out[0]];
+    const int cin = x.c, C = mid.c, slices = (C + 15) / 16, cw = slices * 16;
+    const int ktot = rup(cin, 16), nsteps = (ktot + 63) / 64;
+    if (w.elems() != (size_t)C * cin || (b && b->elems() < (size_t)C)) return 0;
+    PwDwArgs a{};
+    // pointwise operands: weights in MFMA fragment order [slice][step][lane][16 B], lane = (k block of 16) * 16 + channel
+    {
+        const RqFold rq = fold_requant(RQ_CONV_HCL, pw.p.conv.activation, x.scales[0], mid.scales[0], w, C);
+        const int8_t* wd = (const int8_t*)w.data.data();
+        std::vector<int8_t> wf((size_t)slices * nsteps * 1024, 0);
+        for (int c = 0; c < C; c++)
+            for (int k = 0; k < cin; k++)
+                wf[((size_t)((c >> 4) * nsteps + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (c & 15)) * 16 + (k & 15)] = wd[(size_t)c * cin + k];
+        std::vector<int32_t> bp(cw, 0);
+        std::vector<float> sp(cw, 1.f);
+        for (int c = 0; c < C; c++) { bp[c] = b ? ((const int32_t*)b->data.data())[c] : 0; sp[c] = rq.m2[c]; }
+        int8_t* d0; int32_t* d1; float* d2;
+        if (upload(g, wf, &d0) || upload(g, bp, &d1) || upload(g, sp, &d2)) return -1;
+        a.wf = d0; a.bias = d1; a.wscale = d2;
+        a.m1 = rq.m1; a.lo = rq.lo; a.hi = rq.hi; a.out_scale = rq.out_scale;
+    }
+    a.x = (const int8_t*)x.dptr + x.c_off;
+    a.N = x.n; a.H = x.h; a.W = x.w; a.cs_in = x.cs; a.ktot = ktot; a.nsteps = nsteps;
+    a.mode = tmode; a.cw = cw; a.slices = slices;
+    a.y = (int8_t*)y.dptr; a.ldc = y.cs; a.c_off = y.c_off;
+    a.c_limit = y.is_view ? C : std::min(rup(C, 16), y.cs - y.c_off);
+    a.S = 1; a.OH = a.OW = 1; a.TH = a.TW = 1; a.tiles_x = a.tiles_y = 1; a.RH = x.h; a.RW = x.w;
+    if (tmode == 1) {
+        const tamd_conv_param& q = tl.p.conv;
+        HTensor& dwt = g->tensors[tl.in[1]];
+        HTensor* db = tl.in.size() > 2 ? &g->tensors[tl.in[2]] : nullptr;
+        if (dwt.elems() != (size_t)C * 9 || (db && db->elems() < (size_t)C)) return 0;
+        const RqFold rq = fold_requant(conv_mode(q, mid.n, C, C), q.activation, mid.scales[0], y.scales[0], dwt, C);
+        const int8_t* wd = (const int8_t*)dwt.data.data();
+        std::vector<int8_t> wp((size_t)3 * cw * 4, 0);
+        for (int c = 0; c < C; c++)
+            for (int r = 0; r < 3; r++)
+                for (int kx = 0; kx < 3; kx++) wp[((size_t)r * cw + c) * 4 + kx] = wd[(size_t)c * 9 + r * 3 + kx];
+        std::vector<int32_t> bp(cw, 0);
+        std::vector<float> sp(cw, 1.f);
+        for (int c = 0; c < C; c++) { bp[c] = db ? ((const int32_t*)db->data.data())[c] : 0; sp[c] = rq.m2[c]; }
+        int8_t* d0; int32_t* d1; float* d2;
+        if (upload(g, wp, &d0) || upload(g, bp, &d1) || upload(g, sp, &d2)) return -1;
+        a.dw_w = d0; a.dw_bias = d1; a.dw_wscale = d2;
+        a.d_m1 = rq.m1; a.d_lo = rq.lo; a.d_hi = rq.hi; a.d_out_scale = rq.out_scale;
+        a.S = q.stride_h; a.PH = q.pad_h0; a.PW = q.pad_w0; a.OH = y.h; a.OW = y.w;
+    } else {
+        a.pool_method = tl.p.pool.pool_method; a.p_in_scale = mid.scales[0]; a.p_out_scale = y.scales[0];
+    }
+
+    // ---- tile configurations: (TH, TW, threads) ranked by a small cost model, the best few timed on the device ---------
+    struct Cfg { int th, tw, threads; double cost; };
+    std::vector<Cfg> cfgs;
+    auto with_tiles = [&](PwDwArgs v, int th, int tw) {
+        v.TH = th; v.TW = tw; v.tiles_y = (v.OH + th - 1) / th; v.tiles_x = (v.OW + tw - 1) / tw;
+        v.RH = (th - 1) * v.S + 3; v.RW = (tw - 1) * v.S + 3;
+        return v;
+    };
+    if (tmode == 0) {
+        cfgs.push_back({1, 1, 256, 0.0});
+        cfgs.push_back({1, 1, 512, 1.0});
+    } else {
+        std::vector<int> ths, tws;
+        for (int v : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 28, a.OH}) if (v <= a.OH && std::find(ths.begin(), ths.end(), v) == ths.end()) ths.push_back(v);
+        for (int v : {4, 6, 7, 8, 14, 16, 28, 56, a.OW}) if (v <= a.OW && std::find(tws.begin(), tws.end(), v) == tws.end()) tws.push_back(v);
+        for (int th : ths)
+            for (int tw : tws)
+                for (int threads : {256, 512}) {
+                    const PwDwArgs v = with_tiles(a, th, tw);
+                    if (!pwdw_config_ok(v, threads)) continue;
+                    // instruction slots of the busiest wave (a lone wave issues one instruction per 4 cycles): pointwise tiles
+                    // (address + K steps + requantisation) and depthwise tasks, on top of a fixed prologue
+                    const int nw = threads / 64;
+                    const double vp = (double)std::min(v.RH, a.H) * std::min(v.RW, a.W);
+                    const double tiles_w = std::ceil(std::ceil(vp / 16.0) / nw);
+                    const int twl = a.S == 1 ? 2 : 1;
+                    const double tasks_t = std::ceil((double)th * ((tw + twl - 1) / twl) * 4.0 / threads);
+                    const double block = 250.0 + tiles_w * (70.0 + 3.0 * nsteps) + tasks_t * (a.S == 1 ? 150.0 : 100.0) + vp * ktot / 400.0;
+                    const double blocks = (double)a.N * v.tiles_y * v.tiles_x * slices;
+                    const double rounds = std::ceil(blocks / (256.0 * (threads == 256 ? 2 : 1)));
+                    cfgs.push_back({th, tw, threads, rounds * block * (threads == 256 && blocks > 256 ? 1.3 : 1.0)});
+                }
+        std::sort(cfgs.begin(), cfgs.end(), [](const Cfg& l, const Cfg& r) { return l.cost < r.cost; });
+        if (cfgs.size() > 8) cfgs.resize(8);
+    }
+    if (const char* pin = getenv("TAMD_PWDW_CFG")) {
+        int th = 0, tw = 0, threads = 0;
+        if (sscanf(pin, "%d,%d,%d", &th, &tw, &threads) == 3 && tmode == 1) {
+            th = std::min(th, a.OH); tw = std::min(tw, a.OW);
+            if (th >= 1 && tw >= 1 && pwdw_config_ok(with_tiles(a, th, tw), threads)) { cfgs.clear(); cfgs.push_back({th, tw, threads, 0.0}); }
+        }
+    }
+    if (cfgs.empty()) return 0;
+    Step& sa = g->steps[s0];
+    Step& sb = g->steps[s0 + 1];
+    const bool autotune = autotune_enabled() && sa.macs >= 4e6;
+    size_t best = 0;
+    bool fuse = fmode == 2 || (double)a.N * a.H * a.W <= 32768.0;
+    if (autotune) {
+        float best_ms = 1e30f;
+        for (size_t c = 0; c < cfgs.size(); c++) {
+            const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[c].th, cfgs[c].tw) : a;
+            const int threads = cfgs[c].threads;
+            float ms;
+            if (time_fn(g, [v, threads](hipStream_t s) { return launch_pwdw(v, threads, s); }, &ms)) return -1;
+            if (ms < best_ms) { best_ms = ms; best = c; }
+        }
+        if (fmode != 2) {
+            float ta, tb;
+            if (time_fn(g, sa.fn, &ta) || time_fn(g, sb.fn, &tb)) return -1;
+            fuse = best_ms < 0.97f * (ta + tb);
+        }
+    }
+    if (!fuse) return 0;
+    const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[best].th, cfgs[best].tw) : a;
+    const int threads = cfgs[best].threads;
+    Step st;
+    st.node = sa.node + "+" + sb.node;
+    char nm[48];
+    if (tmode == 1) snprintf(nm, sizeof(nm), "pwdw_i8<s%d,%dx%d,%d>", a.S, v.TH, v.TW, threads);
+    else snprintf(nm, sizeof(nm), "pwpool_i8<%d>", threads);
+    st.kernel = nm;
+    st.macs = sa.macs + sb.macs;
+    st.bytes = sa.bytes + sb.bytes;      // SURVEY 8(d) accounting, per layer: the intermediate tensor still counts as algorithmic bytes
+    st.fn = [v, threads](hipStream_t s) { return launch_pwdw(v, threads, s); };
+    g->steps.resize(s0);
+    g->steps.push_back(st);
+    g->fused_away[pw.out[0]] = 1;
     return 0;
 }
 
@@ -542,6 +769,7 @@ static int plan(tamd_graph* g)
         g->in_steps.push_back(st);
     }
     // ---- 2. compile nodes ---------------------------------------------------------------------
+    g->fused_away.assign(g->tensors.size(), 0);
     std::vector<char> fused(g->nodes.size(), 0);
     // conv -> eltwise (-> relu) fusion (ResNet: branch2c / branch1 + residual add + relu): the eltwise is
     // folded into the LATER of its two producers when that one is a group-1 GEMM conv whose output feeds nothing else
@@ -577,7 +805,8 @@ static int plan(tamd_graph* g)
                 }
             }
         fuse_at[later] = fz; has_fuse[later] = 1; fused[ei] = 1;
-        if (fz.relu) fused[relu_node] = 1;
+        g->fused_away[e.in[conv_in]] = 1;        // the conv's own int8 result only exists in registers
+        if (fz.relu) { fused[relu_node] = 1; g->fused_away[e.out[0]] = 1; }
     }
     for (size_t ni = 0; ni < g->nodes.size(); ni++) {
         HNode& n = g->nodes[ni];
@@ -585,29 +814,28 @@ static int plan(tamd_graph* g)
         switch (n.op) {
         case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_CONCAT:
             break;
-        case TAMD_OP_CONV:
+        case TAMD_OP_CONV: {
+            int tmode = -1;
+            const int tail = has_fuse[ni] ? -1 : find_pwdw_tail(g, ni, &tmode);
+            if (tail >= 0 && !fused[tail]) {
+                // the pair is planned here, the tail ahead of its node order (its only input is this conv's output), then
+                // possibly replaced by ONE fused launch
+                const size_t s0 = g->steps.size();
+                if (plan_conv(g, n, false)) return -1;
+                if (tmode == 0 ? plan_pool(g, g->nodes[tail]) : plan_conv(g, g->nodes[tail], false)) return -1;
+                fused[tail] = 1;
+                if (g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, s0)) return -1;
+                break;
+            }
             if (plan_conv(g, n, false, has_fuse[ni] ? &fuse_at[ni] : nullptr)) return -1;
             break;
+        }
         case TAMD_OP_FC:
             if (plan_conv(g, n, true)) return -1;
             break;
-        case TAMD_OP_POOL: {
-            HTensor& x = g->tensors[n.in[0]];
-            HTensor& y = g->tensors[n.out[0]];
-            PoolGeom pg = pool_geom(n.p.pool, x.h, x.w);
-            PoolArgs a{};
-            a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr;
-            a.N = x.n; a.H = x.h; a.W = x.w; a.C = x.c; a.cs_in = x.cs; a.OH = y.h; a.OW = y.w; a.ldc = y.cs; a.c_off = y.c_off;
-            a.KH = pg.kh; a.KW = pg.kw; a.SH = pg.sh; a.SW = pg.sw; a.PH = pg.ph0; a.PW = pg.pw0;
-            a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
-            a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
-            const PoolArgs av = a;
-            Step st; st.node = n.name; st.kernel = "pool_i8";
-            st.bytes = (double)x.n * x.h * x.w * x.c + (double)y.n * y.h * y.w * y.c;
-            st.fn = [av](hipStream_t s) { return launch_pool(av, s); };
-            g->steps.push_back(st);
+        case TAMD_OP_POOL:
+            if (plan_pool(g, n)) return -1;
             break;
-        }
         case TAMD_OP_RELU: {
             HTensor& x = g->tensors[n.in[0]];
             HTensor& y = g->tensors[n.out[0]];
@@ -638,6 +866,7 @@ static int plan(tamd_graph* g)
                         if (ry.is_view) break;
                         a.fuse_relu = ry.scales[0] == a.out_scale ? 2 : 1; a.relu_out_scale = ry.scales[0];
                         y = &ry; fused[nj] = 1; kname = "eltwise_relu_i8";
+                        g->fused_away[n.out[0]] = 1;
                         break;
                     }
                 }
@@ -989,6 +1218,11 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
     if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
     HTensor& t = g->tensors[idx];
     if (t.ttype == TAMD_TT_CONST) { memcpy(host, t.data.data(), std::min(bytes, t.data.size())); return 0; }
+    if ((size_t)idx < g->fused_away.size() && g->fused_away[idx]) {
+        set_error("read_tensor: %s was fused into its consumer's launch and never reaches memory (TAMD_FUSE_PWDW=0 / "
+                  "TAMD_FUSE_ELTWISE=0 / TAMD_FUSE_RELU=0 at prerun materialise it)", t.name.c_str());
+        return -1;
+    }
     size_t need = t.elems() * esize(t.dtype);
     if (bytes != need) { set_error("read_tensor: %zu bytes given, %zu needed", bytes, need); return -1; }
     HIPCHK(hipStreamSynchronize(g->stream));

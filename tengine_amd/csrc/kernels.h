@@ -54,6 +54,28 @@ struct DwArgs {
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
 };
 
+struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.hip)
+    const int8_t* x;       // NHWC input of the pointwise conv (channel offset applied)
+    const int8_t* wf;      // pointwise weights in MFMA fragment order: [16-channel slice][64-deep K step][64 lanes][16 B]
+    const int32_t* bias;   // [slices * 16]
+    const float* wscale;   // [slices * 16] (m2[c] of epilogue.h)
+    float m1, lo, hi, out_scale;       // pointwise requantisation constants
+    int N, H, W, cs_in, ktot, nsteps;  // H x W: the pointwise map == the tail's input map; nsteps = ceil(ktot / 64)
+    int mode;              // 0: global pooling tail, 1: depthwise 3x3 tail
+    const int8_t* dw_w;    // as DwArgs::w
+    const int32_t* dw_bias;
+    const float* dw_wscale;
+    float d_m1, d_lo, d_hi, d_out_scale;
+    int cw;                // depthwise weight row length (channels rounded up to 16)
+    int S, PH, PW, OH, OW; // depthwise stride / leading pads / output map
+    int8_t* y;             // NHWC output of the tail
+    int ldc, c_off, c_limit;
+    int TH, TW, tiles_y, tiles_x, slices;      // depthwise output tile per block, grid
+    int RH, RW;            // input region of a tile: (TH-1)*S+3, (TW-1)*S+3
+    int pool_method;       // mode 0: 0 max, 1 avg
+    float p_in_scale, p_out_scale;
+};
+
 struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-input first layers
     const int8_t* x;
     const int8_t* w;       // OIHW as in the model
@@ -121,6 +143,8 @@ int conv_first_kwp(int C, int KH, int KW, int DW);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 const char* dwconv3x3_kernel_name(const DwArgs& a);   // variant <stride, fragments per row> the launcher will pick
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
+hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s);
+bool pwdw_config_ok(const PwDwArgs& a, int threads);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);
 hipError_t launch_relu(const ReluArgs& a, hipStream_t s);

@@ -276,3 +276,40 @@ def i8_concat_graph(seed, n, c, h, w, axis=1, shrink=False):
     ni = g.add_node("cat", "Concat", [a, b], [y], axis=axis)
     g.output_nodes = [ni]
     return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)
+
+
+def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", pool_alg=1, bias=True):
+    """int8: pointwise 1x1 conv (cin -> c) -> depthwise 3x3 (stride s, pad p) | global pooling: the pair pwdw.hip fuses"""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="pwdw_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, cin, h, w], DT_INT8, [xs], [0])
+    wq = rng.integers(-127, 128, size=(c, cin, 1, 1)).astype(np.int8)
+    ws = _scales(rng, c)
+    ins = [x, g.add_const("w_pw", wq, DT_INT8, ws, [0] * c)]
+    if bias:
+        ins.append(g.add_const("b_pw", rng.integers(-2000, 2000, size=(c,)).astype(np.int32), DT_INT32, [1.0], [0]))
+    ms = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(cin) * 73.0 / 60.0))
+    mid = g.add_tensor("mid", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [ms], [0])
+    g.add_node("pw", "Convolution", ins, [mid], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1, dilation_w=1,
+               input_channel=cin, output_channel=c, group=1, activation=act_pw, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    if tail == "pool":
+        os_ = float(np.float32(ms * rng.uniform(0.3, 0.9)))
+        y = g.add_tensor("out", [n, c, 1, 1], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        ni = g.add_node("pool", "Pooling", [mid], [y], alg=pool_alg, kernel_h=h, kernel_w=w, stride_h=1, stride_w=1,
+                        **{"global": 1}, caffe_flavor=0, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    else:
+        dq = rng.integers(-127, 128, size=(c, 1, 3, 3)).astype(np.int8)
+        dsc = _scales(rng, c)
+        dins = [mid, g.add_const("w_dw", dq, DT_INT8, dsc, [0] * c)]
+        if bias:
+            dins.append(g.add_const("b_dw", rng.integers(-2000, 2000, size=(c,)).astype(np.int32), DT_INT32, [1.0], [0]))
+        oh = (h - 3 + 2 * p) // s + 1
+        ow = (w - 3 + 2 * p) // s + 1
+        os_ = float(np.float32(ms * np.mean(dsc) * 73.0 * 3.0 * 73.0 / 60.0))
+        y = g.add_tensor("out", [n, c, oh, ow], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        ni = g.add_node("dw", "Convolution", dins, [y], kernel_h=3, kernel_w=3, stride_h=s, stride_w=s, dilation_h=1,
+                        dilation_w=1, input_channel=c, output_channel=c, group=c, activation=act_dw, pad_h0=p, pad_w0=p,
+                        pad_h1=p, pad_w1=p)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)

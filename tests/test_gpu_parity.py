@@ -143,25 +143,33 @@ def test_mobilenet_v1_int8_batch1_bit_exact():
     g = models.build("mobilenet_v1", "int8", 1)
     x = models.synth_input(g, 7)
     want = oracle.run_graph(g, x, keep_all=True)
-    gr = capi.Graph(tm2.write_tm2(g))
-    gr.set_input(x)
-    got = gr.run()[0]
-    # layer-by-layer first (pinpoints a regression), then the graph output
-    for n in g.nodes:
-        if n.op in ("Const", "InputOp"):
-            continue
-        t = n.outputs[0]
-        dev = gr.read_tensor(t)
-        assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
     out_t = g.nodes[g.output_nodes[0]].outputs[0]
-    assert np.array_equal(got.reshape(want[out_t].shape), want[out_t])
     golden = os.path.join(os.path.dirname(__file__), "golden", "mobilenet_v1_int8_seed7.npy")
-    if os.path.exists(golden):     # produced by the REAL reference (tests/golden/make_golden.py)
-        assert np.array_equal(got.ravel(), np.load(golden).ravel())
-    # replaying the captured hipGraph is idempotent
-    again = gr.run()[0]
-    assert np.array_equal(again, got)
-    gr.close()
+    # layer by layer with every node in its own launch (pinpoints a regression), then the default plan
+    # (pointwise + depthwise pairs fused, pwdw.hip): same bytes
+    for fuse in ("0", None):
+        if fuse is not None:
+            os.environ["TAMD_FUSE_PWDW"] = fuse
+        try:
+            gr = capi.Graph(tm2.write_tm2(g))
+        finally:
+            os.environ.pop("TAMD_FUSE_PWDW", None)
+        gr.set_input(x)
+        got = gr.run()[0]
+        if fuse == "0":
+            for n in g.nodes:
+                if n.op in ("Const", "InputOp"):
+                    continue
+                t = n.outputs[0]
+                dev = gr.read_tensor(t)
+                assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
+        assert np.array_equal(got.reshape(want[out_t].shape), want[out_t])
+        if os.path.exists(golden):     # produced by the REAL reference (tests/golden/make_golden.py)
+            assert np.array_equal(got.ravel(), np.load(golden).ravel())
+        # replaying the captured hipGraph is idempotent
+        again = gr.run()[0]
+        assert np.array_equal(again, got)
+        gr.close()
 
 
 def test_mobilenet_v1_int8_batch4_matches_per_image_oracle():
@@ -202,7 +210,10 @@ def test_resnet50_int8_batch2_bit_exact():
                 continue
             t = n.outputs[0]
             if t in want and not (n.op == "Eltwise"):      # eltwise outputs are fused into the following relu
-                dev = gr.read_tensor(t)
+                try:
+                    dev = gr.read_tensor(t)
+                except capi.TamdError:                     # conv results folded into an eltwise epilogue never reach memory
+                    continue
                 assert np.array_equal(dev.reshape(want[t].shape), want[t]), "layer %s differs" % n.name
         raise AssertionError("output differs")
     gr.close()
