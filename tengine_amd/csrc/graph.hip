@@ -179,10 +179,12 @@ static int infer_shapes(tamd_graph* g)
 // ---------------------------------------------------------------------------------------------
 int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
 {
-    if (bytes == 0) bytes = 16;
-    HIPCHK(hipMalloc(p, bytes));
+    // slack: the pointwise kernels read whole 64-byte K steps, up to 8 of them past a pixel row's last channel (those
+    // bytes meet zero weights, but must be readable behind the last pixel of a buffer too)
+    const size_t slack = 1024;
+    HIPCHK(hipMalloc(p, bytes + slack));
     g->dev_allocs.push_back(*p);
-    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, g->stream));    // never the legacy stream: it would collide with another thread's capture
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes + slack, g->stream));    // never the legacy stream: it would collide with another thread's capture
     return 0;
 }
 
@@ -241,6 +243,18 @@ static RqFold fold_requant(int mode, int act, float in_s, float out_s, const HTe
         r.out_scale = 1.0f;
     }
     return r;
+}
+
+// make_rq() of epilogue.h on the host: the same binary32 operations (this file is compiled without contraction / fast-math),
+// so kernels that take the folded constants as arguments round exactly like those that fold them on the device
+static void host_rq(const RqFold& r, float* m1, float* lo, float* hi, float* out_scale, float* inv_out)
+{
+    volatile float lim = 127.49f * r.out_scale;
+    *m1 = r.m1; *out_scale = r.out_scale;
+    *lo = std::max(r.lo, -(float)lim);
+    *hi = std::min(r.hi, (float)lim);
+    volatile float inv = 1.0f / r.out_scale;
+    *inv_out = inv;
 }
 
 // average duration of one launch of `fn` on the graph's stream, back to back (plan-time autotune)
@@ -555,7 +569,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
     HTensor& mid = g->tensors[pw.out[0]];
     HTensor& y = g->tensors[tl.out[0]];
     const int cin = x.c, C = mid.c, slices = (C + 15) / 16, cw = slices * 16;
-    const int ktot = rup(cin, 16), nsteps = (ktot + 63) / 64;
+    const int ktot = rup(cin, 16), steps = pwdw_steps((ktot + 63) / 64), nsteps = rup((ktot + 63) / 64, steps);
     if (w.elems() != (size_t)C * cin || (b && b->elems() < (size_t)C)) return 0;
     PwDwArgs a{};
     // pointwise operands: weights in MFMA fragment order [slice][step][lane][16 B], lane = (k block of 16) * 16 + channel
@@ -572,10 +586,10 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
         int8_t* d0; int32_t* d1; float* d2;
         if (upload(g, wf, &d0) || upload(g, bp, &d1) || upload(g, sp, &d2)) return -1;
         a.wf = d0; a.bias = d1; a.wscale = d2;
-        a.m1 = rq.m1; a.lo = rq.lo; a.hi = rq.hi; a.out_scale = rq.out_scale;
+        host_rq(rq, &a.m1, &a.lo, &a.hi, &a.out_scale, &a.inv_out);
     }
     a.x = (const int8_t*)x.dptr + x.c_off;
-    a.N = x.n; a.H = x.h; a.W = x.w; a.cs_in = x.cs; a.ktot = ktot; a.nsteps = nsteps;
+    a.N = x.n; a.H = x.h; a.W = x.w; a.cs_in = x.cs; a.ktot = ktot; a.nsteps = nsteps; a.steps = steps;
     a.mode = tmode; a.cw = cw; a.slices = slices;
     a.y = (int8_t*)y.dptr; a.ldc = y.cs; a.c_off = y.c_off;
     a.c_limit = y.is_view ? C : std::min(rup(C, 16), y.cs - y.c_off);
@@ -597,7 +611,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
         int8_t* d0; int32_t* d1; float* d2;
         if (upload(g, wp, &d0) || upload(g, bp, &d1) || upload(g, sp, &d2)) return -1;
         a.dw_w = d0; a.dw_bias = d1; a.dw_wscale = d2;
-        a.d_m1 = rq.m1; a.d_lo = rq.lo; a.d_hi = rq.hi; a.d_out_scale = rq.out_scale;
+        host_rq(rq, &a.d_m1, &a.d_lo, &a.d_hi, &a.d_out_scale, &a.d_inv_out);
         a.S = q.stride_h; a.PH = q.pad_h0; a.PW = q.pad_w0; a.OH = y.h; a.OW = y.w;
     } else {
         a.pool_method = tl.p.pool.pool_method; a.p_in_scale = mid.scales[0]; a.p_out_scale = y.scales[0];

@@ -59,13 +59,17 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     const int8_t* wf;      // pointwise weights in MFMA fragment order: [16-channel slice][64-deep K step][64 lanes][16 B]
     const int32_t* bias;   // [slices * 16]
     const float* wscale;   // [slices * 16] (m2[c] of epilogue.h)
-    float m1, lo, hi, out_scale;       // pointwise requantisation constants
-    int N, H, W, cs_in, ktot, nsteps;  // H x W: the pointwise map == the tail's input map; nsteps = ceil(ktot / 64)
+    float m1, lo, hi, out_scale, inv_out;      // pointwise requantisation constants: struct Rq of epilogue.h, folded on the host
+    int N, H, W, cs_in, ktot;          // H x W: the pointwise map == the tail's input map
+    int nsteps, steps;                 // 64-deep K steps of the (zero padded) weight panel, a multiple of `steps` = pwdw_steps()
+#ifdef TAMD_PWDW_STAMPS
+    unsigned long long* stamps;        // tools/exp/pwdw_anatomy.hip only
+#endif
     int mode;              // 0: global pooling tail, 1: depthwise 3x3 tail
     const int8_t* dw_w;    // as DwArgs::w
     const int32_t* dw_bias;
     const float* dw_wscale;
-    float d_m1, d_lo, d_hi, d_out_scale;
+    float d_m1, d_lo, d_hi, d_out_scale, d_inv_out;
     int cw;                // depthwise weight row length (channels rounded up to 16)
     int S, PH, PW, OH, OW; // depthwise stride / leading pads / output map
     int8_t* y;             // NHWC output of the tail
@@ -145,6 +149,7 @@ const char* dwconv3x3_kernel_name(const DwArgs& a);   // variant <stride, fragme
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
 hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s);
 bool pwdw_config_ok(const PwDwArgs& a, int threads);
+int pwdw_steps(int nsteps);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);
 hipError_t launch_relu(const ReluArgs& a, hipStream_t s);

@@ -32,12 +32,28 @@ namespace tamd {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-// MODE 0: global pooling tail; 1: depthwise stride 1; 2: depthwise stride 2.  STEPS: 64-deep K steps held in registers.
-template <int STEPS, int MODE>
+#ifdef TAMD_PWDW_STAMPS      // tools/exp/pwdw_anatomy.hip: stage time stamps (s_memrealtime) of wave 0 of every block
+#define PWDW_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define PWDW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PWDW_STAMP(i) do { } while (0)
+#define PWDW_DRAIN() do { } while (0)
+#endif
+
+// MODE 0: global pooling tail; 1: depthwise stride 1, two outputs per lane; 2: depthwise stride 2; 3: depthwise stride 1,
+// one output per lane (small tiles: more lanes busy, shorter chains).  STEPS: 64-deep K steps held in registers; the
+// planner pads the weight panel with zero steps to a multiple of STEPS and the activation buffers carry slack behind
+// their last pixel, so the K loop needs no predicates (bytes read past cin meet zero weights).  CHUNKED: the panel is
+// several times STEPS deep (K > 1024), weights are re-read per tile.
+// A lone wave issues one instruction every 4 cycles and these launches are a few hundred instructions long, so the code
+// is written for instruction count: host-folded requantisation constants, no integer divisions, no predicated loads.
+template <int STEPS, int MODE, bool CHUNKED>
 __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
     constexpr int S = MODE == 2 ? 2 : 1;
+    constexpr bool PINGPONG = !CHUNKED && STEPS <= 8;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
+    PWDW_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kb = lane >> 4;
     const int slice = blockIdx.x, tx = blockIdx.y;
@@ -48,17 +64,16 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     // ---- loads that depend on nothing but the block index go out first ----------------------------------------
     const int4 pb = *reinterpret_cast<const int4*>(a.bias + c_base + 4 * kb);
     const float4 ps = *reinterpret_cast<const float4*>(a.wscale + c_base + 4 * kb);
-    const int8_t* wfp = a.wf + ((size_t)slice * a.nsteps * 64 + lane) * 16;
-    const int nchunks = (a.nsteps + STEPS - 1) / STEPS;
+    const int8_t* wfp = a.wf + ((size_t)slice * a.nsteps * 64 + lane) * 16;      // nsteps: padded to a multiple of STEPS
     const v4i zero4 = {0, 0, 0, 0};
     v4i af[STEPS];
-    if (nchunks == 1) {
+    if (!CHUNKED) {
 #pragma unroll
-        for (int u = 0; u < STEPS; u++) af[u] = u < a.nsteps ? *reinterpret_cast<const v4i*>(wfp + u * 1024) : zero4;
+        for (int u = 0; u < STEPS; u++) af[u] = *reinterpret_cast<const v4i*>(wfp + u * 1024);
     }
-    const int cq = t & 3;                                  // tail phase: this thread's channel quad of the slice
+    const int cq = t & 3;                                  // depthwise phase: this thread's channel quad of the slice
     const int c0 = c_base + cq * 4;
-    unsigned wrow[3][4];
+    unsigned wrow[3][4], wsh[3][4];
     int4 db = {0, 0, 0, 0};
     float4 ds = {1.f, 1.f, 1.f, 1.f};
     if (MODE != 0) {
@@ -80,90 +95,110 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
         vy0 = max(iy0, 0); vx0 = max(ix0, 0);
         vy1 = min(iy0 + (th - 1) * S + 3, a.H); vx1 = min(ix0 + (tw - 1) * S + 3, a.W);
         RW = a.RW;
-        // depthwise zero padding: everything the pointwise phase does not overwrite
-        const uint4 z = {0u, 0u, 0u, 0u};
-        for (int i = t; i < a.RH * a.RW + 4; i += blockDim.x) reinterpret_cast<uint4*>(inter)[i] = z;
-        __syncthreads();
     }
     const int VW = vx1 - vx0, VP = (vy1 - vy0) * VW;
     const float inv_vw = __builtin_amdgcn_rcpf((float)VW);
     const int ntiles = (VP + 15) >> 4;
-    const int klim = a.ktot - kb * 16;                     // this lane's 16 K bytes of step u are real iff u*64 < klim
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = {a.m1, a.lo, a.hi, a.out_scale, a.inv_out};     // make_rq() evaluated on the host (same binary32 operations)
     const int8_t* xn = a.x + (size_t)n * a.H * a.W * a.cs_in + kb * 16;
 
-    // region pixel of lane l15 in tile i: LDS slot and input address
-    auto locate = [&](int i, int& slot, const int8_t*& xp) -> bool {
-        const int v = i * 16 + l15;
+    // region pixel of lane l15 in tile i: LDS dword index (negative: no pixel) and input address; lanes past the last
+    // pixel (and waves past the last tile) re-read the last pixel instead of branching around their loads
+    auto locate = [&](int i, const int8_t*& xp) -> int {
+        const int v = i * 16 + l15, vc = min(v, VP - 1);
         // v / VW without an integer division: (v + 0.5) / VW is at least 0.5 / VW away from an integer, the float error
         // (v < 2^14, 1-ulp rcp) is orders of magnitude smaller
-        const int vy = (int)(((float)v + 0.5f) * inv_vw), vx = v - vy * VW;
+        const int vy = (int)(((float)vc + 0.5f) * inv_vw), vx = vc - vy * VW;
         const int iy = vy0 + vy, ix = vx0 + vx;
-        slot = (iy - iy0) * RW + (ix - ix0);
-        xp = xn + (size_t)(unsigned)((iy * a.W + ix) * a.cs_in);
-        return v < VP;
+        xp = xn + (unsigned)((iy * a.W + ix) * a.cs_in);
+        const int slot = ((iy - iy0) * RW + (ix - ix0)) * 4 + kb;
+        return v < VP ? slot : -1;
+    };
+    auto load_b = [&](const int8_t* xp, v4i (&bf)[STEPS], int chunk) {
+#pragma unroll
+        for (int u = 0; u < STEPS; u++) bf[u] = *reinterpret_cast<const v4i*>(xp + (chunk * STEPS + u) * 64);
+    };
+    auto finish = [&](const v4i& acc, int slot) {
+        const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
+        if (slot >= 0) inter[slot] = p;
     };
 
-    if (nchunks == 1) {
-        v4i bf[STEPS];
-        int slot; const int8_t* xp;
-        bool valid = false;
-        if (wave < ntiles) {
-            valid = locate(wave, slot, xp);
+    // first tile's activations go out before the LDS is prepared
+    v4i b0[STEPS];
+    const int8_t* xp0;
+    int slot0 = locate(wave, xp0);
+    if (!CHUNKED) load_b(xp0, b0, 0);
+    PWDW_STAMP(1);
+    if (MODE != 0) {
+        // depthwise zero padding: everything the pointwise phase does not overwrite
+        const uint4 z = {0u, 0u, 0u, 0u};
+        for (int i = t; i < a.RH * a.RW + 4; i += blockDim.x) reinterpret_cast<uint4*>(inter)[i] = z;
+        if (MODE == 1) {
 #pragma unroll
-            for (int u = 0; u < STEPS; u++) bf[u] = (valid && u * 64 < klim) ? *reinterpret_cast<const v4i*>(xp + u * 64) : zero4;
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) wsh[r][c] = wrow[r][c] << 8;     // taps of the second output of a lane: {0, w0, w1, w2}
         }
-        for (int i = wave; i < ntiles; i += nwaves) {
-            v4i bn[STEPS];
-            int slot_n = 0; const int8_t* xp_n = xn;
-            bool valid_n = false;
-            if (i + nwaves < ntiles) {
-                valid_n = locate(i + nwaves, slot_n, xp_n);
-#pragma unroll
-                for (int u = 0; u < STEPS; u++) bn[u] = (valid_n && u * 64 < klim) ? *reinterpret_cast<const v4i*>(xp_n + u * 64) : zero4;
-            }
+        __syncthreads();
+    }
+    PWDW_STAMP(2);
+
+    if (!CHUNKED) {
+        for (int i = wave; i < ntiles; i += 2 * nwaves) {
+            // b0 holds tile i; b1 takes tile i + nwaves while b0 is multiplied, then the roles swap
+            v4i b1[PINGPONG ? STEPS : 1];
+            const int8_t* xp1 = xn;
+            int slot1 = -1;
+            const bool second = i + nwaves < ntiles;
+            if (PINGPONG && second) { slot1 = locate(i + nwaves, xp1); load_b(xp1, reinterpret_cast<v4i (&)[STEPS]>(b1), 0); }
             v4i acc = zero4;
 #pragma unroll
-            for (int u = 0; u < STEPS; u++)
-                if (u < a.nsteps) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], bf[u], acc, 0, 0, 0);
-            const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
-            if (valid) inter[slot * 4 + kb] = p;
-            if (i + nwaves < ntiles) {
+            for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
+            finish(acc, slot0);
+            if (!second) break;
+            const bool third = i + 2 * nwaves < ntiles;
+            if (PINGPONG) {
+                if (third) { slot0 = locate(i + 2 * nwaves, xp0); load_b(xp0, b0, 0); }
+                acc = zero4;
 #pragma unroll
-                for (int u = 0; u < STEPS; u++) bf[u] = bn[u];
-                slot = slot_n; valid = valid_n;
+                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], reinterpret_cast<v4i (&)[STEPS]>(b1)[u], acc, 0, 0, 0);
+                finish(acc, slot1);
+            } else {
+                // one operand buffer (16 steps in registers): tiles one after the other
+                slot0 = locate(i + nwaves, xp0); load_b(xp0, b0, 0);
+                acc = zero4;
+#pragma unroll
+                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
+                finish(acc, slot0);
+                if (third) { slot0 = locate(i + 2 * nwaves, xp0); load_b(xp0, b0, 0); }
             }
         }
     } else {
-        // deep K (> 8 steps): chunks of STEPS, weights re-read per tile (only the 7x7 layers get here: <= 4 tiles a block)
+        const int nchunks = a.nsteps / STEPS;
         for (int i = wave; i < ntiles; i += nwaves) {
-            int slot; const int8_t* xp;
-            const bool valid = locate(i, slot, xp);
+            if (i != wave) slot0 = locate(i, xp0);
             v4i acc = zero4;
             for (int ch = 0; ch < nchunks; ch++) {
-                v4i bf[STEPS];
 #pragma unroll
-                for (int u = 0; u < STEPS; u++) {
-                    const int s = ch * STEPS + u;
-                    af[u] = s < a.nsteps ? *reinterpret_cast<const v4i*>(wfp + (size_t)s * 1024) : zero4;
-                    bf[u] = (valid && s * 64 < klim) ? *reinterpret_cast<const v4i*>(xp + s * 64) : zero4;
-                }
+                for (int u = 0; u < STEPS; u++) af[u] = *reinterpret_cast<const v4i*>(wfp + (size_t)(ch * STEPS + u) * 1024);
+                load_b(xp0, b0, ch);
 #pragma unroll
-                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], bf[u], acc, 0, 0, 0);
+                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
             }
-            const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
-            if (valid) inter[slot * 4 + kb] = p;
+            finish(acc, slot0);
         }
     }
+    PWDW_STAMP(3);
     __syncthreads();
+    PWDW_STAMP(4);
 
     if (MODE != 0) {
         // ---- depthwise 3x3 from LDS (dwconv.hip's scheme, one 4-pixel fragment per row) --------------------------
-        constexpr int TWL = S == 1 ? 2 : 1;                    // outputs per lane
+        constexpr int TWL = MODE == 1 ? 2 : 1;                 // outputs per lane
         const int strips = (tw + TWL - 1) / TWL;
         const int ntask = th * strips;
         const float inv_strips = __builtin_amdgcn_rcpf((float)strips);
-        const Rq drq = make_rq(a.d_m1, a.d_lo, a.d_hi, a.d_out_scale);
+        const Rq drq = {a.d_m1, a.d_lo, a.d_hi, a.d_out_scale, a.d_inv_out};
         int8_t* yn = a.y + ((size_t)(n * a.OH + ty * a.TH) * a.OW + tx * a.TW) * a.ldc + a.c_off + c0;
         for (int q = t >> 2; q < ntask; q += blockDim.x >> 2) {
             const int oyl = (int)(((float)q + 0.5f) * inv_strips), st = q - oyl * strips;
@@ -183,7 +218,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     acc[0][c] = __builtin_amdgcn_sdot4((int)frag[c], (int)wrow[r][c], acc[0][c], false);
-                    if (TWL == 2) acc[1][c] = __builtin_amdgcn_sdot4((int)frag[c], (int)(wrow[r][c] << 8), acc[1][c], false);
+                    if (TWL == 2) acc[1][c] = __builtin_amdgcn_sdot4((int)frag[c], (int)wsh[r][c], acc[1][c], false);
                 }
             }
 #pragma unroll
@@ -193,57 +228,38 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
                 if (oxl < tw && c0 < a.c_limit) *reinterpret_cast<unsigned*>(yn + ((size_t)oyl * a.OW + oxl) * a.ldc) = p;
             }
         }
-    } else {
-        // ---- global pooling over the region (pooling_kernel_ref_int8.c:84-189; misc_kernels.hip global_pool_i8) ------
-        unsigned* red = inter + (size_t)(VP + 4) * 4;          // [wave][4 quads][4]
-        int s4[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) s4[b] = a.pool_method == 0 ? -128 : 0;
-        for (int p = t >> 2; p < VP; p += blockDim.x >> 2) {
-            const unsigned v = inter[p * 4 + cq];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int e = sx8(v, b);
-                s4[b] = a.pool_method == 0 ? (s4[b] > e ? s4[b] : e) : s4[b] + e;
-            }
+    } else if (wave == 0) {
+        // ---- global pooling over the region (pooling_kernel_ref_int8.c:84-189; misc_kernels.hip global_pool_i8): one wave,
+        // lane = (pixel phase 0..3, channel 0..15): a short serial sum, two cross-lane steps, one requantisation per channel
+        const int ch = lane & 15, part = lane >> 4;
+        int s = a.pool_method == 0 ? -128 : 0;
+        for (int p = part; p < VP; p += 4) {
+            const int e = sx8(inter[p * 4 + (ch >> 2)], ch & 3);
+            s = a.pool_method == 0 ? (s > e ? s : e) : s + e;
         }
 #pragma unroll
-        for (int m = 4; m < 64; m <<= 1)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int o = __shfl_xor(s4[b], m, 64);
-                s4[b] = a.pool_method == 0 ? (s4[b] > o ? s4[b] : o) : s4[b] + o;
-            }
-        if (lane < 4) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) red[(wave * 4 + lane) * 4 + b] = (unsigned)s4[b];
+        for (int m = 16; m < 64; m <<= 1) {
+            const int o = __shfl_xor(s, m, 64);
+            s = a.pool_method == 0 ? (s > o ? s : o) : s + o;
         }
-        __syncthreads();
-        if (t < 4) {
-            int q[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                int r = (int)red[t * 4 + b];
-                for (int w = 1; w < nwaves; w++) {
-                    const int e = (int)red[(w * 4 + t) * 4 + b];
-                    r = a.pool_method == 0 ? (r > e ? r : e) : r + e;
-                }
-                if (a.pool_method == 0) {
-                    q[b] = round_sat(__fmul_rn((float)r, __fdiv_rn(a.p_in_scale, a.p_out_scale)));
-                } else {
-                    float f = __fmul_rn((float)r, a.p_in_scale);
-                    f = __fdiv_rn(f, (float)VP);
-                    q[b] = round_sat(__fdiv_rn(f, a.p_out_scale));
-                }
-            }
-            if (c0 < a.c_limit) *reinterpret_cast<unsigned*>(a.y + (size_t)n * a.ldc + a.c_off + c0) = pack4(q[0], q[1], q[2], q[3]);
+        int q;
+        if (a.pool_method == 0) {
+            q = round_sat(__fmul_rn((float)s, __fdiv_rn(a.p_in_scale, a.p_out_scale)));
+        } else {
+            float f = __fmul_rn((float)s, a.p_in_scale);
+            f = __fdiv_rn(f, (float)VP);
+            q = round_sat(__fdiv_rn(f, a.p_out_scale));
         }
+        if (part == 0 && c_base + ch < a.c_limit) a.y[(size_t)n * a.ldc + a.c_off + c_base + ch] = (int8_t)q;
     }
+    PWDW_STAMP(5);
+    PWDW_DRAIN();
+    PWDW_STAMP(7);
 }
 
 size_t pwdw_lds_bytes(const PwDwArgs& a, int threads)
 {
-    if (a.mode == 0) return ((size_t)a.H * a.W + 4) * 16 + (size_t)(threads / 64) * 64;
+    if (a.mode == 0) return ((size_t)a.H * a.W + 4) * 16;
     return ((size_t)a.RH * a.RW + 8) * 16;
 }
 
@@ -255,23 +271,41 @@ bool pwdw_config_ok(const PwDwArgs& a, int threads)
     return a.TH >= 1 && a.TW >= 1 && a.RH * a.RW < 16384;
 }
 
-template <int STEPS>
+// K steps kept in registers for a layer of `nsteps` real 64-deep steps: the planner pads the weight panel to a multiple
+int pwdw_steps(int nsteps)
+{
+    if (nsteps <= 1) return 1;
+    if (nsteps <= 2) return 2;
+    if (nsteps <= 4) return 4;
+    if (nsteps <= 8) return 8;
+    if (nsteps <= 16) return 16;
+    int best = 16, pad = (nsteps + 15) / 16 * 16;
+    for (int s : {8, 4}) { const int p = (nsteps + s - 1) / s * s; if (p < pad) { pad = p; best = s; } }
+    return best;
+}
+
+template <int STEPS, bool CHUNKED>
 static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
 {
     const dim3 grid(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
     const size_t lds = pwdw_lds_bytes(a, threads);
-    if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0>), grid, dim3(threads), lds, s, a);
-    else if (a.S == 1) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1>), grid, dim3(threads), lds, s, a);
-    else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2>), grid, dim3(threads), lds, s, a);
+    if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0, CHUNKED>), grid, dim3(threads), lds, s, a);
+    else if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2, CHUNKED>), grid, dim3(threads), lds, s, a);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1, CHUNKED>), grid, dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 3, CHUNKED>), grid, dim3(threads), lds, s, a);      // small tile: one output per lane
     return hipGetLastError();
 }
 
 hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s)
 {
-    if (a.nsteps <= 1) return launch_steps<1>(a, threads, s);
-    if (a.nsteps <= 2) return launch_steps<2>(a, threads, s);
-    if (a.nsteps <= 4) return launch_steps<4>(a, threads, s);
-    return launch_steps<8>(a, threads, s);
+    const bool chunked = a.nsteps > a.steps;      // a.nsteps is a multiple of a.steps == pwdw_steps(real steps)
+    switch (a.steps) {
+    case 1: return launch_steps<1, false>(a, threads, s);
+    case 2: return launch_steps<2, false>(a, threads, s);
+    case 4: return chunked ? launch_steps<4, true>(a, threads, s) : launch_steps<4, false>(a, threads, s);
+    case 8: return chunked ? launch_steps<8, true>(a, threads, s) : launch_steps<8, false>(a, threads, s);
+    default: return chunked ? launch_steps<16, true>(a, threads, s) : launch_steps<16, false>(a, threads, s);
+    }
 }
 
 }  // namespace tamd
