@@ -290,6 +290,19 @@ static bool autotune_enabled()
     return !(at_env && atoi(at_env) == 0);
 }
 
+// pointwise weight panel in MFMA fragment order: [16-channel slice][64-deep K step][lane = (k block of 16) * 16 + channel][16 B];
+// `wd` = [C][K] int8 rows (1x1 conv: K = cin; first conv: K = cin*KH*KW in OIHW order), zero padded to nsteps * 64
+static std::vector<int8_t> pack_pw_panel(const int8_t* wd, int C, int K, int nsteps)
+{
+    const int slices = (C + 15) / 16;
+    std::vector<int8_t> wf((size_t)slices * nsteps * 1024, 0);
+    for (int c = 0; c < C; c++)
+        for (int k = 0; k < K; k++)
+            wf[((size_t)((c >> 4) * nsteps + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (c & 15)) * 16 + (k & 15)] = wd[(size_t)c * K + k];
+    return wf;
+}
+
+
 struct FusedElt {            // an eltwise (+ReLU) node folded into the epilogue of the conv that produces its later operand
     int res_tensor;          // the other eltwise operand
     int elt_tensor;          // the eltwise node's own output (its scale)
@@ -452,8 +465,37 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if (!fz && gemm_direct_applicable(a)) cands.push_back({"gemm_direct_i8", [a](hipStream_t s) { return launch_gemm_direct(a, s); }});
         if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
         if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
+        // small maps (batch-1 tails, 1x1-map FC): the lean 16-channel-slice kernel of pwdw.hip without a tail
+        const bool is1x1 = KH == 1 && KW == 1 && p.stride_h == 1 && p.stride_w == 1 && !p.pad_h0 && !p.pad_h1 && !p.pad_w0 && !p.pad_w1;
+        if (!fz && is1x1 && a.M <= 4096 && !(getenv("TAMD_PW_SMALL") && atoi(getenv("TAMD_PW_SMALL")) == 0)) {
+            PwDwArgs v{};
+            const int slices = (cout + 15) / 16, cws = slices * 16;
+            const int steps = pwdw_steps((ckp + 63) / 64), nsteps = rup((ckp + 63) / 64, steps);
+            std::vector<int8_t> w2(wd, wd + (size_t)cout * cin);
+            const std::vector<int8_t> wf = pack_pw_panel(w2.data(), cout, cin, nsteps);
+            std::vector<int32_t> b2(cws, 0);
+            std::vector<float> s2(cws, 1.f);
+            for (int c = 0; c < cout; c++) { b2[c] = bd ? bd[c] : 0; s2[c] = ws[c]; }
+            int8_t* d0; int32_t* d1; float* d2;
+            if (upload(g, wf, &d0) || upload(g, b2, &d1) || upload(g, s2, &d2)) return -1;
+            v.wf = d0; v.bias = d1; v.wscale = d2;
+            host_rq(rqf, &v.m1, &v.lo, &v.hi, &v.out_scale, &v.inv_out);
+            v.x = a.x; v.N = x.n; v.H = x.h; v.W = x.w; v.cs_in = x.cs; v.ktot = ckp; v.nsteps = nsteps; v.steps = steps;
+            v.mode = 2; v.prod = 0; v.slices = slices; v.cw = cws;
+            v.y = a.y; v.ldc = a.ldc; v.c_off = a.c_off; v.c_limit = a.c_limit;
+            v.S = 1; v.OH = x.h; v.OW = x.w; v.TW = x.w; v.tiles_x = 1; v.RH = 1; v.RW = x.w;
+            for (int px : {64, 128, 256}) {          // pixels per block: 1, 2, 4 tiles of 16 per wave at 256 threads
+                int th = std::max(1, std::min(x.h, px / std::max(1, x.w)));
+                v.TH = th; v.tiles_y = (x.h + th - 1) / th;
+                bool dup = false;
+                for (auto& c : cands) dup |= c.name == "pw_small_i8<" + std::to_string(th) + ">";
+                if (dup || !pwdw_config_ok(v, 256)) continue;
+                const PwDwArgs vc = v;
+                cands.push_back({"pw_small_i8<" + std::to_string(th) + ">", [vc](hipStream_t s) { return launch_pwdw(vc, 256, s); }});
+            }
+        }
         const bool heuristic_done = !cands.empty();
-        const bool autotune = autotune_enabled() && st.macs >= 4e6;
+        const bool autotune = autotune_enabled() && st.macs >= 5e5;
         if (!heuristic_done || autotune) {
             if (autotune) {
                 for (int c = 0; c < conv_igemm_num_cfgs(); c++) {
@@ -518,16 +560,25 @@ static int plan_pool(tamd_graph* g, HNode& n)
 
 // ---- pointwise conv + its single consumer (depthwise 3x3 | global pooling) in one launch: pwdw.hip ---------------------
 // Which node, if any, can ride in pointwise conv `ni`'s launch.  *tmode: 1 depthwise 3x3, 0 global pooling.
-static int find_pwdw_tail(tamd_graph* g, size_t ni, int* tmode)
+static int find_pwdw_tail(tamd_graph* g, size_t ni, int* tmode, int* prod)
 {
     const HNode& n = g->nodes[ni];
     if (n.op != TAMD_OP_CONV || n.in.size() < 2) return -1;
     const tamd_conv_param& p = n.p.conv;
     const HTensor& x = g->tensors[n.in[0]];
     const HTensor& y = g->tensors[n.out[0]];
-    if (p.group != 1 || p.kernel_h != 1 || p.kernel_w != 1 || p.stride_h != 1 || p.stride_w != 1 || p.pad_h0 || p.pad_h1 || p.pad_w0
-        || p.pad_w1 || x.nchw_raw || y.is_view || x.dtype != TAMD_DT_INT8 || count_consumers(g, n.out[0]) != 1)
-        return -1;
+    if (p.group != 1 || y.is_view || x.dtype != TAMD_DT_INT8 || count_consumers(g, n.out[0]) != 1) return -1;
+    if (x.nchw_raw) {
+        // the network's first conv, gathered from the NCHW graph input: patch rows of 4 consecutive bytes (KW <= 4, no
+        // x dilation), at most 16 rows (c, ky) = one 64-deep K step; row offsets of 24 bits, ky*DH of 4
+        if (x.c > 4 || p.kernel_w > 4 || p.dilation_w != 1 || x.c * p.kernel_h > 16 || p.dilation_h * (p.kernel_h - 1) > 15
+            || (long)x.c * x.h * x.w >= (1L << 24) || p.pad_h0 < 0 || p.pad_w0 < 0)
+            return -1;
+        *prod = 1;
+    } else {
+        if (p.kernel_h != 1 || p.kernel_w != 1 || p.stride_h != 1 || p.stride_w != 1 || p.pad_h0 || p.pad_h1 || p.pad_w0 || p.pad_w1) return -1;
+        *prod = 0;
+    }
     for (auto& o : g->outputs) if (o.tensor == n.out[0]) return -1;
     for (size_t nj = ni + 1; nj < g->nodes.size(); nj++) {
         const HNode& c = g->nodes[nj];
@@ -542,7 +593,7 @@ static int find_pwdw_tail(tamd_graph* g, size_t ni, int* tmode)
             *tmode = 1;
             return (int)nj;
         }
-        if (c.op == TAMD_OP_POOL) {
+        if (c.op == TAMD_OP_POOL && *prod == 0) {
             const PoolGeom pg = pool_geom(c.p.pool, y.h, y.w);
             const int m = c.p.pool.pool_method;
             if (pg.oh != 1 || pg.ow != 1 || pg.kh != y.h || pg.kw != y.w || pg.ph0 || pg.pw0 || (m != 0 && m != 1) || y.h * y.w > 1024 || o.scales.empty())
@@ -558,7 +609,7 @@ static int find_pwdw_tail(tamd_graph* g, size_t ni, int* tmode)
 // The two nodes were just planned as steps [s0, s0 + 2); build the fused launch, and keep whichever is faster
 // (plan-time measurement; without autotune: fuse the small-map cases where launches, not bytes, are the cost).
 // TAMD_FUSE_PWDW=0 never fuses, =2 always fuses; TAMD_PWDW_CFG="TH,TW,threads" pins the tile configuration (tests).
-static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
+static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, size_t s0)
 {
     const char* fenv = getenv("TAMD_FUSE_PWDW");                 // read at every prerun
     const int fmode = fenv ? atoi(fenv) : 1;
@@ -568,18 +619,25 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
     HTensor* b = pw.in.size() > 2 ? &g->tensors[pw.in[2]] : nullptr;
     HTensor& mid = g->tensors[pw.out[0]];
     HTensor& y = g->tensors[tl.out[0]];
+    const tamd_conv_param& pp = pw.p.conv;
     const int cin = x.c, C = mid.c, slices = (C + 15) / 16, cw = slices * 16;
-    const int ktot = rup(cin, 16), steps = pwdw_steps((ktot + 63) / 64), nsteps = rup((ktot + 63) / 64, steps);
-    if (w.elems() != (size_t)C * cin || (b && b->elems() < (size_t)C)) return 0;
+    const int Kw = prod == 1 ? cin * pp.kernel_h * pp.kernel_w : cin;           // weight row length in the model
+    const int K = prod == 1 ? cin * pp.kernel_h * 4 : cin;                      // reduction length as the kernel walks it
+    const int ktot = prod == 1 ? K : rup(cin, 16), steps = pwdw_steps((ktot + 63) / 64), nsteps = rup((ktot + 63) / 64, steps);
+    if (w.elems() != (size_t)C * Kw || (b && b->elems() < (size_t)C)) return 0;
     PwDwArgs a{};
-    // pointwise operands: weights in MFMA fragment order [slice][step][lane][16 B], lane = (k block of 16) * 16 + channel
     {
-        const RqFold rq = fold_requant(RQ_CONV_HCL, pw.p.conv.activation, x.scales[0], mid.scales[0], w, C);
+        const RqFold rq = fold_requant(RQ_CONV_HCL, pp.activation, x.scales[0], mid.scales[0], w, C);
         const int8_t* wd = (const int8_t*)w.data.data();
-        std::vector<int8_t> wf((size_t)slices * nsteps * 1024, 0);
-        for (int c = 0; c < C; c++)
-            for (int k = 0; k < cin; k++)
-                wf[((size_t)((c >> 4) * nsteps + (k >> 6)) * 64 + ((k >> 4) & 3) * 16 + (c & 15)) * 16 + (k & 15)] = wd[(size_t)c * cin + k];
+        std::vector<int8_t> wrows;
+        if (prod == 1) {                // k = (c*KH + ky)*4 + kx: rows padded to 4 taps
+            wrows.assign((size_t)C * K, 0);
+            for (int c = 0; c < C; c++)
+                for (int r = 0; r < cin * pp.kernel_h; r++)
+                    for (int kx = 0; kx < pp.kernel_w; kx++) wrows[(size_t)c * K + r * 4 + kx] = wd[(size_t)c * Kw + r * pp.kernel_w + kx];
+            wd = wrows.data();
+        }
+        const std::vector<int8_t> wf = pack_pw_panel(wd, C, K, nsteps);
         std::vector<int32_t> bp(cw, 0);
         std::vector<float> sp(cw, 1.f);
         for (int c = 0; c < C; c++) { bp[c] = b ? ((const int32_t*)b->data.data())[c] : 0; sp[c] = rq.m2[c]; }
@@ -588,12 +646,24 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
         a.wf = d0; a.bias = d1; a.wscale = d2;
         host_rq(rq, &a.m1, &a.lo, &a.hi, &a.out_scale, &a.inv_out);
     }
-    a.x = (const int8_t*)x.dptr + x.c_off;
-    a.N = x.n; a.H = x.h; a.W = x.w; a.cs_in = x.cs; a.ktot = ktot; a.nsteps = nsteps; a.steps = steps;
+    a.prod = prod;
+    if (prod == 1) {
+        std::vector<unsigned> rows(16, 0u);
+        for (int r = 0; r < cin * pp.kernel_h; r++) {
+            const int ky = r % pp.kernel_h, ci = r / pp.kernel_h;
+            rows[r] = (unsigned)(ci * x.h * x.w + ky * pp.dilation_h * x.w) | ((unsigned)(ky * pp.dilation_h) << 28);
+        }
+        unsigned* dt;
+        if (upload(g, rows, &dt)) return -1;
+        a.taps = dt; a.in_C = cin; a.in_H = x.h; a.in_W = x.w;
+        a.fSH = pp.stride_h; a.fSW = pp.stride_w; a.fPH = pp.pad_h0; a.fPW = pp.pad_w0;
+    }
+    a.x = (const int8_t*)x.dptr + (prod == 1 ? 0 : x.c_off);
+    a.N = x.n; a.H = mid.h; a.W = mid.w; a.cs_in = x.cs; a.ktot = ktot; a.nsteps = nsteps; a.steps = steps;
     a.mode = tmode; a.cw = cw; a.slices = slices;
     a.y = (int8_t*)y.dptr; a.ldc = y.cs; a.c_off = y.c_off;
     a.c_limit = y.is_view ? C : std::min(rup(C, 16), y.cs - y.c_off);
-    a.S = 1; a.OH = a.OW = 1; a.TH = a.TW = 1; a.tiles_x = a.tiles_y = 1; a.RH = x.h; a.RW = x.w;
+    a.S = 1; a.OH = a.OW = 1; a.TH = a.TW = 1; a.tiles_x = a.tiles_y = 1; a.RH = mid.h; a.RW = mid.w;
     if (tmode == 1) {
         const tamd_conv_param& q = tl.p.conv;
         HTensor& dwt = g->tensors[tl.in[1]];
@@ -665,6 +735,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
     const bool autotune = autotune_enabled() && sa.macs >= 4e6;
     size_t best = 0;
     bool fuse = fmode == 2 || (double)a.N * a.H * a.W <= 32768.0;
+    // cost model inputs below use the map the tail reads (a.H x a.W) and the reduction depth
     if (autotune) {
         float best_ms = 1e30f;
         for (size_t c = 0; c < cfgs.size(); c++) {
@@ -686,7 +757,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, size_t s0)
     Step st;
     st.node = sa.node + "+" + sb.node;
     char nm[48];
-    if (tmode == 1) snprintf(nm, sizeof(nm), "pwdw_i8<s%d,%dx%d,%d>", a.S, v.TH, v.TW, threads);
+    if (tmode == 1) snprintf(nm, sizeof(nm), "%s_i8<s%d,%dx%d,%d>", prod == 1 ? "firstdw" : "pwdw", a.S, v.TH, v.TW, threads);
     else snprintf(nm, sizeof(nm), "pwpool_i8<%d>", threads);
     st.kernel = nm;
     st.macs = sa.macs + sb.macs;
@@ -829,8 +900,8 @@ static int plan(tamd_graph* g)
         case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_CONCAT:
             break;
         case TAMD_OP_CONV: {
-            int tmode = -1;
-            const int tail = has_fuse[ni] ? -1 : find_pwdw_tail(g, ni, &tmode);
+            int tmode = -1, prod = 0;
+            const int tail = has_fuse[ni] ? -1 : find_pwdw_tail(g, ni, &tmode, &prod);
             if (tail >= 0 && !fused[tail]) {
                 // the pair is planned here, the tail ahead of its node order (its only input is this conv's output), then
                 // possibly replaced by ONE fused launch
@@ -838,7 +909,7 @@ static int plan(tamd_graph* g)
                 if (plan_conv(g, n, false)) return -1;
                 if (tmode == 0 ? plan_pool(g, g->nodes[tail]) : plan_conv(g, g->nodes[tail], false)) return -1;
                 fused[tail] = 1;
-                if (g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, s0)) return -1;
+                if (g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, prod, s0)) return -1;
                 break;
             }
             if (plan_conv(g, n, false, has_fuse[ni] ? &fuse_at[ni] : nullptr)) return -1;

@@ -65,7 +65,11 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
 #ifdef TAMD_PWDW_STAMPS
     unsigned long long* stamps;        // tools/exp/pwdw_anatomy.hip only
 #endif
-    int mode;              // 0: global pooling tail, 1: depthwise 3x3 tail
+    int mode;              // tail: 0 global pooling, 1 depthwise 3x3, 2 none (the tile results are stored)
+    int prod;              // producer: 0 pointwise conv of an NHWC tensor, 1 first-layer conv gathered from the NCHW graph input
+    const unsigned* taps;  // prod 1: [16] patch row (c, ky) -> (c*in_H*in_W + ky*DH*in_W) | ky*DH << 28, zero padded; k = row*4 + kx
+    int in_C, in_H, in_W;  // prod 1: the NCHW input;  H x W above is then the first conv's OUTPUT map
+    int fSH, fSW, fPH, fPW;            // prod 1: stride, leading pads
     const int8_t* dw_w;    // as DwArgs::w
     const int32_t* dw_bias;
     const float* dw_wscale;

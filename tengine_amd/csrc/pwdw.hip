@@ -24,6 +24,11 @@
 //   2. depthwise 3x3 from LDS exactly as dwconv.hip does from memory: lane = 4 channels x a strip of outputs, 4x4 byte
 //      transposes + one v_dot4_i32_i8 per filter row, its own requantisation, dword stores to the NHWC output.
 //      (global pooling: per-channel sum / max over the region, the reference's float sequence, one dword per 4 channels)
+// The same block structure serves two more jobs, selected by template parameters:
+//   * PROD 1: the producer is the network's FIRST convolution, gathered straight from the NCHW graph input (<= 64 taps:
+//     MobileNet / SSD conv1 3x3x3) through a k -> (plane offset, dy, dx) table -- conv1 + depthwise 2_1 become one launch;
+//   * MODE 4: no tail at all -- a small-map pointwise conv / 1x1-map FC whose tile results go from the accumulator
+//     registers to memory (the batch-1 layers that have no depthwise behind them: MobileNet fc7).
 #include "dw_common.h"
 #include "epilogue.h"
 #include "kernels.h"
@@ -47,12 +52,13 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // several times STEPS deep (K > 1024), weights are re-read per tile.
 // A lone wave issues one instruction every 4 cycles and these launches are a few hundred instructions long, so the code
 // is written for instruction count: host-folded requantisation constants, no integer divisions, no predicated loads.
-template <int STEPS, int MODE, bool CHUNKED>
+// MODE 4: no tail (results stored from registers).  PROD 1: first-layer gather from the NCHW graph input (STEPS == 1).
+template <int STEPS, int MODE, bool CHUNKED, int PROD>
 __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
     constexpr int S = MODE == 2 ? 2 : 1;
-    constexpr bool PINGPONG = !CHUNKED && STEPS <= 8;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
+    constexpr bool PINGPONG = !CHUNKED && STEPS <= 8 && PROD == 0;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
     PWDW_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kb = lane >> 4;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     unsigned wrow[3][4], wsh[3][4];
     int4 db = {0, 0, 0, 0};
     float4 ds = {1.f, 1.f, 1.f, 1.f};
-    if (MODE != 0) {
+    if (MODE != 0 && MODE != 4) {
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const uint4 v = *reinterpret_cast<const uint4*>(a.dw_w + ((size_t)r * a.cw + c0) * 4);
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 
     // ---- geometry of this block (uniform) ---------------------------------------------------------------------
     int iy0 = 0, ix0 = 0, th = 1, tw = 1, vy0 = 0, vx0 = 0, vy1 = a.H, vx1 = a.W, RW = a.W;
-    if (MODE != 0) {
+    if (MODE == 4) {                 // rows [ty*TH, ty*TH + TH) of the map, full width
+        vy0 = ty * a.TH; vy1 = min(vy0 + a.TH, a.H);
+    } else if (MODE != 0) {
         const int oy0 = ty * a.TH, ox0 = tx * a.TW;
         iy0 = oy0 * S - a.PH; ix0 = ox0 * S - a.PW;
         th = min(a.TH, a.OH - oy0); tw = min(a.TW, a.OW - ox0);
@@ -100,27 +108,63 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     const float inv_vw = __builtin_amdgcn_rcpf((float)VW);
     const int ntiles = (VP + 15) >> 4;
     const Rq rq = {a.m1, a.lo, a.hi, a.out_scale, a.inv_out};     // make_rq() evaluated on the host (same binary32 operations)
-    const int8_t* xn = a.x + (size_t)n * a.H * a.W * a.cs_in + kb * 16;
+    const int8_t* xn = PROD == 0 ? a.x + (size_t)n * a.H * a.W * a.cs_in + kb * 16
+                                 : a.x + (size_t)n * a.in_C * a.in_H * a.in_W;
+    // PROD 1: the four patch rows (c, ky) of this lane's 16 K bytes: k = row * 4 + kx, a row is FOUR consecutive input bytes
+    // (kx = 0..KW-1 real, the rest meets zero weights) -- one unaligned dword load per row instead of KW byte gathers
+    // (conv_first.hip's row trick).  Table entry: (c*in_H*in_W + ky*DH*in_W) | ky*DH << 28; padding rows are 0.
+    unsigned rows[4];
+    if (PROD == 1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.taps + kb * 4);
+        rows[0] = v.x; rows[1] = v.y; rows[2] = v.z; rows[3] = v.w;
+    }
 
     // region pixel of lane l15 in tile i: LDS dword index (negative: no pixel) and input address; lanes past the last
     // pixel (and waves past the last tile) re-read the last pixel instead of branching around their loads
+    int piy = 0, pix = 0;      // map coordinates of the located pixel (MODE 4 stores, PROD 1 gathers)
     auto locate = [&](int i, const int8_t*& xp) -> int {
         const int v = i * 16 + l15, vc = min(v, VP - 1);
         // v / VW without an integer division: (v + 0.5) / VW is at least 0.5 / VW away from an integer, the float error
         // (v < 2^14, 1-ulp rcp) is orders of magnitude smaller
         const int vy = (int)(((float)vc + 0.5f) * inv_vw), vx = vc - vy * VW;
         const int iy = vy0 + vy, ix = vx0 + vx;
-        xp = xn + (unsigned)((iy * a.W + ix) * a.cs_in);
-        const int slot = ((iy - iy0) * RW + (ix - ix0)) * 4 + kb;
+        piy = iy; pix = ix;
+        xp = PROD == 0 ? xn + (unsigned)((iy * a.W + ix) * a.cs_in) : xn;
+        const int slot = MODE == 4 ? (iy * a.W + ix) : ((iy - iy0) * RW + (ix - ix0)) * 4 + kb;
         return v < VP ? slot : -1;
     };
     auto load_b = [&](const int8_t* xp, v4i (&bf)[STEPS], int chunk) {
+        if (PROD == 0) {
 #pragma unroll
-        for (int u = 0; u < STEPS; u++) bf[u] = *reinterpret_cast<const v4i*>(xp + (chunk * STEPS + u) * 64);
+            for (int u = 0; u < STEPS; u++) bf[u] = *reinterpret_cast<const v4i*>(xp + (chunk * STEPS + u) * 64);
+        } else {
+            // patch rows of conv output pixel (piy, pix).  Column handling is the same for every row: bytes left of the image
+            // are shifted in as zeros, bytes right of it masked; rows above / below the image are zero.  All four loads are
+            // unconditional (clamped addresses) so they fly together.
+            const int iyb = piy * a.fSH - a.fPH, ixb = pix * a.fSW - a.fPW;
+            const int sft = max(-ixb, 0), xs = max(ixb, 0), nvalid = a.in_W - ixb;
+            const bool colok = nvalid > 0 && sft < 4;
+            const unsigned cmask = nvalid < 4 ? (1u << (8 * max(nvalid, 0))) - 1u : ~0u;
+            const int base = iyb * a.in_W + xs;
+            unsigned raw[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int iy = iyb + (int)(rows[j] >> 28);
+                ok[j] = colok && (unsigned)iy < (unsigned)a.in_H;
+                __builtin_memcpy(&raw[j], xp + (ok[j] ? base + (int)(rows[j] & 0xffffffu) : 0), 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) bf[0][j] = ok[j] ? (int)((raw[j] << (8 * sft)) & cmask) : 0;
+        }
     };
     auto finish = [&](const v4i& acc, int slot) {
         const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
-        if (slot >= 0) inter[slot] = p;
+        if (MODE == 4) {
+            if (slot >= 0 && c_base + 4 * kb < a.c_limit)
+                *reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb) = p;
+        } else if (slot >= 0)
+            inter[slot] = p;
     };
 
     // first tile's activations go out before the LDS is prepared
@@ -129,7 +173,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     int slot0 = locate(wave, xp0);
     if (!CHUNKED) load_b(xp0, b0, 0);
     PWDW_STAMP(1);
-    if (MODE != 0) {
+    if (MODE != 0 && MODE != 4) {
         // depthwise zero padding: everything the pointwise phase does not overwrite
         const uint4 z = {0u, 0u, 0u, 0u};
         for (int i = t; i < a.RH * a.RW + 4; i += blockDim.x) reinterpret_cast<uint4*>(inter)[i] = z;
@@ -189,6 +233,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
         }
     }
     PWDW_STAMP(3);
+    if (MODE == 4) return;
     __syncthreads();
     PWDW_STAMP(4);
 
@@ -259,6 +304,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 
 size_t pwdw_lds_bytes(const PwDwArgs& a, int threads)
 {
+    if (a.mode == 2) return 0;
     if (a.mode == 0) return ((size_t)a.H * a.W + 4) * 16;
     return ((size_t)a.RH * a.RW + 8) * 16;
 }
@@ -267,7 +313,9 @@ bool pwdw_config_ok(const PwDwArgs& a, int threads)
 {
     if (threads != 256 && threads != 512) return false;
     if (pwdw_lds_bytes(a, threads) > 64 * 1024) return false;
+    if (a.prod == 1 && (a.nsteps != 1 || a.mode != 1)) return false;
     if (a.mode == 0) return a.H * a.W <= 1024;
+    if (a.mode == 2) return a.TH >= 1 && (long)a.TH * a.W < 16384;
     return a.TH >= 1 && a.TW >= 1 && a.RH * a.RW < 16384;
 }
 
@@ -287,17 +335,33 @@ int pwdw_steps(int nsteps)
 template <int STEPS, bool CHUNKED>
 static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
 {
-    const dim3 grid(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
     const size_t lds = pwdw_lds_bytes(a, threads);
-    if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0, CHUNKED>), grid, dim3(threads), lds, s, a);
-    else if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2, CHUNKED>), grid, dim3(threads), lds, s, a);
-    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1, CHUNKED>), grid, dim3(threads), lds, s, a);
-    else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 3, CHUNKED>), grid, dim3(threads), lds, s, a);      // small tile: one output per lane
+    if (a.mode == 2) {
+        const dim3 grid(a.slices, 1, ((a.H + a.TH - 1) / a.TH) * a.N);
+        hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 4, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
+        return hipGetLastError();
+    }
+    const dim3 grid(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
+    if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
+    else if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 3, CHUNKED, 0>), grid, dim3(threads), lds, s, a);      // small tile: one output per lane
+    return hipGetLastError();
+}
+
+static hipError_t launch_first(const PwDwArgs& a, int threads, hipStream_t s)
+{
+    const dim3 grid(a.slices, a.tiles_x, a.tiles_y * a.N);
+    const size_t lds = pwdw_lds_bytes(a, threads);
+    if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<1, 2, false, 1>), grid, dim3(threads), lds, s, a);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<1, 1, false, 1>), grid, dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL((pwdw_i8_kernel<1, 3, false, 1>), grid, dim3(threads), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s)
 {
+    if (a.prod == 1) return launch_first(a, threads, s);
     const bool chunked = a.nsteps > a.steps;      // a.nsteps is a multiple of a.steps == pwdw_steps(real steps)
     switch (a.steps) {
     case 1: return launch_steps<1, false>(a, threads, s);

@@ -278,21 +278,25 @@ def i8_concat_graph(seed, n, c, h, w, axis=1, shrink=False):
     return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)
 
 
-def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", pool_alg=1, bias=True):
-    """int8: pointwise 1x1 conv (cin -> c) -> depthwise 3x3 (stride s, pad p) | global pooling: the pair pwdw.hip fuses"""
+def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", pool_alg=1, bias=True, first=None):
+    """int8: pointwise 1x1 conv (cin -> c) -> depthwise 3x3 (stride s, pad p) | global pooling: the pair pwdw.hip fuses.
+    `first` = (k, stride, pad[, dilation]): the producer is a k x k conv on the graph input instead (network's first layer)"""
     rng = np.random.default_rng(seed)
+    fk, fs, fp, fd = (list(first) + [1])[:4] if first else (1, 1, 0, 1)
     g = Graph(name="pwdw_case")
     xs = float(np.float32(rng.uniform(0.01, 0.05)))
     x = g.add_input("data", [n, cin, h, w], DT_INT8, [xs], [0])
-    wq = rng.integers(-127, 128, size=(c, cin, 1, 1)).astype(np.int8)
+    wq = rng.integers(-127, 128, size=(c, cin, fk, fk)).astype(np.int8)
     ws = _scales(rng, c)
     ins = [x, g.add_const("w_pw", wq, DT_INT8, ws, [0] * c)]
     if bias:
         ins.append(g.add_const("b_pw", rng.integers(-2000, 2000, size=(c,)).astype(np.int32), DT_INT32, [1.0], [0]))
-    ms = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(cin) * 73.0 / 60.0))
+    ms = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(cin * fk * fk) * 73.0 / 60.0))
+    h = (h - fd * (fk - 1) - 1 + 2 * fp) // fs + 1          # from here on: the producer's output map
+    w = (w - fd * (fk - 1) - 1 + 2 * fp) // fs + 1
     mid = g.add_tensor("mid", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [ms], [0])
-    g.add_node("pw", "Convolution", ins, [mid], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1, dilation_w=1,
-               input_channel=cin, output_channel=c, group=1, activation=act_pw, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    g.add_node("pw", "Convolution", ins, [mid], kernel_h=fk, kernel_w=fk, stride_h=fs, stride_w=fs, dilation_h=fd, dilation_w=fd,
+               input_channel=cin, output_channel=c, group=1, activation=act_pw, pad_h0=fp, pad_w0=fp, pad_h1=fp, pad_w1=fp)
     if tail == "pool":
         os_ = float(np.float32(ms * rng.uniform(0.3, 0.9)))
         y = g.add_tensor("out", [n, c, 1, 1], DT_INT8, tm2.TT_VAR, None, [os_], [0])
@@ -312,4 +316,4 @@ def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", p
                         dilation_w=1, input_channel=c, output_channel=c, group=c, activation=act_dw, pad_h0=p, pad_w0=p,
                         pad_h1=p, pad_w1=p)
     g.output_nodes = [ni]
-    return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+    return g, rng.integers(-127, 128, size=g.tensors[x].dims).astype(np.int8)

@@ -29,7 +29,7 @@ SHAPES = [
     (1, 512, 7, 7, 512, 3, 1, 1, 1, 0, True, 1),
 ]
 MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct", "pw_stream",
-           "conv_igemm2"]
+           "conv_igemm2", "pw_small"]
 
 
 @pytest.fixture(scope="module")
@@ -57,6 +57,8 @@ def test_family_member_is_exact_on_every_shape(member, cases):
             gr.close()
             used += member.replace("igemm", "x") in name or member in name
             assert np.array_equal(got, want), "%s (%s) wrong on %s" % (member, name, c)
+        if member == "pw_small":      # the 1x1 shapes with <= 4096 pixels must really have run it
+            assert used >= 5, used
     finally:
         del os.environ["TAMD_FORCE_GEMM"]
 

@@ -34,7 +34,7 @@ def run(g, x, fuse, cfg=None):
 def check(g, x, cfg=None, tag=""):
     want = oracle.run_graph(g, x)[0]
     got, names = run(g, x, 2, cfg)
-    assert len(names) == 1 and (names[0].startswith("pwdw_i8") or names[0].startswith("pwpool_i8")), names
+    assert len(names) == 1 and names[0].split("_i8")[0] in ("pwdw", "pwpool", "firstdw"), names
     got = got.reshape(want.shape)
     bad = np.count_nonzero(got != want)
     assert bad == 0, "%s %s: %d / %d bytes differ (max |d| %d)" % (tag, names[0], bad, want.size, np.abs(got.astype(int) - want.astype(int)).max())
@@ -95,6 +95,29 @@ def test_pointwise_plus_global_pool(alg, shape):
     assert check(g, x).startswith("pwpool_i8")
 
 
+FIRST_CASES = [
+    # n, cin, h, w, C, (k, stride, pad[, dil]) of the first conv, depthwise stride, "TH,TW,threads"
+    (1, 3, 224, 224, 32, (3, 2, 1), 1, None),            # MobileNet-v1 conv1 + conv2_1/dw (the planner's own tile choice)
+    (1, 3, 224, 224, 32, (3, 2, 1), 1, "7,14,512"),
+    (2, 3, 37, 41, 24, (3, 2, 1), 2, "3,4,256"),         # odd sizes, C % 16 != 0, stride-2 tail, batch 2 (naive-ref depthwise epilogue)
+    (1, 3, 30, 30, 16, (3, 1, 1), 1, "8,28,512"),        # stride-1 first conv
+    (1, 1, 20, 22, 16, (3, 2, 2), 1, "4,4,256"),         # one input channel, pad 2: two columns / rows of padding
+    (3, 4, 18, 18, 32, (3, 1, 0), 1, "16,16,256"),       # 4 channels (12 patch rows: third k block), no padding, whole map per block
+    (1, 3, 9, 5, 16, (3, 1, 1), 1, "5,6,256"),           # 5-pixel rows: right border inside the 4-byte row loads
+    (1, 4, 16, 16, 16, (4, 1, 1), 2, "2,3,256"),         # 4x4 kernel, 4 channels: all 16 patch rows, KW = 4
+]
+
+
+@pytest.mark.parametrize("case", FIRST_CASES, ids=[str(c) for c in FIRST_CASES])
+def test_first_conv_plus_depthwise(case):
+    """the network's first conv, gathered from the NCHW graph input, fused with the depthwise 3x3 behind it"""
+    n, cin, h, w, c, first, s, cfg = case
+    g, x = pwdw_graph(700 + h + c + s, n, cin, h, w, c, s, 1, 0, 0, first=first)
+    x[:] = np.random.default_rng(3).integers(-127, 128, size=x.shape)       # dense borders
+    name = check(g, x, cfg, str(case))
+    assert name.startswith("firstdw_i8"), name
+
+
 def test_fused_equals_unfused_on_device_and_intermediate_is_refused():
     g, x = pwdw_graph(77, 1, 128, 28, 28, 128, 1, 1)
     fused, names_f = run(g, x, 2)
@@ -126,5 +149,5 @@ def test_mobilenet_v1_batch1_default_plan_uses_fused_launches():
     names = [k["kernel"] for k in gr.profile(1)]
     gr.close()
     assert np.array_equal(got.reshape(want.shape), want)
-    assert sum(n.startswith("pwdw_i8") or n.startswith("pwpool_i8") for n in names) >= 8, names
-    assert len(names) <= 20, names
+    assert sum(n.split("_i8")[0] in ("pwdw", "pwpool", "firstdw") for n in names) >= 8, names
+    assert len(names) <= 17, names
