@@ -12,6 +12,7 @@
  *   allocator.describe (cuda_device.cc:47-83)           tamd_op_supported
  *   interface.pre_run  (scheduler.c:49-59)              tamd_graph_prerun
  *   interface.run      (scheduler.c:134)                tamd_graph_run  (host in -> H2D -> launches -> D2H)
+ *   interface.async_run / async_wait (device.h:60-63)   tamd_graph_run_async / tamd_graph_wait
  *   interface.post_run / release_graph                  tamd_graph_destroy
  *   set_tensor_buffer / get_tensor_buffer (c_api.c)     tamd_graph_set_input / tamd_graph_get_output
  *
@@ -114,9 +115,14 @@ typedef struct tamd_node_desc {
  * reference's convention, trt_define.h:35-41 / scheduler.c:49-57) */
 typedef struct tamd_options {
     const char* dev_name; /* "HIP"                                                */
+    int size;             /* sizeof(tamd_options) as the CALLER compiled it: set_context_device copies dev_opt_size bytes
+                           * and hands pre_run only the pointer (c_api.c:183-210, scheduler.c:49-57), so the blob
+                           * carries its own size; fields beyond it keep their defaults (0: only dev_name is read) */
     int gpu_index;        /* HIP device ordinal                                   */
     int use_hip_graph;    /* 1: capture the launch list into a hipGraph (default) */
-    int profile;          /* 1: honour TG_DEBUG_TIME-style per-node timing        */
+    int profile;          /* 1: print a per-launch timing table on stderr when the graph is released -- what
+                           * TG_DEBUG_TIME=1 makes the CPU device do (cpu_define.h:41-43, cpu_dump.c:607-697); the
+                           * environment variable itself is honoured too */
 } tamd_options;
 
 typedef struct tamd_graph tamd_graph;
@@ -130,6 +136,11 @@ TAMD_API const char* tamd_last_error(void);
 TAMD_API const char* tamd_version(void);
 /* 1 if (op, dtype) can run on the device -- what allocator.describe publishes */
 TAMD_API int tamd_op_supported(int op, int dtype);
+/* 1 if this node with these parameters and tensors (descriptors only, const payloads are not read) is one the device
+ * compiles; 0 -> leave it to the CPU device.  Replaces the per-op parameter tests a backend makes while it walks a
+ * subgraph (source/device/cuda/cuda_executor.cc:72-134 fails Build() instead; tensorrt: trt_limit.hpp) */
+TAMD_API int tamd_node_supported(const tamd_node_desc* node, const tamd_tensor_desc* inputs, int input_num,
+                                 const tamd_tensor_desc* outputs, int output_num);
 
 /* ---- graph construction: the plugin's pre_run walks `struct subgraph` (source/graph/subgraph.h, node.h:46-70,
  * tensor.h:43-102) and mirrors it through these calls, like CUDAEngine::Build does for its own IR
@@ -159,6 +170,13 @@ TAMD_API int tamd_graph_set_input(tamd_graph* g, int idx, const void* host_nchw,
 TAMD_API int tamd_graph_set_output(tamd_graph* g, int idx, void* host_nchw, size_t bytes);
 /* H2D inputs -> kernels -> D2H outputs; returns when outputs are complete (scheduler is synchronous) */
 TAMD_API int tamd_graph_run(tamd_graph* g);
+/* asynchronous pair <- interface.async_run / async_wait (device.h:60-63; the reference's scheduler never issues them:
+ * run_graph(graph, 0) is rejected, scheduler.c:75-79).  run_async stages the current input buffers, queues H2D -> kernels ->
+ * D2H and returns; up to TWO runs may be in flight (a third submit fails); wait blocks for the OLDEST one and delivers its
+ * outputs to the buffers that were set when it was submitted.  Same stream, same bytes as tamd_graph_run. */
+TAMD_API int tamd_graph_run_async(tamd_graph* g);
+TAMD_API int tamd_graph_wait(tamd_graph* g);
+TAMD_API int tamd_graph_inflight(const tamd_graph* g);   /* runs submitted and not yet waited for */
 /* HBM-resident variants (measurement, multi-GPU harness): stage inputs once, launch without copies */
 TAMD_API int tamd_graph_upload_inputs(tamd_graph* g);
 TAMD_API int tamd_graph_launch(tamd_graph* g);            /* async on the graph's stream          */

@@ -16,7 +16,7 @@ _NP = {DT_FP32: np.float32, DT_FP16: np.float16, DT_INT8: np.int8, DT_UINT8: np.
 
 
 class Options(C.Structure):           # tamd_options
-    _fields_ = [("dev_name", C.c_char_p), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
+    _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
 
 
 class KernelInfo(C.Structure):        # tamd_kernel_info
@@ -25,11 +25,11 @@ class KernelInfo(C.Structure):        # tamd_kernel_info
 
 
 EXPORTS = [
-    "tamd_device_count", "tamd_init", "tamd_shutdown", "tamd_last_error", "tamd_version", "tamd_op_supported",
+    "tamd_device_count", "tamd_init", "tamd_shutdown", "tamd_last_error", "tamd_version", "tamd_op_supported", "tamd_node_supported",
     "tamd_graph_create", "tamd_graph_add_tensor", "tamd_graph_add_node", "tamd_graph_set_inputs",
     "tamd_graph_set_outputs", "tamd_graph_load_tm2", "tamd_graph_set_batch", "tamd_graph_prerun",
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
-    "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_upload_inputs",
+    "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
     "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_download_outputs", "tamd_graph_output_device",
     "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_kernel_num", "tamd_graph_profile",
     "tamd_graph_read_tensor", "tamd_graph_tensor_num", "tamd_graph_tensor_desc", "tamd_graph_destroy",
@@ -66,7 +66,8 @@ def lib():
             "tamd_graph_input_desc": [vp, ci, C.POINTER(ci), C.POINTER(ci)],
             "tamd_graph_output_desc": [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_float), C.POINTER(ci)],
             "tamd_graph_set_input": [vp, ci, vp, C.c_size_t], "tamd_graph_set_output": [vp, ci, vp, C.c_size_t],
-            "tamd_graph_run": [vp], "tamd_graph_upload_inputs": [vp], "tamd_graph_launch": [vp],
+            "tamd_graph_run": [vp], "tamd_graph_run_async": [vp], "tamd_graph_wait": [vp], "tamd_graph_inflight": [vp],
+            "tamd_graph_upload_inputs": [vp], "tamd_graph_launch": [vp],
             "tamd_graph_sync": [vp], "tamd_graph_download_outputs": [vp],
             "tamd_graph_output_device": [vp, ci, C.POINTER(vp), C.POINTER(C.c_size_t)],
             "tamd_graph_stream": [vp], "tamd_graph_time_launches": [vp, ci, C.POINTER(C.c_float)],
@@ -94,14 +95,14 @@ def device_count():
 class Graph:
     """A device graph loaded from tmfile bytes (same bytes the reference's `tengine:m` loader takes)."""
 
-    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True):
+    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False):
         L = lib()
         self._h = L.tamd_graph_load_tm2(tm_bytes, len(tm_bytes))
         if not self._h:
             raise TamdError("tamd_graph_load_tm2 failed: %s" % L.tamd_last_error().decode())
         if batch is not None:
             _check(L.tamd_graph_set_batch(self._h, batch), "set_batch")
-        opt = Options(b"HIP", gpu_index, 1 if use_hip_graph else 0, 0)
+        opt = Options(b"HIP", C.sizeof(Options), gpu_index, 1 if use_hip_graph else 0, 1 if profile else 0)
         _check(L.tamd_graph_prerun(self._h, C.byref(opt)), "prerun")
         self._in, self._out = [], []
         for i in range(L.tamd_graph_output_num(self._h)):
@@ -132,6 +133,24 @@ class Graph:
     def run_noreturn(self):
         """tamd_graph_run() without copying the outputs again (they are in the arrays handed to set_output)"""
         _check(lib().tamd_graph_run(self._h), "run")
+
+    def run_async(self, out_arrays=None):
+        """tamd_graph_run_async(): submit the current input; `out_arrays` (one per output) receive THIS run's results at wait()"""
+        if out_arrays is not None:
+            for i, a in enumerate(out_arrays):
+                _check(lib().tamd_graph_set_output(self._h, i, a.ctypes.data, a.nbytes), "set_output")
+        _check(lib().tamd_graph_run_async(self._h), "run_async")
+
+    def wait(self):
+        _check(lib().tamd_graph_wait(self._h), "wait")
+
+    def bind_default_outputs(self):
+        """point the graph's output buffers back at the arrays run() / download() return"""
+        for i, a in enumerate(self._out):
+            _check(lib().tamd_graph_set_output(self._h, i, a.ctypes.data, a.nbytes), "set_output")
+
+    def output_like(self):
+        return [np.zeros_like(o) for o in self._out]
 
     def output_num(self):
         return lib().tamd_graph_output_num(self._h)

@@ -61,7 +61,14 @@ struct IOBind {
     void* host_out = nullptr;
     size_t bytes = 0;
     void* stage = nullptr;           // device buffer in the reference's NCHW order
-    void* pinned = nullptr;          // pinned host bounce buffer
+    void* pinned = nullptr;          // pinned host bounce buffer (slot 0 of the asynchronous runs)
+    void* pinned2 = nullptr;         // slot 1: tamd_graph_run_async keeps two runs in flight
+};
+
+struct Inflight {                    // one tamd_graph_run_async() that tamd_graph_wait() has not collected yet
+    int slot = 0;
+    std::vector<void*> host_out;     // where the caller wants this run's outputs (set_output at submit time)
+    hipEvent_t done = nullptr;
 };
 
 struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
@@ -90,7 +97,20 @@ struct tamd_graph {
     void* zero_page = nullptr;          // 256 zero bytes (out-of-image taps of the LDS-DMA conv kernel)
     hipStream_t stream = nullptr;
     hipGraph_t hgraph = nullptr;
-    hipGraphExec_t hexec = nullptr;
+    hipGraphExec_t hexec = nullptr;     // == hexecs[0]
+    // several instances of the same captured graph, launched round-robin: back-to-back replays of ONE hipGraphExec_t
+    // leave a ~9 us hole between them on the device (the next launch is not queued behind the running one); with
+    // independent instances the next replay's packets are already in the queue (profiles/r02_*replay*)
+    hipGraphExec_t hexecs[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nexec = 0, next_exec = 0;
+    // host-to-host runs (tamd_graph_run / _run_async): the same launch list with the input upload in front and the output
+    // download behind it as copy KERNELS on the device-mapped pinned buffers of I/O slot 0 | 1, two instances per slot
+    hipGraph_t hgraph_io[2] = {nullptr, nullptr};
+    hipGraphExec_t hexec_io[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int next_io[2] = {0, 0};
+    std::vector<tamd::Inflight> inflight;      // FIFO, at most 2
+    hipEvent_t slot_done[2] = {nullptr, nullptr};
+    int next_slot = 0;
     tamd_options opt{};
     bool prepared = false;
     int gpu = 0;

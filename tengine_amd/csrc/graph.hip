@@ -9,6 +9,7 @@
 #include "graph.h"
 
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -96,7 +97,9 @@ static int infer_shapes(tamd_graph* g)
         HTensor& y = g->tensors[n.out[0]];
         switch (n.op) {
         case TAMD_OP_CONV: {   // convolution.c:35-145
+            if (n.in.size() < 2) { set_error("conv %s: no weight tensor", n.name.c_str()); return -1; }
             if (x.dims.size() != 4) { set_error("conv %s: input is not 4-D", n.name.c_str()); return -1; }
+            if (g->tensors[n.in[1]].dims.size() != 4) { set_error("conv %s: weight is not 4-D", n.name.c_str()); return -1; }
             tamd_conv_param& p = n.p.conv;
             if (p.kernel_w == 0) { p.kernel_w = 1; p.pad_w0 = p.pad_w1 = 0; }
             if (p.kernel_h == 0) p.kernel_h = 1;
@@ -125,6 +128,7 @@ static int infer_shapes(tamd_graph* g)
             break;
         }
         case TAMD_OP_FC: {
+            if (n.in.size() < 2 || g->tensors[n.in[1]].dims.empty() || x.dims.empty()) { set_error("fc %s: no weight tensor", n.name.c_str()); return -1; }
             int nout = n.p.fc.num_output ? n.p.fc.num_output : g->tensors[n.in[1]].dims[0];
             y.dims = {x.dims[0], nout};
             break;
@@ -169,6 +173,53 @@ static int infer_shapes(tamd_graph* g)
         default:
             set_error("infer_shape: unsupported op %d (%s)", n.op, n.name.c_str());
             return -1;
+        }
+    }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// validation: the model bytes may come off the wire (RCCL broadcast, tm2_reader.cc checks the container); the planners
+// index constant payloads by operator parameters, so parameters and payload sizes are reconciled ONCE here -- a
+// malformed graph fails prerun with a message instead of over-reading the host heap
+// ---------------------------------------------------------------------------------------------
+static int validate_graph(tamd_graph* g)
+{
+    auto bad = [&](const HNode& n, const char* what) { set_error("%s: %s", n.name.c_str(), what); return -1; };
+    for (auto& n : g->nodes) {
+        if (n.op != TAMD_OP_CONV && n.op != TAMD_OP_FC) continue;
+        const HTensor& x = g->tensors[n.in[0]];
+        HTensor& w = g->tensors[n.in[1]];
+        const HTensor& y = g->tensors[n.out[0]];
+        if (w.ttype != TAMD_TT_CONST) return bad(n, "weights must be a constant tensor");
+        const size_t es = (size_t)esize(w.dtype);
+        size_t want = 0;
+        int cout = 0;
+        if (n.op == TAMD_OP_CONV) {
+            const tamd_conv_param& p = n.p.conv;
+            cout = y.dims[1];
+            if (p.group < 1 || p.kernel_h < 1 || p.kernel_w < 1 || p.stride_h < 1 || p.stride_w < 1 || p.dilation_h < 1 || p.dilation_w < 1)
+                return bad(n, "kernel / stride / dilation / group must be positive");
+            if (x.dims[1] % p.group || cout % p.group) return bad(n, "group does not divide the channel counts");
+            if (y.dims[2] < 1 || y.dims[3] < 1) return bad(n, "empty output map");
+            want = (size_t)cout * (x.dims[1] / p.group) * p.kernel_h * p.kernel_w;
+            if (w.dims[0] != cout) return bad(n, "weight dims[0] != output channels");
+        } else {
+            cout = y.dims[1];
+            const size_t hidden = x.elems() / (size_t)std::max(1, x.dims[0]);
+            want = (size_t)cout * hidden;
+            // fc_ref.c:351-356 switches to a transposed read (need_trans) when weight dims[0] != num_output, but the operator's own
+            // infer_shape (operator/prototype/fc.c:43-97) sizes the output from weight dims[0] and insists on dims[1] == hidden,
+            // so a consistent model never gets there; such a node is refused here (the plugin leaves it to the CPU device)
+            if (w.dims.size() != 2 || w.dims[0] != cout || (size_t)w.dims[1] != hidden) return bad(n, "fc weight must be [num_output][hidden]");
+        }
+        if (w.elems() != want || w.data.size() != want * es) return bad(n, "weight size does not match the operator parameters");
+        if (!w.scales.empty() && w.scales.size() != 1 && w.scales.size() != (size_t)cout) return bad(n, "weight scale count is neither 1 nor the output channel count");
+        if (n.in.size() > 2) {
+            const HTensor& b = g->tensors[n.in[2]];
+            if (b.ttype != TAMD_TT_CONST || b.elems() < (size_t)cout || b.data.size() < (size_t)cout * esize(b.dtype) || esize(b.dtype) != 4)
+                return bad(n, "bias must be a constant of at least one 32-bit value per output channel");
         }
     }
     return 0;
@@ -328,10 +379,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         p.kernel_h = x.h; p.kernel_w = x.w; p.stride_h = p.stride_w = 1; p.dilation_h = p.dilation_w = 1;
         p.group = 1; p.activation = -1; p.input_channel = x.c; p.output_channel = y.c;
         mode = RQ_FC;
-        if ((size_t)w.elems() != (size_t)y.c * x.c * x.h * x.w || w.dims[0] != y.c) {
-            set_error("fc %s: transposed / mismatching weight layout is not supported", n.name.c_str());
-            return -1;
-        }
+        if ((size_t)w.elems() != (size_t)y.c * x.c * x.h * x.w) { set_error("fc %s: weight size mismatch", n.name.c_str()); return -1; }
     } else {
         p = n.p.conv;
         mode = conv_mode(p, x.n, x.c, y.c);
@@ -775,20 +823,31 @@ static int plan(tamd_graph* g)
     for (auto& t : g->tensors) if (t.ttype != TAMD_TT_CONST) nhwc_geom(t);
     // concat outputs own a buffer; their inputs become views when layouts allow (concat-by-offset:
     // concat/concat_kernel_ref_int8.c with in_scale == out_scale is a pure copy)
+    // An input that cannot be written in place (its scale differs -> the reference rescales, concat_kernel_ref_int8.c:70-80;
+    // channel count / offset not a multiple of 16; produced or also consumed by a kernel that does not address channel
+    // slices; a graph input) keeps its own buffer and is copied by concat_copy_i8 at the concat's position.
     std::vector<int> view_of(g->tensors.size(), -1), view_off(g->tensors.size(), 0);
+    auto producer_op = [&](int t) { for (auto& n : g->nodes) if (!n.out.empty() && n.out[0] == t) return n.op; return -1; };
+    auto slice_capable = [](int op) { return op == TAMD_OP_CONV || op == TAMD_OP_FC || op == TAMD_OP_POOL; };
     for (auto& n : g->nodes) {
         if (n.op != TAMD_OP_CONCAT) continue;
         HTensor& y = g->tensors[n.out[0]];
         int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
-        if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+        if (ax != 1 || y.dims.size() < 2) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+        if (y.scales.empty()) { set_error("concat %s: missing quant params", n.name.c_str()); return -1; }
         int off = 0;
         for (int i : n.in) {
             HTensor& x = g->tensors[i];
-            bool ok = (x.c % 16 == 0) && x.dtype == y.dtype && !x.scales.empty() && !y.scales.empty()
-                      && x.scales[0] == y.scales[0] && x.ttype == TAMD_TT_VAR && view_of[i] < 0;
-            if (!ok) { set_error("concat %s: input %s cannot be written in place (channels %% 16, scale)", n.name.c_str(), x.name.c_str()); return -1; }
-            view_of[i] = n.out[0];
-            view_off[i] = off;
+            if (x.dtype != y.dtype || x.scales.empty()) { set_error("concat %s: input %s: dtype / quant params", n.name.c_str(), x.name.c_str()); return -1; }
+            bool ok = (x.c % 16 == 0) && (off % 16 == 0) && (x.scales[0] == y.scales[0] || n.in.size() == 1) && x.ttype == TAMD_TT_VAR
+                      && view_of[i] < 0 && slice_capable(producer_op(i));
+            for (auto& c : g->nodes)            // every other reader must cope with a channel slice too
+                for (int ci : c.in)
+                    if (ci == i && &c != &n && !(slice_capable(c.op) || c.op == TAMD_OP_CONCAT)) ok = false;
+            int readers = 0;
+            for (int ci : n.in) readers += (ci == i);
+            if (readers > 1) ok = false;        // the same tensor twice: one copy per position
+            if (ok) { view_of[i] = n.out[0]; view_off[i] = off; }
             off += x.c;
         }
     }
@@ -797,8 +856,12 @@ static int plan(tamd_graph* g)
     for (auto& n : g->nodes) {
         if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) {
             HTensor& x = g->tensors[n.in[0]];
-            if (n.op == TAMD_OP_FLATTEN && x.h * x.w != 1) { set_error("flatten %s of a %dx%d map is not supported on the device", n.name.c_str(), x.h, x.w); return -1; }
+            // Flatten of an H x W map: the [N, C*H*W] result is the SAME NCHW element order; on the device it stays the NHWC
+            // buffer and keeps the 4-D geometry, so a following FC (== conv whose kernel covers the map) and the NCHW
+            // output conversion both see (c, h, w)
             alias_of[n.out[0]] = n.in[0];
+            HTensor& yy = g->tensors[n.out[0]];
+            yy.n = x.n; yy.c = x.c; yy.h = x.h; yy.w = x.w;
         }
     }
     // graph inputs: NCHW staging; first conv with <=4 channels reads NCHW directly
@@ -897,8 +960,28 @@ static int plan(tamd_graph* g)
         HNode& n = g->nodes[ni];
         if (fused[ni]) continue;
         switch (n.op) {
-        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_CONCAT:
+        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
             break;
+        case TAMD_OP_CONCAT: {
+            HTensor& y = g->tensors[n.out[0]];
+            int off = 0;
+            for (int i : n.in) {
+                HTensor& x = g->tensors[i];
+                if (!(view_of[i] == n.out[0] && view_off[i] == off && x.is_view)) {
+                    CatCopyArgs a{};
+                    a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr;
+                    a.pixels = (long)x.n * x.h * x.w; a.C = x.c; a.cs_in = x.cs; a.ldc = y.cs; a.c_off = y.c_off + off;
+                    volatile float rs = x.scales[0] / y.scales[0];      // concat_kernel_ref_int8.c:70: rescale = in_scale / out_scale
+                    a.rescale = rs;
+                    a.identity = n.in.size() == 1;                      // :47-57: a single input is copied as it is
+                    Step st; st.node = n.name; st.kernel = "concat_copy_i8"; st.bytes = 2.0 * a.pixels * x.c;
+                    st.fn = [a](hipStream_t s) { return launch_concat_copy_i8(a, s); };
+                    g->steps.push_back(st);
+                }
+                off += x.c;
+            }
+            break;
+        }
         case TAMD_OP_CONV: {
             int tmode = -1, prod = 0;
             const int tail = has_fuse[ni] ? -1 : find_pwdw_tail(g, ni, &tmode, &prod);
@@ -982,19 +1065,69 @@ static int plan(tamd_graph* g)
     return 0;
 }
 
-static int run_steps(tamd_graph* g, hipStream_t s)
+// io_slot < 0: the device-resident launch list; 0 | 1: with the upload of every input from / the download of every output to
+// the pinned buffers of that I/O slot as the first / last launches
+static int run_steps(tamd_graph* g, hipStream_t s, int io_slot = -1)
 {
+    if (io_slot >= 0)
+        for (auto& io : g->inputs) {
+            hipError_t e = launch_copy_bytes(io.stage, io_slot ? io.pinned2 : io.pinned, io.bytes, s);
+            if (e != hipSuccess) { set_error("input upload launch failed: %s", hipGetErrorString(e)); return -1; }
+        }
     for (auto* v : {&g->in_steps, &g->steps, &g->out_steps})
         for (auto& st : *v) {
             hipError_t e = st.fn(s);
             if (e != hipSuccess) { set_error("launch %s (%s) failed: %s", st.kernel.c_str(), st.node.c_str(), hipGetErrorString(e)); return -1; }
         }
+    if (io_slot >= 0)
+        for (auto& io : g->outputs) {
+            hipError_t e = launch_copy_bytes(io_slot ? io.pinned2 : io.pinned, io.stage, io.bytes, s);
+            if (e != hipSuccess) { set_error("output download launch failed: %s", hipGetErrorString(e)); return -1; }
+        }
     return 0;
+}
+
+// one launch of the host-to-host list of I/O slot `slot` on the graph's stream
+static int launch_io(tamd_graph* g, int slot)
+{
+    if (g->hexec_io[slot][0]) {
+        hipGraphExec_t e = g->hexec_io[slot][g->next_io[slot]];
+        g->next_io[slot] ^= 1;
+        HIPCHK(hipGraphLaunch(e, g->stream));
+        return 0;
+    }
+    return run_steps(g, g->stream, slot);
 }
 
 }  // namespace tamd
 
 using namespace tamd;
+
+// A graph lives on the device it was pre-run on; its entry points may be called from any host thread, whose current HIP
+// device is whatever that thread used last (events, eager launches and temporary allocations would land on the wrong
+// device otherwise).  hipSetDevice is a thread-local assignment when nothing changes.
+static int bind_device(tamd_graph* g)
+{
+    if (!g) { set_error("null graph"); return -1; }
+    HIPCHK(hipSetDevice(g->gpu));
+    return 0;
+}
+
+// the TG_DEBUG_TIME analogue (source/device/cpu/cpu_dump.c:607-697 prints per-node times at postrun): one table per device
+// graph on stderr when tamd_options.profile is set or TG_DEBUG_TIME=1 is in the environment, as the CPU device honours it
+static void dump_profile(tamd_graph* g)
+{
+    const int n = (int)g->steps.size();
+    if (n == 0) return;
+    std::vector<tamd_kernel_info> k(n);
+    if (tamd_graph_profile(g, 10, k.data(), n) < 0) return;
+    double tot = 0;
+    for (auto& e : k) tot += e.ms;
+    fprintf(stderr, "Tengine HIP device graph: %d launches, %.3f ms per run (sum of launches)\n", n, tot);
+    for (int i = 0; i < n; i++)
+        fprintf(stderr, "  %3d %-40s %-32s %8.2f us %6.2f%% %9.2f MMAC %9.1f KB\n", i, k[i].node, k[i].kernel, 1e3 * k[i].ms,
+                tot > 0 ? 100.0 * k[i].ms / tot : 0.0, k[i].macs / 1e6, k[i].bytes / 1e3);
+}
 
 // =============================================================================================
 // C ABI
@@ -1033,6 +1166,74 @@ int tamd_op_supported(int op, int dtype)
         return 1;
     default:
         return 0;
+    }
+}
+
+// What allocator.describe cannot say with an operator list alone: is THIS node, with these parameters and tensors, one the
+// planners compile?  The Tengine plugin asks before it claims a subgraph (hip_device.cc: subgraph_runs_on_device), so
+// anything else lands on the CPU device instead of failing pre_run.  Mirrors the planners' own conditions.
+int tamd_node_supported(const tamd_node_desc* n, const tamd_tensor_desc* in, int n_in, const tamd_tensor_desc* out, int n_out)
+{
+    if (!n || n_out < 1 || !out) return 0;
+    const int dt = out[0].dtype;
+    if (!tamd_op_supported(n->op, dt)) return 0;
+    for (int i = 0; i < n_out; i++)
+        if (out[i].dtype != dt || (dt != TAMD_DT_FP32 && out[i].quant_num != 1)) return 0;
+    for (int i = 0; i < n_in; i++)
+        if (in[i].ttype != TAMD_TT_CONST && (in[i].dtype != dt || (dt != TAMD_DT_FP32 && in[i].quant_num != 1))) return 0;
+    auto elems = [](const tamd_tensor_desc& t) { size_t e = 1; for (int i = 0; i < t.dim_num; i++) e *= (size_t)t.dims[i]; return e; };
+    switch (n->op) {
+    case TAMD_OP_CONV: {
+        if (n_in < 2 || !n->param || in[0].dim_num != 4 || in[1].dim_num != 4 || in[1].ttype != TAMD_TT_CONST) return 0;
+        const tamd_conv_param& p = *(const tamd_conv_param*)n->param;
+        const int cin = in[0].dims[1], cout = in[1].dims[0];
+        const int kh = p.kernel_h ? p.kernel_h : 1, kw = p.kernel_w ? p.kernel_w : 1;
+        if (p.group < 1 || cin % p.group || cout % p.group) return 0;
+        if (elems(in[1]) != (size_t)cout * (cin / p.group) * kh * kw) return 0;
+        if (in[1].quant_num != 0 && in[1].quant_num != 1 && in[1].quant_num != cout) return 0;
+        if (dt != TAMD_DT_FP32 && in[1].quant_num == 0) return 0;
+        if (dt == TAMD_DT_UINT8 && in[1].quant_num != 1) return 0;                 // per-tensor weights (conv_kernel_x86.c:76-79)
+        if (dt == TAMD_DT_INT8 && p.group == 1 && kh * kw > 128 && cin > 4) return 0;  // tap table of the implicit GEMM
+        if (n_in > 2 && (in[2].ttype != TAMD_TT_CONST || elems(in[2]) < (size_t)cout)) return 0;
+        return 1;
+    }
+    case TAMD_OP_FC: {
+        if (n_in < 2 || in[1].ttype != TAMD_TT_CONST || in[0].dim_num < 2) return 0;
+        const size_t hidden = elems(in[0]) / (size_t)(in[0].dims[0] > 0 ? in[0].dims[0] : 1);
+        const int nout = out[0].dim_num > 1 ? out[0].dims[1] : 0;
+        if (nout < 1 || in[1].dim_num != 2 || in[1].dims[0] != nout || (size_t)in[1].dims[1] != hidden) return 0;   // [num_output][hidden] only (fc.c:43-97)
+        if (n->param && ((const tamd_fc_param*)n->param)->num_output && ((const tamd_fc_param*)n->param)->num_output != nout) return 0;
+        if (dt == TAMD_DT_UINT8 && hidden * 4 > 60000) return 0;                    // fc_u8 keeps the input row in LDS
+        return 1;
+    }
+    case TAMD_OP_ELTWISE: {
+        const int ty = n->param ? ((const tamd_eltwise_param*)n->param)->type : -1;
+        if (n_in != 2 || (ty != 0 && ty != 2 && ty != 4 && ty != 6)) return 0;
+        if (in[0].dim_num != in[1].dim_num) return 0;
+        for (int i = 0; i < in[0].dim_num; i++) if (in[0].dims[i] != in[1].dims[i]) return 0;
+        return in[0].ttype != TAMD_TT_CONST && in[1].ttype != TAMD_TT_CONST;
+    }
+    case TAMD_OP_CONCAT: {
+        int ax = n->param ? ((const tamd_concat_param*)n->param)->axis : 1;
+        if (ax < 0) ax += out[0].dim_num;
+        return ax == 1 && out[0].dim_num >= 2;
+    }
+    case TAMD_OP_PERMUTE: {
+        if (!n->param || out[0].dim_num != 4) return 0;
+        const int* o = ((const tamd_permute_param*)n->param)->order;
+        return o[0] == 0 && o[1] == 2 && o[2] == 3 && o[3] == 1;
+    }
+    case TAMD_OP_UPSAMPLE: {
+        const float sc = n->param ? ((const tamd_upsample_param*)n->param)->scale : 0.f;
+        return sc >= 1.f && sc == (float)(int)sc;
+    }
+    case TAMD_OP_POOL: {
+        if (!n->param || in[0].dim_num != 4) return 0;
+        const int m = ((const tamd_pool_param*)n->param)->pool_method;
+        return m == 0 || m == 1;
+    }
+    default:
+        return 1;
     }
 }
 
@@ -1117,19 +1318,27 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
     if (g->prepared) return 0;
     std::lock_guard<std::mutex> lk(g_capture_mutex);
     tamd_options o{};
-    o.dev_name = "HIP"; o.gpu_index = 0; o.use_hip_graph = 1; o.profile = 0;
-    if (opt) o = *opt;     // options may be NULL (scheduler.c:49-59)
+    o.dev_name = "HIP"; o.size = (int)sizeof(tamd_options); o.gpu_index = 0; o.use_hip_graph = 1; o.profile = 0;
+    if (opt) {             // options may be NULL (scheduler.c:49-59); only the fields the caller's blob really holds are read
+        const int have = opt->size;
+        if (have >= (int)(offsetof(tamd_options, gpu_index) + sizeof(int))) o.gpu_index = opt->gpu_index;
+        if (have >= (int)(offsetof(tamd_options, use_hip_graph) + sizeof(int))) o.use_hip_graph = opt->use_hip_graph;
+        if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) o.profile = opt->profile;
+    }
+    if (const char* dt = getenv("TG_DEBUG_TIME")) { if (atoi(dt) == 1) o.profile = 1; }     // cpu_define.h:41-43
     g->opt = o;
+    if (infer_shapes(g) || validate_graph(g)) return -1;       // a malformed graph is refused before the device is touched
     if (tamd_init(o.gpu_index)) return -1;
     g->gpu = o.gpu_index;
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    if (infer_shapes(g)) return -1;
     // one quantisation scheme per device graph (the reference's splitter hands over homogeneous subgraphs)
     bool any_u8 = false, any_f32 = false, any_i8 = false;
     for (auto& t : g->tensors)
         if (t.ttype != TAMD_TT_CONST) (t.dtype == TAMD_DT_UINT8 ? any_u8 : t.dtype == TAMD_DT_FP32 ? any_f32 : any_i8) = true;
     if ((int)any_u8 + (int)any_f32 + (int)any_i8 > 1) { set_error("mixed int8 / uint8 / fp32 activations in one device graph"); return -1; }
     if (any_u8 ? plan_u8(g) : any_f32 ? plan_f32(g) : plan(g)) return -1;
+    for (auto* v : {&g->inputs, &g->outputs})
+        for (auto& io : *v) HIPCHK(hipHostMalloc(&io.pinned2, std::max<size_t>(io.bytes, 16), hipHostMallocDefault));
     HIPCHK(hipDeviceSynchronize());
     if (o.use_hip_graph) {
         // one warm eager pass (module load), then capture compute + output layout launches
@@ -1140,7 +1349,18 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         hipError_t e = hipStreamEndCapture(g->stream, &g->hgraph);
         if (rc) return -1;
         HIPCHK(e);
-        HIPCHK(hipGraphInstantiate(&g->hexec, g->hgraph, nullptr, nullptr, 0));
+        const char* ne = getenv("TAMD_GRAPH_EXECS");
+        g->nexec = ne ? std::max(1, std::min(4, atoi(ne))) : 3;
+        for (int i = 0; i < g->nexec; i++) HIPCHK(hipGraphInstantiate(&g->hexecs[i], g->hgraph, nullptr, nullptr, 0));
+        g->hexec = g->hexecs[0];
+        for (int slot = 0; slot < 2; slot++) {      // the host-to-host variants (upload / download as launches)
+            HIPCHK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+            rc = run_steps(g, g->stream, slot);
+            e = hipStreamEndCapture(g->stream, &g->hgraph_io[slot]);
+            if (rc) return -1;
+            HIPCHK(e);
+            for (int i = 0; i < 2; i++) HIPCHK(hipGraphInstantiate(&g->hexec_io[slot][i], g->hgraph_io[slot], nullptr, nullptr, 0));
+        }
     }
     g->prepared = true;
     return 0;
@@ -1189,6 +1409,7 @@ int tamd_graph_set_output(tamd_graph* g, int idx, void* host, size_t bytes)
 
 int tamd_graph_upload_inputs(tamd_graph* g)
 {
+    if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     for (auto& io : g->inputs) {
         if (!io.host_in) { set_error("input buffer not set"); return -1; }
@@ -1200,15 +1421,22 @@ int tamd_graph_upload_inputs(tamd_graph* g)
 
 int tamd_graph_launch(tamd_graph* g)
 {
+    if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
-    if (g->hexec) { HIPCHK(hipGraphLaunch(g->hexec, g->stream)); return 0; }
+    if (g->hexec) {
+        hipGraphExec_t e = g->hexecs[g->next_exec];
+        g->next_exec = (g->next_exec + 1) % g->nexec;
+        HIPCHK(hipGraphLaunch(e, g->stream));
+        return 0;
+    }
     return run_steps(g, g->stream);
 }
 
-int tamd_graph_sync(tamd_graph* g) { HIPCHK(hipStreamSynchronize(g->stream)); return 0; }
+int tamd_graph_sync(tamd_graph* g) { if (bind_device(g)) return -1; HIPCHK(hipStreamSynchronize(g->stream)); return 0; }
 
 int tamd_graph_download_outputs(tamd_graph* g)
 {
+    if (bind_device(g)) return -1;
     for (auto& io : g->outputs) HIPCHK(hipMemcpyAsync(io.pinned, io.stage, io.bytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     for (auto& io : g->outputs)
@@ -1218,10 +1446,60 @@ int tamd_graph_download_outputs(tamd_graph* g)
 
 int tamd_graph_run(tamd_graph* g)
 {
-    if (tamd_graph_upload_inputs(g)) return -1;
-    if (tamd_graph_launch(g)) return -1;
-    return tamd_graph_download_outputs(g);
+    if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
+    if (!g->inflight.empty()) { set_error("tamd_graph_run while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
+    if (bind_device(g)) return -1;
+    for (auto& io : g->inputs) {
+        if (!io.host_in) { set_error("input buffer not set"); return -1; }
+        memcpy(io.pinned, io.host_in, io.bytes);
+    }
+    if (launch_io(g, 0)) return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    for (auto& io : g->outputs)
+        if (io.host_out) memcpy(io.host_out, io.pinned, io.bytes);
+    return 0;
 }
+
+// ---- asynchronous runs: interface.async_run / async_wait of struct interface (source/device/device.h:60-63), which the
+// reference's scheduler never reaches (run_graph(graph, 0) is rejected, scheduler.c:75-79).  Two runs may be in flight:
+// while the device works on run k the host already stages run k+1 (its own pinned buffers), so launch and completion
+// latencies overlap with device work instead of adding to every image.  Everything stays on the graph's one in-order
+// stream: run k+1's H2D queues behind run k's D2H, results cannot mix.
+int tamd_graph_run_async(tamd_graph* g)
+{
+    if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
+    if (bind_device(g)) return -1;
+    if (g->inflight.size() >= 2) { set_error("two runs are already in flight: call tamd_graph_wait first"); return -1; }
+    const int slot = g->next_slot;
+    if (!g->slot_done[slot]) HIPCHK(hipEventCreateWithFlags(&g->slot_done[slot], hipEventDisableTiming));
+    for (auto& io : g->inputs) {
+        if (!io.host_in) { set_error("input buffer not set"); return -1; }
+        memcpy(slot ? io.pinned2 : io.pinned, io.host_in, io.bytes);
+    }
+    if (launch_io(g, slot)) return -1;
+    Inflight f;
+    f.slot = slot; f.done = g->slot_done[slot];
+    for (auto& io : g->outputs) f.host_out.push_back(io.host_out);
+    HIPCHK(hipEventRecord(f.done, g->stream));
+    g->inflight.push_back(f);
+    g->next_slot ^= 1;
+    return 0;
+}
+
+// blocks until the OLDEST run in flight is complete and its outputs are in the buffers that were set when it was submitted
+int tamd_graph_wait(tamd_graph* g)
+{
+    if (!g || g->inflight.empty()) { set_error("tamd_graph_wait: no run in flight"); return -1; }
+    if (bind_device(g)) return -1;
+    const Inflight f = g->inflight.front();
+    HIPCHK(hipEventSynchronize(f.done));
+    for (size_t i = 0; i < g->outputs.size(); i++)
+        if (f.host_out[i]) memcpy(f.host_out[i], f.slot ? g->outputs[i].pinned2 : g->outputs[i].pinned, g->outputs[i].bytes);
+    g->inflight.erase(g->inflight.begin());
+    return 0;
+}
+
+int tamd_graph_inflight(const tamd_graph* g) { return g ? (int)g->inflight.size() : 0; }
 
 int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 {
@@ -1235,6 +1513,7 @@ void* tamd_graph_stream(tamd_graph* g) { return (void*)g->stream; }
 
 int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms)
 {
+    if (bind_device(g)) return -1;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -1253,6 +1532,7 @@ int tamd_graph_kernel_num(const tamd_graph* g) { return (int)g->steps.size(); }
 
 int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out)
 {
+    if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     int n = std::min((int)g->steps.size(), max_out);
     std::vector<hipEvent_t> ev(2 * g->steps.size());
@@ -1301,6 +1581,7 @@ int tamd_graph_tensor_desc(const tamd_graph* g, int idx, int* dims8, int* dtype)
 int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
 {
     if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
+    if (bind_device(g)) return -1;
     HTensor& t = g->tensors[idx];
     if (t.ttype == TAMD_TT_CONST) { memcpy(host, t.data.data(), std::min(bytes, t.data.size())); return 0; }
     if ((size_t)idx < g->fused_away.size() && g->fused_away[idx]) {
@@ -1337,13 +1618,20 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
 void tamd_graph_destroy(tamd_graph* g)
 {
     if (!g) return;
+    if (g->prepared) (void)bind_device(g);
+    if (g->prepared && g->opt.profile) dump_profile(g);
     if (g->stream) hipStreamSynchronize(g->stream);
     std::lock_guard<std::mutex> lk(g_capture_mutex);      // hipFree is device-synchronous: not while another thread captures
-    if (g->hexec) hipGraphExecDestroy(g->hexec);
+    for (int i = 0; i < g->nexec; i++) if (g->hexecs[i]) hipGraphExecDestroy(g->hexecs[i]);
+    for (int slot = 0; slot < 2; slot++) {
+        for (int i = 0; i < 2; i++) if (g->hexec_io[slot][i]) hipGraphExecDestroy(g->hexec_io[slot][i]);
+        if (g->hgraph_io[slot]) hipGraphDestroy(g->hgraph_io[slot]);
+    }
     if (g->hgraph) hipGraphDestroy(g->hgraph);
     for (void* p : g->dev_allocs) hipFree(p);
-    for (auto& io : g->inputs) if (io.pinned) hipHostFree(io.pinned);
-    for (auto& io : g->outputs) if (io.pinned) hipHostFree(io.pinned);
+    for (auto* v : {&g->inputs, &g->outputs})
+        for (auto& io : *v) { if (io.pinned) hipHostFree(io.pinned); if (io.pinned2) hipHostFree(io.pinned2); }
+    for (auto& e : g->slot_done) if (e) hipEventDestroy(e);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
 }

@@ -130,6 +130,14 @@ struct ReluArgs {
     const int8_t* x; int8_t* y; size_t count; float slope, in_scale, out_scale;
 };
 
+struct CatCopyArgs {       // one concat input that cannot be written in place: (re-scaling) copy into its channel slice
+    const int8_t* x; int8_t* y;
+    long pixels;
+    int C, cs_in, ldc, c_off;
+    float rescale;         // in_scale / out_scale
+    int identity;          // plain byte copy (single-input concat)
+};
+
 struct LayoutArgs {        // NCHW <-> NHWC(cs) int8 / generic element size
     const void* src; void* dst; int N, C, H, W, cs; int elem;
 };
@@ -157,6 +165,8 @@ int pwdw_steps(int nsteps);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);
 hipError_t launch_relu(const ReluArgs& a, hipStream_t s);
+hipError_t launch_concat_copy_i8(const CatCopyArgs& a, hipStream_t s);
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // 16-byte aligned buffers
 hipError_t launch_nchw_to_nhwc(const LayoutArgs& a, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);
 

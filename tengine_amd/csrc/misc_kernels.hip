@@ -176,6 +176,51 @@ hipError_t launch_eltwise(const EltArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- host <-> device staging as ordinary launches: the pinned host buffers are device-mapped, so a run's input upload and
+// output download are two more nodes of its hipGraph instead of copy-engine commands the compute queue has to hand over to
+// and back from (each hand-over is a signal round trip of ~10 us; a batch-1 run has two of them)
+__global__ __launch_bounds__(256) void copy_bytes_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, size_t bytes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i == 0)
+        for (size_t b = n16 * 16; b < bytes; b++) reinterpret_cast<uint8_t*>(dst)[b] = reinterpret_cast<const uint8_t*>(src)[b];
+}
+
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)((n16 + 255) / 256 + (n16 == 0))), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16, bytes);
+    return hipGetLastError();
+}
+
+// ---- concat input that is not written in place: concat/concat_kernel_ref_int8.c:60-95 (the same text at every rank/axis)
+// rescale = in_scale / out_scale ; q = roundf((float)x * rescale) ; q > 127 -> 127 ; q < -127 -> **+127** (the reference's
+// lower clamp assigns the wrong sign at all ten sites, :83-84 ...; identical results carry the defect along, as the
+// oracle's orc_requant_copy_int8 does).  One thread per output byte: these copies are launch-latency sized.
+__global__ __launch_bounds__(256) void concat_copy_i8_kernel(CatCopyArgs a)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.pixels * a.C) return;
+    const long pix = idx / a.C;
+    const int c = (int)(idx - pix * a.C);
+    const int x = a.x[pix * a.cs_in + c];
+    int q = x;
+    if (!a.identity) {
+        q = (int)roundf(__fmul_rn((float)x, a.rescale));
+        if (q > 127) q = 127;
+        else if (q < -127) q = 127;
+    }
+    a.y[pix * a.ldc + a.c_off + c] = (int8_t)q;
+}
+
+hipError_t launch_concat_copy_i8(const CatCopyArgs& a, hipStream_t s)
+{
+    const long total = a.pixels * a.C;
+    hipLaunchKernelGGL(concat_copy_i8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- relu / leaky relu: relu/relu_kernel_ref_int8.c:40-94 -------------------------------------------
 __global__ __launch_bounds__(256) void relu_i8_kernel(ReluArgs a)
 {

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <map>
@@ -230,10 +231,16 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
     tamd_graph_set_outputs(hs->g, (int)go.size(), go.data());
 
     tamd_options opt;
-    opt.dev_name = HIP_DEV_NAME; opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
-    if (options) {   // options may be NULL (scheduler.c:49-59); else the blob of set_context_device
+    opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    if (options) {   // options may be NULL (scheduler.c:49-59); else the blob of set_context_device, whose byte count the core
+                     // does not pass on (c_api.c:183-210): it carries its own `size`, and only the fields inside it are read
         const tamd_options* o = (const tamd_options*)options;
-        if (o->dev_name && 0 == strcmp(o->dev_name, HIP_DEV_NAME)) opt = *o;
+        if (o->dev_name && 0 == strcmp(o->dev_name, HIP_DEV_NAME)) {
+            const int have = o->size;
+            if (have >= (int)(offsetof(tamd_options, gpu_index) + sizeof(int))) opt.gpu_index = o->gpu_index;
+            if (have >= (int)(offsetof(tamd_options, use_hip_graph) + sizeof(int))) opt.use_hip_graph = o->use_hip_graph;
+            if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) opt.profile = o->profile;
+        }
     }
     const char* env = getenv("TG_HIP_DEVICE");
     if (env) opt.gpu_index = atoi(env);
@@ -278,6 +285,46 @@ int hip_dev_run(struct device* dev, struct subgraph* subgraph)
     }
     if (tamd_graph_run(hs->g) != 0) {
         TLOG_ERR("Tengine HIP: run failed: %s\n", tamd_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+// interface.async_run / async_wait (device.h:60-63).  The reference's scheduler never calls them (scheduler.c:75-79 rejects
+// run_graph(graph, 0)); a pipelining scheduler can keep two runs of a subgraph in flight with this pair.
+static int bind_io(HipSubgraph* hs, struct graph* ir)
+{
+    for (size_t i = 0; i < hs->in_ir.size(); i++) {
+        struct tensor* t = get_ir_graph_tensor(ir, hs->in_ir[i]);
+        if (!t->data) { TLOG_ERR("Tengine HIP: input tensor %s has no buffer\n", t->name); return -1; }
+        if (tamd_graph_set_input(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) return -1;
+    }
+    for (size_t i = 0; i < hs->out_ir.size(); i++) {
+        struct tensor* t = get_ir_graph_tensor(ir, hs->out_ir[i]);
+        if (tamd_graph_set_output(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) return -1;
+    }
+    return 0;
+}
+
+int hip_dev_async_run(struct device* dev, struct subgraph* subgraph)
+{
+    (void)dev;
+    HipSubgraph* hs = (HipSubgraph*)subgraph->device_graph;
+    if (!hs || bind_io(hs, subgraph->graph) != 0 || tamd_graph_run_async(hs->g) != 0) {
+        TLOG_ERR("Tengine HIP: async_run failed: %s\n", tamd_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+int hip_dev_async_wait(struct device* dev, struct subgraph* subgraph, int try_wait)
+{
+    (void)dev;
+    HipSubgraph* hs = (HipSubgraph*)subgraph->device_graph;
+    if (!hs) return -1;
+    if (try_wait && tamd_graph_inflight(hs->g) == 0) return 0;
+    if (tamd_graph_wait(hs->g) != 0) {
+        TLOG_ERR("Tengine HIP: async_wait failed: %s\n", tamd_last_error());
         return -1;
     }
     return 0;
@@ -352,7 +399,71 @@ int hip_release(struct device* device, struct subgraph* sub_graph)
     return device ? 0 : -1;
 }
 
-// everything this round's kernels cannot express goes back to the CPU device instead of failing at pre_run
+// descriptor of an IR tensor (no payload: tamd_node_supported looks at shapes and quantisation only)
+static tamd_tensor_desc describe_tensor(struct tensor* t)
+{
+    tamd_tensor_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = t->data_type; d.ttype = t->tensor_type; d.dim_num = t->dim_num;
+    for (int i = 0; i < t->dim_num && i < 8; i++) d.dims[i] = t->dims[i];
+    d.quant_num = t->quant_param_num;
+    d.name = t->name;
+    return d;
+}
+
+// parameters the C ABI takes, from the IR node (the same translation pre_run does)
+static bool node_supported(struct graph* ir, struct node* n)
+{
+    const int op = map_op(n->op.type);
+    if (op < 0) return false;
+    if (op == TAMD_OP_INPUT || op == TAMD_OP_CONST) return true;
+    std::vector<tamd_tensor_desc> in, out;
+    for (int k = 0; k < n->input_num; k++) in.push_back(describe_tensor(get_ir_graph_tensor(ir, n->input_tensors[k])));
+    for (int k = 0; k < n->output_num; k++) out.push_back(describe_tensor(get_ir_graph_tensor(ir, n->output_tensors[k])));
+    tamd_conv_param cp; tamd_pool_param pp; tamd_fc_param fp; tamd_eltwise_param ep; tamd_concat_param ccp; tamd_upsample_param up;
+    tamd_permute_param pmp;
+    const void* param = nullptr;
+    switch (op) {
+    case TAMD_OP_CONV: {
+        const struct conv_param* p = (const struct conv_param*)n->op.param_mem;
+        cp = {p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0, p->pad_h1, p->pad_w0, p->pad_w1,
+              p->dilation_h, p->dilation_w, p->input_channel, p->output_channel, p->group, p->activation};
+        param = &cp;
+        break;
+    }
+    case TAMD_OP_POOL: {
+        const struct pool_param* p = (const struct pool_param*)n->op.param_mem;
+        pp = {p->pool_method, p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0_org, p->pad_h1_org, p->pad_w0_org,
+              p->pad_w1_org, p->global, p->caffe_flavor};
+        param = &pp;
+        break;
+    }
+    case TAMD_OP_FC: fp.num_output = ((const struct fc_param*)n->op.param_mem)->num_output; param = &fp; break;
+    case TAMD_OP_ELTWISE: {
+        const struct eltwise_param* p = (const struct eltwise_param*)n->op.param_mem;
+        ep = {p->type, p->caffe_flavor, p->shift, p->power, p->scale};
+        param = &ep;
+        break;
+    }
+    case TAMD_OP_CONCAT: ccp.axis = ((const struct concat_param*)n->op.param_mem)->axis; param = &ccp; break;
+    case TAMD_OP_UPSAMPLE: up.scale = ((const struct upsample_param*)n->op.param_mem)->scale; param = &up; break;
+    case TAMD_OP_PERMUTE: {
+        const struct permute_param* p = (const struct permute_param*)n->op.param_mem;
+        pmp = {{p->order0, p->order1, p->order2, p->order3}};
+        param = &pmp;
+        break;
+    }
+    default: break;
+    }
+    std::vector<int> ii(in.size()), oi(out.size());
+    tamd_node_desc nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.op = op; nd.input_num = (int)in.size(); nd.inputs = ii.data(); nd.output_num = (int)out.size(); nd.outputs = oi.data();
+    nd.param = param; nd.name = n->name;
+    return tamd_node_supported(&nd, in.data(), (int)in.size(), out.data(), (int)out.size()) == 1;
+}
+
+// everything the kernels cannot express goes back to the CPU device instead of failing at pre_run
 bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
 {
     for (int j = 0; j < sg->node_num; j++) {
@@ -366,6 +477,7 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
             if (t->tensor_type != TENSOR_TYPE_CONST && !tamd_op_supported(map_op(n->op.type), t->data_type)) return false;
             if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_FP32 && t->quant_param_num != 1) return false;
         }
+        if (!node_supported(ir, n)) return false;       // this node's parameters / tensor shapes, asked of the backend itself
         if (n->op.type == OP_ELTWISE) {
             int ty = ((const struct eltwise_param*)n->op.param_mem)->type;
             if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
@@ -429,7 +541,7 @@ int hip_split_graph(struct graph* ir_graph)
 }
 
 struct interface hip_interface = {
-    hip_dev_init, hip_dev_prerun, hip_dev_run, hip_dev_postrun, nullptr, nullptr, hip_release_graph, hip_dev_release,
+    hip_dev_init, hip_dev_prerun, hip_dev_run, hip_dev_postrun, hip_dev_async_run, hip_dev_async_wait, hip_release_graph, hip_dev_release,
 };
 struct allocator hip_allocator = {hip_describe, hip_evaluation, hip_allocate, hip_release};
 struct optimizer hip_optimizer = {hip_split_graph, nullptr};

@@ -317,3 +317,4 @@ def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", p
                         pad_h1=p, pad_w1=p)
     g.output_nodes = [ni]
     return g, rng.integers(-127, 128, size=g.tensors[x].dims).astype(np.int8)
+

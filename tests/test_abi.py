@@ -49,3 +49,91 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cc", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "tg_oracle" not in src, f
+
+
+# ---- host logic that needs no GPU: graph validation and the per-node support query -------------------------------------
+def _prerun_error(g):
+    from tengine_amd import capi, tm2
+    with pytest.raises(capi.TamdError) as e:
+        capi.Graph(tm2.write_tm2(g))
+    return str(e.value)
+
+
+def test_malformed_graphs_are_refused_at_prerun_not_over_read():
+    """operator parameters that disagree with the constant payloads (a corrupt / hostile tmfile) fail prerun with a
+    message naming the node -- before the planner indexes the payloads, and before the device is even touched"""
+    from helpers import conv_graph, fc_graph
+    g, _ = conv_graph(1, 1, 16, 8, 8, 32, 3, 1, 1)
+    g.nodes[-1].params["group"] = 0
+    assert "group" in _prerun_error(g)
+    g, _ = conv_graph(1, 1, 16, 8, 8, 32, 3, 1, 1)
+    g.nodes[-1].params["group"] = 3                           # does not divide 16 / 32
+    assert "group" in _prerun_error(g)
+    g, _ = conv_graph(1, 1, 16, 8, 8, 32, 3, 1, 1)
+    g.nodes[-1].params["kernel_h"] = 5                         # weights are 3x3
+    assert "weight size" in _prerun_error(g)
+    g, _ = conv_graph(1, 1, 16, 8, 8, 32, 3, 1, 1)
+    b = [t for t in g.tensors if t.name == "b"][0]
+    b.data = b.data[:7]                                        # bias shorter than the output channels
+    b.dims = [7]
+    assert "bias" in _prerun_error(g)
+    g, _ = conv_graph(1, 1, 16, 8, 8, 32, 3, 1, 1)
+    g.nodes[-1].inputs = g.nodes[-1].inputs[:1]                # no weight tensor at all
+    assert "weight" in _prerun_error(g)
+    g, _ = fc_graph(1, 2, (24,), 10)
+    w = [t for t in g.tensors if t.name == "w"][0]
+    w.data = w.data.T.copy()                                   # [hidden][out]: the reference's own infer_shape refuses it too
+    w.dims = [24, 10]
+    assert "fc weight" in _prerun_error(g) or "weight" in _prerun_error(g)
+
+
+def test_node_supported_query():
+    """tamd_node_supported: what the Tengine plugin asks before it claims a subgraph (no payloads, no device)"""
+    import ctypes as C
+    from tengine_amd import capi
+    L = capi.lib()
+
+    class T(C.Structure):          # tamd_tensor_desc
+        _fields_ = [("dtype", C.c_int), ("ttype", C.c_int), ("dim_num", C.c_int), ("dims", C.c_int * 8), ("data", C.c_void_p),
+                    ("quant_num", C.c_int), ("scales", C.c_void_p), ("zero_points", C.c_void_p), ("name", C.c_char_p)]
+
+    class N(C.Structure):          # tamd_node_desc
+        _fields_ = [("op", C.c_int), ("input_num", C.c_int), ("inputs", C.c_void_p), ("output_num", C.c_int), ("outputs", C.c_void_p),
+                    ("param", C.c_void_p), ("name", C.c_char_p)]
+
+    def t(dtype, ttype, dims, q=1):
+        d = T()
+        d.dtype, d.ttype, d.dim_num, d.quant_num = dtype, ttype, len(dims), q
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        return d
+
+    def ask(op, ins, outs, param=None):
+        n = N()
+        n.op, n.input_num, n.output_num = op, len(ins), len(outs)
+        n.param = C.cast(C.pointer(param), C.c_void_p) if param is not None else None
+        return L.tamd_node_supported(C.byref(n), (T * len(ins))(*ins), len(ins), (T * len(outs))(*outs), len(outs))
+
+    I8, U8, F32, VAR, CONST = 2, 3, 0, 1, 2
+    conv = (C.c_int * 14)(3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 16, 32, 1, 0)          # tamd_conv_param
+    x, y = t(I8, VAR, [1, 16, 8, 8]), t(I8, VAR, [1, 32, 8, 8])
+    assert ask(2, [x, t(I8, CONST, [32, 16, 3, 3], 32)], [y], conv) == 1
+    assert ask(2, [x, t(I8, CONST, [32, 16, 5, 5], 32)], [y], conv) == 0       # weights disagree with the kernel size
+    assert ask(2, [x, t(I8, CONST, [32, 16, 3, 3], 7)], [y], conv) == 0        # 7 scales for 32 channels
+    grp = (C.c_int * 14)(3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 16, 32, 3, 0)
+    assert ask(2, [x, t(I8, CONST, [32, 16, 3, 3], 32)], [y], grp) == 0        # group 3 does not divide the channels
+    big = (C.c_int * 14)(12, 12, 1, 1, 0, 0, 0, 0, 1, 1, 16, 32, 1, 0)
+    assert ask(2, [t(I8, VAR, [1, 16, 20, 20]), t(I8, CONST, [32, 16, 12, 12], 32)], [t(I8, VAR, [1, 32, 9, 9])], big) == 0   # 144 taps
+    assert ask(2, [t(U8, VAR, [1, 16, 8, 8]), t(U8, CONST, [32, 16, 3, 3], 32)], [t(U8, VAR, [1, 32, 8, 8])], conv) == 0     # uint8: per-tensor weights only
+    fc = (C.c_int * 1)(10)
+    assert ask(3, [t(I8, VAR, [2, 24]), t(I8, CONST, [10, 24], 10)], [t(I8, VAR, [2, 10])], fc) == 1
+    assert ask(3, [t(I8, VAR, [2, 24]), t(I8, CONST, [24, 10], 10)], [t(I8, VAR, [2, 10])], fc) == 0      # transposed layout
+    cat0 = (C.c_int * 1)(0)
+    cat1 = (C.c_int * 1)(1)
+    a, b = t(I8, VAR, [1, 8, 4, 4]), t(I8, VAR, [1, 24, 4, 4])
+    assert ask(7, [a, b], [t(I8, VAR, [1, 32, 4, 4])], cat1) == 1              # any channel counts, any scales: rescaling copy
+    assert ask(7, [a, a], [t(I8, VAR, [2, 8, 4, 4])], cat0) == 0               # batch axis
+    elt = (C.c_int * 5)(9, 0, 0, 0, 0)                                          # an eltwise type the device does not run
+    assert ask(6, [a, a], [a], elt) == 0
+    assert ask(12, [a], [a]) == 0                                               # softmax int8 stays on the CPU
+    assert ask(12, [t(F32, VAR, [1, 8], 0)], [t(F32, VAR, [1, 8], 0)]) == 1

@@ -30,13 +30,13 @@ def _load_plugin(ref):
 
 
 class HipOpt(C.Structure):   # == tamd_options; first field dev_name by the reference's convention
-    _fields_ = [("dev_name", C.c_char_p), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
+    _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
 
 
 def test_plugin_registers_and_is_selectable(ref):
     L = _load_plugin(ref)
     ctx = L.create_context(b"t", 1)
-    opt = HipOpt(b"HIP", 0, 1, 0)
+    opt = HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0)
     assert L.set_context_device(ctx, b"HIP", C.byref(opt), C.sizeof(opt)) == 0
     assert L.set_context_device(ctx, b"NOPE", None, 0) != 0
 
@@ -46,7 +46,7 @@ def test_plugin_without_gpu_fails_loudly_not_silently(ref):
         pytest.skip("GPU present")
     _load_plugin(ref)
     g, x = conv_graph(3, 1, 16, 8, 8, 16, 1)
-    rg = ref.RefGraph(tm2.write_tm2(g), ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg = ref.RefGraph(tm2.write_tm2(g), ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
     rg.set_input(x)
     with pytest.raises(RuntimeError):
         rg.prerun()
@@ -65,7 +65,7 @@ def test_hip_device_equals_reference_cpu_device(ref, case):
         x = models.synth_input(g, 7)
     b = tm2.write_tm2(g)
     want = ref.run_model(b, x, ref.MODE_INT8, 4)
-    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
     rg.set_input(x)
     rg.run()
     got = rg.outputs()
@@ -87,7 +87,7 @@ def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
     g.output_nodes = [ni]
     b = tm2.write_tm2(g)
     want = ref.run_model(b, x, ref.MODE_INT8, 1)[0]
-    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
     rg.set_input(x)
     rg.run()
     got = rg.outputs()[0]
@@ -104,7 +104,7 @@ def test_hip_device_fp32_matches_reference_cpu_device(ref):
     x = models.synth_input(g, 5, tm2.DT_FP32)
     b = tm2.write_tm2(g)
     want = ref.run_model(b, x, ref.MODE_FP32, 8)[0]
-    rg = ref.RefGraph(b, ref.MODE_FP32, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg = ref.RefGraph(b, ref.MODE_FP32, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
     rg.set_input(x)
     rg.run()
     got = rg.outputs()[0]
@@ -132,7 +132,7 @@ def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
         x = models.synth_input(g, 3, tm2.DT_UINT8)
     b = tm2.write_tm2(g)
     want = ref.run_model(b, x, ref.MODE_UINT8, 8)
-    rg = ref.RefGraph(b, ref.MODE_UINT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", 0, 1, 0))
+    rg = ref.RefGraph(b, ref.MODE_UINT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
     rg.set_input(x)
     rg.run()
     got = rg.outputs()
@@ -140,3 +140,39 @@ def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     assert len(want) == len(got)
     for w, o in zip(want, got):
         assert np.array_equal(w, o)
+
+
+@pytest.mark.gpu
+def test_int8_rescaling_concat_runs_on_the_device_and_matches_cpu(ref):
+    """an int8 concat whose inputs carry their own scales / ragged channel counts used to fail
+    prerun_graph on "HIP"; now the device copies with the reference's re-scaling arithmetic"""
+    import importlib
+    glue = importlib.import_module("test_gpu_glue_int8")
+    _load_plugin(ref)
+    g, x = glue._two_branch_concat(52, 1, 16, 6, 7, 20, 12)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 2)[0]
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()[0]
+    rg.close()
+    assert np.array_equal(want, got)
+
+
+class ShortOpt(C.Structure):     # an application that only knows the reference's convention: first field dev_name
+    _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int)]
+
+
+@pytest.mark.gpu
+def test_short_option_blob_is_not_over_read(ref):
+    _load_plugin(ref)
+    g, x = conv_graph(33, 1, 32, 10, 10, 48, 3, 1, 1)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 1)[0]
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=ShortOpt(b"HIP", C.sizeof(ShortOpt)))
+    rg.set_input(x)
+    rg.run()
+    got = rg.outputs()[0]
+    rg.close()
+    assert np.array_equal(want, got)
