@@ -58,8 +58,9 @@ enum {
     TAMD_OP_UPSAMPLE = 9,/* param: tamd_upsample_param */
     TAMD_OP_RELU6 = 10,
     TAMD_OP_FLATTEN = 11,
-    TAMD_OP_SOFTMAX = 12, /* fp32 only */
+    TAMD_OP_SOFTMAX = 12, /* param: tamd_softmax_param (NULL: axis 1); fp32 and uint8 graphs */
     TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 graphs, order (0,2,3,1) -- the SSD head permute */
+    TAMD_OP_RESHAPE = 14, /* param: tamd_reshape_param; uint8 / fp32 graphs (dense NCHW on the device: a view)        */
     TAMD_OP_NUM
 };
 
@@ -87,6 +88,10 @@ typedef struct tamd_eltwise_param { int type; int caffe_flavor; float shift, pow
 typedef struct tamd_concat_param { int axis; } tamd_concat_param;
 typedef struct tamd_upsample_param { float scale; } tamd_upsample_param;
 typedef struct tamd_permute_param { int order[4]; } tamd_permute_param;      /* permute_param.h: order0..order3 */
+typedef struct tamd_softmax_param { int axis; } tamd_softmax_param;          /* softmax_param.h */
+/* the RESOLVED output shape of a Reshape node (what reshape.c:37-160 infers from re_shape / is_mxnet / is_onnx); the batch
+ * dimension follows tamd_graph_set_batch */
+typedef struct tamd_reshape_param { int dim_num; int dims[8]; } tamd_reshape_param;
 
 /* == the quantisation-relevant part of struct tensor (source/graph/tensor.h:43-102) */
 typedef struct tamd_tensor_desc {

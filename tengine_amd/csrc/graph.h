@@ -40,6 +40,8 @@ union NodeParam {
     tamd_concat_param concat;
     tamd_upsample_param ups;
     tamd_permute_param perm;
+    tamd_softmax_param softmax;
+    tamd_reshape_param reshape;
 };
 
 struct HNode {

@@ -164,6 +164,16 @@ static int infer_shapes(tamd_graph* g)
             }
             break;
         }
+        case TAMD_OP_RESHAPE: {           // the resolved shape travels in the parameter; only the batch may have been re-set
+            const tamd_reshape_param& rp = n.p.reshape;
+            if (rp.dim_num < 1 || rp.dim_num > 8) { set_error("reshape %s: bad shape", n.name.c_str()); return -1; }
+            y.dims.assign(rp.dims, rp.dims + rp.dim_num);
+            size_t rest = 1;
+            for (int i = 1; i < rp.dim_num; i++) rest *= (size_t)std::max(1, rp.dims[i]);
+            if (y.elems() != x.elems() && rest && x.elems() % rest == 0) y.dims[0] = (int)(x.elems() / rest);
+            if (y.elems() != x.elems()) { set_error("reshape %s: element count changes", n.name.c_str()); return -1; }
+            break;
+        }
         case TAMD_OP_FLATTEN: {
             int f = 1;
             for (size_t i = 1; i < x.dims.size(); i++) f *= x.dims[i];
@@ -1158,7 +1168,8 @@ int tamd_op_supported(int op, int dtype)
 {
     if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
     if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
-    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
+    if (op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
+    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RESHAPE) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
     if (op == TAMD_OP_PERMUTE) return dtype == TAMD_DT_UINT8;      // SSD heads (Permute -> Flatten -> Concat), uint8 graphs
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
@@ -1265,6 +1276,7 @@ int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* d)
     if (!g || !d) return -1;
     HNode n;
     n.op = d->op;
+    if (d->op == TAMD_OP_SOFTMAX) n.p.softmax.axis = 1;
     if (d->name) n.name = d->name;
     for (int i = 0; i < d->input_num; i++) {
         if (d->inputs[i] < 0 || d->inputs[i] >= (int)g->tensors.size()) { set_error("node %s: bad input tensor", n.name.c_str()); return -1; }
@@ -1284,6 +1296,8 @@ int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* d)
         case TAMD_OP_CONCAT: n.p.concat = *(const tamd_concat_param*)d->param; break;
         case TAMD_OP_UPSAMPLE: n.p.ups = *(const tamd_upsample_param*)d->param; break;
         case TAMD_OP_PERMUTE: n.p.perm = *(const tamd_permute_param*)d->param; break;
+        case TAMD_OP_SOFTMAX: n.p.softmax = *(const tamd_softmax_param*)d->param; break;
+        case TAMD_OP_RESHAPE: n.p.reshape = *(const tamd_reshape_param*)d->param; break;
         default: break;
         }
     }

@@ -69,7 +69,7 @@ int plan_f32(tamd_graph* g)
     }
     std::vector<int> alias_of(g->tensors.size(), -1);
     for (auto& n : g->nodes)
-        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) alias_of[n.out[0]] = n.in[0];
+        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN || n.op == TAMD_OP_RESHAPE) alias_of[n.out[0]] = n.in[0];   // dense NCHW: views
     for (auto& io : g->inputs) {
         HTensor& t = g->tensors[io.tensor];
         io.bytes = t.elems() * 4;
@@ -117,7 +117,7 @@ int plan_f32(tamd_graph* g)
     auto out_img = [](const HTensor& t) { return (t.is_view ? t.cs : t.c) * t.h * t.w; };
 
     for (auto& n : g->nodes) {
-        if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST || n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) continue;
+        if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST || n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN || n.op == TAMD_OP_RESHAPE) continue;
         HTensor& x = g->tensors[n.in[0]];
         HTensor& y = g->tensors[n.out[0]];
         switch (n.op) {
@@ -210,10 +210,13 @@ int plan_f32(tamd_graph* g)
             break;
         }
         case TAMD_OP_SOFTMAX: {
-            // softmax_param.axis is 1 (channels) in every config graph; the ABI carries no other axis
             const float* px = (const float*)x.dptr; float* py = (float*)y.dptr;
-            const int N = x.dims[0], C = x.dims.size() > 1 ? x.dims[1] : 1;
-            const int inner = (int)(x.elems() / ((size_t)N * C));
+            int ax = n.p.softmax.axis < 0 ? n.p.softmax.axis + (int)x.dims.size() : n.p.softmax.axis;
+            if (ax < 0 || ax >= (int)x.dims.size()) { set_error("softmax %s: bad axis", n.name.c_str()); return -1; }
+            int N = 1, inner = 1;
+            const int C = x.dims[ax];
+            for (int i = 0; i < ax; i++) N *= x.dims[i];
+            for (size_t i = ax + 1; i < x.dims.size(); i++) inner *= x.dims[i];
             Step st; st.node = n.name; st.kernel = "softmax_f32"; st.bytes = 8.0 * x.elems();
             st.fn = [px, py, N, C, inner](hipStream_t s) { return launch_softmax_f32(px, py, N, C, inner, s); };
             g->steps.push_back(st);

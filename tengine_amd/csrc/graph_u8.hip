@@ -284,7 +284,7 @@ int plan_u8(tamd_graph* g)
     }
     std::vector<int> alias_of(g->tensors.size(), -1);
     for (auto& n : g->nodes)
-        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) alias_of[n.out[0]] = n.in[0];
+        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN || n.op == TAMD_OP_RESHAPE) alias_of[n.out[0]] = n.in[0];   // dense NCHW: views
     for (auto& io : g->inputs) {
         HTensor& t = g->tensors[io.tensor];
         io.bytes = t.elems();
@@ -366,8 +366,25 @@ int plan_u8(tamd_graph* g)
         HNode& n = g->nodes[ni];
         if (fused[ni]) continue;
         switch (n.op) {
-        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
+        case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN: case TAMD_OP_RESHAPE:
             break;
+        case TAMD_OP_SOFTMAX: {            // the quantised part of the SSD tail: Reshape -> Softmax(axis 2) -> Flatten on mbox_conf
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            if (x.is_view || y.is_view) { set_error("softmax %s on a concat view is not supported", n.name.c_str()); return -1; }
+            int ax = n.p.softmax.axis < 0 ? n.p.softmax.axis + (int)x.dims.size() : n.p.softmax.axis;
+            if (ax < 0 || ax >= (int)x.dims.size()) { set_error("softmax %s: bad axis", n.name.c_str()); return -1; }
+            U8SoftmaxArgs a{};
+            a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
+            a.outer = 1; a.inner = 1; a.on = x.dims[ax];
+            for (int i = 0; i < ax; i++) a.outer *= x.dims[i];
+            for (size_t i = ax + 1; i < x.dims.size(); i++) a.inner *= x.dims[i];
+            if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
+            Step st; st.node = n.name; st.kernel = "softmax_u8"; st.bytes = 2.0 * x.elems();
+            st.fn = [a](hipStream_t s) { return launch_softmax_u8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
         case TAMD_OP_CONV: {
             const HNode* relu = nullptr;
             size_t rj = 0;

@@ -248,6 +248,12 @@ struct U8CatArgs {             // flat per-image slice copy: concat on axis 1 of
     U8Q in, out;
 };
 
+struct U8SoftmaxArgs {         // softmax over the middle axis of [outer][on][inner]
+    const uint8_t* x; uint8_t* y;
+    int outer, on, inner;
+    U8Q in, out;
+};
+
 struct U8EltArgs {
     const uint8_t* a; const uint8_t* b; uint8_t* y; size_t count; int type;
     U8Q qa, qb, out;
@@ -319,5 +325,6 @@ hipError_t launch_requant_copy_u8(const U8MapArgs& a, hipStream_t s);
 hipError_t launch_upsample_u8(const U8MapArgs& a, hipStream_t s);
 hipError_t launch_flatcat_u8(const U8CatArgs& a, hipStream_t s);
 hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s);
+hipError_t launch_softmax_u8(const U8SoftmaxArgs& a, hipStream_t s);
 
 }  // namespace tamd

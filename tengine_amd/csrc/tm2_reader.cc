@@ -72,6 +72,7 @@ int map_op(uint32_t t)
     case 16: return TAMD_OP_POOL;
     case 20: return TAMD_OP_RELU;
     case 21: return TAMD_OP_RELU6;
+    case 23: return TAMD_OP_RESHAPE;
     case 28: return TAMD_OP_SOFTMAX;
     case 51: return TAMD_OP_UPSAMPLE;
     default: return -1;
@@ -140,7 +141,16 @@ extern "C" tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size)
         const int op = map_op(optype);
         if (op < 0) { set_error("tm2: operator type %u (%s) is not supported by the device backend", optype, name.c_str()); tamd_graph_destroy(g); return nullptr; }
         NodeParam p{};
-        if (po) {
+        bool have_param = po != 0;
+        if (op == TAMD_OP_RESHAPE) {        // TM2_ReshapeParam carries the recipe (re_shape, is_mxnet, is_onnx: reshape.c:37-160); the
+            // serializer also stores the RESOLVED shape with the output tensor, which is what the device needs
+            if (vo.empty() || vo[0] >= g->tensors.size()) return fail("reshape without output tensor");
+            const HTensor& ot = g->tensors[vo[0]];
+            if (ot.dims.empty() || ot.dims.size() > 8) return fail("reshape output without a shape");
+            p.reshape.dim_num = (int)ot.dims.size();
+            for (size_t i = 0; i < ot.dims.size(); i++) p.reshape.dims[i] = ot.dims[i];
+            have_param = true;
+        } else if (po) {
             switch (op) {
             case TAMD_OP_CONV: {                               // TM2_ConvParam tm2_format.h:419-435 (tm2_conv.c:50-73)
                 tamd_conv_param& c = p.conv;
@@ -165,6 +175,7 @@ extern "C" tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size)
                 p.elt.power = r.f32(po + 12); p.elt.scale = r.f32(po + 16);
                 break;
             case TAMD_OP_CONCAT: p.concat.axis = r.i32(po); break;
+            case TAMD_OP_SOFTMAX: p.softmax.axis = r.i32(po); break;   // TM2_SoftmaxParam {axis}
             case TAMD_OP_UPSAMPLE: p.ups.scale = r.f32(po); break;
             case TAMD_OP_PERMUTE:                              // TM2_PermuteParam {flag, order0..3} (tm2_permute.c)
                 for (int i = 0; i < 4; i++) p.perm.order[i] = r.i32(po + 4 + 4 * i);
@@ -176,7 +187,7 @@ extern "C" tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size)
         std::vector<int> ins(vi.begin(), vi.end()), outs(vo.begin(), vo.end());
         tamd_node_desc d{};
         d.op = op; d.input_num = (int)ins.size(); d.inputs = ins.data(); d.output_num = (int)outs.size();
-        d.outputs = outs.data(); d.param = po ? &p : nullptr; d.name = name.c_str();
+        d.outputs = outs.data(); d.param = have_param ? &p : nullptr; d.name = name.c_str();
         if (tamd_graph_add_node(g, &d) < 0) { tamd_graph_destroy(g); return nullptr; }
     }
     std::vector<int> gi, go;

@@ -768,4 +768,41 @@ hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- uint8 softmax: softmax/softmax_kernel_ref_uint8.c:40-119 over softmax_kernel_ref.h:35-85 -------------------------------
+// dequantise; per (outer, inner) position: max over the axis; o = (float)exp((double)(f - max)) -- the reference calls C `exp`
+// on a float argument, i.e. the DOUBLE routine, and rounds the result to float on the store (:67); sum in fp32 in axis order
+// (:68); o / sum; u = (int)(round(o / out_scale) + out_zp), clamp [0, 255] (:103-113).  exp runs in fp64 here too (ocml, <= 1
+// ulp): its float rounding differs from glibc's correctly rounded exp only when the true value sits within a double ulp of a
+// float rounding midpoint (~2^-29 per call), and that float ulp would then have to straddle a uint8 rounding boundary.
+// One thread per position: the axis is short (21 classes in MobileNet-SSD), exp is evaluated in both passes (deterministic).
+__global__ __launch_bounds__(256) void softmax_u8_kernel(U8SoftmaxArgs a)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)a.outer * a.inner) return;
+    const long o = i / a.inner;
+    const int l = (int)(i - o * a.inner);
+    const uint8_t* x = a.x + (size_t)o * a.on * a.inner + l;
+    uint8_t* y = a.y + (size_t)o * a.on * a.inner + l;
+    const float zp = (float)a.in.zp;
+    auto deq = [&](int j) { return __fmul_rn(__fsub_rn((float)x[(size_t)j * a.inner], zp), a.in.scale); };
+    float mx = deq(0);
+    for (int j = 1; j < a.on; j++) { const float f = deq(j); if (mx < f) mx = f; }
+    float sum = 0.f;
+    for (int j = 0; j < a.on; j++) sum = __fadd_rn(sum, (float)exp((double)__fsub_rn(deq(j), mx)));
+    for (int j = 0; j < a.on; j++) {
+        const float e = (float)exp((double)__fsub_rn(deq(j), mx));
+        const float v = __fdiv_rn(e, sum);
+        int u = (int)(round((double)__fdiv_rn(v, a.out.scale)) + (double)a.out.zp);
+        u = u < 0 ? 0 : (u > 255 ? 255 : u);
+        y[(size_t)j * a.inner] = (uint8_t)u;
+    }
+}
+
+hipError_t launch_softmax_u8(const U8SoftmaxArgs& a, hipStream_t s)
+{
+    const long total = (long)a.outer * a.inner;
+    hipLaunchKernelGGL(softmax_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace tamd

@@ -77,6 +77,7 @@ int map_op(int op)
     case OP_RELU6: return TAMD_OP_RELU6;
     case OP_FLATTEN: return TAMD_OP_FLATTEN;
     case OP_PERMUTE: return TAMD_OP_PERMUTE;
+    case OP_RESHAPE: return TAMD_OP_RESHAPE;
     default: return -1;
     }
 }
@@ -87,7 +88,7 @@ const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_REL
 // SSD head plumbing (Permute -> Flatten -> Concat): on the device for uint8 graphs only, so these two are added to
 // the allowed list per graph (hip_split_graph) instead of globally -- an int8 / fp32 graph keeps them on the CPU
 // without dragging the convolutions around them back there
-const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN};
+const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN, OP_RESHAPE};
 
 bool op_supported(int op, int dtype)
 {
@@ -163,8 +164,18 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
         tamd_concat_param ccp;
         tamd_upsample_param up;
         tamd_permute_param pmp;
+        tamd_softmax_param smp;
+        tamd_reshape_param rsp;
         const void* param = nullptr;
         switch (op) {
+        case TAMD_OP_SOFTMAX: smp.axis = ((const struct softmax_param*)n->op.param_mem)->axis; param = &smp; break;
+        case TAMD_OP_RESHAPE: {          // the resolved shape (reshape.c infer_shape already ran)
+            struct tensor* ot = get_ir_graph_tensor(ir, n->output_tensors[0]);
+            rsp.dim_num = ot->dim_num;
+            for (int k = 0; k < ot->dim_num && k < 8; k++) rsp.dims[k] = ot->dims[k];
+            param = &rsp;
+            break;
+        }
         case TAMD_OP_CONV: {
             const struct conv_param* p = (const struct conv_param*)n->op.param_mem;
             cp = {p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0, p->pad_h1, p->pad_w0, p->pad_w1,
@@ -422,8 +433,18 @@ static bool node_supported(struct graph* ir, struct node* n)
     for (int k = 0; k < n->output_num; k++) out.push_back(describe_tensor(get_ir_graph_tensor(ir, n->output_tensors[k])));
     tamd_conv_param cp; tamd_pool_param pp; tamd_fc_param fp; tamd_eltwise_param ep; tamd_concat_param ccp; tamd_upsample_param up;
     tamd_permute_param pmp;
+    tamd_softmax_param smp;
+    tamd_reshape_param rsp;
     const void* param = nullptr;
     switch (op) {
+    case TAMD_OP_SOFTMAX: smp.axis = ((const struct softmax_param*)n->op.param_mem)->axis; param = &smp; break;
+    case TAMD_OP_RESHAPE: {
+        struct tensor* ot = get_ir_graph_tensor(ir, n->output_tensors[0]);
+        rsp.dim_num = ot->dim_num;
+        for (int k = 0; k < ot->dim_num && k < 8; k++) rsp.dims[k] = ot->dims[k];
+        param = &rsp;
+        break;
+    }
     case TAMD_OP_CONV: {
         const struct conv_param* p = (const struct conv_param*)n->op.param_mem;
         cp = {p->kernel_h, p->kernel_w, p->stride_h, p->stride_w, p->pad_h0, p->pad_h1, p->pad_w0, p->pad_w1,
@@ -483,7 +504,6 @@ bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
             if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
         }
         if (n->op.type == OP_CONCAT && ((const struct concat_param*)n->op.param_mem)->axis != 1) return false;
-        if (n->op.type == OP_SOFTMAX && ((const struct softmax_param*)n->op.param_mem)->axis != 1) return false;
         if (n->op.type == OP_PERMUTE) {
             const struct permute_param* p = (const struct permute_param*)n->op.param_mem;
             if (!(p->order0 == 0 && p->order1 == 2 && p->order2 == 3 && p->order3 == 1)) return false;

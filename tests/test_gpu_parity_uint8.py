@@ -288,3 +288,29 @@ def test_first_layer_u8_valu_kernel(case, leaky):
     assert names[0].startswith("conv_u8_rgb3x3"), names
     assert np.array_equal(got, want), "%d bytes differ" % np.count_nonzero(got != want)
     assert len(np.unique(want)) > 3
+
+
+@pytest.mark.parametrize("dims,axis", [((3, 7, 5), 1), ((2, 50, 21), 2), ((2, 21, 6, 5), 1), ((4, 33), 1), ((1, 5, 4, 3), 3)])
+def test_softmax_u8(dims, axis):
+    """softmax_kernel_ref_uint8.c over any axis: dequantise, exp in fp64 rounded to fp32, sequential fp32 sum, requantise"""
+    g, x = u8_unary_graph(70 + axis + len(dims), "Softmax", dims, axis=axis)
+    t = g.tensors[g.nodes[-1].outputs[0]]
+    t.scales, t.zps = [1.0 / 255.0], [0]                  # the quantiser's choice for a probability tensor
+    check(g, x, "softmax %s axis %d" % (dims, axis))
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_mssd_uint8_quantised_tail_on_device(batch):
+    """mbox_conf -> Reshape(0,-1,21) -> Softmax(axis 2) -> Flatten stays on the device (Reshape / Flatten are
+    views of the dense NCHW tensor, softmax_u8 is one launch); outputs = mbox_loc and the class probabilities"""
+    g = models.build("mssd", "uint8", batch, tail=True)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    want = oracle.run_graph(g, x)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    outs = gr.run()
+    kernels = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert "softmax_u8" in kernels, kernels
+    for w, o in zip(want, outs):
+        assert np.array_equal(o.reshape(w.shape), w), np.count_nonzero(o.reshape(w.shape) != w)

@@ -114,7 +114,7 @@ def test_hip_device_fp32_matches_reference_cpu_device(ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["route", "yolov3_tiny", "ssd_head", "mssd"])
+@pytest.mark.parametrize("case", ["route", "yolov3_tiny", "ssd_head", "mssd", "mssd_tail"])
 def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     """uint8 through the reference's own API: device "HIP" == CPU device, byte for byte."""
     from helpers import u8_route_graph
@@ -124,8 +124,8 @@ def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     elif case == "ssd_head":
         from helpers import u8_ssd_head_graph
         g, x = u8_ssd_head_graph(17, 2, 16, 6, 6)
-    elif case == "mssd":
-        g = models.build("mssd", "uint8", 1)
+    elif case in ("mssd", "mssd_tail"):      # _tail: + Reshape -> Softmax -> Flatten on mbox_conf, all on "HIP"
+        g = models.build("mssd", "uint8", 1, tail=(case == "mssd_tail"))
         x = models.synth_input(g, 5, tm2.DT_UINT8)
     else:
         g = models.build("yolov3_tiny", "uint8", 1)
