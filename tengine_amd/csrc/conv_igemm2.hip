@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "epilogue.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace tamd {
@@ -165,56 +166,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_i8_kernel(ConvArgs a)
         }
     }
 
-    // ---- fused epilogue (identical to conv_igemm.hip) ----
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
-    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0 && (!a.elt.res || ((a.elt.res_ldc | a.elt.res_c_off) & 15) == 0);
-    const float inv_elt = a.elt.res ? __fdiv_rn(1.0f, a.elt.out_scale) : 1.f;
-    const float inv_relu = (a.elt.res && a.elt.relu) ? __fdiv_rn(1.0f, a.elt.relu_out_scale) : 1.f;
-#pragma unroll
-    for (int i = 0; i < TN; i++) {
-        const int cb = n0 + (wn * TN + i) * 32;
-        unsigned pp[TM][4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-            const int4 b4 = *reinterpret_cast<const int4*>(a.bias + cb + 8 * g4 + 4 * hi);
-            const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + cb + 8 * g4 + 4 * hi);
-#pragma unroll
-            for (int j = 0; j < TM; j++)
-                pp[j][g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y,
-                                     acc[i][j][4 * g4 + 2] + b4.z, acc[i][j][4 * g4 + 3] + b4.w, s4, rq);
-        }
-#pragma unroll
-        for (int j = 0; j < TM; j++) {
-            const int m = m0 + (wm * TM + j) * 32 + l31;
-            unsigned p[4] = {pp[j][0], pp[j][1], pp[j][2], pp[j][3]};
-            if (wide) {
-                half_wave_regroup(p);
-                const int c16 = cb + hi * 16;
-                if (m < a.M && c16 < a.c_limit) {
-                    if (a.elt.res) {      // eltwise (+ReLU) tail on the 16 channels this lane now holds
-                        const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16);
-                        p[0] = fuse_elt4(p[0], r.x, a.elt, inv_elt, inv_relu);
-                        p[1] = fuse_elt4(p[1], r.y, a.elt, inv_elt, inv_relu);
-                        p[2] = fuse_elt4(p[2], r.z, a.elt, inv_elt, inv_relu);
-                        p[3] = fuse_elt4(p[3], r.w, a.elt, inv_elt, inv_relu);
-                    }
-                    *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + c16) = make_uint4(p[0], p[1], p[2], p[3]);
-                }
-            } else {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const int c0 = cb + 8 * g4 + 4 * hi;
-                    if (m < a.M && c0 < a.c_limit) {
-                        unsigned v = p[g4];
-                        if (a.elt.res)
-                            v = fuse_elt4(v, *reinterpret_cast<const unsigned*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c0),
-                                          a.elt, inv_elt, inv_relu);
-                        *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = v;
-                    }
-                }
-            }
-        }
-    }
+    igemm_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi);       // gemm_epilogue.h
 }
 
 template <int BN, int STAGES>

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace tamd {
@@ -100,32 +102,33 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
     return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24);
 }
 
+// the rare path of requant4 (~1e-4 of the values): the reference expression itself for the flagged slots.  Kept OUT of line:
+// inlined, its ~60 instructions at each of the 16+ call sites of a GEMM epilogue push the epilogue past the unroller's size
+// budget, the accumulator arrays then get dynamic indices and land in scratch memory (seen: 320 B of scratch in every
+// 128x128 tile variant of conv_igemm.hip)
+__device__ __attribute__((noinline)) static unsigned requant4_exact(float f0, float f1, float f2, float f3, unsigned packed, int flags, float out_scale)
+{
+    int q[4] = {(int)(signed char)(packed & 0xff), (int)(signed char)((packed >> 8) & 0xff), (int)(signed char)((packed >> 16) & 0xff),
+                (int)(signed char)(packed >> 24)};
+    if (flags & 1) q[0] = exact_round_div_sat(f0, out_scale);
+    if (flags & 2) q[1] = exact_round_div_sat(f1, out_scale);
+    if (flags & 4) q[2] = exact_round_div_sat(f2, out_scale);
+    if (flags & 8) q[3] = exact_round_div_sat(f3, out_scale);
+    return pack4(q[0], q[1], q[2], q[3]);
+}
+
 // four consecutive channels -> one packed dword; the exact path is taken once for the group
 __device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, const float4& m2, const Rq& r)
 {
     const float f0 = rq_value(a0, m2.x, r), f1 = rq_value(a1, m2.y, r), f2 = rq_value(a2, m2.z, r), f3 = rq_value(a3, m2.w, r);
     bool k0, k1, k2, k3;
-    int q0 = rq_round_fast(f0, r, k0);
-    int q1 = rq_round_fast(f1, r, k1);
-    int q2 = rq_round_fast(f2, r, k2);
-    int q3 = rq_round_fast(f3, r, k3);
-    if (k0 | k1 | k2 | k3) {
-        // rare (~1e-4 of the values): ONE rolled copy of the exact division serves the four slots, so the
-        // slow path costs ~40 instructions of code instead of 4 x 25 per call site
-#pragma unroll 1
-        for (int e = 0; e < 4; e++) {
-            const float fe = e == 0 ? f0 : (e == 1 ? f1 : (e == 2 ? f2 : f3));
-            const bool ke = e == 0 ? k0 : (e == 1 ? k1 : (e == 2 ? k2 : k3));
-            const int qe = exact_round_div_sat(fe, r.out_scale);
-            if (ke) {
-                q0 = e == 0 ? qe : q0;
-                q1 = e == 1 ? qe : q1;
-                q2 = e == 2 ? qe : q2;
-                q3 = e == 3 ? qe : q3;
-            }
-        }
-    }
-    return pack4(q0, q1, q2, q3);
+    const int q0 = rq_round_fast(f0, r, k0);
+    const int q1 = rq_round_fast(f1, r, k1);
+    const int q2 = rq_round_fast(f2, r, k2);
+    const int q3 = rq_round_fast(f3, r, k3);
+    unsigned p = pack4(q0, q1, q2, q3);
+    if (k0 | k1 | k2 | k3) p = requant4_exact(f0, f1, f2, f3, p, (int)k0 | ((int)k1 << 1) | ((int)k2 << 2) | ((int)k3 << 3), r.out_scale);
+    return p;
 }
 
 // 32x32 MFMA C/D layout puts channels 8g + 4hi + {0..3} of one pixel in packed dword p[g] of lane
@@ -180,6 +183,67 @@ __device__ __forceinline__ unsigned fuse_elt4(unsigned pc, unsigned pr, const El
         q[b] = y;
     }
     return pack4(q[0], q[1], q[2], q[3]);
+}
+
+// 16 channels at once for the GEMM epilogues that hold them after half_wave_regroup.  Out of line (one call per 32x32 tile and
+// lane instead of sixteen inlined copies of the tail: the epilogue stays small enough for the unroller, see requant4_exact),
+// with the uniform choices -- eltwise type, operand order, ReLU flavour -- hoisted out of the per-value work.
+template <int TYPE, bool CONV_FIRST, int RELU>
+__device__ __forceinline__ unsigned fuse_elt4_t(unsigned pc, unsigned pr, const EltFuse& e, float inv_out, float inv_relu)
+{
+    int q[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const float fc = __fmul_rn((float)sx8(pc, b), e.s_conv), fr = __fmul_rn((float)sx8(pr, b), e.s_res);
+        const float fa = CONV_FIRST ? fc : fr, fb = CONV_FIRST ? fr : fc;
+        const float f = TYPE == 0 ? __fmul_rn(fa, fb) : TYPE == 2 ? __fadd_rn(fa, fb) : TYPE == 4 ? __fsub_rn(fa, fb) : (fa > fb ? fa : fb);
+        int y = round_div_sat(f, e.out_scale, inv_out);
+        if (RELU == 2) y = y < 0 ? 0 : y;                     // see fuse_elt4
+        else if (RELU == 1) {
+            float f2 = __fmul_rn((float)y, e.out_scale);
+            f2 = f2 < 0.f ? 0.f : f2;
+            y = round_div_sat(f2, e.relu_out_scale, inv_relu);
+        }
+        q[b] = y;
+    }
+    return pack4(q[0], q[1], q[2], q[3]);
+}
+
+template <int TYPE, bool CONV_FIRST, int RELU>
+__device__ __forceinline__ void fuse_elt16_t(unsigned (&p)[4], const uint4& r, const EltFuse& e, float inv_out, float inv_relu)
+{
+    p[0] = fuse_elt4_t<TYPE, CONV_FIRST, RELU>(p[0], r.x, e, inv_out, inv_relu);
+    p[1] = fuse_elt4_t<TYPE, CONV_FIRST, RELU>(p[1], r.y, e, inv_out, inv_relu);
+    p[2] = fuse_elt4_t<TYPE, CONV_FIRST, RELU>(p[2], r.z, e, inv_out, inv_relu);
+    p[3] = fuse_elt4_t<TYPE, CONV_FIRST, RELU>(p[3], r.w, e, inv_out, inv_relu);
+}
+
+// everything by VALUE: a reference into the kernel's argument block would force the whole block into scratch memory
+__device__ __attribute__((noinline)) static uint4 fuse_elt16(uint4 pv, uint4 r, EltFuse e, float inv_out, float inv_relu)
+{
+    unsigned p[4] = {pv.x, pv.y, pv.z, pv.w};
+    // the ResNet case first: sum + ReLU whose output scale is the eltwise output scale (sum is commutative)
+    if (e.type == 2 && e.relu == 2) fuse_elt16_t<2, true, 2>(p, r, e, inv_out, inv_relu);
+    else if (e.type == 2 && e.relu) fuse_elt16_t<2, true, 1>(p, r, e, inv_out, inv_relu);
+    else if (e.type == 2) fuse_elt16_t<2, true, 0>(p, r, e, inv_out, inv_relu);
+    else {
+        p[0] = fuse_elt4(p[0], r.x, e, inv_out, inv_relu);
+        p[1] = fuse_elt4(p[1], r.y, e, inv_out, inv_relu);
+        p[2] = fuse_elt4(p[2], r.z, e, inv_out, inv_relu);
+        p[3] = fuse_elt4(p[3], r.w, e, inv_out, inv_relu);
+    }
+    return make_uint4(p[0], p[1], p[2], p[3]);
+}
+
+// compile-time loop: indices that MUST be constants (accumulator arrays: a dynamic index sends the array to scratch memory)
+// stay constants whether or not the optimizer chooses to unroll
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 }  // namespace tamd

@@ -1,0 +1,75 @@
+// Fused epilogue of the MFMA GEMM kernels (conv_igemm.hip, conv_igemm2.hip).
+#pragma once
+#include "epilogue.h"
+
+namespace tamd {
+
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// ---- fused epilogue shared by the 32x32-tile GEMM kernels: +bias, requantise (bit-exact, epilogue.h), pack 4 channels,
+// NHWC store.  acc[i][j]: 32x32 tile (cout tile i, pixel tile j) of wave (wm, wn) of the block tile at (m0, n0).
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi)
+{
+    // C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
+    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    // 16-B stores (half-wave regroup) whenever the destination is 16-channel granular; dword stores else
+    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0 && (!a.elt.res || ((a.elt.res_ldc | a.elt.res_c_off) & 15) == 0);
+    const float inv_elt = a.elt.res ? __fdiv_rn(1.0f, a.elt.out_scale) : 1.f;
+    const float inv_relu = (a.elt.res && a.elt.relu) ? __fdiv_rn(1.0f, a.elt.relu_out_scale) : 1.f;
+    // every bias / scale vector of the wave's cout tiles is requested before the first requantisation: loaded one group at a
+    // time inside the loops they cost a memory round trip each (measured: 1.1 us of epilogue on a 64x64 tile,
+    // profiles/r02_igemm_anatomy_*)
+    int4 b4s[TN][4];
+    float4 s4s[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int c = n0 + (wn * TN + i) * 32 + 8 * g4 + 4 * hi;
+            b4s[i][g4] = *reinterpret_cast<const int4*>(a.bias + c);
+            s4s[i][g4] = *reinterpret_cast<const float4*>(a.wscale + c);
+        }
+    static_for<0, TN>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int cb = n0 + (wn * TN + i) * 32;
+        static_for<0, TM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            unsigned p[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int4 b4 = b4s[i][g4];
+                const float4 s4 = s4s[i][g4];
+                p[g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y, acc[i][j][4 * g4 + 2] + b4.z,
+                                 acc[i][j][4 * g4 + 3] + b4.w, s4, rq);
+            }
+            const int m = m0 + (wm * TM + j) * 32 + l31;
+            if (wide) {
+                half_wave_regroup(p);
+                const int c16 = cb + hi * 16;
+                if (m < a.M && c16 < a.c_limit) {
+                    if (a.elt.res) {      // eltwise (+ReLU) tail on the 16 channels this lane now holds
+                        const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16);
+                        const uint4 o = fuse_elt16(make_uint4(p[0], p[1], p[2], p[3]), r, a.elt, inv_elt, inv_relu);
+                        p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = o.w;
+                    }
+                    *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + c16) = make_uint4(p[0], p[1], p[2], p[3]);
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int c0 = cb + 8 * g4 + 4 * hi;
+                    if (m < a.M && c0 < a.c_limit) {
+                        unsigned v = p[g4];
+                        if (a.elt.res)
+                            v = fuse_elt4(v, *reinterpret_cast<const unsigned*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c0),
+                                          a.elt, inv_elt, inv_relu);
+                        *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = v;
+                    }
+                }
+            }
+        });
+    });
+}
+
+}  // namespace tamd

@@ -501,6 +501,8 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.cin = cin; a.ktot = ktot; a.kpad = kpad;
         if (!g->zero_page) { if (dev_alloc(g, &g->zero_page, 256, true)) return -1; }
         a.zeros = (const int8_t*)g->zero_page;
+        a.mg_ohw = ((1ull << 40) + (unsigned)(y.h * y.w) - 1) / (unsigned)(y.h * y.w);
+        a.mg_ow = ((1ull << 40) + (unsigned)y.w - 1) / (unsigned)y.w;
         a.M = y.n * y.h * y.w; a.m1 = in_scale; a.lo = rq_lo; a.hi = rq_hi; a.out_scale = out_scale;
         a.cfg = -1;
         if (fz) {      // conv -> eltwise (-> relu) in one launch: the conv's own int8 rounding is kept, see epilogue.h

@@ -39,7 +39,12 @@ struct ConvArgs {
     int M;                 // N*OH*OW
     float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
+    unsigned long long mg_ohw, mg_ow;   // ceil(2^40 / (OH*OW)), ceil(2^40 / OW): pixel index -> (n, oy, ox) by multiply-high (conv_igemm_fast.h)
     int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
+#ifdef TAMD_IGEMM_STAMPS
+    long long* dbg_stamps; // tools/exp/igemm_anatomy.hip only: s_memtime at the stage boundaries of wave 0 of block 0
+    int dbg_flags;         // .. ablation: 1 no MFMA, 2 no LDS traffic, 4 no global loads
+#endif
     EltFuse elt;           // fused eltwise(+relu) tail (conv_igemm / conv_igemm2 only); y/ldc/c_off then describe ITS output
 };
 

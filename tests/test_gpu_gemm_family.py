@@ -28,7 +28,8 @@ SHAPES = [
     (9, 80, 33, 31, 96, 3, 1, 2, 1, 0, True, 2),
     (1, 512, 7, 7, 512, 3, 1, 1, 1, 0, True, 1),
 ]
-MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct", "pw_stream",
+MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "igemm10", "igemm11",
+           "igemm12", "igemm13", "igemm14", "igemm15", "gemm_direct", "pw_stream",
            "conv_igemm2", "pw_small"]
 
 
@@ -63,7 +64,7 @@ def test_family_member_is_exact_on_every_shape(member, cases):
         del os.environ["TAMD_FORCE_GEMM"]
 
 
-@pytest.mark.parametrize("member", ["pw_stream", "igemm0", "igemm2", "conv_igemm2"])
+@pytest.mark.parametrize("member", ["pw_stream", "igemm0", "igemm2", "igemm10", "igemm14", "conv_igemm2"])
 @pytest.mark.parametrize("etype,own_relu_scale", [(tm2.ELT_SUM, False), (tm2.ELT_SUB, True)])
 def test_fused_eltwise_tail_is_exact_in_every_member(member, etype, own_relu_scale):
     """conv -> eltwise -> ReLU folded into the epilogue of each family member that offers it (ResNet block tails);
