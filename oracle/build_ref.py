@@ -124,5 +124,54 @@ def build(ref="/root/reference", jobs=None, verbose=False):
     return lib
 
 
+def build_tm_benchmark(ref="/root/reference", verbose=False):
+    """INTEGRATION.md route B made literal: the reference's own `benchmark/tm_benchmark.cc`, UNMODIFIED, linked against the
+    unmodified reference objects with our device compiled IN-TREE -- i.e. what adding `source/device/hip/` to the
+    reference's CMake would produce: `device/register.h` regenerated from the two file names cpu_device.c + hip_device.cc
+    (cmake/registry.cmake:11-31), api/c_api.c recompiled against it, hip_device.cc compiled as part of the library.
+    Output: oracle/_ref/tm_benchmark_hip (`-d HIP` selects the device, `-m file.tmfile -f 2` runs a quantised tmfile)."""
+    src = os.path.join(ref, "source")
+    repo = os.path.dirname(HERE)
+    dev_src = os.path.join(repo, "tengine_amd", "device", "hip_device.cc")
+    core = os.path.join(repo, "tengine_amd", "lib", "libtengine_amd.so")
+    lib = build(ref, verbose=verbose)
+    if not (os.path.exists(dev_src) and os.path.exists(core)):
+        return None
+    gen2 = os.path.join(OUT, "gen_hip")
+    _registry(os.path.join(src, "device/register.h.in"), os.path.join(gen2, "device/register.h"), "register_", "unregister_", "",
+              [os.path.join(src, "device/cpu/cpu_device.c"), dev_src])
+    inc = [gen2, src, GEN, os.path.join(src, "device"), os.path.join(GEN, "device/cpu"), os.path.join(src, "device/cpu"),
+           os.path.join(src, "operator/prototype"), os.path.join(src, "serializer"), os.path.join(GEN, "serializer")]
+    iflags = ["-I" + p for p in inc]
+    capi_o = os.path.join(OBJ, "hiptree_c_api.o")
+    subprocess.check_call(["gcc"] + CFLAGS + iflags + ["-c", os.path.join(src, "api/c_api.c"), "-o", capi_o])
+    dev_o = os.path.join(OBJ, "hiptree_hip_device.o")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-w", "-I" + src, "-I" + os.path.join(src, "operator/prototype"), "-I" + GEN,
+                           "-I" + os.path.join(repo, "include"), "-c", dev_src, "-o", dev_o])
+    objs = [o for o in open(os.path.join(OBJ, "link.rsp")).read().split("\n") if o and not o.endswith("_c_api.c.o")]
+    exe = os.path.join(OUT, "tm_benchmark_hip")
+    rsp = os.path.join(OBJ, "link_bench.rsp")
+    open(rsp, "w").write("\n".join(objs + [capi_o, dev_o]))
+    bench = os.path.join(ref, "benchmark")
+    # tm_benchmark.cc includes "tengine/c_api.h" (the installed layout, source/CMakeLists.txt install rules): a symlink farm
+    # under _ref/ stands in for the install step
+    incdir = os.path.join(gen2, "include", "tengine")
+    os.makedirs(incdir, exist_ok=True)
+    for h in ("c_api.h", "defines.h"):
+        link = os.path.join(incdir, h)
+        target = os.path.join(src, "api", h) if h == "c_api.h" else os.path.join(GEN, h)
+        if os.path.lexists(link):
+            os.remove(link)
+        os.symlink(target, link)
+    subprocess.check_call(["g++", "-O2", "-std=c++11", "-w", "-fopenmp", "-I" + os.path.join(gen2, "include"), "-I" + src, "-I" + os.path.join(bench, "common"),
+                           os.path.join(bench, "tm_benchmark.cc"), os.path.join(bench, "common", "timer.cc"), "@" + rsp,
+                           "-L" + os.path.dirname(core), "-ltengine_amd", "-Wl,-rpath,$ORIGIN/../../tengine_amd/lib", "-ldl", "-lm", "-lpthread",
+                           "-o", exe])
+    if verbose:
+        print("unmodified tm_benchmark with the HIP device in-tree: %s" % exe)
+    return exe
+
+
 if __name__ == "__main__":
     build(ref=sys.argv[1] if len(sys.argv) > 1 else "/root/reference", verbose=True)
+    build_tm_benchmark(ref=sys.argv[1] if len(sys.argv) > 1 else "/root/reference", verbose=True)
