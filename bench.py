@@ -278,7 +278,7 @@ def main():
 
 def pmc_traffic(model, dtype, batch, family):
     """HBM bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC summary of this workload
-    (profiles/r01_traffic_<model>_<dtype>_b<batch>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
+    (profiles/r02_traffic_<model>_<dtype>_b<batch>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
     same-session streaming-copy calibration -- tools/collect_profiles.sh, tools/traffic_summary.py); None when this
     workload has no PMC pass (counters cannot be collected from inside the timed process)."""
     path = os.path.join(ROOT, "profiles", "r02_traffic_%s_%s_b%d.json" % (model, dtype, batch))
@@ -286,8 +286,19 @@ def pmc_traffic(model, dtype, batch, family):
         return None
     ks = json.load(open(path))["kernels"]
     tot, n = 0.0, 0
+    import re
+
+    def member(name):
+        # the pwdw_i8_kernel<STEPS, MODE, CHUNKED, PROD> template serves four step families: tell them apart by MODE / PROD
+        m = re.search(r"pwdw_i8_kernel<\s*\d+,\s*(\d+),\s*\w+,\s*(\d+)>", name)
+        if m:
+            mode, prod = int(m.group(1)), int(m.group(2))
+            fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"
+            return fam == family
+        return family in name
+
     for name, v in ks.items():
-        if family in name and v["hbm_read_bytes_per_launch"] is not None:
+        if member(name) and v["hbm_read_bytes_per_launch"] is not None:
             tot += (v["hbm_read_bytes_per_launch"] + (v["hbm_write_bytes_per_launch"] or 0.0)) * v["launches"]
             n += v["launches"]
     return tot / n if n else None

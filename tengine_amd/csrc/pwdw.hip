@@ -62,8 +62,12 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     PWDW_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kb = lane >> 4;
-    const int slice = blockIdx.x, tx = blockIdx.y;
-    int ty = blockIdx.z, n = 0;
+    // block -> XCD is round-robin over the linear block index, and every XCD has its own L2: with the channel slice in grid.x
+    // an XCD sees every tile (the input is fetched once per XCD, the weights once in total); with the tile in grid.x it sees
+    // every slice of its own tiles (input once in total, weights once per XCD).  The planner puts the larger operand on the
+    // "once in total" side (PMC: the early layers read 6-8x their input with slices first, profiles/r02_traffic_*).
+    const int slice = a.tile_major ? blockIdx.z : blockIdx.x, tx = a.tile_major ? blockIdx.x : blockIdx.y;
+    int ty = a.tile_major ? blockIdx.y : blockIdx.z, n = 0;
     if (a.N > 1) { n = ty / a.tiles_y; ty -= n * a.tiles_y; }
     const int c_base = slice * 16;
 
@@ -337,11 +341,13 @@ static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
 {
     const size_t lds = pwdw_lds_bytes(a, threads);
     if (a.mode == 2) {
-        const dim3 grid(a.slices, 1, ((a.H + a.TH - 1) / a.TH) * a.N);
+        const dim3 sm(a.slices, 1, ((a.H + a.TH - 1) / a.TH) * a.N);
+        const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
         hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 4, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
         return hipGetLastError();
     }
-    const dim3 grid(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
+    const dim3 sm(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
+    const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
     if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
     else if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
     else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
@@ -351,7 +357,8 @@ static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
 
 static hipError_t launch_first(const PwDwArgs& a, int threads, hipStream_t s)
 {
-    const dim3 grid(a.slices, a.tiles_x, a.tiles_y * a.N);
+    const dim3 sm(a.slices, a.tiles_x, a.tiles_y * a.N);
+    const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
     const size_t lds = pwdw_lds_bytes(a, threads);
     if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<1, 2, false, 1>), grid, dim3(threads), lds, s, a);
     else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<1, 1, false, 1>), grid, dim3(threads), lds, s, a);

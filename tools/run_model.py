@@ -14,6 +14,7 @@ dtype = sys.argv[4] if len(sys.argv) > 4 else "int8"
 g = models.build(name, dtype, batch, device_only=True)
 gr = capi.Graph(tm2.write_tm2(g), batch=batch, use_hip_graph=False)
 gr.set_input(models.synth_input(g, 3, {"uint8": tm2.DT_UINT8, "fp32": tm2.DT_FP32}.get(dtype, tm2.DT_INT8)))
+print("launches_per_run %d iters %d" % (gr.kernel_num() + 2, iters))     # + upload / download launches of tamd_graph_run
 for _ in range(iters):
     gr.run()
 gr.close()
