@@ -354,6 +354,14 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
         # available cores) on the same input -- kind "port", reported beside the reference figure, never instead of it
         try:
             from oracle import oracle
+            nthr = min(32, logical)
+            cm = cgroup_cpu_max()
+            if cm and cm.split()[0].isdigit():          # "quota period": the container's CPU allowance
+                nthr = max(1, min(nthr, int(cm.split()[0]) // max(1, int(cm.split()[1]))))
+            try:
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(nthr)
+            except OSError:
+                pass
             oracle.run_graph(g, x)
             ts, t_end = [], time.perf_counter() + min(4.0, budget_s / 3)
             while time.perf_counter() < t_end or len(ts) < 2:
@@ -361,7 +369,8 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
                 oracle.run_graph(g, x)
                 ts.append(time.perf_counter() - t0)
             out["port_openmp"] = {"value": batch / min(ts), "unit": "images/s", "min_ms": 1e3 * min(ts), "runs": len(ts),
-                                  "kind": "port", "what": "oracle/tg_oracle.c restatement, OpenMP default thread count"}
+                                  "kind": "port", "threads": nthr,
+                                  "what": "oracle/tg_oracle.c restatement (plain C, OpenMP) on the container's CPU allowance"}
         except Exception as e:       # noqa: BLE001 -- the port is optional evidence
             out["port_openmp"] = {"error": str(e)[:200]}
         return out
