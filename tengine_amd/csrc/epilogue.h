@@ -218,14 +218,60 @@ __device__ __forceinline__ void fuse_elt16_t(unsigned (&p)[4], const uint4& r, c
     p[3] = fuse_elt4_t<TYPE, CONV_FIRST, RELU>(p[3], r.w, e, inv_out, inv_relu);
 }
 
+// The ResNet residual tail -- SUM, optionally followed by a ReLU that keeps the eltwise output scale -- on 16 channels with
+// packed fp32 (v_pk_mul / v_pk_add / v_pk_fma process two values per instruction, IEEE per element like their scalar
+// forms) and the same division-free rounding as requant4:
+//   f = fl(fl(qc*s_conv) + fl(qr*s_res))   (eltwise_ref.c:589-640)   ->  clamp to [-lim | 0, lim], lim = fl(127.49*s)
+//   y = fma(f, fl(1/s), copysign(0.5+eps, f)) ; trunc(y) is the reference's sat127(round(f/s)) unless fract(|y|) < 2 eps,
+//   then the exact division decides (round_div_sat's argument; clamping f first changes nothing: beyond +-lim the reference
+//   saturates to +-127 too, and below 0 a following ReLU maps every result to 0, which is what round(0/s) gives).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+template <bool RELU>
+__device__ __forceinline__ void elt_sum16(unsigned (&p)[4], const uint4& r, const EltFuse& e, float inv_out)
+{
+    const float lim = __fmul_rn(127.49f, e.out_scale);
+    const float lo = RELU ? 0.f : -lim;
+    const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+    const v2f_t sc = {e.s_conv, e.s_conv}, sr = {e.s_res, e.s_res}, inv2 = {inv_out, inv_out};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        float f[4], fr[4];
+        int q[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const v2f_t c = {(float)sx8(p[d], 2 * h), (float)sx8(p[d], 2 * h + 1)};
+            const v2f_t v = {(float)sx8(rr[d], 2 * h), (float)sx8(rr[d], 2 * h + 1)};
+            v2f_t s = c * sc + v * sr;                      // -ffp-contract=off: both products rounded, then the sum
+            s.x = __builtin_amdgcn_fmed3f(s.x, lo, lim);
+            s.y = __builtin_amdgcn_fmed3f(s.y, lo, lim);
+            const v2f_t half = {RELU ? 0.5f + TAMD_RQ_EPS : copysignf(0.5f + TAMD_RQ_EPS, s.x),
+                                RELU ? 0.5f + TAMD_RQ_EPS : copysignf(0.5f + TAMD_RQ_EPS, s.y)};
+            const v2f_t y = __builtin_elementwise_fma(s, inv2, half);
+            f[2 * h] = s.x; f[2 * h + 1] = s.y;
+            q[2 * h] = (int)y.x; q[2 * h + 1] = (int)y.y;
+            fr[2 * h] = __builtin_amdgcn_fractf(fabsf(y.x)); fr[2 * h + 1] = __builtin_amdgcn_fractf(fabsf(y.y));
+        }
+        // one branch per four values (a wave takes it for ~3% of them), as requant4 does
+        if (fminf(fminf(fr[0], fr[1]), fminf(fr[2], fr[3])) < 2.f * TAMD_RQ_EPS) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int qe = exact_round_div_sat(f[k], e.out_scale);
+                q[k] = fr[k] < 2.f * TAMD_RQ_EPS ? qe : q[k];
+            }
+        }
+        p[d] = pack4(q[0], q[1], q[2], q[3]);
+    }
+}
+
 // everything by VALUE: a reference into the kernel's argument block would force the whole block into scratch memory
 __device__ __attribute__((noinline)) static uint4 fuse_elt16(uint4 pv, uint4 r, EltFuse e, float inv_out, float inv_relu)
 {
     unsigned p[4] = {pv.x, pv.y, pv.z, pv.w};
     // the ResNet case first: sum + ReLU whose output scale is the eltwise output scale (sum is commutative)
-    if (e.type == 2 && e.relu == 2) fuse_elt16_t<2, true, 2>(p, r, e, inv_out, inv_relu);
+    if (e.type == 2 && e.relu == 2) elt_sum16<true>(p, r, e, inv_out);
     else if (e.type == 2 && e.relu) fuse_elt16_t<2, true, 1>(p, r, e, inv_out, inv_relu);
-    else if (e.type == 2) fuse_elt16_t<2, true, 0>(p, r, e, inv_out, inv_relu);
+    else if (e.type == 2) elt_sum16<false>(p, r, e, inv_out);
     else {
         p[0] = fuse_elt4(p[0], r.x, e, inv_out, inv_relu);
         p[1] = fuse_elt4(p[1], r.y, e, inv_out, inv_relu);

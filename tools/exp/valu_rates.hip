@@ -122,6 +122,46 @@ __global__ void k_glb(unsigned long long* out, const int* tab, int n, int stride
     if (p == 0x7fffffff) out[1] = 1;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// packed fp32 (v_pk_fma_f32): two values per instruction -- same issue cost as a scalar fma or twice?
+__global__ void k_pk(unsigned long long* out, int dep, float seed)
+{
+    v2f a = {seed, seed + 1.f}, b = {seed + 2.f, seed + 3.f}, c = {seed * 0.5f, seed * 0.25f}, d = {seed + 5.f, seed + 7.f};
+    const v2f m = {0.999f, 1.001f}, k = {1e-3f, -1e-3f};
+    const unsigned long long t0 = clock64();
+    if (dep) {
+#pragma unroll
+        for (int i = 0; i < 256; i++) a = __builtin_elementwise_fma(a, m, k);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            a = __builtin_elementwise_fma(a, m, k);
+            b = __builtin_elementwise_fma(b, m, k);
+            c = __builtin_elementwise_fma(c, m, k);
+            d = __builtin_elementwise_fma(d, m, k);
+        }
+    }
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if (a.x + b.x + c.x + d.x + a.y + b.y + c.y + d.y == 12345.f) out[1] = 1;
+}
+
+// byte extraction folded into the conversion (SDWA source select) -- a full-rate instruction?
+__global__ void k_sdwa(unsigned long long* out, int x)
+{
+    int a = x, b = x + 1, c = x + 2, d = x + 3;
+    float fa, fb, fc, fd;
+    const unsigned long long t0 = clock64();
+    asm volatile(".rept 256\n v_cvt_f32_i32_sdwa %4, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+                 " v_cvt_f32_i32_sdwa %5, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n"
+                 " v_cvt_f32_i32_sdwa %6, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n"
+                 " v_cvt_f32_i32_sdwa %7, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n.endr\n"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=v"(fa), "=v"(fb), "=v"(fc), "=v"(fd));
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if (fa + fb + fc + fd == 12345.f) out[1] = 1;
+}
+
 int main()
 {
     unsigned long long* d; CK(hipMalloc(&d, 64));
@@ -144,6 +184,12 @@ int main()
         for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_mfma32, dim3(256), dim3(256), 0, 0, d, dep);
         report("v_mfma_i32_32x32x32_i8", dep ? "dependent" : "2 independent", 64);
     }
+    for (int dep = 1; dep >= 0; dep--) {
+        for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_pk, dim3(256), dim3(256), 0, 0, d, dep, 1.5f);
+        report("v_pk_fma_f32", dep ? "dependent" : "4 independent", 256);
+    }
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_sdwa, dim3(256), dim3(256), 0, 0, d, 77);
+    report("v_cvt_f32_i32_sdwa", "4 independent", 1024);
     for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_lds, dim3(256), dim3(256), 0, 0, d, 256);
     report("ds_read_b32 pointer chase", "latency", 256);
     int* tab; CK(hipMalloc(&tab, 4 << 20));
