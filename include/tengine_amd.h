@@ -61,6 +61,8 @@ enum {
     TAMD_OP_SOFTMAX = 12, /* param: tamd_softmax_param (NULL: axis 1); fp32 and uint8 graphs */
     TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 graphs, order (0,2,3,1) -- the SSD head permute */
     TAMD_OP_RESHAPE = 14, /* param: tamd_reshape_param; uint8 / fp32 graphs (dense NCHW on the device: a view)        */
+    TAMD_OP_PRIORBOX = 15,/* param: tamd_priorbox_param; uint8 / fp32 graphs, batch 1.  Depends on shapes only: evaluated ONCE
+                           * at prerun (priorbox_ref.c:53-199 re-computes the same numbers at every run), no launch at run   */
     TAMD_OP_NUM
 };
 
@@ -92,6 +94,16 @@ typedef struct tamd_softmax_param { int axis; } tamd_softmax_param;          /* 
 /* the RESOLVED output shape of a Reshape node (what reshape.c:37-160 infers from re_shape / is_mxnet / is_onnx); the batch
  * dimension follows tamd_graph_set_batch */
 typedef struct tamd_reshape_param { int dim_num; int dims[8]; } tamd_reshape_param;
+
+/* == struct priorbox_param (source/operator/prototype/priorbox_param.h:28-52) with the float vectors inline; num_priors /
+ * out_dim are re-derived as priorbox.c:37-64 does.  inputs: [0] feature map, [1] the image ("data") -- shapes only */
+#define TAMD_PRIORBOX_MAX 8
+typedef struct tamd_priorbox_param {
+    int min_size_num, max_size_num, aspect_ratio_num;
+    float min_size[TAMD_PRIORBOX_MAX], max_size[TAMD_PRIORBOX_MAX], aspect_ratio[TAMD_PRIORBOX_MAX], variance[4];
+    int flip, clip, image_h, image_w;
+    float step_h, step_w, offset;
+} tamd_priorbox_param;
 
 /* == the quantisation-relevant part of struct tensor (source/graph/tensor.h:43-102) */
 typedef struct tamd_tensor_desc {

@@ -250,6 +250,30 @@ def softmax_uint8(x, axis, in_q, out_q):
     return y
 
 
+def priorbox(feat_dims, data_dims, p, dtype, out_q=None):
+    """PriorBox node (priorbox_ref.c:53-213): [1, 2, out_dim, 1] in the output tensor's dtype."""
+    fa = lambda v: np.ascontiguousarray(v, np.float32)
+    mn, mx, ar, var = fa(p["min_size"]), fa(p.get("max_size", [])), fa(p.get("aspect_ratio", [])), fa(p["variance"])
+    num = (len(ar) * (2 if p.get("flip", 0) else 1) + 1 + (1 if len(mx) else 0)) * len(mn)
+    dim = feat_dims[2] * feat_dims[3] * num * 4
+    f = np.zeros((1, 2, dim, 1), np.float32)
+    fn = lib().orc_priorbox_f32
+    fn.restype = C.c_int
+    rc = fn(_p(f), feat_dims[2], feat_dims[3], data_dims[2], data_dims[3], int(p.get("img_h", 0)), int(p.get("img_w", 0)),
+            C.c_float(p.get("step_h", 0.0)), C.c_float(p.get("step_w", 0.0)), C.c_float(p.get("offset", 0.5)), _p(mn),
+            len(mn), _p(mx), len(mx), _p(ar), len(ar), _p(var), int(p.get("flip", 0)), int(p.get("clip", 0)))
+    assert rc == num, rc
+    if dtype == DT_FP32:
+        return f
+    if dtype == DT_UINT8:
+        y = np.empty(f.shape, np.uint8)
+        lib().orc_priorbox_quant_uint8(_p(f), _p(y), C.c_size_t(f.size), C.c_float(out_q[0]), int(out_q[1]))
+        return y
+    y = np.empty(f.shape, np.int8)
+    lib().orc_priorbox_quant_int8(_p(f), _p(y), C.c_size_t(f.size), C.c_float(out_q[0]))
+    return y
+
+
 def eltwise_uint8(a, b, etype, qa, qb, out_q):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
@@ -281,7 +305,11 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
         i0, o0 = n.inputs[0], n.outputs[0]
         a = vals[i0]
         dt = T[o0].dtype
-        if op == "Convolution":
+        if op == "PriorBox":
+            if T[o0].dims[0] != 1:      # priorbox_ref.c fills image 0 only; the rest of the tensor is whatever malloc returned
+                raise NotImplementedError("PriorBox with batch > 1 is undefined in the reference")
+            y = priorbox(T[i0].dims, T[n.inputs[1]].dims, p, dt, qp(o0) if dt != DT_FP32 else None)
+        elif op == "Convolution":
             w = vals[n.inputs[1]]
             b = vals[n.inputs[2]] if len(n.inputs) > 2 else None
             if dt == DT_INT8:

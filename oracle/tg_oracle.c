@@ -539,6 +539,96 @@ ORC_API int orc_softmax_uint8(const uint8_t* x, uint8_t* y, int out_size, int on
     return 0;
 }
 
+/* PriorBox -- priorbox/priorbox_ref.c:53-199.  Depends on shapes and parameters only.  C arithmetic kept as written
+ * there: `int min_size_ = param->min_size[s]` truncates (:110); the square prior of (min, max) is the DOUBLE sqrt of the
+ * INT product (:123-126); the aspect-ratio priors multiply / divide that int by the DOUBLE sqrt of the float ratio
+ * (:136-139); every corner is (centre -+ size * 0.5f) / image extent in float; the flipped prior divides x by image_h and
+ * y by image_w (:146-150, as written there); clip (:157-164) covers the boxes, then out_dim/4 copies of variance[4]
+ * (:166-175).  Output: [1][2][out_dim][1] floats, out_dim = feat_h * feat_w * num_priors * 4 (priorbox.c:37-75).        */
+ORC_API int orc_priorbox_f32(float* out, int feat_h, int feat_w, int data_h, int data_w, int image_h_p, int image_w_p,
+                             float step_h_p, float step_w_p, float offset, const float* min_size, int n_min,
+                             const float* max_size, int n_max, const float* ratio, int n_ratio, const float* variance,
+                             int flip, int clip)
+{
+    if (n_max > 0 && n_max != n_min) return -1;                            /* priorbox.c:48-61 */
+    const int num_priors = (n_ratio * (flip ? 2 : 1) + 1 + (n_max > 0 ? 1 : 0)) * n_min;
+    const int dim = feat_h * feat_w * num_priors * 4;
+    int image_w, image_h;
+    if (image_h_p == 0 || image_w_p == 0) { image_w = data_w; image_h = data_h; }
+    else { image_w = image_w_p; image_h = image_h_p; }
+    float step_w, step_h;
+    if (step_h_p == 0 || step_w_p == 0) { step_w = (float)(image_w) / feat_w; step_h = (float)(image_h) / feat_h; }
+    else { step_w = step_w_p; step_h = step_h_p; }
+    for (int h = 0; h < feat_h; ++h)
+    {
+        float* box = out + h * num_priors * 4 * feat_w;
+        for (int w = 0; w < feat_w; ++w)
+        {
+            float center_x = (w + offset) * step_w;
+            float center_y = (h + offset) * step_h;
+            float bw, bh;
+            for (int s = 0; s < n_min; ++s)
+            {
+                int mn = min_size[s];
+                bw = bh = mn;
+                box[0] = (center_x - bw * 0.5f) / image_w; box[1] = (center_y - bh * 0.5f) / image_h;
+                box[2] = (center_x + bw * 0.5f) / image_w; box[3] = (center_y + bh * 0.5f) / image_h;
+                box += 4;
+                if (n_max > 0)
+                {
+                    int mx = max_size[s];
+                    bw = bh = sqrt(mn * mx);
+                    box[0] = (center_x - bw * 0.5f) / image_w; box[1] = (center_y - bh * 0.5f) / image_h;
+                    box[2] = (center_x + bw * 0.5f) / image_w; box[3] = (center_y + bh * 0.5f) / image_h;
+                    box += 4;
+                }
+                for (int r = 0; r < n_ratio; ++r)
+                {
+                    float ar = ratio[r];
+                    bw = mn * sqrt(ar);
+                    bh = mn / sqrt(ar);
+                    box[0] = (center_x - bw * 0.5f) / image_w; box[1] = (center_y - bh * 0.5f) / image_h;
+                    box[2] = (center_x + bw * 0.5f) / image_w; box[3] = (center_y + bh * 0.5f) / image_h;
+                    box += 4;
+                    if (flip)
+                    {
+                        box[0] = (center_x - bh * 0.5f) / image_h; box[1] = (center_y - bw * 0.5f) / image_w;
+                        box[2] = (center_x + bh * 0.5f) / image_h; box[3] = (center_y + bw * 0.5f) / image_w;
+                        box += 4;
+                    }
+                }
+            }
+        }
+    }
+    if (clip)
+        for (int d = 0; d < dim; ++d) out[d] = out[d] < 0.f ? 0.f : (out[d] > 1.f ? 1.f : out[d]);
+    float* v = out + dim;
+    for (int i = 0; i < dim / 4; i++, v += 4) { v[0] = variance[0]; v[1] = variance[1]; v[2] = variance[2]; v[3] = variance[3]; }
+    return num_priors;
+}
+
+/* its quantisation: uint8 (int)(f / scale + zp) -- TRUNCATION, float arithmetic -- clamp [0,255] (priorbox_ref.c:178-195);
+ * int8 round(f / scale) clamp [-127,127] (:197-213)                                                                    */
+ORC_API int orc_priorbox_quant_uint8(const float* f, uint8_t* y, size_t n, float scale, int zp)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        int u = (int)(f[i] / scale + zp);
+        y[i] = u > 255 ? 255 : (u < 0 ? 0 : u);
+    }
+    return 0;
+}
+
+ORC_API int orc_priorbox_quant_int8(const float* f, int8_t* y, size_t n, float scale)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        int q = round(f[i] / scale);
+        y[i] = (int8_t)(q > 127 ? 127 : (q < -127 ? -127 : q));
+    }
+    return 0;
+}
+
 /* fc uint8 -- fc/fc_ref.c:121-207: data = (float)bias*bias_scale; data = fma(xf, wf, data) j ascending;
  * round(data/out_s) + out_zp, clamp [0,255].  bias_scale == bias_tensor->scale.                            */
 ORC_API int orc_fc_uint8(const uint8_t* x, const uint8_t* w, const int32_t* bias, uint8_t* y, int batch, int hidden,

@@ -28,6 +28,7 @@ struct HTensor {               // host IR tensor == the parts of struct tensor t
     int c_off = 0;             // channel offset inside the buffer pixel (concat-by-offset views)
     bool is_view = false;      // aliases another tensor's buffer
     bool nchw_raw = false;     // graph input kept in NCHW for a direct first conv
+    bool prerun_const = false; // written once at prerun (PriorBox and what only depends on it), never by a run
     size_t elems() const { size_t e = 1; for (int d : dims) e *= (size_t)d; return e; }
 };
 
@@ -42,6 +43,7 @@ union NodeParam {
     tamd_permute_param perm;
     tamd_softmax_param softmax;
     tamd_reshape_param reshape;
+    tamd_priorbox_param priorbox;
 };
 
 struct HNode {
@@ -55,6 +57,7 @@ struct Step {                  // one device launch of the compiled plan
     std::string node, kernel;
     double macs = 0, bytes = 0;
     std::function<hipError_t(hipStream_t)> fn;
+    bool once = false;         // every input is a prerun constant (PriorBox outputs): launched once at the end of prerun
 };
 
 struct IOBind {
@@ -125,6 +128,9 @@ PoolGeom pool_geom(const tamd_pool_param& p, int h, int w);
 int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
 void nhwc_geom(HTensor& t);
 int count_consumers(const tamd_graph* g, int tensor);
+int priorbox_count(const tamd_priorbox_param& p);
+void priorbox_eval(const tamd_priorbox_param& p, int feat_h, int feat_w, int data_h, int data_w, std::vector<float>* out);
+void priorbox_quant_u8(const std::vector<float>& f, float scale, int zp, std::vector<uint8_t>* q);
 int plan_u8(tamd_graph* g);        // graph_u8.hip: every activation tensor is uint8
 int plan_f32(tamd_graph* g);       // graph_f32.hip: every activation tensor is fp32
 

@@ -88,6 +88,67 @@ PoolGeom pool_geom(const tamd_pool_param& p, int h, int w)
     return g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// PriorBox: the SSD anchor boxes depend on tensor SHAPES and node parameters only, so the node is evaluated
+// once at prerun and its output tensor is a device constant; the reference recomputes the same numbers at every run
+// (priorbox_ref.c:53-175).  Arithmetic types follow that file: sizes are truncated to int (:110,:121); the (min, max)
+// prior is the double sqrt of the int product; ratio priors are int * | / double sqrt(ratio), stored as float; corners are
+// (centre -+ size * 0.5f) / extent in float; a flipped prior swaps the sizes AND the extents it divides by (:146-150).
+// ---------------------------------------------------------------------------------------------
+int priorbox_count(const tamd_priorbox_param& p)
+{
+    return (1 + (p.max_size_num > 0 ? 1 : 0) + p.aspect_ratio_num * (p.flip ? 2 : 1)) * p.min_size_num;       // priorbox.c:37-64
+}
+
+void priorbox_eval(const tamd_priorbox_param& p, int feat_h, int feat_w, int data_h, int data_w, std::vector<float>* out)
+{
+    struct Prior { float w, h; bool flipped; };
+    std::vector<Prior> cell;                                     // the priors of one feature-map cell, in output order
+    for (int s = 0; s < p.min_size_num; s++) {
+        const int mn = (int)p.min_size[s];
+        cell.push_back({(float)mn, (float)mn, false});
+        if (p.max_size_num > 0) {
+            const float q = (float)std::sqrt((double)(mn * (int)p.max_size[s]));
+            cell.push_back({q, q, false});
+        }
+        for (int r = 0; r < p.aspect_ratio_num; r++) {
+            const double root = std::sqrt((double)p.aspect_ratio[r]);
+            const Prior pr{(float)(mn * root), (float)(mn / root), false};
+            cell.push_back(pr);
+            if (p.flip) cell.push_back({pr.w, pr.h, true});
+        }
+    }
+    const bool own_image = p.image_h != 0 && p.image_w != 0, own_step = p.step_h != 0 && p.step_w != 0;
+    const float iw = (float)(own_image ? p.image_w : data_w), ih = (float)(own_image ? p.image_h : data_h);
+    const float step_w = own_step ? p.step_w : iw / (float)feat_w, step_h = own_step ? p.step_h : ih / (float)feat_h;
+    const size_t dim = (size_t)feat_h * feat_w * cell.size() * 4;
+    out->assign(2 * dim, 0.f);
+    float* o = out->data();
+    for (int y = 0; y < feat_h; y++)
+        for (int x = 0; x < feat_w; x++) {
+            const float cx = ((float)x + p.offset) * step_w, cy = ((float)y + p.offset) * step_h;
+            for (const Prior& pr : cell) {
+                const float hx = (pr.flipped ? pr.h : pr.w) * 0.5f, hy = (pr.flipped ? pr.w : pr.h) * 0.5f;
+                const float ex = pr.flipped ? ih : iw, ey = pr.flipped ? iw : ih;
+                o[0] = (cx - hx) / ex; o[1] = (cy - hy) / ey; o[2] = (cx + hx) / ex; o[3] = (cy + hy) / ey;
+                o += 4;
+            }
+        }
+    if (p.clip)
+        for (size_t i = 0; i < dim; i++) (*out)[i] = std::min(std::max((*out)[i], 0.f), 1.f);
+    for (size_t i = 0; i < dim; i++) (*out)[dim + i] = p.variance[i & 3];
+}
+
+// its quantisation (priorbox_ref.c:178-213): uint8 truncates (int)(f / scale + zp); int8 rounds
+void priorbox_quant_u8(const std::vector<float>& f, float scale, int zp, std::vector<uint8_t>* q)
+{
+    q->resize(f.size());
+    for (size_t i = 0; i < f.size(); i++) {
+        const int u = (int)(f[i] / scale + (float)zp);
+        (*q)[i] = (uint8_t)std::min(std::max(u, 0), 255);
+    }
+}
+
 static int infer_shapes(tamd_graph* g)
 {
     for (auto& n : g->nodes) {
@@ -180,6 +241,14 @@ static int infer_shapes(tamd_graph* g)
             y.dims = {x.dims[0], f};
             break;
         }
+        case TAMD_OP_PRIORBOX: {          // priorbox.c:33-75: [n][2][feat_h * feat_w * num_priors * 4][1]
+            const tamd_priorbox_param& pb = n.p.priorbox;
+            if (x.dims.size() != 4 || n.in.size() < 2 || g->tensors[n.in[1]].dims.size() != 4) { set_error("priorbox %s: needs a 4-D feature map and the 4-D image tensor", n.name.c_str()); return -1; }
+            if (pb.min_size_num < 1 || pb.min_size_num > TAMD_PRIORBOX_MAX || pb.aspect_ratio_num < 0 || pb.aspect_ratio_num > TAMD_PRIORBOX_MAX
+                || (pb.max_size_num != 0 && pb.max_size_num != pb.min_size_num)) { set_error("priorbox %s: bad size / ratio counts", n.name.c_str()); return -1; }
+            y.dims = {x.dims[0], 2, x.dims[2] * x.dims[3] * priorbox_count(pb) * 4, 1};
+            break;
+        }
         default:
             set_error("infer_shape: unsupported op %d (%s)", n.op, n.name.c_str());
             return -1;
@@ -198,6 +267,8 @@ static int validate_graph(tamd_graph* g)
 {
     auto bad = [&](const HNode& n, const char* what) { set_error("%s: %s", n.name.c_str(), what); return -1; };
     for (auto& n : g->nodes) {
+        // priorbox_ref.c fills image 0 of its output only (:99-175); what a batch > 1 tensor holds behind it is undefined there
+        if (n.op == TAMD_OP_PRIORBOX && g->tensors[n.out[0]].dims[0] != 1) return bad(n, "PriorBox is defined for batch 1 only");
         if (n.op != TAMD_OP_CONV && n.op != TAMD_OP_FC) continue;
         const HTensor& x = g->tensors[n.in[0]];
         HTensor& w = g->tensors[n.in[1]];
@@ -1178,7 +1249,7 @@ int tamd_op_supported(int op, int dtype)
     if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
     if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
     if (op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
-    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RESHAPE) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
+    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RESHAPE || op == TAMD_OP_PRIORBOX) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
     if (op == TAMD_OP_PERMUTE) return dtype == TAMD_DT_UINT8;      // SSD heads (Permute -> Flatten -> Concat), uint8 graphs
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
@@ -1236,7 +1307,14 @@ int tamd_node_supported(const tamd_node_desc* n, const tamd_tensor_desc* in, int
     case TAMD_OP_CONCAT: {
         int ax = n->param ? ((const tamd_concat_param*)n->param)->axis : 1;
         if (ax < 0) ax += out[0].dim_num;
-        return ax == 1 && out[0].dim_num >= 2;
+        if (dt == TAMD_DT_INT8) return ax == 1 && out[0].dim_num >= 2;       // NHWC device tensors: channel concat
+        return ax >= 0 && ax < out[0].dim_num;                               // dense NCHW: any axis
+    }
+    case TAMD_OP_PRIORBOX: {
+        if (!n->param || n_in < 2 || in[0].dim_num != 4 || in[1].dim_num != 4 || out[0].dim_num < 1 || out[0].dims[0] != 1) return 0;
+        const tamd_priorbox_param& p = *(const tamd_priorbox_param*)n->param;
+        return p.min_size_num >= 1 && p.min_size_num <= TAMD_PRIORBOX_MAX && p.aspect_ratio_num >= 0 && p.aspect_ratio_num <= TAMD_PRIORBOX_MAX
+               && (p.max_size_num == 0 || p.max_size_num == p.min_size_num);
     }
     case TAMD_OP_PERMUTE: {
         if (!n->param || out[0].dim_num != 4) return 0;
@@ -1307,6 +1385,7 @@ int tamd_graph_add_node(tamd_graph* g, const tamd_node_desc* d)
         case TAMD_OP_PERMUTE: n.p.perm = *(const tamd_permute_param*)d->param; break;
         case TAMD_OP_SOFTMAX: n.p.softmax = *(const tamd_softmax_param*)d->param; break;
         case TAMD_OP_RESHAPE: n.p.reshape = *(const tamd_reshape_param*)d->param; break;
+        case TAMD_OP_PRIORBOX: n.p.priorbox = *(const tamd_priorbox_param*)d->param; break;
         default: break;
         }
     }
@@ -1360,6 +1439,10 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         if (t.ttype != TAMD_TT_CONST) (t.dtype == TAMD_DT_UINT8 ? any_u8 : t.dtype == TAMD_DT_FP32 ? any_f32 : any_i8) = true;
     if ((int)any_u8 + (int)any_f32 + (int)any_i8 > 1) { set_error("mixed int8 / uint8 / fp32 activations in one device graph"); return -1; }
     if (any_u8 ? plan_u8(g) : any_f32 ? plan_f32(g) : plan(g)) return -1;
+    // launches whose inputs are all prerun constants (the Concat of the PriorBox outputs) run now and never again
+    for (auto& st : g->steps)
+        if (st.once) HIPCHK(st.fn(g->stream));
+    g->steps.erase(std::remove_if(g->steps.begin(), g->steps.end(), [](const Step& st) { return st.once; }), g->steps.end());
     for (auto* v : {&g->inputs, &g->outputs})
         for (auto& io : *v) HIPCHK(hipHostMalloc(&io.pinned2, std::max<size_t>(io.bytes, 16), hipHostMallocDefault));
     HIPCHK(hipDeviceSynchronize());

@@ -180,22 +180,40 @@ int plan_f32(tamd_graph* g)
             g->steps.push_back(st);
             break;
         }
+        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph.hip priorbox_eval); no launch at run
+            const HTensor& img = g->tensors[n.in[1]];
+            std::vector<float> boxes;
+            priorbox_eval(n.p.priorbox, x.dims[2], x.dims[3], img.dims[2], img.dims[3], &boxes);
+            if (boxes.size() != y.elems()) { set_error("priorbox %s: output shape mismatch", n.name.c_str()); return -1; }
+            HIPCHK(hipMemcpyAsync(y.dptr, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+            y.prerun_const = true;
+            break;
+        }
         case TAMD_OP_CONCAT: {
             int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
-            if (ax != 1) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
+            if (ax < 0 || ax >= (int)y.dims.size()) { set_error("concat %s: bad axis", n.name.c_str()); return -1; }
+            // dense tensors: any axis is a channel concat of the [outer][dims[ax]][1][inner] view
+            int outer = 1, inner = 1;
+            for (int d = 0; d < ax; d++) outer *= y.dims[d];
+            for (size_t d = ax + 1; d < y.dims.size(); d++) inner *= y.dims[d];
+            bool all_const = true;
+            for (int i : n.in) all_const &= g->tensors[i].prerun_const;
             int off = 0;
             for (int i : n.in) {
                 HTensor& xi = g->tensors[i];
-                if (xi.is_view && xi.dptr == y.dptr) { off += xi.c; continue; }      // written in place by its producer
+                if (xi.is_view && xi.dptr == y.dptr) { off += xi.dims[ax]; continue; }      // written in place by its producer
                 F32MapArgs a{};
                 a.x = (const float*)xi.dptr; a.y = (float*)y.dptr;
-                a.N = xi.n; a.C = xi.c; a.H = xi.h; a.W = xi.w; a.scale = 1;
-                a.out_img = y.c * y.h * y.w; a.out_c0 = off;
+                a.N = outer; a.C = xi.dims[ax]; a.H = 1; a.W = inner; a.scale = 1;
+                a.out_img = y.dims[ax] * inner; a.out_c0 = off;
                 Step st; st.node = n.name; st.kernel = "concat_f32"; st.bytes = 8.0 * xi.elems();
+                st.once = all_const;
                 st.fn = [a](hipStream_t s) { return launch_map_f32(a, 1, s); };
                 g->steps.push_back(st);
-                off += xi.c;
+                off += xi.dims[ax];
             }
+            y.prerun_const = all_const;
             break;
         }
         case TAMD_OP_ELTWISE: {

@@ -450,20 +450,42 @@ int plan_u8(tamd_graph* g)
             g->steps.push_back(st);
             break;
         }
+        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph.hip priorbox_eval); no launch at run
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            const HTensor& img = g->tensors[n.in[1]];
+            U8Q qy;
+            if (q_of(y, &qy, "tensor")) return -1;
+            std::vector<float> boxes;
+            std::vector<uint8_t> q;
+            priorbox_eval(n.p.priorbox, x.dims[2], x.dims[3], img.dims[2], img.dims[3], &boxes);
+            if (boxes.size() != y.elems()) { set_error("priorbox %s: output shape mismatch", n.name.c_str()); return -1; }
+            priorbox_quant_u8(boxes, qy.scale, qy.zp, &q);
+            HIPCHK(hipMemcpyAsync(y.dptr, q.data(), q.size(), hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+            y.prerun_const = true;
+            break;
+        }
         case TAMD_OP_CONCAT: {
             HTensor& y = g->tensors[n.out[0]];
             int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
-            if (ax != 1) { set_error("concat %s: only axis 1 is supported on the device", n.name.c_str()); return -1; }
-            // axis 1 of [n][c][...]: every input is one contiguous slice of each output image
-            const int out_img = (int)(y.elems() / y.dims[0]);
+            if (ax < 0 || ax >= (int)y.dims.size()) { set_error("concat %s: bad axis", n.name.c_str()); return -1; }
+            // dense tensors: for every index in front of the axis, each input is one contiguous slice of the output's slice
+            // (axis 1 of [n][c][...]: one slice per image)
+            size_t outer = 1, inner = 1;
+            for (int d = 0; d < ax; d++) outer *= (size_t)y.dims[d];
+            for (size_t d = ax + 1; d < y.dims.size(); d++) inner *= (size_t)y.dims[d];
+            const int out_img = (int)(y.dims[ax] * inner);
+            bool all_const = true;
+            for (int i : n.in) all_const &= g->tensors[i].prerun_const;
             int off = 0;
             for (int i : n.in) {
                 HTensor& x = g->tensors[i];
-                const int in_img = (int)(x.elems() / x.dims[0]);
+                const int in_img = (int)(x.dims[ax] * inner);
                 if (x.is_view && x.dptr == y.dptr) { off += in_img; continue; }       // written in place by its producer
                 U8CatArgs a{};
                 a.x = (const uint8_t*)x.dptr; a.y = (uint8_t*)y.dptr;
-                a.N = x.dims[0]; a.in_img = in_img; a.out_img = out_img; a.out_off = off;
+                a.N = (int)outer; a.in_img = in_img; a.out_img = out_img; a.out_off = off;
                 if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
                 // roundf((u - zp) * 1 + zp) == u: equal parameters make the rescale a copy
                 a.identity = a.in.scale == a.out.scale && a.in.zp == a.out.zp;
@@ -474,10 +496,12 @@ int plan_u8(tamd_graph* g)
                     kname = "permute_concat_u8";
                 }
                 Step st; st.node = n.name; st.kernel = kname; st.bytes = 2.0 * x.elems();
+                st.once = all_const;                                     // e.g. mbox_priorbox: PriorBox outputs only
                 st.fn = [a](hipStream_t s) { return launch_flatcat_u8(a, s); };
                 g->steps.push_back(st);
                 off += in_img;
             }
+            y.prerun_const = all_const;
             break;
         }
         case TAMD_OP_ELTWISE: {

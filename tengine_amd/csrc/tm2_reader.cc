@@ -70,6 +70,7 @@ int map_op(uint32_t t)
     case 12: return TAMD_OP_INPUT;
     case 15: return TAMD_OP_PERMUTE;
     case 16: return TAMD_OP_POOL;
+    case 18: return TAMD_OP_PRIORBOX;
     case 20: return TAMD_OP_RELU;
     case 21: return TAMD_OP_RELU6;
     case 23: return TAMD_OP_RESHAPE;
@@ -177,6 +178,24 @@ extern "C" tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size)
             case TAMD_OP_CONCAT: p.concat.axis = r.i32(po); break;
             case TAMD_OP_SOFTMAX: p.softmax.axis = r.i32(po); break;   // TM2_SoftmaxParam {axis}
             case TAMD_OP_UPSAMPLE: p.ups.scale = r.f32(po); break;
+            case TAMD_OP_PRIORBOX: {                           // TM2_PriorBoxParam :526-542 (tm2_priorbox.c:43-84)
+                tamd_priorbox_param& q = p.priorbox;
+                auto floats = [&](uint32_t vo_, float* dst, int cap, int* num) {      // TM2_Vector_floats {v_num, data[]}
+                    const uint32_t n = r.u32(vo_);
+                    if (!r.ok || n > (uint32_t)cap) { r.ok = false; return; }
+                    for (uint32_t i = 0; i < n; i++) dst[i] = r.f32(vo_ + 4 + 4 * i);
+                    if (num) *num = (int)n;
+                };
+                int nvar = 0;
+                floats(r.u32(po), q.min_size, TAMD_PRIORBOX_MAX, &q.min_size_num);
+                floats(r.u32(po + 4), q.max_size, TAMD_PRIORBOX_MAX, &q.max_size_num);
+                floats(r.u32(po + 8), q.variance, 4, &nvar);
+                floats(r.u32(po + 12), q.aspect_ratio, TAMD_PRIORBOX_MAX, &q.aspect_ratio_num);
+                if (nvar != 4) r.ok = false;
+                q.flip = r.i32(po + 16); q.clip = r.i32(po + 20); q.image_h = r.i32(po + 28); q.image_w = r.i32(po + 32);
+                q.step_w = r.f32(po + 36); q.step_h = r.f32(po + 40); q.offset = r.f32(po + 44);
+                break;
+            }
             case TAMD_OP_PERMUTE:                              // TM2_PermuteParam {flag, order0..3} (tm2_permute.c)
                 for (int i = 0; i < 4; i++) p.perm.order[i] = r.i32(po + 4 + 4 * i);
                 break;

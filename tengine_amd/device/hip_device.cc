@@ -43,6 +43,7 @@ extern "C" {
 #include "flatten_param.h"
 #include "permute_param.h"
 #include "pooling_param.h"
+#include "priorbox_param.h"
 #include "relu_param.h"
 #include "softmax_param.h"
 #include "upsample_param.h"
@@ -78,6 +79,7 @@ int map_op(int op)
     case OP_FLATTEN: return TAMD_OP_FLATTEN;
     case OP_PERMUTE: return TAMD_OP_PERMUTE;
     case OP_RESHAPE: return TAMD_OP_RESHAPE;
+    case OP_PRIORBOX: return TAMD_OP_PRIORBOX;
     default: return -1;
     }
 }
@@ -88,7 +90,23 @@ const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_REL
 // SSD head plumbing (Permute -> Flatten -> Concat): on the device for uint8 graphs only, so these two are added to
 // the allowed list per graph (hip_split_graph) instead of globally -- an int8 / fp32 graph keeps them on the CPU
 // without dragging the convolutions around them back there
-const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN, OP_RESHAPE};
+const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN, OP_RESHAPE, OP_PRIORBOX};
+
+// struct priorbox_param (priorbox_param.h:28-52, float vectors on the heap) -> the inline-array form of the C ABI
+bool translate_priorbox(const struct priorbox_param* p, tamd_priorbox_param* q)
+{
+    memset(q, 0, sizeof(*q));
+    if (p->min_size_num < 1 || p->min_size_num > TAMD_PRIORBOX_MAX || p->max_size_num < 0 || p->max_size_num > TAMD_PRIORBOX_MAX
+        || p->aspect_ratio_size < 0 || p->aspect_ratio_size > TAMD_PRIORBOX_MAX || !p->variance) return false;
+    q->min_size_num = p->min_size_num; q->max_size_num = p->max_size_num; q->aspect_ratio_num = p->aspect_ratio_size;
+    for (int i = 0; i < p->min_size_num; i++) q->min_size[i] = p->min_size[i];
+    for (int i = 0; i < p->max_size_num; i++) q->max_size[i] = p->max_size[i];
+    for (int i = 0; i < p->aspect_ratio_size; i++) q->aspect_ratio[i] = p->aspect_ratio[i];
+    for (int i = 0; i < 4; i++) q->variance[i] = p->variance[i];
+    q->flip = p->flip; q->clip = p->clip; q->image_h = p->image_h; q->image_w = p->image_w;
+    q->step_h = p->step_h; q->step_w = p->step_w; q->offset = p->offset;
+    return true;
+}
 
 bool op_supported(int op, int dtype)
 {
@@ -166,8 +184,12 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
         tamd_permute_param pmp;
         tamd_softmax_param smp;
         tamd_reshape_param rsp;
+        tamd_priorbox_param pbp;
         const void* param = nullptr;
         switch (op) {
+        case TAMD_OP_PRIORBOX:
+            if (translate_priorbox((const struct priorbox_param*)n->op.param_mem, &pbp)) param = &pbp;
+            break;
         case TAMD_OP_SOFTMAX: smp.axis = ((const struct softmax_param*)n->op.param_mem)->axis; param = &smp; break;
         case TAMD_OP_RESHAPE: {          // the resolved shape (reshape.c infer_shape already ran)
             struct tensor* ot = get_ir_graph_tensor(ir, n->output_tensors[0]);
@@ -435,8 +457,13 @@ static bool node_supported(struct graph* ir, struct node* n)
     tamd_permute_param pmp;
     tamd_softmax_param smp;
     tamd_reshape_param rsp;
+    tamd_priorbox_param pbp;
     const void* param = nullptr;
     switch (op) {
+    case TAMD_OP_PRIORBOX:
+        if (!translate_priorbox((const struct priorbox_param*)n->op.param_mem, &pbp)) return false;
+        param = &pbp;
+        break;
     case TAMD_OP_SOFTMAX: smp.axis = ((const struct softmax_param*)n->op.param_mem)->axis; param = &smp; break;
     case TAMD_OP_RESHAPE: {
         struct tensor* ot = get_ir_graph_tensor(ir, n->output_tensors[0]);

@@ -137,6 +137,19 @@ class _B:
         self.g.add_node(name, "Reshape", [x], [y], is_mxnet=0, reverse=0, is_onnx=1, re_shape=list(re_shape))
         return y
 
+    def priorbox(self, name, feat, data, min_size, max_size, aspect_ratio, variance=(0.1, 0.1, 0.2, 0.2), flip=1, clip=0,
+                 offset=0.5):
+        """priorbox.c:33-75: [n, 2, feat_h * feat_w * num_priors * 4, 1]"""
+        d = self.dims(feat)
+        num = (len(aspect_ratio) * (2 if flip else 1) + 1 + (1 if max_size else 0)) * len(min_size)
+        out_dim = d[2] * d[3] * num * 4
+        y = self.g.add_tensor(name + "/0", [d[0], 2, out_dim, 1], DT_FP32)
+        self.g.add_node(name, "PriorBox", [feat, data], [y], min_size=[float(v) for v in min_size],
+                        max_size=[float(v) for v in max_size], aspect_ratio=[float(v) for v in aspect_ratio],
+                        variance=[float(v) for v in variance], flip=flip, clip=clip, offset=offset, num_priors=num,
+                        out_dim=out_dim)
+        return y
+
     def finish(self, outs):
         for o in outs:
             for ni, n in enumerate(self.g.nodes):
@@ -275,7 +288,7 @@ def yolov3_tiny_fp32(batch=1, res=416, nout=255):
     return b.finish([head2, head1])
 
 
-def mssd_fp32(batch=1, res=300, classes=21, tail=False):
+def mssd_fp32(batch=1, res=300, classes=21, tail=False, priorbox=False):
     """MobileNet-v1-SSD 300x300 (benchmark/models/mssd_benchmark.tmfile, the BASELINE "MobileNet-SSD" stand-in,
     SURVEY §8d): 47 convs = conv0 + 13 (dw, pw) pairs + 4 (1x1, 3x3 s2) extra pairs + 6 loc and 6 conf 1x1 heads on
     conv11 (19x19, 3 priors), conv13 (10x10), conv14_2 (5x5), conv15_2 (3x3), conv16_2 (2x2), conv17_2 (1x1) (6 priors
@@ -283,8 +296,12 @@ def mssd_fp32(batch=1, res=300, classes=21, tail=False):
     mbox_conf [N, 1917*classes]; the Reshape/Softmax/PriorBox/DetectionOutput tail of the tmfile is host-side
     post-processing the splitter leaves on the CPU device.  `tail=True` appends the quantised part of that tail --
     Reshape(0,-1,classes) -> Softmax(axis 2) -> Flatten on mbox_conf -- for oracle-vs-reference tests of the next
-    row; the device graphs are built without it."""
+    row; the device graphs are built without it.  `priorbox=True` adds the six PriorBox nodes of the
+    MobileNet-SSD deploy prototxt (min / max sizes 60 | 105,150 | 150,195 | 195,240 | 240,285 | 285,300, aspect ratios
+    2 | 2,3, flip, no clip, variances .1 .1 .2 .2, offset 0.5) and their Concat(axis 2) -> mbox_priorbox [1, 2, 7668, 1]:
+    with both, the graph ends exactly at detection_output's three inputs."""
     b = _B("mssd", [batch, 3, res, res])
+    data = b.cur
     x = b.conv("conv0", b.cur, 32, 3, 2, 1, act=0)
     cfg = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1),
            (1024, 2), (1024, 1)]
@@ -311,6 +328,11 @@ def mssd_fp32(batch=1, res=300, classes=21, tail=False):
         y = b.reshape("mbox_conf_reshape", outs[1], [0, -1, classes])
         y = b.softmax("mbox_conf_softmax", y, axis=2)
         outs[1] = b.flatten("mbox_conf_flatten", y)
+    if priorbox:
+        sizes = [(60, None), (105, 150), (150, 195), (195, 240), (240, 285), (285, 300)]
+        pbs = [b.priorbox("%s_mbox_priorbox" % name, f, data, [mn], [mx] if mx else [], [2.0] if npri == 3 else [2.0, 3.0])
+               for (name, f, npri), (mn, mx) in zip(feats, sizes)]
+        outs.append(b.concat("mbox_priorbox", pbs, axis=2))
     return b.finish(outs)
 
 
@@ -388,6 +410,10 @@ def fp32_forward(g: Graph, x: np.ndarray):
             y = a.permute(*p["order"]).contiguous()
         elif op == "Reshape":
             y = a.reshape(g.tensors[n.outputs[0]].dims)
+        elif op == "PriorBox":      # value range only (the table assigns these tensors an a-priori range, see calib_table)
+            y = torch.zeros(g.tensors[n.outputs[0]].dims)
+            y[:, 0] = 0.5
+            y[:, 1] = 0.1
         else:
             raise NotImplementedError(op)
         vals[n.outputs[0]] = y
@@ -600,7 +626,9 @@ def calib_table(name, gf=None, write=False, dtype="int8"):
         if gf is not None and dtype == "uint8":      # optional tail tensors (mssd tail=True): ranges known a priori
             for t in gf.tensors:
                 if t.ttype == tm2.TT_VAR and t.name not in table:
-                    table[t.name] = table["mbox_conf/0"] if t.name == "mbox_conf_reshape/0" else [0.0, 1.0]
+                    # prior boxes: corners of boxes centred inside the image, up to ~0.8 image sizes wide; variances 0.1 / 0.2
+                    table[t.name] = table["mbox_conf/0"] if t.name == "mbox_conf_reshape/0" else \
+                        ([-0.5, 1.5] if "priorbox" in t.name else [0.0, 1.0])
         return table
     gf = gf if gf is not None else BUILDERS[name]()
     table = calibrate_absmax(gf) if dtype == "int8" else calibrate_minmax(gf)
@@ -639,7 +667,7 @@ def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
         table = calib_table(name, gf) if not kw else None
         g = set_batch(quantize_int8(gf, table=table), batch)
     elif dtype == "uint8":
-        table = calib_table(name, gf, dtype="uint8") if (not kw or set(kw) == {"tail"}) else None
+        table = calib_table(name, gf, dtype="uint8") if (not kw or set(kw) <= {"tail", "priorbox"}) else None
         g = set_batch(quantize_uint8(gf, table=table), batch)
     else:
         raise NotImplementedError(dtype)

@@ -27,7 +27,7 @@ LAYOUT_NCHW = 0
 # tm2 operator type codes (tm2_format.h:157-264)
 OPTYPE = {
     "Concat": 3, "Const": 4, "Convolution": 5, "Dropout": 8, "Eltwise": 9, "Flatten": 10,
-    "FullyConnected": 11, "InputOp": 12, "Permute": 15, "Pooling": 16, "ReLU": 20, "ReLU6": 21,
+    "FullyConnected": 11, "InputOp": 12, "Permute": 15, "Pooling": 16, "PriorBox": 18, "ReLU": 20, "ReLU6": 21,
     "Reshape": 23, "Softmax": 28, "Upsample": 51,
 }
 OPNAME = {v: k for k, v in OPTYPE.items()}
@@ -155,6 +155,16 @@ def _unpack_param(op: str, b: bytes, off: int) -> Dict:
     if op == "Permute":
         v = struct.unpack_from("<5i", b, off)
         return {"flag": v[0], "order": list(v[1:])}
+    if op == "PriorBox":        # TM2_PriorBoxParam (tm2_format.h:526-542): four TM2_Vector_floats offsets, then scalars
+        v = struct.unpack_from("<4I5i3f2i", b, off)
+
+        def vf(o):
+            n = struct.unpack_from("<I", b, o)[0]
+            return list(struct.unpack_from("<%df" % n, b, o + 4)) if n else []
+
+        return {"min_size": vf(v[0]), "max_size": vf(v[1]), "variance": vf(v[2]), "aspect_ratio": vf(v[3]), "flip": v[4],
+                "clip": v[5], "img_size": v[6], "img_h": v[7], "img_w": v[8], "step_w": v[9], "step_h": v[10],
+                "offset": v[11], "num_priors": v[12], "out_dim": v[13]}
     if op == "Reshape":
         is_mx, rev, voff, is_onnx = struct.unpack_from("<iiIi", b, off)
         n = struct.unpack_from("<I", b, voff)[0] if voff else 0
@@ -189,6 +199,9 @@ class _Blob:
     def vec_i32(self, vals) -> int:
         return self.put(struct.pack("<I%di" % len(vals), len(vals), *vals))
 
+    def vec_f32(self, vals) -> int:
+        return self.put(struct.pack("<I%df" % len(vals), len(vals), *vals))
+
 
 def write_tm2(g: Graph) -> bytes:
     """Serialise `g` to tmfile v2 bytes loadable by the reference (`create_graph(ctx,"tengine",f)`)."""
@@ -220,6 +233,13 @@ def write_tm2(g: Graph) -> bytes:
         if n.op == "Reshape":    # TM2_ReshapeParam {is_mxnet, reverse, offset_re_shape -> TM2_Vector_dims, is_onnx} (tm2_format.h:565-571)
             pb = struct.pack("<iiIi", n.params.get("is_mxnet", 0), n.params.get("reverse", 0),
                              bl.vec_i32(n.params["re_shape"]), n.params.get("is_onnx", 1))
+        elif n.op == "PriorBox":  # TM2_PriorBoxParam; the loader dereferences all four vector offsets (tm2_priorbox.c:49-52): empty
+            q = n.params        # vectors are written as {v_num = 0}
+            pb = struct.pack("<4I5i3f2i", bl.vec_f32(q["min_size"]), bl.vec_f32(q.get("max_size", [])),
+                             bl.vec_f32(q["variance"]), bl.vec_f32(q.get("aspect_ratio", [])), q.get("flip", 0),
+                             q.get("clip", 0), q.get("img_size", 0), q.get("img_h", 0), q.get("img_w", 0),
+                             q.get("step_w", 0.0), q.get("step_h", 0.0), q.get("offset", 0.5), q.get("num_priors", 0),
+                             q.get("out_dim", 0))
         else:
             pb = _pack_param(n.op, n.params)
         po = bl.put(pb) if pb else 0

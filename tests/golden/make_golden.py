@@ -15,8 +15,29 @@ from tengine_amd import models, tm2     # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def priorbox_fixture():
+    """PriorBox outputs of the real reference (priorbox_ref.c) for tests/helpers.py PRIORBOX_CASES, uint8 and fp32, and
+    mbox_priorbox of the uint8 MobileNet-SSD: python tests/golden/make_golden.py priorbox"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import PRIORBOX_CASES, priorbox_graph
+    out = {}
+    for case, kw in sorted(PRIORBOX_CASES.items()):
+        for dt, mode, tag in ((tm2.DT_UINT8, ref_capi.MODE_UINT8, "uint8"), (tm2.DT_FP32, ref_capi.MODE_FP32, "fp32")):
+            g, x = priorbox_graph(dtype=dt, **kw)
+            out["%s_%s" % (case, tag)] = np.asarray(ref_capi.run_model(tm2.write_tm2(g), x, mode, 2)[0])
+    g = models.build("mssd", "uint8", 1, tail=True, priorbox=True)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    out["mssd_mbox_priorbox_uint8"] = np.asarray(ref_capi.run_model(tm2.write_tm2(g), x, ref_capi.MODE_UINT8, os.cpu_count())[2])
+    path = os.path.join(HERE, "priorbox_cases.npz")
+    np.savez_compressed(path, **out)
+    print(path, {k: (v.shape, str(v.dtype)) for k, v in out.items()})
+
+
 def main():
     build_ref.build()
+    if sys.argv[1:] == ["priorbox"]:
+        return priorbox_fixture()
+    priorbox_fixture()
     for name, batch, seed in [("mobilenet_v1", 1, 7)]:
         g = models.build(name, "int8", batch)
         x = models.synth_input(g, seed)

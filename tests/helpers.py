@@ -318,3 +318,78 @@ def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", p
     g.output_nodes = [ni]
     return g, rng.integers(-127, 128, size=g.tensors[x].dims).astype(np.int8)
 
+
+
+def priorbox_graph(seed, dtype, img_h, img_w, feats, min_sizes, max_sizes, ratios, flip=1, clip=0, offset=0.5, step=0.0,
+                   img_param=0, variance=(0.1, 0.1, 0.2, 0.2), q=(2.0 / 255, 63)):
+    """data -> chain of ReLU + max-pool nodes down to each (h, w) of `feats` -> one PriorBox per feature map -> Concat(axis 2):
+    the priors part of an SSD tail with arbitrary (also non-square) image / map sizes.  Outputs: the concat, and every
+    PriorBox alone when there is only one.  dtype: tm2.DT_UINT8 | tm2.DT_FP32."""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="priorbox_case")
+    u8 = dtype == tm2.DT_UINT8
+    qa = dict(scales=[float(np.float32(0.02))], zps=[int(rng.integers(100, 150))]) if u8 else dict(scales=None, zps=None)
+    x = g.add_input("data", [1, 3, img_h, img_w], dtype, qa["scales"], qa["zps"])
+    pbs = []
+    for i, (fh, fw) in enumerate(feats):
+        kh, kw = img_h // fh, img_w // fw
+        f = g.add_tensor("feat%d" % i, [1, 3, fh, fw], dtype, tm2.TT_VAR, None, qa["scales"], qa["zps"])
+        g.add_node("pool%d" % i, "Pooling", [x], [f], alg=0, kernel_h=kh, kernel_w=kw, stride_h=kh, stride_w=kw,
+                   **{"global": 0}, caffe_flavor=0, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+        mn, mx = [float(v) for v in min_sizes[i]], [float(v) for v in max_sizes[i]]
+        num = (len(ratios[i]) * (2 if flip else 1) + 1 + (1 if mx else 0)) * len(mn)
+        y = g.add_tensor("pb%d" % i, [1, 2, fh * fw * num * 4, 1], dtype, tm2.TT_VAR, None,
+                         [float(np.float32(q[0]))] if u8 else None, [int(q[1])] if u8 else None)
+        g.add_node("priorbox%d" % i, "PriorBox", [f, x], [y], min_size=mn, max_size=mx,
+                   aspect_ratio=[float(v) for v in ratios[i]], variance=[float(v) for v in variance], flip=flip, clip=clip,
+                   offset=offset, step_w=float(step), step_h=float(step), img_h=img_param, img_w=img_param, num_priors=num,
+                   out_dim=fh * fw * num * 4)
+        pbs.append(y)
+    if len(pbs) == 1:
+        g.output_nodes = [len(g.nodes) - 1]
+    else:
+        total = sum(g.tensors[t].dims[2] for t in pbs)
+        # a different output scale on purpose: the (once-only) concat launch requantises like any other uint8 concat
+        cat = g.add_tensor("mbox_priorbox", [1, 2, total, 1], dtype, tm2.TT_VAR, None,
+                           [float(np.float32(q[0] * 1.25))] if u8 else None, [int(q[1]) - 9] if u8 else None)
+        ni = g.add_node("mbox_priorbox", "Concat", pbs, [cat], axis=2)
+        g.output_nodes = [ni]
+    xin = rng.integers(0, 256, size=(1, 3, img_h, img_w)).astype(np.uint8) if u8 else \
+        rng.uniform(-1, 1, size=(1, 3, img_h, img_w)).astype(np.float32)
+    return g, xin
+
+
+def axis_concat_graph(seed, dtype, dims, axis, branches=3):
+    """data -> `branches` leaky ReLUs (own slope, own output quantisation) -> Concat on `axis` (2, 3, -1 ...): a concat of
+    run-time tensors on an axis other than the channels -- dense NCHW device tensors, uint8 (per-input rescale) or fp32."""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="axis_concat_case")
+    u8 = dtype == tm2.DT_UINT8
+    x = g.add_input("data", list(dims), dtype, [0.03] if u8 else None, [120] if u8 else None)
+    parts = []
+    for i in range(branches):
+        qs = ([float(np.float32(0.03 * rng.uniform(0.6, 1.5)))], [int(rng.integers(90, 160))]) if u8 else (None, None)
+        r = g.add_tensor("r%d" % i, list(dims), dtype, tm2.TT_VAR, None, qs[0], qs[1])
+        g.add_node("relu%d" % i, "ReLU", [x], [r], negative_slope=0.1 * (i + 1))
+        parts.append(r)
+    od = list(dims)
+    od[axis] = dims[axis] * branches
+    y = g.add_tensor("cat", od, dtype, tm2.TT_VAR, None, [0.035] if u8 else None, [131] if u8 else None)
+    g.output_nodes = [g.add_node("cat", "Concat", parts, [y], axis=axis)]
+    xin = rng.integers(0, 256, size=dims).astype(np.uint8) if u8 else rng.uniform(-1, 1, size=dims).astype(np.float32)
+    return g, xin
+
+
+# PriorBox parameter sets shared by the CPU (oracle vs reference / golden) and GPU (device vs oracle / golden) tests
+PRIORBOX_CASES = {
+    "ssd304_conv11": dict(seed=1, img_h=304, img_w=304, feats=[(19, 19)], min_sizes=[[60]], max_sizes=[[]], ratios=[[2]]),
+    "ssd_three_maps_concat": dict(seed=2, img_h=96, img_w=96, feats=[(12, 12), (6, 6), (3, 3)], min_sizes=[[20], [35], [50]],
+                                  max_sizes=[[35], [50], [70]], ratios=[[2], [2, 3], [2, 3]]),
+    "non_square_fractional_sizes_clip": dict(seed=3, img_h=48, img_w=64, feats=[(6, 8), (3, 4), (1, 2)],
+                                             min_sizes=[[20], [30, 35.7], [40]], max_sizes=[[], [44, 50.2], [60]],
+                                             ratios=[[2], [2, 3], [1.5, 2.5, 3]], clip=1),
+    "no_flip_own_step_and_image": dict(seed=4, img_h=64, img_w=64, feats=[(8, 8), (4, 4)], min_sizes=[[16], [32]],
+                                       max_sizes=[[24], [48]], ratios=[[2, 3], [2]], flip=0, step=7.5, img_param=60, offset=0.25,
+                                       variance=(0.1, 0.15, 0.2, 0.3)),
+    "no_ratios": dict(seed=5, img_h=32, img_w=32, feats=[(4, 4)], min_sizes=[[8, 12]], max_sizes=[[12, 20]], ratios=[[]]),
+}

@@ -137,3 +137,23 @@ def test_node_supported_query():
     assert ask(6, [a, a], [a], elt) == 0
     assert ask(12, [a], [a]) == 0                                               # softmax int8 stays on the CPU
     assert ask(12, [t(F32, VAR, [1, 8], 0)], [t(F32, VAR, [1, 8], 0)]) == 1
+    # uint8 / fp32 device tensors are dense NCHW: concat on any axis; int8 (NHWC blocks): channels only
+    cat2 = (C.c_int * 1)(2)
+    ua = t(U8, VAR, [1, 2, 100, 1])
+    assert ask(7, [ua, ua], [t(U8, VAR, [1, 2, 200, 1])], cat2) == 1
+    assert ask(7, [t(I8, VAR, [1, 2, 100, 1])] * 2, [t(I8, VAR, [1, 2, 200, 1])], cat2) == 0
+
+    class PB(C.Structure):         # tamd_priorbox_param
+        _fields_ = [("min_size_num", C.c_int), ("max_size_num", C.c_int), ("aspect_ratio_num", C.c_int), ("min_size", C.c_float * 8),
+                    ("max_size", C.c_float * 8), ("aspect_ratio", C.c_float * 8), ("variance", C.c_float * 4), ("flip", C.c_int),
+                    ("clip", C.c_int), ("image_h", C.c_int), ("image_w", C.c_int), ("step_h", C.c_float), ("step_w", C.c_float),
+                    ("offset", C.c_float)]
+    pb = PB()
+    pb.min_size_num, pb.max_size_num, pb.aspect_ratio_num, pb.flip, pb.offset = 1, 1, 2, 1, 0.5
+    feat, img = t(U8, VAR, [1, 64, 5, 5]), t(U8, VAR, [1, 3, 80, 80])
+    assert ask(15, [feat, img], [t(U8, VAR, [1, 2, 600, 1])], pb) == 1
+    assert ask(15, [feat, img], [t(U8, VAR, [2, 2, 600, 1])], pb) == 0           # batch > 1: undefined in the reference
+    assert ask(15, [feat], [t(U8, VAR, [1, 2, 600, 1])], pb) == 0                # needs the image tensor too
+    assert ask(15, [t(I8, VAR, [1, 64, 5, 5]), t(I8, VAR, [1, 3, 80, 80])], [t(I8, VAR, [1, 2, 600, 1])], pb) == 0   # int8 graphs: CPU
+    pb.max_size_num = 2
+    assert ask(15, [feat, img], [t(U8, VAR, [1, 2, 600, 1])], pb) == 0           # max sizes must pair with min sizes (priorbox.c:48-61)

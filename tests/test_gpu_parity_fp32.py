@@ -72,3 +72,25 @@ def test_fp32_models(name, batch):
     for w, o in zip(want, got):
         assert np.allclose(o.reshape(w.shape), w, **TOL), "max |d| %g" % np.abs(o.reshape(w.shape) - w).max()
         assert np.abs(w).max() > 1e-3
+
+
+@pytest.mark.parametrize("case", ["ssd_three_maps_concat", "non_square_fractional_sizes_clip", "no_flip_own_step_and_image"])
+def test_priorbox_fp32_exact(case):
+    """PriorBox in an fp32 graph: evaluated at prerun with the reference's own operations -> EXACT floats (== oracle == golden of
+    the real reference), not merely 1e-4"""
+    import os
+    from helpers import PRIORBOX_CASES, priorbox_graph
+    g, x = priorbox_graph(dtype=DT_FP32, **PRIORBOX_CASES[case])
+    want = oracle.run_graph(g, x)[0]
+    got = run_hip(g, x)[0].reshape(want.shape)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, np.load(os.path.join(os.path.dirname(__file__), "golden", "priorbox_cases.npz"))["%s_fp32" % case])
+
+
+@pytest.mark.parametrize("dims,axis", [([1, 5, 6, 7], 2), ([2, 3, 4, 9], 3), ([2, 8, 5], -1)])
+def test_concat_any_axis_fp32(dims, axis):
+    from helpers import axis_concat_graph
+    g, x = axis_concat_graph(31 + axis, DT_FP32, dims, axis)
+    want = oracle.run_graph(g, x)[0]
+    got = run_hip(g, x)[0].reshape(want.shape)
+    assert np.array_equal(got, want)       # leaky ReLU + copies: no rounding differences possible

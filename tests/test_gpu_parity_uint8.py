@@ -4,7 +4,10 @@ sgemm).  Bar: byte-identical -- the device performs the reference's fp32 operati
 import numpy as np
 import pytest
 
-from helpers import (u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph, u8_ssd_head_graph, u8_unary_graph)
+import os
+
+from helpers import (PRIORBOX_CASES, axis_concat_graph, priorbox_graph, u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph,
+                     u8_ssd_head_graph, u8_unary_graph)
 from oracle import oracle
 from tengine_amd import capi, models, tm2
 
@@ -314,3 +317,57 @@ def test_mssd_uint8_quantised_tail_on_device(batch):
     assert "softmax_u8" in kernels, kernels
     for w, o in zip(want, outs):
         assert np.array_equal(o.reshape(w.shape), w), np.count_nonzero(o.reshape(w.shape) != w)
+
+
+GOLDEN_PRIORBOX = os.path.join(os.path.dirname(__file__), "golden", "priorbox_cases.npz")
+
+
+@pytest.mark.parametrize("case", sorted(PRIORBOX_CASES))
+def test_priorbox_uint8_is_a_prerun_constant(case):
+    """PriorBox depends on shapes only -- evaluated once at prerun (graph.hip priorbox_eval), its Concat runs
+    once at prerun too; a run launches nothing for them.  Bytes == oracle == the real reference's (golden fixture)."""
+    g, x = priorbox_graph(dtype=tm2.DT_UINT8, **PRIORBOX_CASES[case])
+    want = oracle.run_graph(g, x)[0]
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    again = gr.run()[0].reshape(want.shape)          # the constant survives runs
+    kernels = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert np.array_equal(got, want) and np.array_equal(again, want), np.count_nonzero(got != want)
+    assert np.array_equal(got, np.load(GOLDEN_PRIORBOX)["%s_uint8" % case])
+    assert not any("concat" in k for k in kernels), kernels
+
+
+@pytest.mark.parametrize("dims,axis", [([1, 5, 6, 7], 2), ([2, 3, 4, 9], 3), ([2, 8, 5], -1), ([3, 6, 4, 4], 1), ([1, 2, 700, 1], 2)])
+def test_concat_any_axis_uint8(dims, axis):
+    g, x = axis_concat_graph(21 + axis, tm2.DT_UINT8, dims, axis)
+    check(g, x, "concat %s axis %d" % (dims, axis))
+
+
+def test_mssd_uint8_ends_at_detection_output_inputs():
+    """the whole uint8 MobileNet-SSD as ONE device graph up to detection_output's three inputs (mbox_loc, softmaxed mbox_conf,
+    mbox_priorbox); the priors add no launch to a run"""
+    g = models.build("mssd", "uint8", 1, tail=True, priorbox=True)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    want = oracle.run_graph(g, x)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    outs = gr.run()
+    n_launch = gr.kernel_num()
+    gr.close()
+    g0 = models.build("mssd", "uint8", 1, tail=True)
+    gr0 = capi.Graph(tm2.write_tm2(g0))
+    n0 = gr0.kernel_num()
+    gr0.close()
+    assert len(outs) == 3 and n_launch == n0, (n_launch, n0)
+    for w, o in zip(want, outs):
+        assert np.array_equal(o.reshape(w.shape), w), np.count_nonzero(o.reshape(w.shape) != w)
+    assert np.array_equal(outs[2].reshape(want[2].shape), np.load(GOLDEN_PRIORBOX)["mssd_mbox_priorbox_uint8"])
+
+
+def test_priorbox_batch_2_is_refused():
+    """priorbox_ref.c fills image 0 only; the backend refuses instead of inventing the rest"""
+    g = models.build("mssd", "uint8", 2, tail=True, priorbox=True)
+    with pytest.raises(RuntimeError, match="batch 1"):
+        capi.Graph(tm2.write_tm2(g))

@@ -4,7 +4,8 @@ covering every kernel-selection branch of the reference and on w
 import numpy as np
 import pytest
 
-from helpers import conv_graph, eltwise_relu_graph, fc_graph, i8_concat_graph, pool_graph
+from helpers import (PRIORBOX_CASES, axis_concat_graph, conv_graph, eltwise_relu_graph, fc_graph, i8_concat_graph, pool_graph,
+                     priorbox_graph)
 from oracle import oracle
 from tengine_amd import models, tm2
 
@@ -109,3 +110,36 @@ def test_resnet50_int8_whole_model(ref):
     got = oracle.run_graph(g, x)[0]
     assert np.array_equal(want.reshape(got.shape), got)
     assert np.abs(got.astype(int)).max() > 40
+
+
+@pytest.mark.parametrize("dtype", [tm2.DT_UINT8, tm2.DT_FP32], ids=["uint8", "fp32"])
+@pytest.mark.parametrize("case", sorted(PRIORBOX_CASES))
+def test_priorbox_oracle_equals_reference(ref, case, dtype):
+    """priorbox_ref.c:53-213 -- int truncation of the sizes, double sqrt, flipped priors, clip, explicit step /
+    image size, the truncating uint8 quantisation; fp32 compared exactly too (same operations in the same order)"""
+    g, x = priorbox_graph(dtype=dtype, **PRIORBOX_CASES[case])
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_UINT8 if dtype == tm2.DT_UINT8 else ref.MODE_FP32, 2)
+    got = oracle.run_graph(g, x)
+    assert len(want) == len(got) == 1
+    assert np.array_equal(np.asarray(want[0]).reshape(got[0].shape), got[0])
+    assert len(np.unique(got[0])) > 20
+
+
+@pytest.mark.parametrize("dtype", [tm2.DT_UINT8, tm2.DT_FP32], ids=["uint8", "fp32"])
+@pytest.mark.parametrize("dims,axis", [([1, 5, 6, 7], 2), ([2, 3, 4, 9], 3), ([2, 8, 5], -1), ([3, 6, 4, 4], 1)])
+def test_concat_any_axis_oracle_equals_reference(ref, dims, axis, dtype):
+    g, x = axis_concat_graph(21 + axis, dtype, dims, axis)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_UINT8 if dtype == tm2.DT_UINT8 else ref.MODE_FP32, 2)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(np.asarray(want).reshape(got.shape), got)
+
+
+def test_mssd_full_tail_oracle_equals_reference(ref):
+    """the whole uint8 MobileNet-SSD up to detection_output's three inputs: mbox_loc, softmaxed mbox_conf, mbox_priorbox"""
+    g = models.build("mssd", "uint8", 1, tail=True, priorbox=True)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_UINT8, 8)
+    got = oracle.run_graph(g, x)
+    assert [tuple(o.shape) for o in got] == [(1, 7668), (1, 40257), (1, 2, 7668, 1)]
+    for w, o in zip(want, got):
+        assert np.array_equal(np.asarray(w).reshape(o.shape), o)

@@ -114,7 +114,7 @@ def test_hip_device_fp32_matches_reference_cpu_device(ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["route", "yolov3_tiny", "ssd_head", "mssd", "mssd_tail"])
+@pytest.mark.parametrize("case", ["route", "yolov3_tiny", "ssd_head", "mssd", "mssd_tail", "mssd_full", "priorbox"])
 def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     """uint8 through the reference's own API: device "HIP" == CPU device, byte for byte."""
     from helpers import u8_route_graph
@@ -127,6 +127,12 @@ def test_hip_device_uint8_equals_reference_cpu_device(ref, case):
     elif case in ("mssd", "mssd_tail"):      # _tail: + Reshape -> Softmax -> Flatten on mbox_conf, all on "HIP"
         g = models.build("mssd", "uint8", 1, tail=(case == "mssd_tail"))
         x = models.synth_input(g, 5, tm2.DT_UINT8)
+    elif case == "mssd_full":                # + the six PriorBox nodes and their Concat: the graph ends at detection_output's inputs
+        g = models.build("mssd", "uint8", 1, tail=True, priorbox=True)
+        x = models.synth_input(g, 5, tm2.DT_UINT8)
+    elif case == "priorbox":                 # non-square image, fractional sizes, clip; the concat of the priors re-quantises
+        from helpers import PRIORBOX_CASES, priorbox_graph
+        g, x = priorbox_graph(dtype=tm2.DT_UINT8, **PRIORBOX_CASES["non_square_fractional_sizes_clip"])
     else:
         g = models.build("yolov3_tiny", "uint8", 1)
         x = models.synth_input(g, 3, tm2.DT_UINT8)

@@ -139,6 +139,22 @@ def test_mssd_uint8_300_oracle_matches_golden_of_real_reference():
         assert np.array_equal(o.ravel(), golden["out%d" % i].ravel())
 
 
+@pytest.mark.parametrize("tag", ["uint8", "fp32"])
+def test_priorbox_oracle_matches_golden_of_real_reference(tag):
+    """PriorBox (priorbox_ref.c) outputs of the real reference, committed as tests/golden/priorbox_cases.npz
+    (make_golden.py priorbox): the oracle reproduces every byte / every float exactly"""
+    from helpers import PRIORBOX_CASES, priorbox_graph
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "priorbox_cases.npz"))
+    for case, kw in sorted(PRIORBOX_CASES.items()):
+        g, x = priorbox_graph(dtype=tm2.DT_UINT8 if tag == "uint8" else tm2.DT_FP32, **kw)
+        out = oracle.run_graph(g, x)[0]
+        assert np.array_equal(out, golden["%s_%s" % (case, tag)]), case
+    if tag == "uint8":
+        g = models.build("mssd", "uint8", 1, tail=True, priorbox=True)
+        outs = oracle.run_graph(g, models.synth_input(g, 5, tm2.DT_UINT8))
+        assert np.array_equal(outs[2], golden["mssd_mbox_priorbox_uint8"])
+
+
 @needs_ref
 def test_softmax_and_reshape_uint8_oracle_is_the_reference():
     """the quantised part of the SSD tail (next row): Softmax (C `exp` on a double, sequential fp32 sum)
