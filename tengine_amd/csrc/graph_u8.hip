@@ -28,7 +28,9 @@ static int q_of(const HTensor& t, U8Q* q, const char* what)
     return 0;
 }
 
-static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
+// `pool`: a 2x2 / stride 2 max-pool node to apply in the conv epilogue (U8PoolFuse); returns 2 when the kernel this conv gets
+// cannot carry the requested fused tail (the caller plans again without it)
+static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, const HNode* pool = nullptr)
 {
     HTensor& x = g->tensors[n.in[0]];
     HTensor& w = g->tensors[n.in[1]];
@@ -58,6 +60,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
     // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~28k taps it does not fit next to the
     // operand tiles (160 KB per CU) and the DMA kernel (table read with scalar loads) takes over
     if (p.group == 1 && (size_t)(rup(K, 64) + 2 * (64 + 64) * 36) * 4 > 150 * 1024) use_dma = true;
+    if (pool && (use_dma || p.group != 1)) return 2;       // the pooled epilogue lives in conv_u8_gemm / conv_u8_rgb3x3
     if (p.group == 1 && use_dma && relu) return 2;           // the DMA kernel has no fused ReLU tail: plan the two nodes apart
     if (p.group == 1 && use_dma && (p.kernel_h - 1) * p.dilation_h <= 15 && (p.kernel_w - 1) * p.dilation_w <= 15
         && (size_t)x.c * x.h * x.w < (1u << 24)) {
@@ -154,6 +157,16 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
         a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp; a.relu = fr;
+        if (pool) {
+            HTensor& yp = g->tensors[pool->out[0]];
+            a.pool.on = 1;
+            a.pool.y = (uint8_t*)yp.dptr;
+            a.pool.out_img = (yp.is_view ? yp.cs : cout) * yp.h * yp.w; a.pool.out_c0 = yp.c_off;
+            if (q_of(y, &a.pool.in, "tensor") || q_of(yp, &a.pool.out, "tensor")) return -1;
+            a.pool.write_full = count_consumers(g, pool->in[0]) > 1;
+            for (auto& io : g->outputs) a.pool.write_full |= (io.tensor == pool->in[0]);
+            st.bytes += (double)yp.elems() - (a.pool.write_full ? 0.0 : (double)y.elems());
+        }
         // plan-time autotune over the tile configurations (every one produces the same bytes: the chain order of an
         // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
         static const char* at_env = getenv("TAMD_AUTOTUNE");
@@ -206,7 +219,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
                 if (time_of([&]() { return launch_conv_u8_rgb3x3(ac, g->stream); }, &ms)) return -1;
                 if (ms < best_ms * 0.96f || (rgb_env && atoi(rgb_env) == 1)) {
                     hipEventDestroy(e0); hipEventDestroy(e1);
-                    st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "");
+                    st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
                     st.fn = [ac](hipStream_t s) { return launch_conv_u8_rgb3x3(ac, s); };
                     g->steps.push_back(st);
                     return 0;
@@ -217,7 +230,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr)
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
-        st.kernel = std::string(conv_u8_gemm_kernel_name(a)) + (relu ? "+relu" : "");
+        st.kernel = std::string(conv_u8_gemm_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
         st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
     } else {
         std::vector<float> wf((size_t)cout * K);
@@ -391,10 +404,31 @@ int plan_u8(tamd_graph* g)
             if (!(fuse_env && atoi(fuse_env) == 0) && count_consumers(g, n.out[0]) == 1)
                 for (size_t nj = ni + 1; nj < g->nodes.size(); nj++)
                     if (g->nodes[nj].op == TAMD_OP_RELU && g->nodes[nj].in[0] == n.out[0]) { relu = &g->nodes[nj]; rj = nj; break; }
-            int rc = plan_conv_u8(g, n, relu);
+            // conv (-> ReLU) -> 2x2 stride-2 max-pool (YOLOv3-tiny: conv0..conv3): the pool is applied to the final
+            // bytes in the conv epilogue -- the window's four pixels are computed by four neighbouring lanes -- when the map is
+            // even-sized and has no reference "tail" pixels (OH*OW % 8 == 0); TAMD_FUSE_POOL=0 keeps the pool_u8 launch
+            const HNode* pool = nullptr;
+            size_t pj = 0;
+            const char* pool_env = getenv("TAMD_FUSE_POOL");         // read at every prerun (tests switch it)
+            {
+                const int full = relu ? relu->out[0] : n.out[0];
+                const HTensor& yf = g->tensors[full];
+                if (!(pool_env && atoi(pool_env) == 0) && yf.dims.size() == 4
+                    && yf.h % 2 == 0 && yf.w % 2 == 0 && (yf.h * yf.w) % 8 == 0 && !yf.is_view)
+                    for (size_t nj = ni + 1; nj < g->nodes.size() && !pool; nj++) {
+                        const HNode& m = g->nodes[nj];
+                        if (m.op != TAMD_OP_POOL || m.in[0] != full || fused[nj]) continue;
+                        const PoolGeom pg = pool_geom(m.p.pool, yf.h, yf.w);
+                        if (m.p.pool.pool_method == 0 && pg.kh == 2 && pg.kw == 2 && pg.sh == 2 && pg.sw == 2 && pg.ph0 == 0 && pg.pw0 == 0
+                            && pg.oh == yf.h / 2 && pg.ow == yf.w / 2) { pool = &m; pj = nj; }
+                    }
+            }
+            int rc = plan_conv_u8(g, n, relu, pool);
+            if (rc == 2 && pool) { pool = nullptr; rc = plan_conv_u8(g, n, relu, nullptr); }
             if (rc == 2) { relu = nullptr; rc = plan_conv_u8(g, n, nullptr); }       // kernel without the fused tail
             if (rc) return -1;
             if (relu) fused[rj] = 1;
+            if (pool) fused[pj] = 1;
             break;
         }
         case TAMD_OP_FC:

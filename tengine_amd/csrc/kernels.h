@@ -188,6 +188,15 @@ struct U8Q { float scale; int zp; };
 // (relu_kernel_ref_uint8.c:48-95 on that byte), so the bytes equal the two-launch sequence
 struct U8Relu { int on; float slope; U8Q out; };
 
+struct U8PoolFuse {            // a 2x2 / stride 2 / unpadded MAX-pool node applied to the conv's final bytes in the conv epilogue
+    int on;                    // the kernel then enumerates output pixels window-major: j = 4 * window + 2 * dy + dx (so the four
+                               // pixels of a window sit in four neighbouring lanes); needs OH, OW even and OH*OW % 8 == 0
+    int write_full;            // the unpooled tensor has other readers (or is a graph output): store it as well
+    uint8_t* y;                // pooled output, NCHW, image stride out_img bytes, first channel at out_c0
+    int out_img, out_c0;
+    U8Q in, out;               // quantisation of the pool node's input (== what the conv epilogue produced) and output
+};
+
 struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
     const uint8_t* x;          // NCHW
     const uint8_t* wq;         // raw uint8 weights, [cout tile of BM][stage of 32 k][BM rows][32 slots]; BM =
@@ -210,6 +219,7 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     U8Relu relu;               // fused ReLU / leaky ReLU node (y, out_img, out_c0 then describe ITS output)
     const float* wf;           // conv_u8_rgb3x3 only: dequantised weights, [cout][wf_ld] rows in OIHW k order
     int wf_ld;
+    U8PoolFuse pool;           // fused max-pool node (conv_u8_gemm main tiles and conv_u8_rgb3x3)
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC

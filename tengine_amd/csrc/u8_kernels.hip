@@ -47,6 +47,36 @@ __device__ __forceinline__ uint8_t fused_relu(uint8_t q, float scale, int zp, co
     return quant_round_in(f, r.out);
 }
 
+// Output pixel j of a conv launch -> (oy, ox).  Row-major normally; with a fused 2x2 max-pool (U8PoolFuse) window-major, so
+// that lanes 4w..4w+3 of a pixel column group hold the window w = (py, px): j = 4 * (py * OW/2 + px) + 2 * dy + dx.
+// The reference's main / tail split of a pixel (j < (OH*OW)&~7) is a property of its ROW-MAJOR index; the planner only
+// fuses when OH*OW % 8 == 0, where every pixel is a main pixel whatever the order.
+__device__ __forceinline__ void conv_pixel(const U8ConvArgs& a, int j, int* oy, int* ox)
+{
+    if (a.pool.on) {
+        const int half = a.OW >> 1, w = j >> 2, py = w / half, px = w - py * half;
+        *oy = 2 * py + ((j >> 1) & 1); *ox = 2 * px + (j & 1);
+    } else {
+        *oy = j / a.OW; *ox = j - *oy * a.OW;
+    }
+}
+
+// max over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1])
+__device__ __forceinline__ int quad_max(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    return max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+}
+
+// the pool node on the window maximum m: pooling_kernel_ref_uint8.c:91-200 dequantises every byte, takes the fp32 max (the
+// dequantisation is monotone: that is the dequantised max byte), then round(f / out_scale) + out_zp with ONLY the upper clamp
+__device__ __forceinline__ uint8_t pooled_byte(int m, const U8PoolFuse& p)
+{
+    const float f = ((float)(m - p.in.zp)) * p.in.scale;
+    const int od = quant_round_div(f, p.out.scale, p.out.zp);
+    return (uint8_t)(od > 255 ? 255 : od);
+}
+
 // =================================================================================================================
 // group == 1 convolution: conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8, k = (c,ky,kx),
 // 0.0f at out-of-image taps), :322-960 sgemm_fp, :1703-1794 bias / activation / requantise.
@@ -91,7 +121,8 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
     const int sp = tid % BN, su = tid / BN;
     const int sj = jbase + sp;
     const bool svalid = sj < jlimit;
-    const int soy = svalid ? sj / a.OW : 0, sox = svalid ? sj - soy * a.OW : 0;
+    int soy = 0, sox = 0;
+    if (svalid) conv_pixel(a, sj, &soy, &sox);
     const int iy0 = soy * a.SH - a.PH, ix0 = sox * a.SW - a.PW;
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int pbase = iy0 * a.W + ix0;
@@ -239,7 +270,9 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
     for (int j = 0; j < TN; j++) {
         const int pj = jbase + (wn * TN + j) * 16 + l15;
         if (pj >= jlimit) continue;
-        const int oy = pj / a.OW, ox = pj - oy * a.OW;
+        int oy, ox;
+        conv_pixel(a, pj, &oy, &ox);
+        const int opix = oy * a.OW + ox;
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -271,7 +304,11 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
                 uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
                 if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
-                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = q;
+                if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
+                if (a.pool.on) {                 // jlimit and co are uniform over a quad of lanes: all four pixels of the window are here
+                    const int m = quad_max((int)q);
+                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = pooled_byte(m, a.pool);
+                }
             }
     }
 }
@@ -366,8 +403,9 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
     __syncthreads();
     const int OHW = a.OH * a.OW;
     const int pj = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (pj >= OHW) return;
-    const int oy = pj / a.OW, ox = pj - oy * a.OW;
+    if (pj >= OHW) return;           // OHW % 4 == 0 with a fused pool: a quad of lanes leaves together
+    int oy, ox;
+    conv_pixel(a, pj, &oy, &ox);
     const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
     const uint8_t* xin = a.x + (size_t)n * C * a.H * a.W;
     unsigned u[K];
@@ -384,7 +422,8 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
 #pragma unroll
     for (int k = 0; k < K; k++) xf[k] = (okm >> k & 1ull) ? dequant((uint8_t)u[k], a.in_zp, a.in_scale) : 0.f;   // im2col zero
     const bool tail = pj >= (OHW & ~7);
-    uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + pj;
+    uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + oy * a.OW + ox;
+    uint8_t* yp = a.pool.on ? a.pool.y + (size_t)n * a.pool.out_img + (size_t)a.pool.out_c0 * (OHW >> 2) + (pj >> 2) : nullptr;
     for (int co = 0; co < a.cout; co++) {
         float w[LD];
 #pragma unroll
@@ -415,7 +454,11 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
         if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
         uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
         if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
-        yo[(size_t)co * OHW] = q;
+        if (!a.pool.on || a.pool.write_full) yo[(size_t)co * OHW] = q;
+        if (a.pool.on) {
+            const int m = quad_max((int)q);
+            if ((threadIdx.x & 3) == 0) yp[(size_t)co * (OHW >> 2)] = pooled_byte(m, a.pool);
+        }
     }
 }
 

@@ -393,3 +393,31 @@ PRIORBOX_CASES = {
                                        variance=(0.1, 0.15, 0.2, 0.3)),
     "no_ratios": dict(seed=5, img_h=32, img_w=32, feats=[(4, 4)], min_sizes=[[8, 12]], max_sizes=[[12, 20]], ratios=[[]]),
 }
+
+
+def u8_conv_pool_graph(seed, n, cin, h, w, cout, k=3, p=1, slope=0.1, relu=True, second_reader=False, pool_k=2, pool_s=2,
+                       same_q=False):
+    """conv (-> leaky ReLU) -> max-pool, the YOLOv3-tiny stage; `second_reader`: the unpooled tensor also feeds
+    a ReLU that is a graph output (the fused kernel must still store it); pool input / output quantisation differ unless
+    same_q (the quantiser normally hands the pool's parameters back to its input: both cases occur)."""
+    g, x = u8_conv_graph(seed, n, cin, h, w, cout, k, 1, p, act=-1)
+    rng = np.random.default_rng(seed + 1000)
+    t = g.tensors[g.nodes[-1].outputs[0]]
+    oh, ow = t.dims[2], t.dims[3]
+    cur = g.nodes[-1].outputs[0]
+    outs = []
+    if relu:
+        r = g.add_tensor("lk", [n, cout, oh, ow], DT_UINT8, tm2.TT_VAR, None, [float(np.float32(t.scales[0] * 0.9))], [int(rng.integers(20, 60))])
+        g.add_node("leaky", "ReLU", [cur], [r], negative_slope=slope)
+        cur = r
+    ct = g.tensors[cur]
+    qs = (ct.scales, ct.zero_points) if same_q else ([float(np.float32(ct.scales[0] * 1.07))], [int(rng.integers(0, 40))])
+    ph, pw = (oh - pool_k) // pool_s + 1, (ow - pool_k) // pool_s + 1
+    po = g.add_tensor("pooled", [n, cout, ph, pw], DT_UINT8, tm2.TT_VAR, None, list(qs[0]), list(qs[1]))
+    outs.append(g.add_node("maxpool", "Pooling", [cur], [po], alg=0, kernel_h=pool_k, kernel_w=pool_k, stride_h=pool_s,
+                           stride_w=pool_s, **{"global": 0}, caffe_flavor=0, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0))
+    if second_reader:
+        r2 = g.add_tensor("side", [n, cout, oh, ow], DT_UINT8, tm2.TT_VAR, None, [float(np.float32(ct.scales[0] * 1.2))], [17])
+        outs.append(g.add_node("side_relu", "ReLU", [cur], [r2], negative_slope=0.0))
+    g.output_nodes = outs
+    return g, x

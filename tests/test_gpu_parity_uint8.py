@@ -6,7 +6,7 @@ import pytest
 
 import os
 
-from helpers import (PRIORBOX_CASES, axis_concat_graph, priorbox_graph, u8_conv_graph, u8_fc_graph, u8_pool_graph, u8_route_graph,
+from helpers import (PRIORBOX_CASES, axis_concat_graph, priorbox_graph, u8_conv_graph, u8_conv_pool_graph, u8_fc_graph, u8_pool_graph, u8_route_graph,
                      u8_ssd_head_graph, u8_unary_graph)
 from oracle import oracle
 from tengine_amd import capi, models, tm2
@@ -371,3 +371,50 @@ def test_priorbox_batch_2_is_refused():
     g = models.build("mssd", "uint8", 2, tail=True, priorbox=True)
     with pytest.raises(RuntimeError, match="batch 1"):
         capi.Graph(tm2.write_tm2(g))
+
+
+CONV_POOL = [
+    # n, cin, h, w, cout, k, p, kwargs                      -> fused?
+    ((1, 3, 32, 32, 16, 3, 1), dict(), True),                                   # first layer (per-pixel kernel), leaky, YOLO conv0 class
+    ((2, 3, 24, 40, 16, 3, 1), dict(same_q=True), True),                        # batch 2, non-square, the quantiser's shared parameters
+    ((1, 16, 16, 16, 32, 3, 1), dict(), True),                                  # MFMA GEMM kernel, 256 px
+    ((2, 32, 12, 20, 70, 3, 1), dict(slope=0.0), True),                         # plain ReLU, cout % 16 != 0, 240 px (not a tile multiple)
+    ((1, 16, 16, 16, 32, 1, 0), dict(relu=False), True),                        # conv -> pool directly (1x1 conv)
+    ((1, 16, 16, 16, 32, 3, 1), dict(second_reader=True), True),                # the unpooled tensor is read again: stored too
+    ((1, 16, 26, 26, 32, 3, 1), dict(), False),                                 # 676 px: 4 reference tail pixels -> separate pool_u8
+    ((1, 16, 13, 13, 32, 3, 1), dict(pool_s=1), False),                         # YOLO maxpool5 (stride 1): separate
+    ((1, 16, 16, 18, 32, 3, 1), dict(pool_k=3), False),                         # 3x3 windows: separate
+]
+
+
+@pytest.mark.parametrize("dims,kw,fused", CONV_POOL, ids=[str(c[0]) + str(sorted(c[1].items())) for c in CONV_POOL])
+def test_conv_relu_maxpool_fused_in_the_conv_epilogue(dims, kw, fused, monkeypatch):
+    """SURVEY 8 f1 (remainder): conv (-> leaky ReLU) -> 2x2 stride-2 max-pool as ONE launch; bytes == oracle (pinned to the
+    reference's pooling_kernel_ref_uint8.c), == the unfused launches; geometries the fused kernel does not cover keep pool_u8"""
+    g, x = u8_conv_pool_graph(90 + dims[1] + dims[2], *dims, **kw)
+    want = oracle.run_graph(g, x)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TAMD_FUSE_POOL", mode)
+        gr = capi.Graph(tm2.write_tm2(g))
+        gr.set_input(x)
+        outs[mode] = [o.copy() for o in gr.run()]
+        kernels = [k["kernel"] for k in gr.profile(1)]
+        gr.close()
+        if mode == "1":
+            assert any("+maxpool" in k for k in kernels) == fused, kernels
+            assert ("pool_u8" in kernels) == (not fused), kernels
+        else:
+            assert "pool_u8" in kernels and not any("+maxpool" in k for k in kernels), kernels
+    for w, a, b in zip(want, outs["1"], outs["0"]):
+        assert np.array_equal(a.reshape(w.shape), w), "%d bytes differ" % np.count_nonzero(a.reshape(w.shape) != w)
+        assert np.array_equal(a, b)
+        assert len(np.unique(w)) > 3
+
+
+def test_yolov3_tiny_fuses_its_first_four_pools():
+    g = models.build("yolov3_tiny", "uint8", 1)
+    gr = capi.Graph(tm2.write_tm2(g))
+    kernels = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert sum("+maxpool" in k for k in kernels) == 4 and kernels.count("pool_u8") == 2, kernels
