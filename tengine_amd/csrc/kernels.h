@@ -90,6 +90,18 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     float p_in_scale, p_out_scale;
 };
 
+#ifdef TAMD_PWDW_CHAIN_EXPERIMENT      // tools/exp/chain_anatomy.hip only (why the chained launch is not in the product)
+struct PwChainArgs {       // several PwDwArgs layers as ONE launch, ordered by counters (pwdw.hip: pwdw_chain_kernel)
+    const PwDwArgs* layers;    // device array [nlayers]
+    int nlayers;
+    int first_block[17];       // blocks of layer l: [first_block[l], first_block[l + 1])
+    short variant[16];         // kernel variant of layer l: MODE | PROD << 3 | steps << 4 (pwdw_chain_variant)
+    short gx[16], gy[16];      // its grid (x, y; z follows from the block count)
+    int* flags;                // [32 * nlayers] finished-block counter of layer l at [32 * l] (a cache line each); never reset
+    int* sync;                 // [0] epoch, [1] finished blocks of the last layer, [2] a bounded wait gave up
+};
+#endif
+
 struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-input first layers
     const int8_t* x;
     const int8_t* w;       // OIHW as in the model
@@ -166,6 +178,11 @@ hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 const char* dwconv3x3_kernel_name(const DwArgs& a);   // variant <stride, fragments per row> the launcher will pick
 hipError_t launch_conv_direct(const DirectArgs& a, hipStream_t s);
 hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s);
+size_t pwdw_lds_bytes(const PwDwArgs& a, int threads);
+#ifdef TAMD_PWDW_CHAIN_EXPERIMENT
+int pwdw_chain_variant(const PwDwArgs& a, int threads, int* gx, int* gy, int* gz);
+hipError_t launch_pwdw_chain(const PwChainArgs& c, int threads, size_t lds, hipStream_t s);
+#endif
 bool pwdw_config_ok(const PwDwArgs& a, int threads);
 int pwdw_steps(int nsteps);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);

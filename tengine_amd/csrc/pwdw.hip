@@ -53,21 +53,62 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // A lone wave issues one instruction every 4 cycles and these launches are a few hundred instructions long, so the code
 // is written for instruction count: host-folded requantisation constants, no integer divisions, no predicated loads.
 // MODE 4: no tail (results stored from registers).  PROD 1: first-layer gather from the NCHW graph input (STEPS == 1).
-template <int STEPS, int MODE, bool CHUNKED, int PROD>
-__global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
+//
+// CHAINED: the block runs inside pwdw_chain_kernel -- several of these layers in ONE launch, ordered by flags instead of
+// kernel boundaries (see there).  Everything that does not depend on the previous layer (weight fragments, bias / scale
+// vectors, the LDS zero fill) is done BEFORE the block waits for its producers; the block publishes its own flag at the end.
+struct ChainDep {
+    const int* wait_counter;   // finished-block counter of the previous layer of the chain (nullptr: nothing to wait for)
+    int wait_target;           // its value once every block of that layer has finished in THIS run (counters only grow: epoch * blocks)
+    int* my_counter;           // this layer's counter
+    int* err;                  // set when a wait gives up (bounded spin: a logic error must not hang the GPU)
+};
+
+// Tensors handed from layer to layer INSIDE a chained launch never rely on the (per-XCD, mutually incoherent) L2s: a chained
+// block stores its results write-through (agent-scope stores, sc1) and reads its input with agent-scope loads (sc1: served
+// by the memory side, never by a stale L1 / L2 line).  Ordering then needs no cache maintenance at all: producer = wait for
+// its own stores (vmcnt) -> barrier -> one relaxed fetch-add; consumer = poll -> barrier.  (A release / acquire pair per block
+// -- buffer_wbl2 / buffer_inv -- serialises on the XCD's L2: measured 10-19 us per layer with 128-512 blocks a layer.)
+__device__ __forceinline__ void chain_wait(const ChainDep& d)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
+    if (d.wait_counter) {
+        if (threadIdx.x == 0) {          // ONE uncached load per block and round: hundreds of blocks watch the same word
+            bool done = false;
+            for (int spin = 0; spin < (1 << 17) && !done; spin++) {
+                // counters and targets wrap together (unsigned arithmetic): compare their distance
+                done = (int)((unsigned)__hip_atomic_load(d.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)d.wait_target) >= 0;
+                if (!done) __builtin_amdgcn_s_sleep(8);
+            }
+            if (!done) *d.err = 1;
+        }
+        __syncthreads();                 // also keeps the compiler from moving the input loads above the poll
+    }
+}
+
+__device__ __forceinline__ void chain_signal(const ChainDep& d)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have reached the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(d.my_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void chain_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int STEPS, int MODE, bool CHUNKED, int PROD, bool CHAINED>
+__device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restrict__ inter, const int bx, const int by, const int bz,
+                                           const int nthreads, const ChainDep& dep)
+{
     constexpr int S = MODE == 2 ? 2 : 1;
     constexpr bool PINGPONG = !CHUNKED && STEPS <= 8 && PROD == 0;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
     PWDW_STAMP(0);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = nthreads >> 6;
     const int l15 = lane & 15, kb = lane >> 4;
     // block -> XCD is round-robin over the linear block index, and every XCD has its own L2: with the channel slice in grid.x
     // an XCD sees every tile (the input is fetched once per XCD, the weights once in total); with the tile in grid.x it sees
     // every slice of its own tiles (input once in total, weights once per XCD).  The planner puts the larger operand on the
     // "once in total" side (PMC: the early layers read 6-8x their input with slices first, profiles/r02_traffic_*).
-    const int slice = a.tile_major ? blockIdx.z : blockIdx.x, tx = a.tile_major ? blockIdx.x : blockIdx.y;
-    int ty = a.tile_major ? blockIdx.y : blockIdx.z, n = 0;
+    const int slice = a.tile_major ? bz : bx, tx = a.tile_major ? bx : by;
+    int ty = a.tile_major ? by : bz, n = 0;
     if (a.N > 1) { n = ty / a.tiles_y; ty -= n * a.tiles_y; }
     const int c_base = slice * 16;
 
@@ -137,8 +178,14 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
         const int slot = MODE == 4 ? (iy * a.W + ix) : ((iy - iy0) * RW + (ix - ix0)) * 4 + kb;
         return v < VP ? slot : -1;
     };
+    // chained: agent-scope (sc1) buffer loads of the previous layer's write-through output
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7fffffff, 0x00020000);
     auto load_b = [&](const int8_t* xp, v4i (&bf)[STEPS], int chunk) {
-        if (PROD == 0) {
+        if (PROD == 0 && CHAINED) {
+            const int voff = (int)(xp - a.x);
+#pragma unroll
+            for (int u = 0; u < STEPS; u++) bf[u] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, (chunk * STEPS + u) * 64, 16 /* sc1 */);
+        } else if (PROD == 0) {
 #pragma unroll
             for (int u = 0; u < STEPS; u++) bf[u] = *reinterpret_cast<const v4i*>(xp + (chunk * STEPS + u) * 64);
         } else {
@@ -165,29 +212,35 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     auto finish = [&](const v4i& acc, int slot) {
         const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
         if (MODE == 4) {
-            if (slot >= 0 && c_base + 4 * kb < a.c_limit)
-                *reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb) = p;
+            if (slot >= 0 && c_base + 4 * kb < a.c_limit) {
+                unsigned* dst = reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb);
+                if (CHAINED) chain_store(dst, p); else *dst = p;
+            }
         } else if (slot >= 0)
             inter[slot] = p;
     };
 
-    // first tile's activations go out before the LDS is prepared
+    // first tile's activations go out before the LDS is prepared (chained: after the producers' flags, and the LDS first)
     v4i b0[STEPS];
     const int8_t* xp0;
     int slot0 = locate(wave, xp0);
-    if (!CHUNKED) load_b(xp0, b0, 0);
+    if (!CHAINED && !CHUNKED) load_b(xp0, b0, 0);
     PWDW_STAMP(1);
     if (MODE != 0 && MODE != 4) {
         // depthwise zero padding: everything the pointwise phase does not overwrite
         const uint4 z = {0u, 0u, 0u, 0u};
-        for (int i = t; i < a.RH * a.RW + 4; i += blockDim.x) reinterpret_cast<uint4*>(inter)[i] = z;
+        for (int i = t; i < a.RH * a.RW + 4; i += nthreads) reinterpret_cast<uint4*>(inter)[i] = z;
         if (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) wsh[r][c] = wrow[r][c] << 8;     // taps of the second output of a lane: {0, w0, w1, w2}
         }
-        __syncthreads();
+        if (!CHAINED || !dep.wait_counter) __syncthreads();    // (chain_wait ends with a barrier of its own)
+    }
+    if (CHAINED) {
+        chain_wait(dep);
+        if (!CHUNKED) load_b(xp0, b0, 0);
     }
     PWDW_STAMP(2);
 
@@ -237,7 +290,10 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
         }
     }
     PWDW_STAMP(3);
-    if (MODE == 4) return;
+    if (MODE == 4) {
+        if (CHAINED) chain_signal(dep);
+        return;
+    }
     __syncthreads();
     PWDW_STAMP(4);
 
@@ -249,7 +305,7 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
         const float inv_strips = __builtin_amdgcn_rcpf((float)strips);
         const Rq drq = {a.d_m1, a.d_lo, a.d_hi, a.d_out_scale, a.d_inv_out};
         int8_t* yn = a.y + ((size_t)(n * a.OH + ty * a.TH) * a.OW + tx * a.TW) * a.ldc + a.c_off + c0;
-        for (int q = t >> 2; q < ntask; q += blockDim.x >> 2) {
+        for (int q = t >> 2; q < ntask; q += nthreads >> 2) {
             const int oyl = (int)(((float)q + 0.5f) * inv_strips), st = q - oyl * strips;
             const unsigned* row = inter + ((oyl * S) * RW + st * TWL * S) * 4 + cq;
             int acc[TWL][4];
@@ -274,7 +330,10 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
             for (int j = 0; j < TWL; j++) {
                 const int oxl = st * TWL + j;
                 const unsigned p = requant4(acc[j][0] + db.x, acc[j][1] + db.y, acc[j][2] + db.z, acc[j][3] + db.w, ds, drq);
-                if (oxl < tw && c0 < a.c_limit) *reinterpret_cast<unsigned*>(yn + ((size_t)oyl * a.OW + oxl) * a.ldc) = p;
+                if (oxl < tw && c0 < a.c_limit) {
+                    unsigned* dst = reinterpret_cast<unsigned*>(yn + ((size_t)oyl * a.OW + oxl) * a.ldc);
+                    if (CHAINED) chain_store(dst, p); else *dst = p;
+                }
             }
         }
     } else if (wave == 0) {
@@ -299,12 +358,100 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
             f = __fdiv_rn(f, (float)VP);
             q = round_sat(__fdiv_rn(f, a.p_out_scale));
         }
-        if (part == 0 && c_base + ch < a.c_limit) a.y[(size_t)n * a.ldc + a.c_off + c_base + ch] = (int8_t)q;
+        if (part == 0 && c_base + ch < a.c_limit) {
+            int8_t* dst = a.y + (size_t)n * a.ldc + a.c_off + c_base + ch;
+            if (CHAINED) __hip_atomic_store(dst, (int8_t)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = (int8_t)q;
+        }
     }
     PWDW_STAMP(5);
     PWDW_DRAIN();
     PWDW_STAMP(7);
+    if (CHAINED) chain_signal(dep);
+    PWDW_STAMP(6);
 }
+
+template <int STEPS, int MODE, bool CHUNKED, int PROD>
+__global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
+    const ChainDep none = {nullptr, 0, nullptr, nullptr};
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, false>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+}
+
+#ifdef TAMD_PWDW_CHAIN_EXPERIMENT
+// =================================================================================================================
+// A CHAIN of these layers in one launch (batch-1 MobileNet: conv1+dw2_1 ... conv6/sep+pool6, fc7).
+// A dependent launch costs 1.25-1.45 us of gap + dispatch ramp, and the new kernel's first loads (weights, bias) only start
+// behind it.  A flag hand-over between two resident workgroups costs ~0.55 us (tools/exp/flag_handoff.hip,
+// profiles/r02_flag_handoff_device_clock.txt).  So the blocks of ALL layers of the chain are one grid, layer after layer in
+// block-index order (workgroups are dispatched in index order: a block's producers are resident or finished before it starts,
+// so waiting on them cannot deadlock).  A block fetches its weights, prepares its LDS, THEN waits until the previous layer's
+// finished-block counter (one release fetch-add per block; counters only grow, the target is epoch * blocks) says the layer
+// is complete (one uncached load per block and polling round) and runs the layer body -- with write-through stores and
+// agent-scope loads for the tensors that travel inside the chain (see chain_wait), so no cache is flushed or invalidated.  "Previous layer complete"
+// implies all earlier layers complete, so any tensor of the chain may be read.  The last finisher of the last layer bumps
+// the epoch for the next launch.  Waits are bounded; a give-up raises sync[2] (checked by the host in tests / at prerun).
+// =================================================================================================================
+template <int STEPS, int MODE, int PROD>
+__device__ __forceinline__ void chain_variant(const PwDwArgs& a, unsigned* inter, int bx, int by, int bz, int nthreads, const ChainDep& d)
+{
+    pwdw_block<STEPS, MODE, false, PROD, true>(a, inter, bx, by, bz, nthreads, d);
+}
+
+template <int MODE>
+__device__ __forceinline__ void chain_steps(int steps, const PwDwArgs& a, unsigned* inter, int bx, int by, int bz, int nthreads, const ChainDep& d)
+{
+    switch (steps) {
+    case 1: chain_variant<1, MODE, 0>(a, inter, bx, by, bz, nthreads, d); break;
+    case 2: chain_variant<2, MODE, 0>(a, inter, bx, by, bz, nthreads, d); break;
+    case 4: chain_variant<4, MODE, 0>(a, inter, bx, by, bz, nthreads, d); break;
+    case 8: chain_variant<8, MODE, 0>(a, inter, bx, by, bz, nthreads, d); break;
+    default: chain_variant<16, MODE, 0>(a, inter, bx, by, bz, nthreads, d); break;
+    }
+}
+
+__global__ __launch_bounds__(512) void pwdw_chain_kernel(const PwChainArgs c)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned inter[];
+    const int b = blockIdx.x;
+    int l = 0;
+    while (l + 1 < c.nlayers && b >= c.first_block[l + 1]) l++;
+    const int local = b - c.first_block[l];
+    const int gx = c.gx[l], gy = c.gy[l];
+    const int bz = local / (gx * gy), rem = local - bz * gx * gy, by = rem / gx, bx = rem - by * gx;
+    const int epoch = __hip_atomic_load(c.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ChainDep d;                       // counters: one per layer, a cache line apart
+    d.wait_counter = l ? c.flags + 32 * (l - 1) : nullptr;
+    d.wait_target = l ? (int)((unsigned)epoch * (unsigned)(c.first_block[l] - c.first_block[l - 1])) : 0;
+    d.my_counter = c.flags + 32 * l;
+    d.err = c.sync + 2;
+    const PwDwArgs a = c.layers[l];
+    const int nthreads = blockDim.x;
+    const int v = c.variant[l];                 // MODE | PROD << 3 | steps << 4
+    const int mode = v & 7, steps = v >> 4;
+    if (v & 8) {
+        if (mode == 1) chain_variant<1, 1, 1>(a, inter, bx, by, bz, nthreads, d);
+        else if (mode == 2) chain_variant<1, 2, 1>(a, inter, bx, by, bz, nthreads, d);
+        else chain_variant<1, 3, 1>(a, inter, bx, by, bz, nthreads, d);
+    } else {
+        switch (mode) {
+        case 0: chain_steps<0>(steps, a, inter, bx, by, bz, nthreads, d); break;
+        case 1: chain_steps<1>(steps, a, inter, bx, by, bz, nthreads, d); break;
+        case 2: chain_steps<2>(steps, a, inter, bx, by, bz, nthreads, d); break;
+        case 3: chain_steps<3>(steps, a, inter, bx, by, bz, nthreads, d); break;
+        default: chain_steps<4>(steps, a, inter, bx, by, bz, nthreads, d); break;
+        }
+    }
+    // the last block of the last layer to finish opens the next epoch (every block has read the current one by then)
+    if (l == c.nlayers - 1 && threadIdx.x == 0) {
+        const int nlast = c.first_block[l + 1] - c.first_block[l];
+        if (atomicAdd(c.sync + 1, 1) == nlast - 1) {
+            __hip_atomic_store(c.sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.sync, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // next reader: the next launch
+        }
+    }
+}
+#endif   // TAMD_PWDW_CHAIN_EXPERIMENT
 
 size_t pwdw_lds_bytes(const PwDwArgs& a, int threads)
 {
@@ -365,6 +512,36 @@ static hipError_t launch_first(const PwDwArgs& a, int threads, hipStream_t s)
     else hipLaunchKernelGGL((pwdw_i8_kernel<1, 3, false, 1>), grid, dim3(threads), lds, s, a);
     return hipGetLastError();
 }
+
+#ifdef TAMD_PWDW_CHAIN_EXPERIMENT
+// the template instance launch_pwdw() would pick for this layer, as a code for pwdw_chain_kernel, and its grid
+int pwdw_chain_variant(const PwDwArgs& a, int threads, int* gx, int* gy, int* gz)
+{
+    if (a.nsteps > a.steps) return -1;                      // chunked K loops stay stand-alone
+    int mode;
+    dim3 sm;
+    if (a.prod == 1 || (a.mode != 2 && a.mode != 0)) {
+        sm = dim3(a.slices, a.tiles_x, a.tiles_y * a.N);
+        mode = a.S == 2 ? 2 : (a.TH * ((a.TW + 1) / 2) * 4 >= threads ? 1 : 3);
+    } else if (a.mode == 2) {
+        sm = dim3(a.slices, 1, ((a.H + a.TH - 1) / a.TH) * a.N);
+        mode = 4;
+    } else {
+        sm = dim3(a.slices, 1, a.N);
+        mode = 0;
+    }
+    const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
+    *gx = (int)grid.x; *gy = (int)grid.y; *gz = (int)grid.z;
+    if (grid.x > 32767 || grid.y > 32767) return -1;
+    return mode | (a.prod == 1 ? 8 : 0) | (a.prod == 1 ? 1 : a.steps) << 4;
+}
+
+hipError_t launch_pwdw_chain(const PwChainArgs& c, int threads, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL(pwdw_chain_kernel, dim3(c.first_block[c.nlayers]), dim3(threads), lds, s, c);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s)
 {
