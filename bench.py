@@ -59,6 +59,14 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo plumbing check of the N-rank path (spawn, tmfile broadcast, sharding, gather of every "
                          "output); no device work, the JSON line carries value null and dry_run true")
+    ap.add_argument("--gather", choices=["final", "every"], default="final",
+                    help="N > 1: the images are independent, a step needs no collective.  final (default): the outputs stay resident in "
+                         "each rank's HBM like at N = 1 and every output of the LAST step is all-gathered once, inside the timed region; "
+                         "every: one overlapped all_gather of every output per step (a serving front end that wants all results on all ranks)")
+    ap.add_argument("--direct", type=int, choices=[0, 1], default=1,
+                    help="1 (default): tamd_graph_launch dispatches the launch list as AQL packets on the graph's own HSA queue "
+                         "(tamd_options.direct_dispatch, csrc/direct.cc); 0: hipGraph replay on the graph's HIP stream.  "
+                         "--gather every needs the stream order and always uses 0")
     ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args()
 
@@ -110,7 +118,10 @@ def main():
     # S graph instances on S HIP streams: independent batch-1 requests in flight concurrently (serving mode).
     # Default S=1 == tm_benchmark's semantics (one blocking run_graph after the other).
     S = max(1, args.streams)
-    grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank) for _ in range(S)]
+    # one HSA queue per graph: with several batch-1 streams the extra queues oversubscribe the hardware queues (measured: 4
+    # streams 8.2 k img/s direct against 27.3 k on HIP streams), so the concurrent-streams mode stays on hipGraph replay
+    direct = bool(args.direct) and S == 1 and not (use_dist and args.gather == "every")
+    grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank, direct_dispatch=direct) for _ in range(S)]
     gr = grs[0]
     u8 = args.dtype == "uint8"
     x = models.synth_input(g, 1000 + rank, tm2.DT_UINT8 if u8 else tm2.DT_INT8)   # each rank owns its own shard of images
@@ -142,19 +153,28 @@ def main():
         slots = [[torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
         gathered = [[torch.empty(slot_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
 
+    def gather(i, s):
+        for oi in range(n_out):
+            slots[i][s][slot_off[oi]:slot_off[oi] + out_sizes[oi]].copy_(views[i][oi], non_blocking=True)
+        works[(i, s)] = dist.all_gather_into_tensor(gathered[i][s], slots[i][s], async_op=True)
+
     def step(k):
         i = k % S
         grs[i].launch()
-        if use_dist:
+        if use_dist and args.gather == "every":
             s = (k // S) & 1
             with torch.cuda.stream(exts[i]):
                 if works.get((i, s)) is not None:
                     works[(i, s)].wait()         # slot free again (gather issued two rounds ago is done)
-                for oi in range(n_out):
-                    slots[i][s][slot_off[oi]:slot_off[oi] + out_sizes[oi]].copy_(views[i][oi], non_blocking=True)
-                works[(i, s)] = dist.all_gather_into_tensor(gathered[i][s], slots[i][s], async_op=True)
+                gather(i, s)
 
     def drain():
+        if use_dist and args.gather == "final":          # the last step's outputs of every stream, one collective each
+            for q in grs:
+                q.sync()                                 # direct dispatch: the passes are not on the stream the copies run on
+            for i in range(S):
+                with torch.cuda.stream(exts[i]):
+                    gather(i, 0)
         if use_dist:
             for (i, s), w in works.items():
                 if w is not None:
@@ -249,8 +269,23 @@ def main():
         cpu = cpu_baseline(tm_bytes, g, x, args.batch, args.cpu_seconds, u8)
 
     out = gr.download()[0]
+    n_direct = gr.direct_packets()
     for q in grs:
         q.close()
+
+    def flush_c_stdio():
+        # librccl announces itself through C stdio ("Librccl path : ..."), which a pipe buffers until exit: every rank flushes it
+        # BEFORE rank 0 prints, so that the JSON line is the last line of the job's stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+
+    flush_c_stdio()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+        flush_c_stdio()
     if rank == 0:
         value = total_images * args.steps / el
         line = {
@@ -260,20 +295,21 @@ def main():
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32 (uint8 simulated in fp32, as the reference)" if u8 else "int8",
             "data": "synthetic",
             "config": {"workload": "%s %s batch=%d per GPU%s, weights = seeded synthetic tmfile, input resident in HBM, "
-                                   "hipGraph replay, %d stream(s)" % (args.model, args.dtype, args.batch,
-                                                                      " (BASELINE configs[1])" if (args.model, args.dtype, args.batch) == ("mobilenet_v1", "int8", 1) else "", S),
+                                   "%s, %d stream(s)" % (args.model, args.dtype, args.batch,
+                                                                      " (BASELINE configs[1])" if (args.model, args.dtype, args.batch) == ("mobilenet_v1", "int8", 1) else "",
+                                                                      "direct AQL dispatch of the launch list (%d packets per step)" % n_direct if n_direct else "hipGraph replay", S),
                        "streams": S,
                        "global_batch": total_images, "parallelism": "dp%d" % world,
-                       "collectives": "rccl broadcast(tmfile) once + one all_gather of all %d output(s) (%d B/image) per step"
-                                      % (n_out, sum(per_image)) if use_dist else "none"},
+                       "collectives": ("rccl broadcast(tmfile) once + one all_gather of all %d output(s) (%d B/image) %s"
+                                       % (n_out, sum(per_image), "per step, overlapped" if args.gather == "every"
+                                          else "of the last step, inside the timed region (no per-step collective: independent images)"))
+                       if use_dist else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "host_to_host": host_to_host,
             "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
         }
         if cpu:
             line["speedup_vs_cpu_reference"] = value / cpu["value"] if cpu["value"] else None
-        print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
+        print(json.dumps(line), flush=True)
 
 
 def pmc_traffic(model, dtype, batch, family):

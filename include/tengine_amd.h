@@ -140,6 +140,11 @@ typedef struct tamd_options {
     int profile;          /* 1: print a per-launch timing table on stderr when the graph is released -- what
                            * TG_DEBUG_TIME=1 makes the CPU device do (cpu_define.h:41-43, cpu_dump.c:607-697); the
                            * environment variable itself is honoured too */
+    int direct_dispatch;  /* 1: tamd_graph_launch replays the launch list as AQL packets on the graph's own HSA queue instead
+                           * of hipGraphLaunch (shorter launch boundaries, no hole between replays; csrc/direct.cc).  The
+                           * passes are ordered among themselves and observed by tamd_graph_sync / _download_outputs /
+                           * _run; work on tamd_graph_stream() is NOT ordered behind them.  TAMD_DIRECT_DISPATCH=0|1
+                           * overrides.  Falls back to the hipGraph silently when the list cannot be dispatched directly. */
 } tamd_options;
 
 typedef struct tamd_graph tamd_graph;
@@ -198,6 +203,8 @@ TAMD_API int tamd_graph_inflight(const tamd_graph* g);   /* runs submitted and n
 TAMD_API int tamd_graph_upload_inputs(tamd_graph* g);
 TAMD_API int tamd_graph_launch(tamd_graph* g);            /* async on the graph's stream          */
 TAMD_API int tamd_graph_sync(tamd_graph* g);
+/* packets per pass when tamd_graph_launch dispatches directly (tamd_options.direct_dispatch took effect), else 0 */
+TAMD_API int tamd_graph_direct_packets(const tamd_graph* g);
 TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
 /* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather) */
 TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);

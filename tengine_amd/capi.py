@@ -16,7 +16,8 @@ _NP = {DT_FP32: np.float32, DT_FP16: np.float16, DT_INT8: np.int8, DT_UINT8: np.
 
 
 class Options(C.Structure):           # tamd_options
-    _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int)]
+    _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int),
+                ("direct_dispatch", C.c_int)]
 
 
 class KernelInfo(C.Structure):        # tamd_kernel_info
@@ -30,7 +31,7 @@ EXPORTS = [
     "tamd_graph_set_outputs", "tamd_graph_load_tm2", "tamd_graph_set_batch", "tamd_graph_prerun",
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
     "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
-    "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_download_outputs", "tamd_graph_output_device",
+    "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
     "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_kernel_num", "tamd_graph_profile",
     "tamd_graph_read_tensor", "tamd_graph_tensor_num", "tamd_graph_tensor_desc", "tamd_graph_destroy",
 ]
@@ -68,7 +69,7 @@ def lib():
             "tamd_graph_set_input": [vp, ci, vp, C.c_size_t], "tamd_graph_set_output": [vp, ci, vp, C.c_size_t],
             "tamd_graph_run": [vp], "tamd_graph_run_async": [vp], "tamd_graph_wait": [vp], "tamd_graph_inflight": [vp],
             "tamd_graph_upload_inputs": [vp], "tamd_graph_launch": [vp],
-            "tamd_graph_sync": [vp], "tamd_graph_download_outputs": [vp],
+            "tamd_graph_sync": [vp], "tamd_graph_direct_packets": [vp], "tamd_graph_download_outputs": [vp],
             "tamd_graph_output_device": [vp, ci, C.POINTER(vp), C.POINTER(C.c_size_t)],
             "tamd_graph_stream": [vp], "tamd_graph_time_launches": [vp, ci, C.POINTER(C.c_float)],
             "tamd_graph_kernel_num": [vp], "tamd_graph_profile": [vp, ci, C.POINTER(KernelInfo), ci],
@@ -95,14 +96,14 @@ def device_count():
 class Graph:
     """A device graph loaded from tmfile bytes (same bytes the reference's `tengine:m` loader takes)."""
 
-    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False):
+    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False, direct_dispatch=False):
         L = lib()
         self._h = L.tamd_graph_load_tm2(tm_bytes, len(tm_bytes))
         if not self._h:
             raise TamdError("tamd_graph_load_tm2 failed: %s" % L.tamd_last_error().decode())
         if batch is not None:
             _check(L.tamd_graph_set_batch(self._h, batch), "set_batch")
-        opt = Options(b"HIP", C.sizeof(Options), gpu_index, 1 if use_hip_graph else 0, 1 if profile else 0)
+        opt = Options(b"HIP", C.sizeof(Options), gpu_index, 1 if use_hip_graph else 0, 1 if profile else 0, 1 if direct_dispatch else 0)
         _check(L.tamd_graph_prerun(self._h, C.byref(opt)), "prerun")
         self._in, self._out = [], []
         for i in range(L.tamd_graph_output_num(self._h)):
@@ -180,6 +181,10 @@ class Graph:
 
     def stream(self):
         return lib().tamd_graph_stream(self._h)
+
+    def direct_packets(self):
+        """AQL packets per launch() when direct dispatch is active, else 0"""
+        return lib().tamd_graph_direct_packets(self._h)
 
     def kernel_num(self):
         """number of compute launches of one forward pass"""

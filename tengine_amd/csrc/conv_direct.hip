@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void conv_direct_i8_kernel(DirectArgs a)
         }
         acc[j] = s;
     }
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     int q[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int co = co0 + j;
         if (co < a.cout) {
             const int b = a.bias ? a.bias[co] : 0;
-            q[j] = requant1(acc[j] + b, a.wscale[co], rq);
+            q[j] = requant1(acc[j] + b, a.wscale[co], co, rq);
         } else {
             q[j] = 0;
         }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_first_i8_kernel(FirstArgs a)
     }
 
     // epilogue (C/D layout: col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> cout)
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < CT; i++) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_first_i8_kernel(FirstArgs a)
             const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
             const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
             p[g4] = requant4(acc[i][4 * g4 + 0] + b4.x, acc[i][4 * g4 + 1] + b4.y, acc[i][4 * g4 + 2] + b4.z,
-                             acc[i][4 * g4 + 3] + b4.w, s4, rq);
+                             acc[i][4 * g4 + 3] + b4.w, s4, c0, rq);
         }
         if (wide) {
             half_wave_regroup(p);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_first_rows_i8_kernel(FirstArgs a)
         }
 
     // epilogue (C/D layout: col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> cout)
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < CT; i++) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_first_rows_i8_kernel(FirstArgs a)
             const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
             const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
             p[g4] = requant4(acc[i][4 * g4 + 0] + b4.x, acc[i][4 * g4 + 1] + b4.y, acc[i][4 * g4 + 2] + b4.z,
-                             acc[i][4 * g4 + 3] + b4.w, s4, rq);
+                             acc[i][4 * g4 + 3] + b4.w, s4, c0, rq);
         }
         if (wide) {
             half_wave_regroup(p);

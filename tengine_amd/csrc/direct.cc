@@ -1,0 +1,277 @@
+// Direct dispatch: a device graph's launch list replayed as AQL packets on a private HSA queue.
+//
+// Why: at batch 1 the graph is fifteen dependent launches of 2-4 microseconds, and the boundary between two of them is what
+// the step is made of.  Measured on the same chain of short kernels (tools/exp/aql_chain.cpp, profiles/r02_aql_chain.txt):
+// hipGraph replay 1.6-1.75 us per boundary, eager HIP launches 1.47 us (host-bound below ~2.6 us of kernel), raw AQL packets
+// with the barrier bit and agent-scope fences 1.26 us -- and no hole between replays, because the host only writes 64-byte
+// packets into the ring and rings the doorbell once per pass; it is far ahead of the device.
+//
+// How: prerun records the launch list once (launch_rec.h: kernel handle, geometry, explicit argument bytes).  Each record is
+// resolved to its kernel descriptor through the HSA loader's view of the code objects HIP has already loaded (kernel name from
+// hipKernelNameRefByPtr -> "<name>.kd" symbol), its argument segment is completed with the code-object-v5 hidden arguments
+// (block counts, group sizes, grid dimensionality at align8(explicit size) + 0 / 12 / 64), and all segments live in one device
+// buffer written once: the arguments never change between passes (tensors are at fixed addresses).  A pass = one
+// kernel-dispatch packet per record, every packet with the barrier bit (the list is a dependency chain) and agent-scope acquire /
+// release -- what one kernel needs to see of the previous one across the XCDs' L2s.  System scope is paid once per BURST, not
+// per pass: the first packet after the graph's stream was drained acquires at system scope (inputs uploaded by a copy engine),
+// and direct_wait closes the burst with one barrier packet that releases at system scope (outputs read by the host or a
+// copy engine) and carries the completion signal.  Measured on MobileNet-v1 batch 1: 59.4 us per pass with system scope at
+// both ends of every pass, 57.0 with it at the ends of the burst, 61.8 for the hipGraph replay (profiles/r02_direct_dispatch.txt).
+//
+// Not covered, by construction: stream ordering with the graph's HIP stream (tamd_graph_sync / download / run wait for the
+// queue; graph.hip drains the stream before the first packet of a burst is written).  Kernels with a scratch frame pass their
+// private segment size in the packet; the runtime backs the queue's scratch on demand as it does for HIP's queues.
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/hsa_ven_amd_loader.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "launch_rec.h"
+
+namespace tamd {
+
+thread_local std::vector<LaunchRec>* g_launch_rec = nullptr;
+
+namespace {
+
+struct KernelSym { uint64_t object; uint32_t kernarg, group, priv; };
+
+struct DeviceCtx {
+    bool tried = false, ok = false;
+    hsa_agent_t agent{}, cpu{};
+    bool have_cpu = false;
+    std::map<std::string, KernelSym> syms;
+};
+std::mutex g_mu;
+std::map<int, DeviceCtx> g_ctx;
+hsa_ven_amd_loader_1_03_pfn_t g_loader{};
+bool g_loader_ok = false;
+
+struct AgentPick { int want_bus, want_dev, index, seen; hsa_agent_t by_bdf, by_index, cpu; bool have_bdf, have_index, have_cpu; };
+
+hsa_status_t pick_agent(hsa_agent_t a, void* data)
+{
+    AgentPick* p = (AgentPick*)data;
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_CPU && !p->have_cpu) { p->cpu = a; p->have_cpu = true; }
+    if (t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS
+        && (int)((bdf >> 8) & 0xff) == p->want_bus && (int)((bdf >> 3) & 0x1f) == p->want_dev && !p->have_bdf) { p->by_bdf = a; p->have_bdf = true; }
+    if (p->seen == p->index) { p->by_index = a; p->have_index = true; }
+    p->seen++;
+    return HSA_STATUS_SUCCESS;
+}
+
+struct SymScan { DeviceCtx* ctx; };
+
+hsa_status_t scan_symbol(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t s, void* data)
+{
+    DeviceCtx* ctx = ((SymScan*)data)->ctx;
+    hsa_symbol_kind_t kind;
+    if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL) return HSA_STATUS_SUCCESS;
+    uint32_t len = 0;
+    if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len) != HSA_STATUS_SUCCESS || len == 0 || len > 4096) return HSA_STATUS_SUCCESS;
+    std::string name(len, '\0');
+    if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME, &name[0]) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    KernelSym k{};
+    if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    (void)hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg);
+    (void)hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group);
+    (void)hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.priv);
+    ctx->syms[name] = k;
+    return HSA_STATUS_SUCCESS;
+}
+
+hsa_status_t scan_executable(hsa_executable_t exe, void* data)
+{
+    DeviceCtx* ctx = ((SymScan*)data)->ctx;
+    (void)hsa_executable_iterate_agent_symbols(exe, ctx->agent, scan_symbol, data);
+    return HSA_STATUS_SUCCESS;
+}
+
+// (re)reads the kernel symbols of every code object loaded so far (HIP loads a module's code object at its first launch)
+void rescan(DeviceCtx* ctx)
+{
+    if (!g_loader_ok) return;
+    SymScan sc{ctx};
+    (void)g_loader.hsa_ven_amd_loader_iterate_executables(scan_executable, &sc);
+}
+
+DeviceCtx* device_ctx(int gpu)
+{
+    DeviceCtx& c = g_ctx[gpu];
+    if (c.tried) return c.ok ? &c : nullptr;
+    c.tried = true;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;           // reference counted: HIP holds the runtime already
+    if (!g_loader_ok)
+        g_loader_ok = hsa_system_get_major_extension_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof(g_loader), &g_loader) == HSA_STATUS_SUCCESS
+                      && g_loader.hsa_ven_amd_loader_iterate_executables != nullptr;
+    if (!g_loader_ok) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, gpu) != hipSuccess) return nullptr;
+    AgentPick p{};
+    p.want_bus = prop.pciBusID; p.want_dev = prop.pciDeviceID; p.index = gpu;
+    if (hsa_iterate_agents(pick_agent, &p) != HSA_STATUS_SUCCESS) return nullptr;
+    if (!p.have_bdf && !p.have_index) return nullptr;
+    c.agent = p.have_bdf ? p.by_bdf : p.by_index;
+    c.cpu = p.cpu; c.have_cpu = p.have_cpu;
+    c.ok = true;
+    return &c;
+}
+
+}  // namespace
+
+struct DirectProgram {
+    hsa_queue_t* q = nullptr;
+    hsa_signal_t done{};                                // counts bursts down from kStart
+    std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
+    void* kernargs = nullptr;
+    uint64_t bursts = 0;                                // closed by direct_wait
+    bool open = false;                                  // passes submitted since the last direct_wait
+    static constexpr hsa_signal_value_t kStart = (hsa_signal_value_t)1 << 40;
+    uint16_t h_open = 0, h_mid = 0, h_close = 0;
+};
+
+DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why)
+{
+    static const char* reason = "";
+    *why = reason;
+    if (recs.empty()) { *why = "empty launch list"; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* ctx = device_ctx(gpu);
+    if (!ctx) { *why = "no HSA agent / loader extension for this device"; return nullptr; }
+    DirectProgram* p = new DirectProgram;
+    std::vector<unsigned char> blob;
+    std::vector<size_t> offs;
+    bool scanned = false;
+    for (const LaunchRec& r : recs) {
+        const char* nm = hipKernelNameRefByPtr(r.func, stream);
+        if (!nm) { *why = "kernel without a name"; delete p; return nullptr; }
+        const std::string key = std::string(nm) + ".kd";
+        auto it = ctx->syms.find(key);
+        if (it == ctx->syms.end() && !scanned) { rescan(ctx); scanned = true; it = ctx->syms.find(key); }
+        if (it == ctx->syms.end()) { *why = "kernel descriptor not found among the loaded code objects"; delete p; return nullptr; }
+        const KernelSym& k = it->second;
+        // scratch (the out-of-line hand-over paths of a few epilogues reserve a call frame): the packet carries the size and the
+        // runtime backs the queue's scratch on demand, as it does for HIP's own queues; TAMD_DIRECT_SCRATCH=0 refuses instead
+        static const bool allow_scratch = !(getenv("TAMD_DIRECT_SCRATCH") && atoi(getenv("TAMD_DIRECT_SCRATCH")) == 0);
+        if (k.priv != 0 && !allow_scratch) { *why = "a kernel of the list uses scratch memory"; delete p; return nullptr; }
+        const size_t hid = (r.args.size() + 7) & ~(size_t)7;
+        if (r.args.size() > k.kernarg) { *why = "recorded arguments exceed the kernel's argument segment"; delete p; return nullptr; }
+        const size_t seg = std::max<size_t>(k.kernarg, hid + 72);
+        const size_t off = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(off + seg, 0);
+        memcpy(blob.data() + off, r.args.data(), r.args.size());
+        const uint32_t bc[3] = {r.grid.x, r.grid.y, r.grid.z};
+        const uint16_t gs[3] = {(uint16_t)r.block.x, (uint16_t)r.block.y, (uint16_t)r.block.z};
+        const uint16_t dims = r.grid.z * r.block.z > 1 ? 3 : (r.grid.y * r.block.y > 1 ? 2 : 1);
+        memcpy(blob.data() + off + hid, bc, 12);
+        memcpy(blob.data() + off + hid + 12, gs, 6);
+        memcpy(blob.data() + off + hid + 64, &dims, 2);
+        offs.push_back(off);
+        hsa_kernel_dispatch_packet_t pk{};
+        pk.setup = (uint16_t)(dims << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+        pk.workgroup_size_x = gs[0]; pk.workgroup_size_y = gs[1]; pk.workgroup_size_z = gs[2];
+        pk.grid_size_x = r.grid.x * r.block.x; pk.grid_size_y = r.grid.y * r.block.y; pk.grid_size_z = r.grid.z * r.block.z;
+        pk.private_segment_size = k.priv;
+        pk.group_segment_size = k.group + r.shmem;
+        pk.kernel_object = k.object;
+        p->pkts.push_back(pk);
+    }
+    if (hipMalloc(&p->kernargs, blob.size()) != hipSuccess || hipMemcpy(p->kernargs, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        *why = "kernel-argument buffer"; direct_destroy(p); return nullptr;
+    }
+    // tools that intercept the queue (rocprofv3) read kernel-argument segments from the host, as they can for HIP's own
+    // (BAR-mapped) argument buffers: map this one for the CPU agent too; without a host mapping it simply stays device-only
+    if (ctx->have_cpu) {
+        hsa_agent_t both[2] = {ctx->agent, ctx->cpu};
+        (void)hsa_amd_agents_allow_access(2, both, nullptr, p->kernargs);
+    }
+    for (size_t i = 0; i < p->pkts.size(); i++) p->pkts[i].kernarg_address = (char*)p->kernargs + offs[i];
+    uint32_t qsize = 1024;
+    while (qsize < 8 * p->pkts.size()) qsize *= 2;
+    if (hsa_queue_create(ctx->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p->q) != HSA_STATUS_SUCCESS) {
+        *why = "hsa_queue_create"; p->q = nullptr; direct_destroy(p); return nullptr;
+    }
+    if (hsa_signal_create(DirectProgram::kStart, 0, nullptr, &p->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; direct_destroy(p); return nullptr; }
+    auto header = [](int type, int acq, int rel) {
+        return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) | (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)
+                          | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+    };
+    p->h_mid = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT);
+    p->h_open = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_AGENT);
+    p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+    return p;
+}
+
+int direct_packets(const DirectProgram* p) { return p ? (int)p->pkts.size() : 0; }
+
+int direct_submit(DirectProgram* p)
+{
+    const uint64_t n = p->pkts.size();
+    hsa_queue_t* q = p->q;
+    const uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, n);
+    while (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size) {}      // ring full: the packet processor is behind
+    hsa_kernel_dispatch_packet_t* base = (hsa_kernel_dispatch_packet_t*)q->base_address;
+    const uint64_t mask = q->size - 1;
+    for (uint64_t i = 0; i < n; i++) {
+        hsa_kernel_dispatch_packet_t* d = base + ((idx0 + i) & mask);
+        const hsa_kernel_dispatch_packet_t& s = p->pkts[i];
+        d->setup = s.setup;
+        d->workgroup_size_x = s.workgroup_size_x; d->workgroup_size_y = s.workgroup_size_y; d->workgroup_size_z = s.workgroup_size_z;
+        d->reserved0 = 0;
+        d->grid_size_x = s.grid_size_x; d->grid_size_y = s.grid_size_y; d->grid_size_z = s.grid_size_z;
+        d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
+        d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
+        d->completion_signal.handle = 0;
+        __atomic_store_n(&d->header, (i == 0 && !p->open) ? p->h_open : p->h_mid, __ATOMIC_RELEASE);
+    }
+    // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor (rocprofv3) is
+    // never handed a batch that is not contiguous in memory
+    const uint64_t to_end = q->size - (idx0 & mask);
+    if (to_end < n) hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + to_end - 1));
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + n - 1));
+    p->open = true;
+    return 0;
+}
+
+// closes the burst: one barrier packet behind everything submitted (barrier bit: it waits for the last kernel), system-scope
+// release, completion signal; returns when it has executed
+int direct_wait(DirectProgram* p)
+{
+    if (!p->open) return 0;
+    hsa_queue_t* q = p->q;
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+    while (idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size) {}
+    hsa_barrier_and_packet_t* b = (hsa_barrier_and_packet_t*)q->base_address + (idx & (q->size - 1));
+    b->reserved0 = 0; b->reserved1 = 0; b->reserved2 = 0;
+    for (int i = 0; i < 5; i++) b->dep_signal[i].handle = 0;
+    b->completion_signal = p->done;
+    __atomic_store_n(&b->header, p->h_close, __ATOMIC_RELEASE);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+    p->bursts++;
+    p->open = false;
+    const hsa_signal_value_t target = DirectProgram::kStart - (hsa_signal_value_t)p->bursts;
+    while (hsa_signal_wait_scacquire(p->done, HSA_SIGNAL_CONDITION_LT, target + 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) > target) {}
+    return 0;
+}
+
+void direct_destroy(DirectProgram* p)
+{
+    if (!p) return;
+    if (p->q) { (void)direct_wait(p); (void)hsa_queue_destroy(p->q); }
+    if (p->done.handle) (void)hsa_signal_destroy(p->done);
+    if (p->kernargs) (void)hipFree(p->kernargs);
+    delete p;
+}
+
+}  // namespace tamd

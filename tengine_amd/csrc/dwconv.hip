@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
         }
     }
 
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
     const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
 #pragma unroll
     for (int j = 0; j < TW; j++) {
         const int ox = ox0 + j;
-        const unsigned p = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, rq);
+        const unsigned p = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, c0, rq);
         if (ox < a.OW)
             *reinterpret_cast<unsigned*>(a.y + (((size_t)n * a.OH + oy) * a.OW + ox) * a.ldc + a.c_off + c0) = p;
     }

@@ -56,44 +56,49 @@ __device__ __forceinline__ int round_div_sat(float f, float s, float inv)
     return q;
 }
 
-struct Rq {            // per-launch requantisation constants (see the header comment)
-    float m1, lo, hi, out_scale, inv_out;
-};
+// ---- conv / FC requantisation: ONE fused multiply-add per value ------------------------------------------------------------
+// The reference chain (header comment) is  f = clamp(fl(fl(a * m1) * m2[c]), lo, hi),  q = sat127(round_half_away(fl(f / s)))
+// with a = (float)(acc + bias).  The planner folds M[c] = RN32(double(m1) * double(m2[c]) / double(s)) and the kernels evaluate
+//
+//     y  = fma(a, M[c], 128.5 + e)                 e = 2^-14; one rounding, the result biased into (0, 256)
+//     yc = med3(y, ylo, yhi)                       ylo = 128 + q(lo) + 0.25, yhi = 128 + q(hi) + 0.75, q(.) = the reference's
+//                                                  sat127(round(fl(. / s))) evaluated by the planner on the clamp bounds
+//     q + 128 = trunc(yc)                          unless fract(yc) < 2e: then the reference chain itself decides (~6e-5 of values)
+//
+// Exactness.  Let d = fl(f / s) be the value the reference rounds (f unclamped) and |d| < 128.6.  d carries three roundings of
+// the real number D = a * m1 * m2 / s, a * M one (of M) and y one more (|y| < 512, half an ulp = 2^-16):
+//     |y - (d + 128.5 + e)| <= |D| * 4.001 * 2^-24 + 2^-16 < 4.6e-5 < e,      hence     0 < y - (d + 128.5) < 2e.
+// An integer lies between d + 128.5 and y only if fract(y) < 2e, and a tie (d + 128.5 integral) puts y within 2e above that
+// integer as well; so for every value that is not handed over, trunc(y) = floor(d + 128.5) = round_half_away(d) + 128 for both
+// signs (they differ only at ties).  The clamp: R(x) = sat127(round(fl(x / s))) is monotone, so R(clamp(f, lo, hi)) =
+// clamp(R(f), R(lo), R(hi)) -- which clamping y to [128 + R(lo) + 0.25, 128 + R(hi) + 0.75] implements (values beyond the
+// window, including |d| >= 128.6 where the bound above no longer holds, are on the far side of the window by > 0.2); the
+// window's ends have fract 0.25 / 0.75, so a clamped value is never handed over.  M is folded only when every factor is a
+// normal number of moderate size (host_rq in graph.hip); otherwise thr = 2 sends every value down the reference chain.
+// tests/csrc/fold_requant_check.c replays fast path and chain on the host (identical IEEE operations) over random layers and
+// boundary-hugging accumulators.
+#define TAMD_RQ_E 0x1p-14f
 
-// lo/hi additionally fold the +-127 saturation: any f beyond +-127.49*out_scale rounds to +-127 either way,
-// so clamping f there keeps |y| < 128 and the int result needs no further clamp.
-__device__ __forceinline__ Rq make_rq(float m1, float lo, float hi, float out_scale)
+typedef RqArgs Rq;
+
+__device__ __forceinline__ float rq_biased(int acc, float mf, const Rq& r)
 {
-    Rq r;
-    const float lim = __fmul_rn(127.49f, out_scale);
-    r.m1 = m1; r.out_scale = out_scale;
-    r.lo = fmaxf(lo, -lim);
-    r.hi = fminf(hi, lim);
-    r.inv_out = __fdiv_rn(1.0f, out_scale);
-    return r;
+    return __builtin_amdgcn_fmed3f(__fmaf_rn((float)acc, mf, 128.5f + TAMD_RQ_E), r.ylo, r.yhi);
 }
 
-__device__ __forceinline__ float rq_value(int acc, float m2, const Rq& r)
+// the reference chain for one accumulator (acc already includes the int32 bias: the reference adds it before converting)
+__device__ __forceinline__ int rq_chain(int acc, float m2, const Rq& r)
 {
-    float f = __fmul_rn(__fmul_rn((float)acc, r.m1), m2);
-    return __builtin_amdgcn_fmed3f(f, r.lo, r.hi);          // activation clamp + saturation in one op
+    const float f = __fmul_rn(__fmul_rn((float)acc, r.m1), m2);
+    return exact_round_div_sat(__builtin_amdgcn_fmed3f(f, r.lo, r.hi), r.out_scale);
 }
 
-// fast path on a pre-clamped f: 4 VALU (bfi, fma, fract, cvt) + the risky compare
-__device__ __forceinline__ int rq_round_fast(float f, const Rq& r, bool& risky)
+// c: channel of this value (index into Rq::m2 for the hand-over path)
+__device__ __forceinline__ int requant1(int acc, float mf, int c, const Rq& r)
 {
-    const float y = __fmaf_rn(f, r.inv_out, copysignf(0.5f + TAMD_RQ_EPS, f));
-    risky = __builtin_amdgcn_fractf(fabsf(y)) < 2.f * TAMD_RQ_EPS;
-    return (int)y;
-}
-
-// acc already includes the int32 bias (the reference adds bias in int32 before converting)
-__device__ __forceinline__ int requant1(int acc, float m2, const Rq& r)
-{
-    const float f = rq_value(acc, m2, r);
-    bool risky;
-    int q = rq_round_fast(f, r, risky);
-    if (risky) q = exact_round_div_sat(f, r.out_scale);
+    const float y = rq_biased(acc, mf, r);
+    int q = (int)y - 128;
+    if (__builtin_amdgcn_fractf(y) < r.thr) q = rq_chain(acc, r.m2[c], r);
     return q;
 }
 
@@ -102,32 +107,34 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
     return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24);
 }
 
-// the rare path of requant4 (~1e-4 of the values): the reference expression itself for the flagged slots.  Kept OUT of line:
-// inlined, its ~60 instructions at each of the 16+ call sites of a GEMM epilogue push the epilogue past the unroller's size
-// budget, the accumulator arrays then get dynamic indices and land in scratch memory (seen: 320 B of scratch in every
-// 128x128 tile variant of conv_igemm.hip)
-__device__ __attribute__((noinline)) static unsigned requant4_exact(float f0, float f1, float f2, float f3, unsigned packed, int flags, float out_scale)
+// the hand-over path of requant4 (a wave takes it for ~1.5 % of its groups): the reference chain for the flagged slots.  Kept
+// OUT of line: inlined, its ~60 instructions at each of the 16+ call sites of a GEMM epilogue push the epilogue past the
+// unroller's size budget, the accumulator arrays then get dynamic indices and land in scratch memory.  Everything by value.
+__device__ __attribute__((noinline)) static unsigned requant4_chain(int a0, int a1, int a2, int a3, float4 mf, unsigned packed, const float* m2c,
+                                                                   float m1, float lo, float hi, float out_scale, float ylo, float yhi, float thr)
 {
-    int q[4] = {(int)(signed char)(packed & 0xff), (int)(signed char)((packed >> 8) & 0xff), (int)(signed char)((packed >> 16) & 0xff),
-                (int)(signed char)(packed >> 24)};
-    if (flags & 1) q[0] = exact_round_div_sat(f0, out_scale);
-    if (flags & 2) q[1] = exact_round_div_sat(f1, out_scale);
-    if (flags & 4) q[2] = exact_round_div_sat(f2, out_scale);
-    if (flags & 8) q[3] = exact_round_div_sat(f3, out_scale);
-    return pack4(q[0], q[1], q[2], q[3]);
+    Rq r;
+    r.m1 = m1; r.lo = lo; r.hi = hi; r.out_scale = out_scale; r.ylo = ylo; r.yhi = yhi; r.thr = thr; r.m2 = m2c;
+    const int a[4] = {a0, a1, a2, a3};
+    const float m[4] = {mf.x, mf.y, mf.z, mf.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (__builtin_amdgcn_fractf(rq_biased(a[k], m[k], r)) < thr)
+            packed = (packed & ~(0xffu << (8 * k))) | ((unsigned)(rq_chain(a[k], m2c[k], r) & 0xff) << (8 * k));
+    return packed;
 }
 
-// four consecutive channels -> one packed dword; the exact path is taken once for the group
-__device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, const float4& m2, const Rq& r)
+// four consecutive channels c .. c+3 -> one packed dword of int8; mf = M[c .. c+3]
+__device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, const float4& mf, int c, const Rq& r)
 {
-    const float f0 = rq_value(a0, m2.x, r), f1 = rq_value(a1, m2.y, r), f2 = rq_value(a2, m2.z, r), f3 = rq_value(a3, m2.w, r);
-    bool k0, k1, k2, k3;
-    const int q0 = rq_round_fast(f0, r, k0);
-    const int q1 = rq_round_fast(f1, r, k1);
-    const int q2 = rq_round_fast(f2, r, k2);
-    const int q3 = rq_round_fast(f3, r, k3);
-    unsigned p = pack4(q0, q1, q2, q3);
-    if (k0 | k1 | k2 | k3) p = requant4_exact(f0, f1, f2, f3, p, (int)k0 | ((int)k1 << 1) | ((int)k2 << 2) | ((int)k3 << 3), r.out_scale);
+    const float y0 = rq_biased(a0, mf.x, r), y1 = rq_biased(a1, mf.y, r), y2 = rq_biased(a2, mf.z, r), y3 = rq_biased(a3, mf.w, r);
+    // fract >= 0: the order of the bit patterns is the order of the values (v_min3_u32 instead of IEEE minimum + canonicalisation)
+    const unsigned f0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y0)), f1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y1));
+    const unsigned f2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y2)), f3 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y3));
+    const unsigned fm = min(min(f0, f1), min(f2, f3));
+    // yc in [1.25, 255.75]: the truncated values are bytes, biased by 128
+    unsigned p = ((unsigned)y0 | ((unsigned)y1 << 8) | ((unsigned)y2 << 16) | ((unsigned)y3 << 24)) ^ 0x80808080u;
+    if (fm < __builtin_bit_cast(unsigned, r.thr)) p = requant4_chain(a0, a1, a2, a3, mf, p, r.m2 + c, r.m1, r.lo, r.hi, r.out_scale, r.ylo, r.yhi, r.thr);
     return p;
 }
 
@@ -262,6 +269,72 @@ __device__ __forceinline__ void elt_sum16(unsigned (&p)[4], const uint4& r, cons
         }
         p[d] = pack4(q[0], q[1], q[2], q[3]);
     }
+}
+
+// ---- the ResNet residual tail in two fused multiply-adds per value ------------------------------------------------------------
+// Reference (eltwise_ref.c:589-640 SUM, then relu_kernel_ref_int8.c:40-94 when the ReLU keeps the scale):
+//     f = fl(fl(qc * s_conv) + fl(qr * s_res)),  y = sat127(round_half_away(fl(f / s))),  [y = max(y, 0)]
+// Fast path on the BIASED bytes uc = qc + 128, ur = qr + 128 (v_cvt_f32_ubyteN converts a byte of a dword in one instruction):
+//     t = fma(uc, Mc, K0),  yb = fma(ur, Mr, t),  Mc = RN32(s_conv / s), Mr = RN32(s_res / s), K0 = RN32(128.5 + e - 128 (Mc + Mr))
+//     q + 128 = trunc(med3(yb, ylo, yhi))     unless fract < 2e, then the reference expression decides
+// Error against d = fl(f / s) for |d| < 128.6, S = Mc + Mr, u = 2^-24: the reference rounds the two products, the sum and the
+// quotient, <= u (127 S + 257.2); the fast path rounds Mc, Mr (<= 255 S u), K0 (|K0| < 256: 2^-17), t and yb (< 512: 2^-16
+// each): |yb - (d + 128.5 + e)| <= u (382 S + 257.2) + 2^-17 + 2^-15 <= 9.9e-5 for S <= 2, below e = 2^-13 -- the planner folds
+// only then (EltFuse::thr = 0 otherwise and the tail below runs).  Window and hand-over argument as for requant4.
+// tests/csrc/fold_requant_check.c replays this path as well.
+__device__ __attribute__((noinline)) static unsigned elt_sum4_chain(unsigned uc, unsigned ur, unsigned packed, float mc, float mr, float k0, float ylo,
+                                                                   float yhi, float thr, float s_conv, float s_res, float out_scale, int relu)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float fc = (float)((uc >> (8 * k)) & 0xffu), fr = (float)((ur >> (8 * k)) & 0xffu);
+        const float y = __builtin_amdgcn_fmed3f(__fmaf_rn(fr, mr, __fmaf_rn(fc, mc, k0)), ylo, yhi);
+        if (__builtin_amdgcn_fractf(y) < thr) {
+            const float f = __fadd_rn(__fmul_rn(fc - 128.f, s_conv), __fmul_rn(fr - 128.f, s_res));      // u - 128: exact
+            int q = exact_round_div_sat(f, out_scale);
+            if (relu) q = q < 0 ? 0 : q;
+            packed = (packed & ~(0xffu << (8 * k))) | ((unsigned)(q & 0xff) << (8 * k));
+        }
+    }
+    return packed;
+}
+
+// pc: four int8 results of the conv, pr: the residual operand's bytes of the same channels -> the eltwise (+ReLU) result
+__device__ __forceinline__ unsigned elt_sum4_fold(unsigned pc, unsigned pr, const EltFuse& e)
+{
+    const unsigned uc = pc ^ 0x80808080u, ur = pr ^ 0x80808080u;
+    float y[4];
+    unsigned fb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float fc = (float)((uc >> (8 * k)) & 0xffu), fr = (float)((ur >> (8 * k)) & 0xffu);
+        y[k] = __builtin_amdgcn_fmed3f(__fmaf_rn(fr, e.mr, __fmaf_rn(fc, e.mc, e.k0)), e.ylo, e.yhi);
+        fb[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y[k]));
+    }
+    unsigned q = ((unsigned)y[0] | ((unsigned)y[1] << 8) | ((unsigned)y[2] << 16) | ((unsigned)y[3] << 24)) ^ 0x80808080u;
+    if (min(min(fb[0], fb[1]), min(fb[2], fb[3])) < __builtin_bit_cast(unsigned, e.thr))
+        q = elt_sum4_chain(uc, ur, q, e.mc, e.mr, e.k0, e.ylo, e.yhi, e.thr, e.s_conv, e.s_res, e.out_scale, e.relu);
+    return q;
+}
+
+// p: the conv's int8 results (16 channels of one pixel), r: the residual operand's; result in p
+__device__ __forceinline__ void elt_sum16_fold(unsigned (&p)[4], const uint4& r, const EltFuse& e)
+{
+    p[0] = elt_sum4_fold(p[0], r.x, e);
+    p[1] = elt_sum4_fold(p[1], r.y, e);
+    p[2] = elt_sum4_fold(p[2], r.z, e);
+    p[3] = elt_sum4_fold(p[3], r.w, e);
+}
+
+// the general tail (any eltwise type / ReLU flavour) out of line, for epilogues whose hot path is elt_sum4_fold; scalars only
+// (a struct argument travels through scratch memory)
+__device__ __attribute__((noinline)) static unsigned fuse_elt4_cold(unsigned pc, unsigned pr, int type, int conv_is_first, float s_conv, float s_res,
+                                                                   float out_scale, int relu, float relu_out_scale, float inv_out, float inv_relu)
+{
+    EltFuse e;
+    e.type = type; e.conv_is_first = conv_is_first; e.s_conv = s_conv; e.s_res = s_res; e.out_scale = out_scale; e.relu = relu;
+    e.relu_out_scale = relu_out_scale;
+    return fuse_elt4(pc, pr, e, inv_out, inv_relu);
 }
 
 // everything by VALUE: a reference into the kernel's argument block would force the whole block into scratch memory

@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void gemm_direct_i8_kernel(ConvArgs a)
     }
     if (!nvalid) return;
 
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
         const int c0 = n0 + 8 * g4 + 4 * hi;
         const int4 b4 = *reinterpret_cast<const int4*>(a.bias + c0);
         const float4 s4 = *reinterpret_cast<const float4*>(a.wscale + c0);
         const unsigned p = requant4(acc[4 * g4 + 0] + b4.x, acc[4 * g4 + 1] + b4.y, acc[4 * g4 + 2] + b4.z,
-                                    acc[4 * g4 + 3] + b4.w, s4, rq);
+                                    acc[4 * g4 + 3] + b4.w, s4, c0, rq);
         if (mvalid && c0 < a.c_limit) *reinterpret_cast<unsigned*>(a.y + (size_t)m * a.ldc + a.c_off + c0) = p;
     }
 }

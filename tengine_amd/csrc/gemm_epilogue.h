@@ -12,7 +12,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi)
 {
     // C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     // 16-B stores (half-wave regroup) whenever the destination is 16-channel granular; dword stores else
     const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0 && (!a.elt.res || ((a.elt.res_ldc | a.elt.res_c_off) & 15) == 0);
     const float inv_elt = a.elt.res ? __fdiv_rn(1.0f, a.elt.out_scale) : 1.f;
@@ -41,7 +41,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[
                 const int4 b4 = b4s[i][g4];
                 const float4 s4 = s4s[i][g4];
                 p[g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y, acc[i][j][4 * g4 + 2] + b4.z,
-                                 acc[i][j][4 * g4 + 3] + b4.w, s4, rq);
+                                 acc[i][j][4 * g4 + 3] + b4.w, s4, cb + 8 * g4 + 4 * hi, rq);
             }
             const int m = m0 + (wm * TM + j) * 32 + l31;
             if (wide) {
@@ -50,8 +50,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[
                 if (m < a.M && c16 < a.c_limit) {
                     if (a.elt.res) {      // eltwise (+ReLU) tail on the 16 channels this lane now holds
                         const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16);
-                        const uint4 o = fuse_elt16(make_uint4(p[0], p[1], p[2], p[3]), r, a.elt, inv_elt, inv_relu);
-                        p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = o.w;
+                        if (a.elt.thr > 0.f) {
+                            elt_sum16_fold(p, r, a.elt);
+                        } else {
+                            const uint4 o = fuse_elt16(make_uint4(p[0], p[1], p[2], p[3]), r, a.elt, inv_elt, inv_relu);
+                            p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = o.w;
+                        }
                     }
                     *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + c16) = make_uint4(p[0], p[1], p[2], p[3]);
                 }

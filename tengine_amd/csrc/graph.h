@@ -116,6 +116,8 @@ struct tamd_graph {
     std::vector<tamd::Inflight> inflight;      // FIFO, at most 2
     hipEvent_t slot_done[2] = {nullptr, nullptr};
     int next_slot = 0;
+    tamd::DirectProgram* direct = nullptr;     // tamd_options.direct_dispatch: the launch list as AQL packets (direct.cc)
+    bool direct_busy = false;                  // passes submitted since the last wait
     tamd_options opt{};
     bool prepared = false;
     int gpu = 0;

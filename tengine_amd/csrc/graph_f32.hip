@@ -1,10 +1,14 @@
 // Planner for fp32 device graphs (config #1 plumbing, parity bar 1e-4, order-free).
 // Dense NCHW fp32 tensors -- the reference's own order, no layout pass at the graph edges.  group == 1 convolutions
-// and FC run on the matrix cores (conv_f32_mfma.hip, LDS-DMA operand ring); the reference's Winograd F(4,3) path
-// (wino_conv_kernel_x86.c) is a CPU speed-up with the same mathematical result, so it has no device counterpart.
+// and FC run on the matrix cores (conv_f32_mfma.hip, LDS-DMA operand ring).  3x3 / stride 1 convolutions also have a
+// Winograd F(2,3) form (winograd_f32.hip; the reference's CPU backend uses F(4,3), wino_conv_kernel_x86.c -- the same
+// mathematical result): the planner times both and keeps the faster (TAMD_F32_WINOGRAD=0 never, 1 always).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+
+#include <algorithm>
 
 #include "graph.h"
 
@@ -56,6 +60,93 @@ static int plan_gemm_f32(tamd_graph* g, HNode& n, const float* xdev, int N, int 
     st.bytes = 4.0 * ((double)N * C * H * W + (double)N * cout * OH * OW + (double)cout * K);
     st.fn = [a](hipStream_t s) { return launch_conv_f32_mfma(a, s); };
     g->steps.push_back(st);
+    return 0;
+}
+
+// per-launch time of a list of launches run back to back (best of two bursts)
+static int time_steps(tamd_graph* g, const std::vector<std::function<hipError_t(hipStream_t)>>& fns, float* ms_out)
+{
+    hipEvent_t e0, e1;
+    *ms_out = 1e30f;
+    for (auto& f : fns)
+        if (f(g->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int round = 0; round < 2; round++) {
+        float t = 0;
+        HIPCHK(hipEventRecord(e0, g->stream));
+        for (int it = 0; it < 10; it++)
+            for (auto& f : fns) (void)f(g->stream);
+        HIPCHK(hipEventRecord(e1, g->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = std::min(*ms_out, t / 10);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+// Winograd F(2,3) form of the 3x3 / stride 1 convolution whose direct form is the LAST step of g->steps: replaces it when it
+// is faster (or when TAMD_F32_WINOGRAD=1).  U = G g G^T with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], evaluated in double
+// and rounded once.
+static int plan_winograd_f32(tamd_graph* g, HNode& n, const HTensor& x, const HTensor& y, int oimg)
+{
+    const char* env = getenv("TAMD_F32_WINOGRAD");                // read at every prerun (tests switch it)
+    const int mode = env ? atoi(env) : -1;
+    const tamd_conv_param& p = n.p.conv;
+    if (mode == 0 || p.group != 1 || p.kernel_h != 3 || p.kernel_w != 3 || p.stride_h != 1 || p.stride_w != 1 || p.dilation_h != 1
+        || p.dilation_w != 1) return 0;
+    HTensor& w = g->tensors[n.in[1]];
+    HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;
+    F32WinoArgs a{};
+    a.N = x.n; a.C = x.c; a.H = x.h; a.W = x.w; a.OH = y.h; a.OW = y.w; a.cout = y.c; a.PH = p.pad_h0; a.PW = p.pad_w0;
+    a.TH = (y.h + 1) / 2; a.TW = (y.w + 1) / 2; a.T = x.n * a.TH * a.TW; a.Tpad = rup(a.T, 64);
+    a.Cpad = rup(x.c, 16); a.Mpad = rup(y.c, 64);
+    a.out_img = oimg; a.out_c0 = y.c_off; a.act = p.activation;
+    const size_t ws_bytes = 16ull * ((size_t)a.Cpad + a.Mpad) * a.Tpad * 4;
+    if (ws_bytes > (1ull << 30)) return 0;                        // transformed tensors of this layer would not be "small"
+    // only worth timing when the multiplications matter at all (the plan-time decision is by measurement anyway)
+    if (mode != 1 && (double)a.T * y.c * x.c < 2e6) return 0;
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const float* wsrc = (const float*)w.data.data();
+    std::vector<float> U((size_t)16 * a.Mpad * a.Cpad, 0.f);
+    for (int co = 0; co < y.c; co++)
+        for (int c = 0; c < x.c; c++) {
+            const float* gk = wsrc + ((size_t)co * x.c + c) * 9;
+            double t[4][3];
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 3; j++) t[i][j] = G[i][0] * gk[j] + G[i][1] * gk[3 + j] + G[i][2] * gk[6 + j];
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++)
+                    U[((size_t)(4 * i + j) * a.Mpad + co) * a.Cpad + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+    float* dU = nullptr; float* db = nullptr;
+    void* dV = nullptr; void* dM = nullptr;
+    if (upload(g, U, &dU)) return -1;
+    if (b) {
+        std::vector<float> hb((const float*)b->data.data(), (const float*)b->data.data() + y.c);
+        if (upload(g, hb, &db)) return -1;
+    }
+    if (dev_alloc(g, &dV, 16ull * a.Cpad * a.Tpad * 4, false) || dev_alloc(g, &dM, 16ull * a.Mpad * a.Tpad * 4, false)) return -1;
+    a.x = (const float*)x.dptr; a.U = dU; a.bias = db; a.V = (float*)dV; a.M = (float*)dM; a.y = (float*)y.dptr;
+    Step direct = g->steps.back();
+    std::vector<std::function<hipError_t(hipStream_t)>> wino = {[a](hipStream_t s) { return launch_wino_in_f32(a, s); },
+                                                                 [a](hipStream_t s) { return launch_wino_gemm_f32(a, s); },
+                                                                 [a](hipStream_t s) { return launch_wino_out_f32(a, s); }};
+    bool use = mode == 1;
+    if (mode != 1) {
+        float tw = 0, td = 0;
+        if (time_steps(g, wino, &tw) || time_steps(g, {direct.fn}, &td)) return -1;
+        use = tw * 3.f < td * 0.97f;                              // time_steps reports per launch: three against one
+    }
+    if (!use) return 0;
+    g->steps.pop_back();
+    const char* names[3] = {"wino_in_f32", "wino_gemm_f32<F(2,3)>", "wino_out_f32"};
+    for (int k = 0; k < 3; k++) {
+        Step st; st.node = n.name; st.kernel = names[k];
+        if (k == 1) { st.macs = 16.0 * a.T * y.c * x.c; st.bytes = direct.bytes; }     // SURVEY 8(d) bytes of the node, once
+        st.fn = wino[k];
+        g->steps.push_back(st);
+    }
     return 0;
 }
 
@@ -126,6 +217,7 @@ int plan_f32(tamd_graph* g)
             if (p.group == 1) {
                 if (plan_gemm_f32(g, n, (const float*)x.dptr, x.n, x.c, x.h, x.w, y.h, y.w, y.c, p.kernel_h, p.kernel_w, p.stride_h,
                                   p.stride_w, p.pad_h0, p.pad_w0, p.dilation_h, p.dilation_w, p.activation, (float*)y.dptr, out_img(y), y.c_off)) return -1;
+                if (plan_winograd_f32(g, n, x, y, out_img(y))) return -1;
             } else {
                 HTensor& w = g->tensors[n.in[1]];
                 HTensor* b = n.in.size() > 2 ? &g->tensors[n.in[2]] : nullptr;

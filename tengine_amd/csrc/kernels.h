@@ -17,13 +17,28 @@ struct EltFuse {              // eltwise (+ReLU) node applied in the conv epilog
     float out_scale;          // eltwise output scale
     int relu;                 // a ReLU (slope 0) node follows
     float relu_out_scale;
+    // SUM (+ ReLU that keeps the eltwise scale) in two fused multiply-adds per value (epilogue.h: elt_sum16_fold), folded by the
+    // planner: mc = RN32(s_conv / out_scale), mr = RN32(s_res / out_scale), k0 = RN32(128.5 + e - 128 * (mc + mr)), window
+    // [ylo, yhi] = [128 + (relu ? 0 : -127) + 0.25, 255.75], hand-over threshold thr = 2e; thr = 0: not applicable
+    float mc, mr, k0, ylo, yhi, thr;
+};
+
+// Requantisation constants of one conv / FC node, folded by the planner (graph.hip: fold_requant + host_rq; the arithmetic and
+// its exactness argument are in epilogue.h).  The kernels' per-channel vector `wscale[]` holds the FAST-path multiplier
+// M[c] = RN32(m1 * m2[c] / out_scale); the reference chain's own factors stay here for the values the fast path hands over.
+struct RqArgs {
+    float m1, lo, hi, out_scale;   // reference chain: f = clamp(fl(fl((float)acc * m1) * m2[c]), lo, hi), q = sat127(round(f / out_scale));
+                                   // lo / hi already fold the +-127.49 * out_scale saturation
+    float ylo, yhi;                // fast path: clamp of the biased value, 128 + q(lo) + 0.25 / 128 + q(hi) + 0.75
+    float thr;                     // fast path: hand over when fract(y) < thr (2^-13; 2.0 = always, when the constants are out of range)
+    const float* m2;               // [as wscale] m2[c] of the reference chain, read on the hand-over path only
 };
 
 struct ConvArgs {
     const int8_t* x;       // NHWC input, channel stride cs_in
     const int8_t* w;       // packed weights [cout_pad][kpad]
     const int32_t* bias;   // [cout_pad] (zeros when the node has no bias)
-    const float* wscale;   // [cout_pad]
+    const float* wscale;   // [cout_pad] fast-path multipliers M[c] (see RqArgs)
     int8_t* y;             // NHWC output base
     int N, H, W, cs_in;    // cs_in: bytes between consecutive input pixels
     int ckp;               // K bytes per tap = roundup(cin,16) (== cs_in unless x is a concat view)
@@ -37,7 +52,7 @@ struct ConvArgs {
     int ktot;              // KH*KW*ckp
     int kpad;              // weight row stride (multiple of the K tile)
     int M;                 // N*OH*OW
-    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
+    RqArgs rq;             // requantisation constants, see epilogue.h (wscale[] holds M[c])
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
     unsigned long long mg_ohw, mg_ow;   // ceil(2^40 / (OH*OW)), ceil(2^40 / OW): pixel index -> (n, oy, ox) by multiply-high (conv_igemm_fast.h)
     int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
@@ -56,15 +71,15 @@ struct DwArgs {
     int8_t* y;
     int N, H, W, C, cs_in, cw, OH, OW, ldc, c_off;
     int S, PH, PW;
-    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
+    RqArgs rq;             // requantisation constants, see epilogue.h (wscale[] holds M[c])
 };
 
 struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.hip)
     const int8_t* x;       // NHWC input of the pointwise conv (channel offset applied)
     const int8_t* wf;      // pointwise weights in MFMA fragment order: [16-channel slice][64-deep K step][64 lanes][16 B]
     const int32_t* bias;   // [slices * 16]
-    const float* wscale;   // [slices * 16] (m2[c] of epilogue.h)
-    float m1, lo, hi, out_scale, inv_out;      // pointwise requantisation constants: struct Rq of epilogue.h, folded on the host
+    const float* wscale;   // [slices * 16] (M[c] of epilogue.h)
+    RqArgs rq;             // pointwise requantisation constants
     int N, H, W, cs_in, ktot;          // H x W: the pointwise map == the tail's input map
     int nsteps, steps;                 // 64-deep K steps of the (zero padded) weight panel, a multiple of `steps` = pwdw_steps()
 #ifdef TAMD_PWDW_STAMPS
@@ -78,7 +93,7 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     const int8_t* dw_w;    // as DwArgs::w
     const int32_t* dw_bias;
     const float* dw_wscale;
-    float d_m1, d_lo, d_hi, d_out_scale, d_inv_out;
+    RqArgs d_rq;
     int cw;                // depthwise weight row length (channels rounded up to 16)
     int S, PH, PW, OH, OW; // depthwise stride / leading pads / output map
     int8_t* y;             // NHWC output of the tail
@@ -111,7 +126,7 @@ struct DirectArgs {        // generic direct conv (any group / cin), also NCHW-i
     int N, C, H, W, cs_in; // cs_in == 0 => x is NCHW (graph input), else NHWC with that stride
     int OH, OW, cout, ldc, c_off;
     int KH, KW, SH, SW, PH, PW, DH, DW, group;
-    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
+    RqArgs rq;             // requantisation constants, see epilogue.h (wscale[] holds M[c])
 };
 
 struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on MFMA
@@ -124,7 +139,7 @@ struct FirstArgs {         // first layer from the NCHW graph input (C <= 4) on 
     int KH, KW, SH, SW, PH, PW, DH, DW;
     int kp;                // roundup(C*KH*KW, 32) <= 256
     int kwp;               // 0: k = OIHW order (gather kernel); 4 / 8: k = (c*KH+ky)*kwp + kx, kp = roundup(C*KH*kwp, 32) <= 192
-    float m1, lo, hi, out_scale;   // requantisation constants, see epilogue.h (wscale[] holds m2[c])
+    RqArgs rq;             // requantisation constants, see epilogue.h (wscale[] holds M[c])
 };
 
 struct PoolArgs {
@@ -172,6 +187,8 @@ bool conv_igemm2_applicable(const ConvArgs& a);
 const char* conv_igemm2_kernel_name(const ConvArgs& a);
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
 bool pw_stream_applicable(const ConvArgs& a);
+hipError_t launch_pw_rows(const ConvArgs& a, hipStream_t s);       // 1x1, shallow K, many pixels: row-major epilogue, persistent pipelined waves
+bool pw_rows_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
 int conv_first_kwp(int C, int KH, int KW, int DW);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
@@ -330,6 +347,23 @@ const char* conv_f32_mfma_kernel_name(const F32ConvArgs& a);
 hipError_t launch_conv_f32_mfma(const F32ConvArgs& a, hipStream_t s);
 hipError_t launch_dequant_u8_f32(const uint8_t* x, float* y, size_t n, float zp, float scale, hipStream_t s);
 
+// Winograd F(2x2, 3x3) for fp32 3x3 / stride 1 / dilation 1 / group 1 convolutions (winograd_f32.hip): three launches
+struct F32WinoArgs {
+    const float* x;            // NCHW input
+    const float* U;            // transformed weights [16][Mpad][Cpad] (host: G g G^T), zero padded
+    const float* bias;         // may be null
+    float* V;                  // workspace [16][Cpad][Tpad]: transformed input tiles
+    float* M;                  // workspace [16][Mpad][Tpad]: products
+    float* y;                  // NCHW output, image stride out_img elements, first channel out_c0
+    int N, C, H, W, OH, OW, cout, PH, PW;
+    int TH, TW, T, Tpad;       // tiles per image (rows, columns), tiles in total, padded to 64
+    int Cpad, Mpad;            // cin padded to 16, cout padded to 64
+    int out_img, out_c0, act;
+};
+hipError_t launch_wino_in_f32(const F32WinoArgs& a, hipStream_t s);
+hipError_t launch_wino_gemm_f32(const F32WinoArgs& a, hipStream_t s);
+hipError_t launch_wino_out_f32(const F32WinoArgs& a, hipStream_t s);
+
 // ---- fp32 models (f32_kernels.hip): dense NCHW fp32 ------------------------------------------------------------------
 struct F32DirectArgs {         // grouped / depthwise convolution
     const float* x; const float* w; const float* bias; float* y;
@@ -361,3 +395,9 @@ hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s);
 hipError_t launch_softmax_u8(const U8SoftmaxArgs& a, hipStream_t s);
 
 }  // namespace tamd
+
+// every launch of the backend goes through the launch recorder (launch_rec.h): a plain launch, plus -- while prerun records
+// the launch list for direct dispatch -- a copy of what was launched
+#include "launch_rec.h"
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::tamd::launch_rec(kernel, grid, block, shmem, stream, __VA_ARGS__)

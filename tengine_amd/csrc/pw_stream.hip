@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
             af[i][s] = *reinterpret_cast<const v4i*>(a.w + (size_t)(n0 + i * 32 + l31) * a.kpad + s * 32 + hi * 16);
     __syncthreads();
 
-    const Rq rq = make_rq(a.m1, a.lo, a.hi, a.out_scale);
+    const Rq rq = a.rq;
     const float inv_elt = ELT ? __fdiv_rn(1.0f, a.elt.out_scale) : 1.f;
     const float inv_relu = (ELT && a.elt.relu) ? __fdiv_rn(1.0f, a.elt.relu_out_scale) : 1.f;
     const int tiles_m = (a.M + 31) / 32;
@@ -69,17 +69,19 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
                 const int4 b4 = *reinterpret_cast<const int4*>(&sbias[c]);
                 const float4 s4 = *reinterpret_cast<const float4*>(&sscale[c]);
                 p[g4] = requant4(acc[4 * g4 + 0] + b4.x, acc[4 * g4 + 1] + b4.y, acc[4 * g4 + 2] + b4.z,
-                                 acc[4 * g4 + 3] + b4.w, s4, rq);
+                                 acc[4 * g4 + 3] + b4.w, s4, n0 + c, rq);
             }
             half_wave_regroup(p);
             const int cb = n0 + i * 32 + hi * 16;
             if (mvalid && cb < a.c_limit) {
                 if (ELT) {         // residual operand: the same pixel, the 16 channels this lane now holds
                     const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + cb);
-                    p[0] = fuse_elt4(p[0], r.x, a.elt, inv_elt, inv_relu);
-                    p[1] = fuse_elt4(p[1], r.y, a.elt, inv_elt, inv_relu);
-                    p[2] = fuse_elt4(p[2], r.z, a.elt, inv_elt, inv_relu);
-                    p[3] = fuse_elt4(p[3], r.w, a.elt, inv_elt, inv_relu);
+                    if (a.elt.thr > 0.f) {
+                        elt_sum16_fold(p, r, a.elt);
+                    } else {
+                        const uint4 o = fuse_elt16(make_uint4(p[0], p[1], p[2], p[3]), r, a.elt, inv_elt, inv_relu);
+                        p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = o.w;
+                    }
                 }
                 *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldc + a.c_off + cb) = make_uint4(p[0], p[1], p[2], p[3]);
             }

@@ -152,7 +152,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     const int VW = vx1 - vx0, VP = (vy1 - vy0) * VW;
     const float inv_vw = __builtin_amdgcn_rcpf((float)VW);
     const int ntiles = (VP + 15) >> 4;
-    const Rq rq = {a.m1, a.lo, a.hi, a.out_scale, a.inv_out};     // make_rq() evaluated on the host (same binary32 operations)
+    const Rq rq = a.rq;                  // folded on the host (graph.hip: host_rq)
     const int8_t* xn = PROD == 0 ? a.x + (size_t)n * a.H * a.W * a.cs_in + kb * 16
                                  : a.x + (size_t)n * a.in_C * a.in_H * a.in_W;
     // PROD 1: the four patch rows (c, ky) of this lane's 16 K bytes: k = row * 4 + kx, a row is FOUR consecutive input bytes
@@ -210,7 +210,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         }
     };
     auto finish = [&](const v4i& acc, int slot) {
-        const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, rq);
+        const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, c_base + 4 * kb, rq);
         if (MODE == 4) {
             if (slot >= 0 && c_base + 4 * kb < a.c_limit) {
                 unsigned* dst = reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb);
@@ -303,7 +303,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         const int strips = (tw + TWL - 1) / TWL;
         const int ntask = th * strips;
         const float inv_strips = __builtin_amdgcn_rcpf((float)strips);
-        const Rq drq = {a.d_m1, a.d_lo, a.d_hi, a.d_out_scale, a.d_inv_out};
+        const Rq drq = a.d_rq;
         int8_t* yn = a.y + ((size_t)(n * a.OH + ty * a.TH) * a.OW + tx * a.TW) * a.ldc + a.c_off + c0;
         for (int q = t >> 2; q < ntask; q += nthreads >> 2) {
             const int oyl = (int)(((float)q + 0.5f) * inv_strips), st = q - oyl * strips;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
 #pragma unroll
             for (int j = 0; j < TWL; j++) {
                 const int oxl = st * TWL + j;
-                const unsigned p = requant4(acc[j][0] + db.x, acc[j][1] + db.y, acc[j][2] + db.z, acc[j][3] + db.w, ds, drq);
+                const unsigned p = requant4(acc[j][0] + db.x, acc[j][1] + db.y, acc[j][2] + db.z, acc[j][3] + db.w, ds, c0, drq);
                 if (oxl < tw && c0 < a.c_limit) {
                     unsigned* dst = reinterpret_cast<unsigned*>(yn + ((size_t)oyl * a.OW + oxl) * a.ldc);
                     if (CHAINED) chain_store(dst, p); else *dst = p;

@@ -265,6 +265,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
 
     tamd_options opt;
     opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    opt.direct_dispatch = 0;      // the plugin's run is the blocking host-to-host tamd_graph_run: nothing for direct dispatch to replay
     if (options) {   // options may be NULL (scheduler.c:49-59); else the blob of set_context_device, whose byte count the core
                      // does not pass on (c_api.c:183-210): it carries its own `size`, and only the fields inside it are read
         const tamd_options* o = (const tamd_options*)options;

@@ -11,3 +11,16 @@ def test_round_div_sat_is_exact(tmp_path):
     out = subprocess.run([exe, "4000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_one_fma_requant_is_exact(tmp_path):
+    """requant4 / requant1 of epilogue.h: y = fma(acc, M[c], 128.5 + e), clamp window, truncate -- equal to the reference chain
+    (two multiplications, clamp, division, round half away, saturate) on every value the fast path keeps; random layers
+    (scales over six decades, every activation window) x random and boundary-hugging accumulators
+    (tests/csrc/fold_requant_check.c, same IEEE operations as the device)."""
+    src = os.path.join(os.path.dirname(__file__), "csrc", "fold_requant_check.c")
+    exe = str(tmp_path / "foldc")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", src, "-o", exe, "-lm"])
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout

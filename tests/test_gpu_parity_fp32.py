@@ -94,3 +94,50 @@ def test_concat_any_axis_fp32(dims, axis):
     want = oracle.run_graph(g, x)[0]
     got = run_hip(g, x)[0].reshape(want.shape)
     assert np.array_equal(got, want)       # leaky ReLU + copies: no rounding differences possible
+
+
+# ---- Winograd F(2,3) (the reference's CPU backend: conv/x86/wino_conv_kernel_x86.c, F(4,3)) -------------------
+WINO = [
+    # n, cin, h, w, cout, pad, act, bias
+    (1, 16, 8, 8, 64, 1, -1, True),
+    (2, 64, 20, 20, 128, 1, 0, True),
+    (3, 7, 9, 11, 13, 1, -1, True),          # odd maps (ragged last tile row / column), channels below every padding unit
+    (1, 33, 15, 14, 70, 0, 6, False),        # pad 0, relu6, no bias
+    (1, 256, 13, 13, 512, 1, 0, True),
+    (4, 32, 56, 56, 32, 1, 0, True),         # tiles of several images in one GEMM column block
+]
+
+
+@pytest.mark.parametrize("case", WINO, ids=[str(c) for c in WINO])
+def test_conv_f32_winograd_forced(case, monkeypatch):
+    n, cin, h, w, cout, p, act, bias = case
+    g, x = conv_graph_f32(11 + cin + cout, n, cin, h, w, cout, 3, 1, p, 1, act, bias, 1)
+    want = oracle.run_graph(g, x)[0]
+    monkeypatch.setenv("TAMD_F32_WINOGRAD", "1")
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    names = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert names == ["wino_in_f32", "wino_gemm_f32<F(2,3)>", "wino_out_f32"], names
+    assert np.allclose(got, want, **TOL), "max |d| %g" % np.abs(got - want).max()
+    monkeypatch.setenv("TAMD_F32_WINOGRAD", "0")
+    direct = run_hip(g, x)[0].reshape(want.shape)
+    assert np.abs(direct - got).max() <= 2e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_squeezenet_fp32_winograd_modes(mode, monkeypatch):
+    """the fire modules' expand3x3 convolutions write into the concat at a channel offset: both forms of the 3x3 land there"""
+    monkeypatch.setenv("TAMD_F32_WINOGRAD", mode)
+    g = models.build("squeezenet_v1.1", "fp32", 2)
+    x = models.synth_input(g, 5, DT_FP32)
+    want = oracle.run_graph(g, x)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()
+    names = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert any(k.startswith("wino_gemm") for k in names) == (mode == "1"), names
+    for w_, o in zip(want, got):
+        assert np.allclose(o.reshape(w_.shape), w_, **TOL), "max |d| %g" % np.abs(o.reshape(w_.shape) - w_).max()

@@ -23,9 +23,14 @@ SHAPES = {
                      (256, 28, 256, 1, 1, 0), (256, 14, 512, 1, 1, 0), (512, 14, 512, 1, 1, 0), (512, 7, 1024, 1, 1, 0),
                      (1024, 7, 1024, 1, 1, 0)],
     "custom": [(64, 56, 64, 3, 1, 1), (256, 14, 256, 3, 1, 1)],
+    # shallow-K pointwise layers (pw_stream / pw_rows territory): ResNet-50 2a / 2c / 3c, MobileNet-v1 2_1 .. 3_2
+    "pw": [(64, 56, 64, 1, 1, 0), (64, 56, 256, 1, 1, 0), (128, 28, 512, 1, 1, 0), (32, 112, 64, 1, 1, 0), (64, 56, 128, 1, 1, 0),
+           (128, 56, 128, 1, 1, 0), (128, 28, 256, 1, 1, 0)],
 }
 MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct",
-           "pw_stream", "conv_igemm2"]
+           "pw_stream", "pw_rows", "conv_igemm2"]
+if os.environ.get("BENCH_MEMBERS"):
+    MEMBERS = os.environ["BENCH_MEMBERS"].split(",")
 
 
 def main():

@@ -54,7 +54,7 @@ int main()
     a.x = x; a.w = w; a.bias = bias; a.wscale = sc; a.y = y; a.zeros = z;
     a.N = N; a.H = H; a.W = W; a.cs_in = C; a.ckp = C; a.OH = H; a.OW = W; a.cout = CO; a.ldc = CO; a.c_off = 0; a.c_limit = CO;
     a.KH = a.KW = 3; a.SH = a.SW = 1; a.PH = a.PW = 1; a.DH = a.DW = 1; a.cin = C; a.ktot = 9 * C; a.kpad = 9 * C; a.M = N * H * W;
-    a.m1 = 0.02f; a.lo = 0.f; a.hi = 3e38f; a.out_scale = 0.5f; a.cfg = -1;
+    a.rq = {0.02f, 0.f, 63.7f, 0.5f, 128.25f, 255.75f, 0x1p-13f, sc}; a.cfg = -1;
     a.mg_ohw = ((1ull << 40) + H * W - 1) / (H * W); a.mg_ow = ((1ull << 40) + W - 1) / W;
     run<64, 64, 2, 2, 3>("64x64 ring3", a, st, ds);
     run<128, 64, 2, 2, 3>("128px x 64co ring3", a, st, ds);

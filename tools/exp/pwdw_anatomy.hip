@@ -50,11 +50,11 @@ int main()
     printf("%-44s %8s %6s %6s %6s | %6s %6s %6s %6s %6s %6s\n", "case", "us/lnch", "gap", "ramp", "body", "issued", "zeroed", "pw", "barr", "tail", "acked");
     for (const Case& c : cases) {
         PwDwArgs a{};
-        a.wf = wf; a.bias = bias; a.wscale = scale; a.m1 = 0.02f; a.lo = 0.f; a.hi = 6.f; a.out_scale = 0.05f; a.inv_out = 1.0f / a.out_scale;
+        a.wf = wf; a.bias = bias; a.wscale = scale; a.rq = {0.02f, 0.f, 6.f, 0.05f, 128.25f, 248.75f, 0x1p-13f, scale};
         a.N = 1; a.H = c.H; a.W = c.W; a.cs_in = (c.cin + 15) / 16 * 16; a.ktot = a.cs_in;
         const int real = (a.ktot + 63) / 64;
         a.steps = pwdw_steps(real); a.nsteps = (real + a.steps - 1) / a.steps * a.steps;
-        a.mode = c.mode; a.dw_w = dww; a.dw_bias = bias; a.dw_wscale = scale; a.d_m1 = 0.05f; a.d_lo = 0.f; a.d_hi = 12.f; a.d_out_scale = 0.1f; a.d_inv_out = 1.0f / a.d_out_scale;
+        a.mode = c.mode; a.dw_w = dww; a.dw_bias = bias; a.dw_wscale = scale; a.d_rq = {0.05f, 0.f, 12.f, 0.1f, 128.25f, 248.75f, 0x1p-13f, scale};
         a.slices = (c.C + 15) / 16; a.cw = a.slices * 16;
         a.S = c.S; a.PH = a.PW = 1; a.OH = (c.H - 1) / c.S + 1; a.OW = (c.W - 1) / c.S + 1;
         a.ldc = a.cw; a.c_off = 0; a.c_limit = a.cw;
