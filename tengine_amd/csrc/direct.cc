@@ -15,7 +15,10 @@
 // release -- what one kernel needs to see of the previous one across the XCDs' L2s.  System scope is paid once per BURST, not
 // per pass: the first packet after the graph's stream was drained acquires at system scope (inputs uploaded by a copy engine),
 // and direct_wait closes the burst with one barrier packet that releases at system scope (outputs read by the host or a
-// copy engine) and carries the completion signal.  Measured on MobileNet-v1 batch 1: 59.4 us per pass with system scope at
+// copy engine) and carries the completion signal.  Launches of the COHERENT kernel instances (pwdw.hip: agent-scope loads of
+// what other launches wrote, write-through stores of what other launches read) carry fence scope "none": nothing has to be
+// written back or invalidated around them, which is 0.84 us per boundary instead of 1.26 (tools/exp/aql_chain.cpp) and leaves
+// the read-only weights resident in the L2s across launches and passes.  Measured on MobileNet-v1 batch 1: 59.4 us per pass with system scope at
 // both ends of every pass, 57.0 with it at the ends of the burst, 61.8 for the hipGraph replay (profiles/r02_direct_dispatch.txt).
 //
 // Not covered, by construction: stream ordering with the graph's HIP stream (tamd_graph_sync / download / run wait for the
@@ -28,6 +31,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -133,11 +137,12 @@ struct DirectProgram {
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};                                // counts bursts down from kStart
     std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
+    std::vector<char> coherent;                         // packet i is a coherent launch (pwdw.hip): no fences at its boundaries
     void* kernargs = nullptr;
     uint64_t bursts = 0;                                // closed by direct_wait
     bool open = false;                                  // passes submitted since the last direct_wait
     static constexpr hsa_signal_value_t kStart = (hsa_signal_value_t)1 << 40;
-    uint16_t h_open = 0, h_mid = 0, h_close = 0;
+    uint16_t h_open = 0, h_mid = 0, h_none = 0, h_close = 0;
 };
 
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why)
@@ -185,6 +190,9 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         pk.group_segment_size = k.group + r.shmem;
         pk.kernel_object = k.object;
         p->pkts.push_back(pk);
+        // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores) announce it by name
+        static const bool allow_none = !(getenv("TAMD_DIRECT_COHERENT") && atoi(getenv("TAMD_DIRECT_COHERENT")) == 0);
+        p->coherent.push_back(allow_none && strstr(nm, "_coh_kernel") != nullptr);
     }
     if (hipMalloc(&p->kernargs, blob.size()) != hipSuccess || hipMemcpy(p->kernargs, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
@@ -208,6 +216,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
                           | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     };
     p->h_mid = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT);
+    p->h_none = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
     p->h_open = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_AGENT);
     p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     return p;
@@ -233,7 +242,7 @@ int direct_submit(DirectProgram* p)
         d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
         d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
         d->completion_signal.handle = 0;
-        __atomic_store_n(&d->header, (i == 0 && !p->open) ? p->h_open : p->h_mid, __ATOMIC_RELEASE);
+        __atomic_store_n(&d->header, (i == 0 && !p->open) ? p->h_open : (p->coherent[i] ? p->h_none : p->h_mid), __ATOMIC_RELEASE);
     }
     // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor (rocprofv3) is
     // never handed a batch that is not contiguous in memory

@@ -651,6 +651,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             v.wf = d0; v.bias = d1;
             v.x = a.x; v.N = x.n; v.H = x.h; v.W = x.w; v.cs_in = x.cs; v.ktot = ckp; v.nsteps = nsteps; v.steps = steps;
             v.mode = 2; v.prod = 0; v.slices = slices; v.cw = cws;
+            v.coherent = g->opt.direct_dispatch ? 1 : 0;
             v.tile_major = (double)x.h * x.w * x.cs > (double)cout * ckp && slices <= 65535 ? 1 : 0;
             v.y = a.y; v.ldc = a.ldc; v.c_off = a.c_off; v.c_limit = a.c_limit;
             v.S = 1; v.OH = x.h; v.OW = x.w; v.TW = x.w; v.tiles_x = 1; v.RH = 1; v.RW = x.w;
@@ -815,6 +816,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         a.wf = d0; a.bias = d1;
     }
     a.prod = prod;
+    a.coherent = g->opt.direct_dispatch ? 1 : 0;
     // the larger operand is the one every XCD should fetch only its share of (pwdw.hip: block -> XCD mapping)
     a.tile_major = (double)x.h * x.w * (prod == 1 ? x.c : x.cs) * (slices >= 8 ? 8 : slices) > (double)C * ktot * 8.0 ? 1 : 0;
     if (slices > 65535) a.tile_major = 0;

@@ -85,6 +85,8 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
 #ifdef TAMD_PWDW_STAMPS
     unsigned long long* stamps;        // tools/exp/pwdw_anatomy.hip only
 #endif
+    int coherent;          // 1: the coherent instance (agent-scope loads of x, write-through stores of y): its launch needs no cache
+                           // maintenance at its boundaries (pwdw.hip: pwdw_i8_coh_kernel; set when the graph dispatches directly)
     int mode;              // tail: 0 global pooling, 1 depthwise 3x3, 2 none (the tile results are stored)
     int prod;              // producer: 0 pointwise conv of an NHWC tensor, 1 first-layer conv gathered from the NCHW graph input
     const unsigned* taps;  // prod 1: [16] patch row (c, ky) -> (c*in_H*in_W + ky*DH*in_W) | ky*DH << 28, zero padded; k = row*4 + kx

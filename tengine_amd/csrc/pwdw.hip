@@ -87,6 +87,7 @@ __device__ __forceinline__ void chain_wait(const ChainDep& d)
 
 __device__ __forceinline__ void chain_signal(const ChainDep& d)
 {
+    if (!d.my_counter) return;           // coherent stand-alone launch (pwdw_i8_coh_kernel): the kernel boundary orders the layers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have reached the memory side
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(d.my_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -224,7 +225,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     v4i b0[STEPS];
     const int8_t* xp0;
     int slot0 = locate(wave, xp0);
-    if (!CHAINED && !CHUNKED) load_b(xp0, b0, 0);
+    if ((!CHAINED || !dep.wait_counter) && !CHUNKED) load_b(xp0, b0, 0);
     PWDW_STAMP(1);
     if (MODE != 0 && MODE != 4) {
         // depthwise zero padding: everything the pointwise phase does not overwrite
@@ -238,7 +239,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         }
         if (!CHAINED || !dep.wait_counter) __syncthreads();    // (chain_wait ends with a barrier of its own)
     }
-    if (CHAINED) {
+    if (CHAINED && dep.wait_counter) {
         chain_wait(dep);
         if (!CHUNKED) load_b(xp0, b0, 0);
     }
@@ -378,6 +379,21 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
     pwdw_block<STEPS, MODE, CHUNKED, PROD, false>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
 }
 
+// The COHERENT form of the same launch (PwDwArgs::coherent, used under direct dispatch -- direct.cc): every tensor the launch
+// receives from or hands to another launch travels with agent-scope accesses -- input rows by sc1 buffer loads (served by the
+// memory side, never by a stale L1 / L2 line), results by write-through sc1 stores -- exactly the per-access form of the
+// chained experiment below.  Such a launch needs NO cache maintenance at its boundaries: its AQL packet carries fence scope
+// "none" (0.84 us per boundary against 1.26 us with agent-scope fences, tools/exp/aql_chain.cpp), and the weights / bias /
+// multiplier vectors, which nobody ever writes, stay valid in the L2s from one pass to the next.  The first convolution's
+// graph input (PROD 1) is read with ordinary loads: it changes only between bursts, behind a system-scope acquire.
+template <int STEPS, int MODE, bool CHUNKED, int PROD>
+__global__ __launch_bounds__(512) void pwdw_i8_coh_kernel(PwDwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned inter[];
+    const ChainDep none = {nullptr, 0, nullptr, nullptr};
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, true>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+}
+
 #ifdef TAMD_PWDW_CHAIN_EXPERIMENT
 // =================================================================================================================
 // A CHAIN of these layers in one launch (batch-1 MobileNet: conv1+dw2_1 ... conv6/sep+pool6, fc7).
@@ -483,6 +499,13 @@ int pwdw_steps(int nsteps)
     return best;
 }
 
+// plain or coherent instance of one variant
+#define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_)                                                                          \
+    do {                                                                                                                     \
+        if (a.coherent) hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a); \
+        else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a);            \
+    } while (0)
+
 template <int STEPS, bool CHUNKED>
 static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
 {
@@ -490,15 +513,15 @@ static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
     if (a.mode == 2) {
         const dim3 sm(a.slices, 1, ((a.H + a.TH - 1) / a.TH) * a.N);
         const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
-        hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 4, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
+        PWDW_LAUNCH(STEPS, 4, CHUNKED, 0);
         return hipGetLastError();
     }
     const dim3 sm(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
     const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
-    if (a.mode == 0) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 0, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
-    else if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 2, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
-    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 1, CHUNKED, 0>), grid, dim3(threads), lds, s, a);
-    else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS, 3, CHUNKED, 0>), grid, dim3(threads), lds, s, a);      // small tile: one output per lane
+    if (a.mode == 0) PWDW_LAUNCH(STEPS, 0, CHUNKED, 0);
+    else if (a.S == 2) PWDW_LAUNCH(STEPS, 2, CHUNKED, 0);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH(STEPS, 1, CHUNKED, 0);
+    else PWDW_LAUNCH(STEPS, 3, CHUNKED, 0);      // small tile: one output per lane
     return hipGetLastError();
 }
 
@@ -507,9 +530,9 @@ static hipError_t launch_first(const PwDwArgs& a, int threads, hipStream_t s)
     const dim3 sm(a.slices, a.tiles_x, a.tiles_y * a.N);
     const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
     const size_t lds = pwdw_lds_bytes(a, threads);
-    if (a.S == 2) hipLaunchKernelGGL((pwdw_i8_kernel<1, 2, false, 1>), grid, dim3(threads), lds, s, a);
-    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) hipLaunchKernelGGL((pwdw_i8_kernel<1, 1, false, 1>), grid, dim3(threads), lds, s, a);
-    else hipLaunchKernelGGL((pwdw_i8_kernel<1, 3, false, 1>), grid, dim3(threads), lds, s, a);
+    if (a.S == 2) PWDW_LAUNCH(1, 2, false, 1);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH(1, 1, false, 1);
+    else PWDW_LAUNCH(1, 3, false, 1);
     return hipGetLastError();
 }
 

@@ -84,3 +84,38 @@ def test_direct_dispatch_env_switch(monkeypatch):
     gr = capi.Graph(b, direct_dispatch=True)
     assert gr.direct_packets() == 0
     gr.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_direct_dispatch_coherent_launches_never_serve_stale_tensors(batch):
+    """Under direct dispatch the pointwise+depthwise family runs its COHERENT instances (agent-scope loads, write-through
+    stores) and their packets carry no fences.  Every pass rewrites the same tensors at the same addresses, so a stale L1 / L2
+    line would show as the PREVIOUS input's result: alternate two inputs over many bursts of several passes."""
+    g = models.build("mobilenet_v1", "int8", batch)
+    b = tm2.write_tm2(g)
+    xs = [models.synth_input(g, 300 + i, DT_INT8) for i in range(3)]
+    ref = capi.Graph(b)
+    wants = [_resident(ref, x, 1) for x in xs]
+    ref.close()
+    assert not np.array_equal(wants[0][0], wants[1][0])
+    gr = capi.Graph(b, direct_dispatch=True)
+    assert gr.direct_packets() > 0
+    for it in range(90):
+        k = (it * 7 + it // 3) % 3
+        got = _resident(gr, xs[k], 1 + it % 4)
+        assert np.array_equal(got[0], wants[k][0]), "burst %d (input %d)" % (it, k)
+    got = _resident(gr, xs[1], 300)          # one long burst
+    assert np.array_equal(got[0], wants[1][0])
+    gr.close()
+
+
+def test_direct_dispatch_coherent_kernels_with_fences_kept(monkeypatch):
+    monkeypatch.setenv("TAMD_DIRECT_COHERENT", "0")      # the same coherent instances behind agent-scope fences
+    g = models.build("mobilenet_v1", "int8", 1)
+    x = models.synth_input(g, 9, DT_INT8)
+    want = oracle.run_graph(g, x)
+    gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True)
+    got = _resident(gr, x, 5)
+    gr.close()
+    for w, o in zip(want, got):
+        assert np.array_equal(o.reshape(w.shape), w)

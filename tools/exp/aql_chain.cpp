@@ -103,6 +103,7 @@ int main(int argc, char** argv)
     printf("AQL: kernel object %llx kernarg %u B group %u private %u, queue size %u\n", (unsigned long long)kobj, kasz, gsz, psz, q->size);
     hsa_signal_t done; HK(hsa_signal_create(1, 0, nullptr, &done));
     char* kargs; CK(hipMalloc(&kargs, 4096));          // kernarg block in device memory (zero-filled hidden arguments)
+    for (int scope : {HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM})
     for (int ticks : {100, 200, 400}) {
         std::vector<char> host(kasz > 256 ? kasz : 256, 0);
         Args a{counter, scratch, ticks};
@@ -118,7 +119,7 @@ int main(int argc, char** argv)
         const uint32_t mask = q->size - 1;
         hsa_kernel_dispatch_packet_t* base = (hsa_kernel_dispatch_packet_t*)q->base_address;
         const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER)
-                                | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                                | (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
         const uint16_t header_last = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER)
                                      | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
         const long total = (long)steps * links;
@@ -140,7 +141,8 @@ int main(int argc, char** argv)
         while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) {}
         double t_aql = (now_us() - t0) / steps;
         unsigned long long c; CK(hipMemcpy(&c, counter, 8, hipMemcpyDeviceToHost));
-        printf("work/link %.0f us: AQL %.2f us/step (host submit %.2f us/step; counter %llu of %ld)\n", ticks / 100.0, t_aql, t_sub, c, total);
+        printf("work/link %.0f us, fence scope %s: AQL %.2f us/step = %.2f us per link boundary (counter %llu of %ld)\n", ticks / 100.0,
+               scope == HSA_FENCE_SCOPE_NONE ? "none" : scope == HSA_FENCE_SCOPE_AGENT ? "agent" : "system", t_aql, t_aql / links - ticks / 100.0, c, total);
     }
     hsa_queue_destroy(q);
     return 0;
