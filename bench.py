@@ -229,9 +229,10 @@ def main():
         host_to_host = {"pipelined_images_per_s": args.batch * n_h2h / tp,
                         "images_per_s_min": args.batch / ts[0], "images_per_s_median": args.batch / ts[len(ts) // 2],
                         "ms_min": 1e3 * ts[0], "ms_median": 1e3 * ts[len(ts) // 2], "runs": n_h2h,
-                        "what": "tamd_graph_run(): memcpy into the pinned input (%d B) + ONE hipGraph (upload kernel, launch list, download "
-                                "kernel: %d B) + stream sync + copy out, blocking, 1 stream -- what tm_benchmark times; pipelined = "
-                                "tamd_graph_run_async / tamd_graph_wait with two runs in flight" % (in_bytes, sum(out_sizes))}
+                        "what": "tamd_graph_run(): memcpy into the pinned input (%d B) + ONE %s (upload kernel, launch list, download "
+                                "kernel: %d B) + wait + copy out, blocking, 1 stream -- what tm_benchmark times; pipelined = "
+                                "tamd_graph_run_async / tamd_graph_wait with two runs in flight (hipGraph on the stream)"
+                                % (in_bytes, "direct AQL pass on the graph's HSA queue" if gr.direct_packets() else "hipGraph", sum(out_sizes))}
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, same process) -----------
     roofline = None

@@ -133,19 +133,24 @@ DeviceCtx* device_ctx(int gpu)
 
 }  // namespace
 
-struct DirectProgram {
+struct DirectQueue {                                     // one HSA queue, shared by the programs of a graph
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};                                // counts bursts down from kStart
-    std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
-    std::vector<char> coherent;                         // packet i is a coherent launch (pwdw.hip): no fences at its boundaries
-    void* kernargs = nullptr;
     uint64_t bursts = 0;                                // closed by direct_wait
     bool open = false;                                  // passes submitted since the last direct_wait
+    int refs = 0;
     static constexpr hsa_signal_value_t kStart = (hsa_signal_value_t)1 << 40;
-    uint16_t h_open = 0, h_mid = 0, h_none = 0, h_close = 0;
 };
 
-DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why)
+struct DirectProgram {
+    DirectQueue* dq = nullptr;
+    std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
+    std::vector<uint16_t> hdr;                          // header of packet i inside a burst (the first packet of a burst: h_open)
+    void* kernargs = nullptr;
+    uint16_t h_open = 0, h_close = 0;
+};
+
+DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share)
 {
     static const char* reason = "";
     *why = reason;
@@ -156,6 +161,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
     DirectProgram* p = new DirectProgram;
     std::vector<unsigned char> blob;
     std::vector<size_t> offs;
+    std::vector<char> coherent;                         // packet i is a coherent launch (pwdw.hip)
     bool scanned = false;
     for (const LaunchRec& r : recs) {
         const char* nm = hipKernelNameRefByPtr(r.func, stream);
@@ -192,7 +198,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         p->pkts.push_back(pk);
         // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores) announce it by name
         static const bool allow_none = !(getenv("TAMD_DIRECT_COHERENT") && atoi(getenv("TAMD_DIRECT_COHERENT")) == 0);
-        p->coherent.push_back(allow_none && strstr(nm, "_coh_kernel") != nullptr);
+        coherent.push_back(allow_none && strstr(nm, "_coh_kernel") != nullptr);
     }
     if (hipMalloc(&p->kernargs, blob.size()) != hipSuccess || hipMemcpy(p->kernargs, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
@@ -205,19 +211,33 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         (void)hsa_amd_agents_allow_access(2, both, nullptr, p->kernargs);
     }
     for (size_t i = 0; i < p->pkts.size(); i++) p->pkts[i].kernarg_address = (char*)p->kernargs + offs[i];
-    uint32_t qsize = 1024;
-    while (qsize < 8 * p->pkts.size()) qsize *= 2;
-    if (hsa_queue_create(ctx->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p->q) != HSA_STATUS_SUCCESS) {
-        *why = "hsa_queue_create"; p->q = nullptr; direct_destroy(p); return nullptr;
+    if (share) {
+        p->dq = share->dq;
+    } else {
+        p->dq = new DirectQueue;
+        uint32_t qsize = 1024;
+        while (qsize < 8 * p->pkts.size()) qsize *= 2;
+        if (hsa_queue_create(ctx->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p->dq->q) != HSA_STATUS_SUCCESS) {
+            *why = "hsa_queue_create"; p->dq->q = nullptr; p->dq->refs = 1; direct_destroy(p); return nullptr;
+        }
+        if (hsa_signal_create(DirectQueue::kStart, 0, nullptr, &p->dq->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; p->dq->refs = 1; direct_destroy(p); return nullptr; }
     }
-    if (hsa_signal_create(DirectProgram::kStart, 0, nullptr, &p->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; direct_destroy(p); return nullptr; }
+    p->dq->refs++;
+    if (p->pkts.size() * 2 > p->dq->q->size) { *why = "launch list longer than the shared queue"; direct_destroy(p); return nullptr; }
     auto header = [](int type, int acq, int rel) {
         return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) | (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)
                           | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     };
-    p->h_mid = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT);
-    p->h_none = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
-    p->h_open = header(HSA_PACKET_TYPE_KERNEL_DISPATCH, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_AGENT);
+    // fences inside a burst.  An ordinary launch acquires and releases at agent scope.  A coherent launch reads what other
+    // launches wrote through agent-scope loads and writes through: nothing to write back behind it (release none), and
+    // nothing to invalidate in front of it -- unless its predecessor is an ordinary launch: the first convolution reads the
+    // graph input with ordinary loads, and in the host-to-host list that input was just written by the upload launch.
+    const int K = HSA_PACKET_TYPE_KERNEL_DISPATCH;
+    for (size_t i = 0; i < p->pkts.size(); i++) {
+        if (!coherent[i]) p->hdr.push_back(header(K, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT));
+        else p->hdr.push_back(header(K, (i > 0 && !coherent[i - 1]) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE));
+    }
+    p->h_open = header(K, HSA_FENCE_SCOPE_SYSTEM, coherent[0] ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT);
     p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     return p;
 }
@@ -227,7 +247,8 @@ int direct_packets(const DirectProgram* p) { return p ? (int)p->pkts.size() : 0;
 int direct_submit(DirectProgram* p)
 {
     const uint64_t n = p->pkts.size();
-    hsa_queue_t* q = p->q;
+    DirectQueue* dq = p->dq;
+    hsa_queue_t* q = dq->q;
     const uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, n);
     while (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size) {}      // ring full: the packet processor is behind
     hsa_kernel_dispatch_packet_t* base = (hsa_kernel_dispatch_packet_t*)q->base_address;
@@ -242,43 +263,52 @@ int direct_submit(DirectProgram* p)
         d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
         d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
         d->completion_signal.handle = 0;
-        __atomic_store_n(&d->header, (i == 0 && !p->open) ? p->h_open : (p->coherent[i] ? p->h_none : p->h_mid), __ATOMIC_RELEASE);
+        __atomic_store_n(&d->header, (i == 0 && !dq->open) ? p->h_open : p->hdr[i], __ATOMIC_RELEASE);
     }
-    // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor (rocprofv3) is
-    // never handed a batch that is not contiguous in memory
+    // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor is never handed
+    // a batch that is not contiguous in memory
     const uint64_t to_end = q->size - (idx0 & mask);
     if (to_end < n) hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + to_end - 1));
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + n - 1));
-    p->open = true;
+    dq->open = true;
     return 0;
 }
 
-// closes the burst: one barrier packet behind everything submitted (barrier bit: it waits for the last kernel), system-scope
-// release, completion signal; returns when it has executed
+// closes the burst: one barrier packet behind everything submitted to the queue (barrier bit: it waits for the last kernel),
+// system-scope release, completion signal; returns when it has executed.  The host spins on the signal first (a blocking
+// run is a latency measurement: an interrupt-driven wake-up costs more than the pass) and only then sleeps on it.
 int direct_wait(DirectProgram* p)
 {
-    if (!p->open) return 0;
-    hsa_queue_t* q = p->q;
+    DirectQueue* dq = p->dq;
+    if (!dq->open) return 0;
+    hsa_queue_t* q = dq->q;
     const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
     while (idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size) {}
     hsa_barrier_and_packet_t* b = (hsa_barrier_and_packet_t*)q->base_address + (idx & (q->size - 1));
     b->reserved0 = 0; b->reserved1 = 0; b->reserved2 = 0;
     for (int i = 0; i < 5; i++) b->dep_signal[i].handle = 0;
-    b->completion_signal = p->done;
+    b->completion_signal = dq->done;
     __atomic_store_n(&b->header, p->h_close, __ATOMIC_RELEASE);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
-    p->bursts++;
-    p->open = false;
-    const hsa_signal_value_t target = DirectProgram::kStart - (hsa_signal_value_t)p->bursts;
-    while (hsa_signal_wait_scacquire(p->done, HSA_SIGNAL_CONDITION_LT, target + 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) > target) {}
+    dq->bursts++;
+    dq->open = false;
+    const hsa_signal_value_t target = DirectQueue::kStart - (hsa_signal_value_t)dq->bursts;
+    if (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, 2000000 /* timestamp ticks of spinning */, HSA_WAIT_STATE_ACTIVE) <= target) return 0;
+    while (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) > target) {}
     return 0;
 }
 
 void direct_destroy(DirectProgram* p)
 {
     if (!p) return;
-    if (p->q) { (void)direct_wait(p); (void)hsa_queue_destroy(p->q); }
-    if (p->done.handle) (void)hsa_signal_destroy(p->done);
+    if (p->dq) {
+        if (p->dq->q) (void)direct_wait(p);
+        if (--p->dq->refs <= 0) {
+            if (p->dq->q) (void)hsa_queue_destroy(p->dq->q);
+            if (p->dq->done.handle) (void)hsa_signal_destroy(p->dq->done);
+            delete p->dq;
+        }
+    }
     if (p->kernargs) (void)hipFree(p->kernargs);
     delete p;
 }

@@ -117,6 +117,7 @@ struct tamd_graph {
     hipEvent_t slot_done[2] = {nullptr, nullptr};
     int next_slot = 0;
     tamd::DirectProgram* direct = nullptr;     // tamd_options.direct_dispatch: the launch list as AQL packets (direct.cc)
+    tamd::DirectProgram* direct_io = nullptr;  // .. the host-to-host list of I/O slot 0 (tamd_graph_run), same HSA queue
     bool direct_busy = false;                  // passes submitted since the last wait
     tamd_options opt{};
     bool prepared = false;

@@ -1522,6 +1522,17 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
             const char* why = "";
             g->direct = direct_build(g->gpu, g->stream, recs, &why);
             if (!g->direct && getenv("TAMD_DEBUG")) fprintf(stderr, "tengine_amd: direct dispatch not used: %s\n", why);
+            if (g->direct && g->hexec_io[0][0]) {
+                // the host-to-host list of I/O slot 0 (upload launch, compute, download launch) on the same queue: tamd_graph_run
+                recs.clear();
+                g_launch_rec = &recs;
+                rc = run_steps(g, g->stream, 0);
+                g_launch_rec = nullptr;
+                if (rc) return -1;
+                HIPCHK(hipStreamSynchronize(g->stream));
+                g->direct_io = direct_build(g->gpu, g->stream, recs, &why, g->direct);
+                if (!g->direct_io && getenv("TAMD_DEBUG")) fprintf(stderr, "tengine_amd: direct dispatch not used for host-to-host runs: %s\n", why);
+            }
         }
     }
     g->prepared = true;
@@ -1633,8 +1644,13 @@ int tamd_graph_run(tamd_graph* g)
         if (!io.host_in) { set_error("input buffer not set"); return -1; }
         memcpy(io.pinned, io.host_in, io.bytes);
     }
-    if (launch_io(g, 0)) return -1;
-    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->direct_io) {          // the same list as AQL packets: system-scope acquire in front, closing barrier packet behind
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (direct_submit(g->direct_io) || direct_wait(g->direct_io)) return -1;
+    } else {
+        if (launch_io(g, 0)) return -1;
+        HIPCHK(hipStreamSynchronize(g->stream));
+    }
     for (auto& io : g->outputs)
         if (io.host_out) memcpy(io.host_out, io.pinned, io.bytes);
     return 0;
@@ -1815,6 +1831,7 @@ void tamd_graph_destroy(tamd_graph* g)
     if (g->prepared && g->opt.profile) dump_profile(g);
     if (g->stream) hipStreamSynchronize(g->stream);
     std::lock_guard<std::mutex> lk(g_capture_mutex);      // hipFree is device-synchronous: not while another thread captures
+    if (g->direct_io) { direct_destroy(g->direct_io); g->direct_io = nullptr; }
     if (g->direct) { direct_destroy(g->direct); g->direct = nullptr; }
     for (int i = 0; i < g->nexec; i++) if (g->hexecs[i]) hipGraphExecDestroy(g->hexecs[i]);
     for (int slot = 0; slot < 2; slot++) {

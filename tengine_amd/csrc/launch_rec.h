@@ -46,7 +46,8 @@ inline void launch_rec(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem
 struct DirectProgram;
 // Builds the AQL form of a recorded launch list for HIP device `gpu`; nullptr (with *why) when something in the list cannot be
 // dispatched directly (a kernel that needs scratch memory, an unresolved symbol, no HSA queue): the caller keeps the hipGraph.
-DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why);
+// `share`: a program of the same graph whose HSA queue (and burst state) the new one uses as well.
+DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share = nullptr);
 int direct_submit(DirectProgram* p);        // one pass over the list: packets + one doorbell; returns without waiting
 int direct_wait(DirectProgram* p);          // until every submitted pass has completed
 int direct_packets(const DirectProgram* p);
