@@ -144,6 +144,7 @@ struct DirectQueue {                                     // one HSA queue, share
 
 struct DirectProgram {
     DirectQueue* dq = nullptr;
+
     std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
     std::vector<uint16_t> hdr;                          // header of packet i inside a burst (the first packet of a burst: h_open)
     void* kernargs = nullptr;

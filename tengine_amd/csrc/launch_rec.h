@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace tamd {

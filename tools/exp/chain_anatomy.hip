@@ -2,7 +2,7 @@
 // product source compiled with TAMD_PWDW_STAMPS.  Per layer (averaged over its blocks, microseconds since the first block of
 // the launch entered): entry of its first / last block, when its blocks left the producer wait, pointwise done, tail done,
 // stores acknowledged, counter bumped; "done" = the last block's counter bump, i.e. what the next layer waits for.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_PWDW_STAMPS -DTAMD_PWDW_CHAIN_EXPERIMENT -I../../tengine_amd/csrc -o chain_anatomy.bin chain_anatomy.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_PWDW_STAMPS -DTAMD_PWDW_CHAIN_EXPERIMENT -I../../tengine_amd/csrc -o chain_anatomy.bin chain_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
 #include "../../tengine_amd/csrc/pwdw.hip"
 
 #include <stdio.h>

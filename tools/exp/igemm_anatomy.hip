@@ -2,7 +2,7 @@
 // ResNet-50 3x3 layer at batch 32 (res3x_branch2b: 32 x 28 x 28 x 128 -> 128, K = 1152), random operands, per tile shape:
 // launch time (events, 20 back-to-back), shader-clock stamps of wave 0 of block 0 (prologue, every stage, epilogue), and
 // ablations: no MFMA / no LDS traffic / no global loads -- which resource the ~15 us of every variant is spent on.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_IGEMM_STAMPS -I../../tengine_amd/csrc -o igemm_anatomy.bin igemm_anatomy.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_IGEMM_STAMPS -I../../tengine_amd/csrc -o igemm_anatomy.bin igemm_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
 #include "conv_igemm_fast.h"
 
 #include <stdio.h>

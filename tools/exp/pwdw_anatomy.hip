@@ -2,7 +2,7 @@
 // TAMD_PWDW_STAMPS, chained 12 launches deep in a hipGraph on MobileNet-v1 layer shapes (random operands: timing only).
 // Columns: us/launch (events), gap / ramp / body as in launch_chain2.hip, then wave 0's stamps since block entry:
 //   loads issued | LDS zeroed + barrier | pointwise tiles done | barrier | tail done (stores issued) | stores acked
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_PWDW_STAMPS -I../../tengine_amd/csrc -o pwdw_anatomy.bin pwdw_anatomy.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTAMD_PWDW_STAMPS -I../../tengine_amd/csrc -o pwdw_anatomy.bin pwdw_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
 #include "../../tengine_amd/csrc/pwdw.hip"
 
 #include <stdio.h>
