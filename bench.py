@@ -262,7 +262,20 @@ def main():
                          "mfma_util_pct": 100.0 * 2.0 * sum(f["macs"] for f in fam.values())
                          / (max(sum(f["ms"] for f in fam.values()), 1e-12) * 1e-3) / (mfma_peak * 1e12),
                          "kernel_time_share": d["ms"] / max(sum(f["ms"] for f in fam.values()), 1e-12),
-                         "sum_kernel_ms_per_step": sum(f["ms"] for f in fam.values())})
+                         "sum_kernel_ms_per_step": sum(f["ms"] for f in fam.values()),
+                         "launch_durations": "HIP events around eager back-to-back launches of each kernel on the graph's stream "
+                                             "(tamd_graph_profile) -- the figure rocprofv3 --kernel-trace agrees with"})
+        if gr.direct_packets():
+            # the timed loop dispatched the same launches as AQL packets with cheaper boundaries (csrc/direct.cc): HIP events do not see
+            # that queue.  The step's own clock bounds what a launch of the dominant family cost there: its share of the step
+            sum_ms = max(sum(f["ms"] for f in fam.values()), 1e-12)
+            est_us = 1e3 * (d["ms"] / sum_ms) * (el / args.steps * 1e3) / d["launches"]
+            roofline["direct_dispatch"] = {
+                "avg_launch_us_from_step_clock": est_us,
+                "frac_from_step_clock": (d["bytes"] / d["launches"]) / (est_us * 1e-6) / 1e9 / HBM_PEAK_GBS if t_hbm >= t_mfma
+                else (2.0 * d["macs"] / d["launches"]) / (est_us * 1e-6) / 1e12 / mfma_peak,
+                "what": "timed loop = direct AQL dispatch: ms_per_step x the family's share of the summed HIP-event durations / its launches; "
+                        "`frac` above stays the HIP-event figure (conservative: it carries HIP's launch boundary)"}
 
     # ---- CPU baseline: the real reference backend on this host's cores (rank 0, N=1 only) ----------
     cpu = None

@@ -47,7 +47,7 @@ def main():
         g = models.build(key, dtype, a.batch, device_only=True)
         b = tm2.write_tm2(g)
     dt = {"fp32": tm2.DT_FP32, "int8": tm2.DT_INT8, "uint8": tm2.DT_UINT8}[dtype]
-    gr = capi.Graph(b, batch=a.batch)
+    gr = capi.Graph(b, batch=a.batch, direct_dispatch=True)      # the plugin's default: the blocking run as one AQL pass
     x = models.synth_input(models.set_batch(g, a.batch), 1, dt)
     gr.set_input(x)
     gr.run()                                  # warm-up, as tm_benchmark does
