@@ -30,12 +30,44 @@ __device__ __forceinline__ int quant_round_div(float s, float out_scale, int zp)
 }
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
 
+// sat_u8(quant_round_div(s, out_scale, zp)) without the IEEE division on the common path (it was a third of the VALU work of
+// a depthwise output).  y = fma(s, fl(1/out_scale), copysign(0.5 + e, s)), e = 2^-13: for |d| < 300, d = fl(s / out_scale),
+// |s * inv - d| <= 2 |d| 2^-24 and y rounds within 2^-16, together < 5.1e-5 < e, so trunc(y) = round_half_away(d) unless
+// fract(|y|) < 2e -- those ~2.4e-4 of the values take the reference expression.  Beyond |y| = 300 the byte is saturated
+// whatever the rounding did (0 <= zp <= 255), so nothing there is handed over.  Only for SATURATING call sites: the pooling
+// node has no lower clamp (pooled_byte wraps), it keeps quant_round_div.  tests/csrc/u8_round_check.c replays this on the host.
+__device__ __forceinline__ uint8_t quant_round_sat_u8(float s, float out_scale, int zp)
+{
+    if ((unsigned)zp > 255u) return sat_u8(quant_round_div(s, out_scale, zp));       // uniform; never taken for a uint8 tensor
+    const float inv = __fdiv_rn(1.0f, out_scale);                                    // uniform: hoisted out of the pixel loops
+    const float y = __fmaf_rn(s, inv, copysignf(0.5f + 0x1p-13f, s));
+    const float ay = fabsf(y);
+    int r = (int)fminf(fmaxf(y, -65536.f), 65536.f);                                 // truncates
+    if (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f) r = (int)fminf(fmaxf(roundf(__fdiv_rn(s, out_scale)), -65536.f), 65536.f);
+    return sat_u8(r + zp);
+}
+
 // round(f / out_scale + zp), clamp -- relu_kernel_ref_uint8.c:83-89, upsample_ref.c:118-125 (zero point INSIDE the round)
-__device__ __forceinline__ uint8_t quant_round_in(float f, U8Q q)
+__device__ __forceinline__ uint8_t quant_round_in_exact(float f, U8Q q)
 {
     float r = roundf(__fdiv_rn(f, q.scale) + (float)q.zp);
     r = fminf(fmaxf(r, -65536.f), 65536.f);
     return sat_u8((int)r);
+}
+// The same without the division on the common path (the fused ReLU of every uint8 conv output goes through here).  The
+// reference rounds x = fl(fl(f / s) + zp); y = fma(f, fl(1/s), zp) is within 2|d| 2^-24 + 2 * 2^-16 < 6.6e-5 of it for |x| < 300
+// (the quotient's rounding, the sum's, the fma's), the half is added with one more rounding (2^-16): 8.1e-5 < e = 2^-13, so
+// trunc(y + copysign(0.5 + e, y)) is round_half_away(x) unless its fraction is below 2e -- then the reference expression
+// decides; beyond 300 the byte is saturated either way.  tests/csrc/u8_round_check.c replays it.
+__device__ __forceinline__ uint8_t quant_round_in(float f, U8Q q)
+{
+    if ((unsigned)q.zp > 255u) return quant_round_in_exact(f, q);                     // uniform; never taken for a uint8 tensor
+    const float inv = __fdiv_rn(1.0f, q.scale);
+    const float y = __fmaf_rn(f, inv, (float)q.zp);
+    const float y2 = y + copysignf(0.5f + 0x1p-13f, y);
+    const float ay = fabsf(y2);
+    if (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f) return quant_round_in_exact(f, q);
+    return sat_u8((int)fminf(fmaxf(y2, -65536.f), 65536.f));
 }
 __device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { return ((float)u - zp) * scale; }
 
@@ -302,7 +334,7 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                 if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
+                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
                 if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
                 if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
                 if (a.pool.on) {                 // jlimit and co are uniform over a quad of lanes: all four pixels of the window are here
@@ -452,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
         if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
         if (a.act == 0) s = s < 0.f ? 0.f : s;
         if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-        uint8_t q = sat_u8(quant_round_div(s, a.out_scale, a.out_zp));
+        uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
         if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
         if (!a.pool.on || a.pool.write_full) yo[(size_t)co * OHW] = q;
         if (a.pool.on) {
@@ -517,7 +549,7 @@ __global__ __launch_bounds__(256) void conv_u8_direct_k(const U8DirectArgs a)
         if (total > 6.f && a.act == 6) total = 6.f;
         if (total < -1.f && a.act == 1) total = -1.f;
     }
-    uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+    uint8_t q = quant_round_sat_u8(total, a.out_scale, a.out_zp);
     if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
     a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + oc) * OHW + pj] = q;
 }
@@ -563,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_u8_dw3_k(const U8DirectArgs a)
         if (total > 6.f && a.act == 6) total = 6.f;
         if (total < -1.f && a.act == 1) total = -1.f;
     }
-    uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+    uint8_t q = quant_round_sat_u8(total, a.out_scale, a.out_zp);
     if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
     a.y[(size_t)n * a.out_img + (size_t)a.out_c0 * OHW + idx] = q;
 }
@@ -583,18 +615,31 @@ __global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
     const int ox0 = xq * 4, iy0 = oy * S - 1, ix0 = ox0 * S - 1;
     const uint8_t* xc = a.x + ((size_t)n * a.C + oc) * a.H * a.W;
     const float* wk = a.wf + (size_t)oc * 9;
+    // the NC input bytes of a row as unaligned DWORD loads (2 for stride 1, 3 for stride 2) instead of NC byte gathers: the op
+    // is bound by the number of load instructions (a wave's byte gather occupies the address unit for 16 cycles whatever it
+    // fetches), not by bytes.  The window starts at column max(ix0, 0) (never in front of the buffer) and may run past the row
+    // or the tensor (allocations carry slack); columns outside the image are masked below and enter the chain as 0.0f.
+    constexpr int ND = (NC + 1 + 3) / 4;                // dwords that cover NC bytes from a start shifted by at most one
     unsigned u[3][NC];
     unsigned okm = 0;
+    const int sh = ix0 < 0 ? 1 : 0;                     // left border: the window's first column is outside the image
 #pragma unroll
     for (int ky = 0; ky < 3; ky++) {
         const int iy = iy0 + ky;
         const bool rok = (unsigned)iy < (unsigned)a.H;
-        const uint8_t* row = xc + (rok ? iy : 0) * a.W;
+        const uint8_t* row = xc + (rok ? iy : 0) * a.W + (ix0 + sh);
+        unsigned d[ND], e[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) __builtin_memcpy(&d[k], row + 4 * k, 4);
+        // at the left border the loaded window starts one column late: shift it up by a byte so that byte c is column c again
+        // (byte 0 is then a don't-care: that column is masked)
+#pragma unroll
+        for (int k = 0; k < ND; k++) e[k] = sh ? ((d[k] << 8) | (k ? d[k - 1] >> 24 : 0u)) : d[k];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const int ix = ix0 + c;
             const bool ok = rok & ((unsigned)ix < (unsigned)a.W);
-            u[ky][c] = row[ok ? ix : 0];
+            u[ky][c] = (e[c >> 2] >> (8 * (c & 3))) & 0xffu;
             okm |= ok ? 1u << (ky * NC + c) : 0u;
         }
     }
@@ -625,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
             if (total > 6.f && a.act == 6) total = 6.f;
             if (total < -1.f && a.act == 1) total = -1.f;
         }
-        uint8_t q = sat_u8(quant_round_div(total, a.out_scale, a.out_zp));
+        uint8_t q = quant_round_sat_u8(total, a.out_scale, a.out_zp);
         if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
         if (ox0 + j < a.OW) yo[j] = q;
     }
@@ -673,7 +718,7 @@ __global__ __launch_bounds__(256) void fc_u8_k(const U8FcArgs a)
         for (int u = 0; u < 8; u++) data = __builtin_fmaf(xrow[j + u], wv[u], data);
     }
     for (; j < a.hidden; j++) data = __builtin_fmaf(xrow[j], w[(size_t)j * a.nout_pad], data);
-    a.y[(size_t)b * a.nout + o] = sat_u8(quant_round_div(data, a.out_scale, a.out_zp));
+    a.y[(size_t)b * a.nout + o] = quant_round_sat_u8(data, a.out_scale, a.out_zp);
 }
 
 hipError_t launch_fc_u8(const U8FcArgs& a, hipStream_t s)
@@ -802,7 +847,7 @@ __global__ __launch_bounds__(256) void eltwise_u8_k(const U8EltArgs a)
     case 4: r = fa - fb; break;
     default: r = fa > fb ? fa : fb; break;
     }
-    a.y[i] = sat_u8(quant_round_div(r, a.out.scale, a.out.zp));
+    a.y[i] = quant_round_sat_u8(r, a.out.scale, a.out.zp);
 }
 
 hipError_t launch_eltwise_u8(const U8EltArgs& a, hipStream_t s)

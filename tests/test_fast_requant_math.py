@@ -24,3 +24,14 @@ def test_one_fma_requant_is_exact(tmp_path):
     out = subprocess.run([exe, "20000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_uint8_saturating_round_is_exact(tmp_path):
+    """quant_round_sat_u8 of u8_kernels.hip (uint8 conv / depthwise / FC / eltwise epilogues): the division-free rounding against
+    sat_u8((int)clamp(roundf(s / scale)) + zp) on random, far-out-of-range and boundary-hugging values (tests/csrc/u8_round_check.c)."""
+    src = os.path.join(os.path.dirname(__file__), "csrc", "u8_round_check.c")
+    exe = str(tmp_path / "u8c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", src, "-o", exe, "-lm"])
+    out = subprocess.run([exe, "6000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout
