@@ -157,3 +157,30 @@ def test_node_supported_query():
     assert ask(15, [t(I8, VAR, [1, 64, 5, 5]), t(I8, VAR, [1, 3, 80, 80])], [t(I8, VAR, [1, 2, 600, 1])], pb) == 0   # int8 graphs: CPU
     pb.max_size_num = 2
     assert ask(15, [feat, img], [t(U8, VAR, [1, 2, 600, 1])], pb) == 0           # max sizes must pair with min sizes (priorbox.c:48-61)
+
+
+def test_launch_recorder_packs_arguments_like_the_code_object(tmp_path):
+    """Direct dispatch replays recorded launches as AQL packets: the explicit argument segment the recorder packs
+    (tengine_amd/csrc/launch_rec.h: rec_pack) must put every by-value argument at its natural alignment, in order -- checked on
+    the host against a struct of the same members (tests/csrc/rec_pack_check.cc; no device involved)."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "rec_pack_check")
+    subprocess.check_call([hipcc, "-std=c++17", "-I", os.path.join(ROOT, "tengine_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "csrc", "rec_pack_check.cc"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
+
+
+def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
+    """tamd_options grew a field (direct_dispatch): a caller compiled against the older, shorter struct still passes its own
+    `size`, and the binding's struct matches the header's field order."""
+    from tengine_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "tengine_amd.h")).read()
+    body = hdr[hdr.index("typedef struct tamd_options {"):hdr.index("} tamd_options;")]
+    fields = re.findall(r"^\s+(?:const\s+)?\w+\*?\s+(\w+);", body, re.M)
+    assert fields == [f[0] for f in capi.Options._fields_], (fields, capi.Options._fields_)
+    assert fields[-1] == "direct_dispatch" and ctypes.sizeof(capi.Options) == 32
