@@ -6,15 +6,20 @@
 A "step" = one forward pass of the hot path over one batch (default batch 1 = BASELINE configs[1]) of
 synthetic int8 input that is already resident in HBM.  Weights: the seeded synthetic int8 model written
 as a real tmfile; at N>1 rank 0 RCCL-broadcasts the tmfile bytes once (north_star), every rank loads them
-with the native loader, the images are sharded (each rank owns its own batch, weak scaling) and the
-outputs are all-gathered over RCCL every step, double-buffered so the gather of step k overlaps step k+1.
+with the native loader, the images are sharded (each rank owns its own batch, weak scaling); a step needs no
+collective (independent images, outputs resident in each rank's HBM as at N = 1): every output of the LAST step is
+all-gathered once over RCCL inside the timed region (--gather every: one overlapped all_gather per step instead).
+Each step is one pass over the graph's launch list, dispatched directly as AQL packets on the graph's own HSA
+queue (tamd_options.direct_dispatch, csrc/direct.cc; --direct 0 / --streams > 1 / a profiler attached: hipGraph replay).
 
 Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on
 both sides, MAX over ranks.  value = N * batch * K / t.
 
 Extra objects on the JSON line:
   roofline      dominant kernel family, algorithmic bytes / average launch duration measured with HIP
-                events on the launch stream in this same process (tamd_graph_profile), vs the HBM peak
+                events on the launch stream in this same process (tamd_graph_profile), vs the HBM peak;
+                roofline.direct_dispatch: the same with the launch's cost read off the direct step's clock
+  host_to_host  the blocking tamd_graph_run (what tm_benchmark times) and the two-in-flight asynchronous pair
   cpu_baseline  the REAL reference CPU backend (oracle/_ref, built from the unmodified sources) timed on
                 this host's cores on a bounded sample (rank 0, N=1 only); falls back to the C oracle port
 """
