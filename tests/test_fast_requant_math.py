@@ -35,3 +35,23 @@ def test_uint8_saturating_round_is_exact(tmp_path):
     out = subprocess.run([exe, "6000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_one_fma_requant_exhaustive_on_model_constants(tmp_path):
+    """EVERY accumulator value (not a sample) for the real quantisation constants of MobileNet-v1's first layers and its FC, in the
+    three reference formulas (tools/exhaustive_requant.py + tests/csrc/exhaustive_requant.c; the whole of MobileNet-v1 and
+    ResNet-50 -- 1.4e10 accumulators, 0 mismatches -- is in profiles/r02_exhaustive_requant.txt)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import exhaustive_requant as ex
+    rec = ex.records("mobilenet_v1")
+    sub = rec[:256]                                  # conv1, conv2_1/dw, conv2_1/sep x (A1, A2)
+    fc = rec[rec[:, 4] == 1.0][:64]                  # the FC's A5 records (out_scale folded to 1)
+    assert len(fc) == 64
+    path = str(tmp_path / "rec.bin")
+    import numpy as np
+    np.concatenate([sub, fc]).astype(np.float32).tofile(path)
+    exe = str(tmp_path / "exh")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(os.path.dirname(__file__), "csrc", "exhaustive_requant.c"), "-o", exe, "-lm"])
+    out = subprocess.run([exe, path], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout and "records 320" in out.stdout, out.stdout
