@@ -38,7 +38,7 @@ def test_uint8_saturating_round_is_exact(tmp_path):
 
 
 def test_one_fma_requant_exhaustive_on_model_constants(tmp_path):
-    """EVERY accumulator value (not a sample) for the real quantisation constants of MobileNet-v1's first layers and its FC, in the
+    """EVERY accumulator value (not a sample) for the real quantisation constants of MobileNet-v1's first layers and of ResNet-50's FC, in the
     three reference formulas (tools/exhaustive_requant.py + tests/csrc/exhaustive_requant.c; the whole of MobileNet-v1 and
     ResNet-50 -- 1.4e10 accumulators, 0 mismatches -- is in profiles/r02_exhaustive_requant.txt)."""
     import sys
@@ -46,7 +46,8 @@ def test_one_fma_requant_exhaustive_on_model_constants(tmp_path):
     import exhaustive_requant as ex
     rec = ex.records("mobilenet_v1")
     sub = rec[:256]                                  # conv1, conv2_1/dw, conv2_1/sep x (A1, A2)
-    fc = rec[rec[:, 4] == 1.0][:64]                  # the FC's A5 records (out_scale folded to 1)
+    rn = ex.records("resnet50")
+    fc = rn[rn[:, 4] == 1.0][:64]                    # ResNet-50's fc1000 in formula A5 (out_scale folded to 1)
     assert len(fc) == 64
     path = str(tmp_path / "rec.bin")
     import numpy as np
