@@ -636,6 +636,24 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if (pw_stream_applicable(a)) cands.push_back({"pw_stream_i8", [a](hipStream_t s) { return launch_pw_stream(a, s); }});
         if (pw_rows_applicable(a)) cands.push_back({"pw_rows_i8", [a](hipStream_t s) { return launch_pw_rows(a, s); }});
         if (conv_igemm2_applicable(a)) cands.push_back({conv_igemm2_kernel_name(a), [a](hipStream_t s) { return launch_conv_igemm2(a, s); }});
+        // lean-loop kernels (conv_pgemm.hip): fragment-ordered weights, k x k activations as an LDS-resident patch
+        {
+            int8_t* packed[2] = {nullptr, nullptr};       // per cout-tile width (64 / 128), packed on first use
+            for (int v = 0; v < conv_pgemm_num_variants(); v++) {
+                if (!conv_pgemm_applicable(a, v)) continue;
+                if ((v & 2) && a.M >= 16384) continue;    // 64-pixel tiles: only where 128-pixel tiles leave CUs idle
+                ConvArgs ap = a;
+                conv_pgemm_prepare(ap, v);
+                const int bn = conv_pgemm_bn(v), slot = bn == 128;
+                if (!packed[slot]) {
+                    std::vector<int8_t> wf(conv_pgemm_packed_bytes(ap, bn) + 256, 0);
+                    conv_pgemm_pack(ap, wp.data(), cout_pad, bn, wf.data());
+                    if (upload(g, wf, &packed[slot])) return -1;
+                }
+                ap.wfrag = packed[slot];
+                cands.push_back({conv_pgemm_kernel_name(ap), [ap](hipStream_t s) { return launch_conv_pgemm(ap, s); }});
+            }
+        }
         // small maps (batch-1 tails, 1x1-map FC): the lean 16-channel-slice kernel of pwdw.hip without a tail
         const bool is1x1 = KH == 1 && KW == 1 && p.stride_h == 1 && p.stride_w == 1 && !p.pad_h0 && !p.pad_h1 && !p.pad_w0 && !p.pad_w1;
         if (!fz && is1x1 && a.M <= 4096 && !(getenv("TAMD_PW_SMALL") && atoi(getenv("TAMD_PW_SMALL")) == 0)) {

@@ -56,6 +56,13 @@ struct ConvArgs {
     const int8_t* zeros;   // >= 16 zero bytes (source of out-of-image taps for the LDS-DMA kernel)
     unsigned long long mg_ohw, mg_ow;   // ceil(2^40 / (OH*OW)), ceil(2^40 / OW): pixel index -> (n, oy, ox) by multiply-high (conv_igemm_fast.h)
     int cfg;               // tile configuration of the chosen GEMM kernel (-1: the launcher's heuristic), set by the planner
+    // conv_pgemm.hip only (conv_pgemm_prepare / the planner fill these; other kernels ignore them)
+    const int8_t* wfrag;   // weights in MFMA fragment order: [cout tile of BN][stage][BN/32 x 2 fragments][64 lanes][16 B]
+    int pg_ns;             // 64-deep K stages; stage = (64-channel chunk) * KH*KW + tap
+    int pg_variant;        // tile shape, see conv_pgemm_bn()
+    int pg_npad;           // patch pixels of the worst pixel tile, rounded up to 64 (k x k convolutions)
+    int pg_hp, pg_wp;      // rows per image / columns of the virtual padded input the patch is cut from
+    unsigned long long mg_hp, mg_wp;     // ceil(2^40 / pg_hp), ceil(2^40 / pg_wp)
 #ifdef TAMD_IGEMM_STAMPS
     long long* dbg_stamps; // tools/exp/igemm_anatomy.hip only: s_memtime at the stage boundaries of wave 0 of block 0
     int dbg_flags;         // .. ablation: 1 no MFMA, 2 no LDS traffic, 4 no global loads
@@ -187,6 +194,15 @@ bool gemm_direct_applicable(const ConvArgs& a);
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t s);  // LDS-DMA 3-stage ring, large problems
 bool conv_igemm2_applicable(const ConvArgs& a);
 const char* conv_igemm2_kernel_name(const ConvArgs& a);
+// lean-loop implicit GEMM: fragment-ordered weights by LDS-DMA, k x k activations as an LDS-resident input patch (conv_pgemm.hip)
+int conv_pgemm_num_variants();
+int conv_pgemm_bn(int variant);                                    // cout tile of a variant (the weight packing unit)
+bool conv_pgemm_applicable(const ConvArgs& a, int variant);
+void conv_pgemm_prepare(ConvArgs& a, int variant);                 // fills pg_* / mg_hp / mg_wp
+size_t conv_pgemm_packed_bytes(const ConvArgs& a, int bn);
+void conv_pgemm_pack(const ConvArgs& a, const int8_t* w, int cout_pad, int bn, int8_t* out);   // w: [cout_pad][kpad] family layout
+const char* conv_pgemm_kernel_name(const ConvArgs& a);
+hipError_t launch_conv_pgemm(const ConvArgs& a, hipStream_t s);
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
 bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_pw_rows(const ConvArgs& a, hipStream_t s);       // 1x1, shallow K, many pixels: row-major epilogue, persistent pipelined waves

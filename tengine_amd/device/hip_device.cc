@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <map>
+#include <string>
 #include <vector>
 
 extern "C" {
@@ -514,33 +515,88 @@ static bool node_supported(struct graph* ir, struct node* n)
     return tamd_node_supported(&nd, in.data(), (int)in.size(), out.data(), (int)out.size()) == 1;
 }
 
-// everything the kernels cannot express goes back to the CPU device instead of failing at pre_run
-bool subgraph_runs_on_device(struct graph* ir, struct subgraph* sg)
+// Can THIS node run on the device?  Op / dtype pair, quantisation form, and the node's own parameters and shapes -- the
+// last asked of the backend itself (tamd_node_supported: the planners' conditions), so that the splitter and pre_run cannot
+// disagree.  (Round 2 also kept two leftover guards here -- Concat axis != 1, Permute order -- from before the backend learnt
+// them; the Concat one silently sent the whole of MobileNet-SSD-with-priors to the CPU device.  They are gone.)
+bool node_runs_on_device(struct graph* ir, struct node* n)
 {
-    for (int j = 0; j < sg->node_num; j++) {
-        struct node* n = get_ir_graph_node(ir, sg->node_list[j]);
-        const int out_dt = n->output_num ? get_ir_graph_tensor(ir, n->output_tensors[0])->data_type : -1;
-        if (!op_supported(n->op.type, out_dt)) return false;
-        for (int k = 0; k < n->output_num; k++) {
-            struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
-            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8
-                && t->data_type != TENGINE_DT_FP32) return false;
-            if (t->tensor_type != TENSOR_TYPE_CONST && !tamd_op_supported(map_op(n->op.type), t->data_type)) return false;
-            if (t->tensor_type != TENSOR_TYPE_CONST && t->data_type != TENGINE_DT_FP32 && t->quant_param_num != 1) return false;
-        }
-        if (!node_supported(ir, n)) return false;       // this node's parameters / tensor shapes, asked of the backend itself
-        if (n->op.type == OP_ELTWISE) {
-            int ty = ((const struct eltwise_param*)n->op.param_mem)->type;
-            if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
-        }
-        if (n->op.type == OP_CONCAT && ((const struct concat_param*)n->op.param_mem)->axis != 1) return false;
-        if (n->op.type == OP_PERMUTE) {
-            const struct permute_param* p = (const struct permute_param*)n->op.param_mem;
-            if (!(p->order0 == 0 && p->order1 == 2 && p->order2 == 3 && p->order3 == 1)) return false;
-        }
-        if (n->op.type == OP_FLATTEN && ((const struct flatten_param*)n->op.param_mem)->axis != 1) return false;
+    const int out_dt = n->output_num ? get_ir_graph_tensor(ir, n->output_tensors[0])->data_type : -1;
+    if (!op_supported(n->op.type, out_dt)) return false;
+    for (int k = 0; k < n->output_num; k++) {
+        struct tensor* t = get_ir_graph_tensor(ir, n->output_tensors[k]);
+        if (t->tensor_type == TENSOR_TYPE_CONST) continue;
+        if (t->data_type != TENGINE_DT_INT8 && t->data_type != TENGINE_DT_UINT8 && t->data_type != TENGINE_DT_FP32) return false;
+        if (!tamd_op_supported(map_op(n->op.type), t->data_type)) return false;
+        if (t->data_type != TENGINE_DT_FP32 && t->quant_param_num != 1) return false;
     }
-    return true;
+    if (n->op.type == OP_ELTWISE) {
+        const int ty = ((const struct eltwise_param*)n->op.param_mem)->type;
+        if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
+    }
+    if (n->op.type == OP_FLATTEN && ((const struct flatten_param*)n->op.param_mem)->axis != 1) return false;
+    return node_supported(ir, n);
+}
+
+// does a run of nodes contain anything worth a device subgraph?  (views and constants alone are not: the hand-over would cost
+// more than the CPU device spends on them)
+bool op_is_work(int op)
+{
+    return op != OP_INPUT && op != OP_CONST && op != OP_RESHAPE && op != OP_FLATTEN && op != OP_DROPOUT;
+}
+
+struct Piece { std::vector<uint16_t> nodes; struct device* dev; };
+
+// Re-split every subgraph the reference's type-based splitter (split.c:140-312) gave to this device AROUND the nodes the
+// device cannot run: maximal runs of supported nodes stay on "HIP", the unsupported nodes (and supported runs without any real
+// work) go to the CPU device -- instead of surrendering the whole subgraph for one exotic node.  Node lists are contiguous
+// ascending ranges (split.c builds them that way), the list itself runs from the graph's last nodes to its first.
+void resplit_around_unsupported(struct graph* ir, struct device* hip)
+{
+    struct device* cpu = find_default_device();
+    std::vector<Piece> pieces;                                   // in list order (descending node ranges)
+    const int count = get_vector_num(ir->subgraph_list);
+    bool changed = false;
+    for (int i = 0; i < count; i++) {
+        struct subgraph* sg = *(struct subgraph**)get_vector_data(ir->subgraph_list, i);
+        if (sg->device != hip) { pieces.push_back({std::vector<uint16_t>(sg->node_list, sg->node_list + sg->node_num), sg->device}); continue; }
+        std::vector<Piece> runs;                                 // ascending inside this subgraph
+        for (int j = 0; j < sg->node_num; j++) {
+            struct node* n = get_ir_graph_node(ir, sg->node_list[j]);
+            struct device* d = node_runs_on_device(ir, n) ? hip : cpu;
+            if (runs.empty() || runs.back().dev != d) runs.push_back({{}, d});
+            runs.back().nodes.push_back(sg->node_list[j]);
+        }
+        for (Piece& r : runs) {
+            if (r.dev != hip) continue;
+            bool work = false;
+            for (uint16_t id : r.nodes) work = work || op_is_work(get_ir_graph_node(ir, id)->op.type);
+            if (!work) r.dev = cpu;
+        }
+        if (runs.size() != 1 || runs[0].dev != hip) changed = true;
+        for (int r = (int)runs.size() - 1; r >= 0; r--) pieces.push_back(runs[r]);
+    }
+    if (!changed) return;
+    // merge neighbours on the same device (list order is descending: the later piece holds the EARLIER nodes)
+    std::vector<Piece> merged;
+    for (Piece& p : pieces) {
+        if (!merged.empty() && merged.back().dev == p.dev) merged.back().nodes.insert(merged.back().nodes.begin(), p.nodes.begin(), p.nodes.end());
+        else merged.push_back(p);
+    }
+    for (int i = count - 1; i >= 0; i--) {
+        struct subgraph* sg = *(struct subgraph**)get_vector_data(ir->subgraph_list, i);
+        release_ir_subgraph(ir, sg);
+        remove_vector_via_index(ir->subgraph_list, i);
+    }
+    for (Piece& p : merged) {
+        struct subgraph* sg = (struct subgraph*)sys_malloc(sizeof(struct subgraph));
+        init_ir_subgraph(ir, sg, 0);
+        sg->node_num = (uint16_t)p.nodes.size();
+        sg->node_list = (uint16_t*)sys_malloc(sizeof(uint16_t) * p.nodes.size());
+        for (size_t j = 0; j < p.nodes.size(); j++) sg->node_list[j] = p.nodes[j];
+        sg->device = p.dev;
+        push_vector_data(ir->subgraph_list, &sg);
+    }
 }
 
 int hip_split_graph(struct graph* ir_graph)
@@ -569,12 +625,9 @@ int hip_split_graph(struct graph* ir_graph)
     release_vector(blocked_ops);
     release_vector(precision);
 
-    // split.c's precision test lets every quantised tensor through (split.c:53-66): hand subgraphs the
-    // device cannot run (uint8 / fp32 / exotic params) back to the CPU device before IO generation
-    for (int i = 0; i < get_vector_num(ir_graph->subgraph_list); i++) {
-        struct subgraph* sg = *(struct subgraph**)get_vector_data(ir_graph->subgraph_list, i);
-        if (sg->device == cur_dev && !subgraph_runs_on_device(ir_graph, sg)) sg->device = find_default_device();
-    }
+    // split.c decides by operator TYPE and lets every quantised tensor through its precision test (split.c:53-66): nodes whose
+    // parameters / dtypes the kernels cannot express are cut out of the device subgraphs before IO generation
+    resplit_around_unsupported(ir_graph, cur_dev);
 
     generate_sub_graph_io(ir_graph);
     add_sub_graph_to_ir_graph(ir_graph);
@@ -610,6 +663,32 @@ __attribute__((visibility("default"))) int register_hip_device(void)
     }
     TLOG_INFO("Tengine plugin device %s is registered.\n", hip_device.name);
     return 0;
+}
+
+// Introspection for tests and tools: where did the splitter put the nodes of a prerun graph?  One line per subgraph,
+// "<index> <device name> <nodes> <nodes that are not Input/Const> <their operator names, comma separated>"; returns the number of
+// subgraphs, or -1 when `cap` is too small.  (struct graph is the reference's own; this library is compiled against its headers.)
+__attribute__((visibility("default"))) int hip_device_placement(void* graph, char* buf, int cap)
+{
+    struct graph* ir = (struct graph*)graph;
+    int used = 0;
+    const int count = get_vector_num(ir->subgraph_list);
+    for (int i = 0; i < count; i++) {
+        struct subgraph* sg = *(struct subgraph**)get_vector_data(ir->subgraph_list, i);
+        int real = 0;
+        std::string ops;
+        for (int j = 0; j < sg->node_num; j++) {
+            const int op = get_ir_graph_node(ir, sg->node_list[j])->op.type;
+            if (op == OP_INPUT || op == OP_CONST) continue;
+            const char* nm = find_op_name(op);
+            ops += (real ? "," : "") + (nm ? std::string(nm) : std::to_string(op));
+            real++;
+        }
+        const int n = snprintf(buf + used, cap > used ? (size_t)(cap - used) : 0, "%d %s %d %d %s\n", i, sg->device ? sg->device->name : "?", (int)sg->node_num, real, ops.c_str());
+        if (n < 0 || used + n >= cap) return -1;
+        used += n;
+    }
+    return count;
 }
 
 __attribute__((visibility("default"))) int unregister_hip_device(void)

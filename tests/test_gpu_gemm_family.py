@@ -32,7 +32,7 @@ SHAPES = [
 ]
 MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "igemm10", "igemm11",
            "igemm12", "igemm13", "igemm14", "igemm15", "gemm_direct", "pw_stream", "pw_rows",
-           "conv_igemm2", "pw_small"]
+           "conv_igemm2", "pw_small", "conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
 
 
 @pytest.fixture(scope="module")
@@ -64,11 +64,14 @@ def test_family_member_is_exact_on_every_shape(member, cases):
             assert used >= 5, used
         if member == "pw_rows":       # 1x1, cin <= 128, >= 2048 pixels
             assert used >= 4, used
+        if member.startswith("conv_pgemm"):      # every 1x1 shape with >= 32 channels, every k x k shape with cin % 64 == 0
+            assert used >= (8 if "<64x64" in member else 5), used
     finally:
         del os.environ["TAMD_FORCE_GEMM"]
 
 
-@pytest.mark.parametrize("member", ["pw_stream", "pw_rows", "igemm0", "igemm2", "igemm10", "igemm14", "conv_igemm2"])
+@pytest.mark.parametrize("member", ["pw_stream", "pw_rows", "igemm0", "igemm2", "igemm10", "igemm14", "conv_igemm2", "conv_pgemm_i8<128x64",
+                                    "conv_pgemm_i8<64x64"])
 @pytest.mark.parametrize("etype,own_relu_scale", [(tm2.ELT_SUM, False), (tm2.ELT_SUB, True)])
 def test_fused_eltwise_tail_is_exact_in_every_member(member, etype, own_relu_scale):
     """conv -> eltwise -> ReLU folded into the epilogue of each family member that offers it (ResNet block tails);
@@ -93,7 +96,7 @@ def test_fused_eltwise_tail_is_exact_in_every_member(member, etype, own_relu_sca
     assert len(np.unique(want)) > 3
 
 
-@pytest.mark.parametrize("member", ["pw_stream", "pw_rows", "igemm0", "igemm10"])
+@pytest.mark.parametrize("member", ["pw_stream", "pw_rows", "igemm0", "igemm10", "conv_pgemm"])
 @pytest.mark.parametrize("variant", ["sum_relu_fold", "sum_norelu_fold", "sum_relu_scales_too_wide", "sum_relu_fold_disabled"])
 def test_residual_tail_two_fma_form_and_its_fallbacks(member, variant, monkeypatch):
     """the SUM (+ scale-keeping ReLU) tail runs as two fused multiply-adds per value when (s_conv + s_res) / s_out <= 2
@@ -116,5 +119,5 @@ def test_residual_tail_two_fma_form_and_its_fallbacks(member, variant, monkeypat
     names = [k["kernel"] for k in gr.profile(1)]
     gr.close()
     assert np.array_equal(got, want), names
-    assert any("+eltwise" in k and member.replace("igemm", "conv_igemm")[:8] in k for k in names), names
+    assert any("+eltwise" in k and (member if member == "conv_pgemm" else member.replace("igemm", "conv_igemm")[:8]) in k for k in names), names
     assert len(np.unique(want)) > 20

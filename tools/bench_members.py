@@ -28,7 +28,7 @@ SHAPES = {
            (128, 56, 128, 1, 1, 0), (128, 28, 256, 1, 1, 0)],
 }
 MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct",
-           "pw_stream", "pw_rows", "conv_igemm2"]
+           "pw_stream", "pw_rows", "conv_igemm2", "conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
 if os.environ.get("BENCH_MEMBERS"):
     MEMBERS = os.environ["BENCH_MEMBERS"].split(",")
 
@@ -57,7 +57,7 @@ def main():
             macs = conv["macs"]
             # the cell names the kernel that actually ran: a member that does not apply to the shape falls back to the
             # planner's default, which shows as a different name in its column
-            kn = conv["kernel"].replace("conv_igemm_i8", "ig").replace("conv_igemm2_i8", "ig2").replace("_i8", "")
+            kn = conv["kernel"].replace("conv_igemm_i8", "ig").replace("conv_igemm2_i8", "ig2").replace("conv_pgemm_i8", "pg").replace("_i8", "")
             cells.append("%18s" % ("%.1f %s" % (conv["ms"] * 1e3, kn[:11])))
         print("%-34s" % ("%dx%d^2 -> %d k%d s%d  %.0f MMAC" % (cin, hw, cout, k, s, macs / 1e6)) + "".join(cells))
 
