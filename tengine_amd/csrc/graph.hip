@@ -641,12 +641,12 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             int8_t* packed[2] = {nullptr, nullptr};       // per cout-tile width (64 / 128), packed on first use
             for (int v = 0; v < conv_pgemm_num_variants(); v++) {
                 if (!conv_pgemm_applicable(a, v)) continue;
-                if ((v & 2) && a.M >= 16384) continue;    // 64-pixel tiles: only where 128-pixel tiles leave CUs idle
+                if ((v & 2) && a.M >= 65536) continue;    // 64-pixel tiles: only where 128-pixel tiles leave CUs idle
                 ConvArgs ap = a;
                 conv_pgemm_prepare(ap, v);
                 const int bn = conv_pgemm_bn(v), slot = bn == 128;
                 if (!packed[slot]) {
-                    std::vector<int8_t> wf(conv_pgemm_packed_bytes(ap, bn) + 256, 0);
+                    std::vector<int8_t> wf(conv_pgemm_packed_bytes(ap, bn), 0);
                     conv_pgemm_pack(ap, wp.data(), cout_pad, bn, wf.data());
                     if (upload(g, wf, &packed[slot])) return -1;
                 }

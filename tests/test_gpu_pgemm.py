@@ -14,6 +14,7 @@ from tengine_amd import capi, tm2
 pytestmark = pytest.mark.gpu
 
 VARIANTS = ["conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
+KS2 = ["conv_pgemm_i8<128x64,3x3,ks2", "conv_pgemm_i8<128x128,3x3,ks2"]       # 512-thread blocks, intra-block split-K (3x3, cin % 128 == 0)
 
 # n, cin, h, w, cout, k, s, p, group, act, bias, dil
 PATCH_CASES = [
@@ -27,6 +28,8 @@ PATCH_CASES = [
     (2, 64, 11, 11, 80, 3, 1, 3, 1, 0, True, 1),      # pad larger than the halo: whole border ring of zeros
     (1, 256, 56, 56, 64, 3, 1, 1, 1, 0, True, 1),     # wide rows: > 256 patch pixels (two pieces per wave)
     (7, 64, 5, 5, 64, 3, 1, 1, 1, 0, True, 1),        # 25-pixel images, M = 175 (ragged last tile)
+    (9, 512, 7, 7, 96, 3, 1, 1, 1, 0, True, 1),       # eight chunks (four per wave group with ks2), tiles over three images
+    (3, 128, 17, 17, 256, 3, 2, 1, 1, 0, True, 1),    # stride 2, two cout tiles of 128
 ]
 ROW_CASES = [
     (3, 64, 27, 31, 200, 1, 1, 0, 1, -1, True, 1),    # M = 2511 (ragged), cout ragged
@@ -56,12 +59,12 @@ def _run(member, case, seed):
     return want, got, name
 
 
-@pytest.mark.parametrize("member", VARIANTS)
+@pytest.mark.parametrize("member", VARIANTS + KS2)
 @pytest.mark.parametrize("ci", range(len(PATCH_CASES)))
 def test_patch_kernel_is_exact(member, ci):
     want, got, name = _run(member, PATCH_CASES[ci], 900 + ci)
     if member in name:       # a variant that does not apply to the shape (e.g. 128-pixel tiles on 64 pixels) falls back
-        assert "patch" in name, name
+        assert "patch" in name or "3x3" in name, name
     assert np.array_equal(got, want), (name, PATCH_CASES[ci], int((got != want).sum()))
     assert len(np.unique(want)) > 5
 
@@ -81,9 +84,21 @@ def test_variants_really_run():
         for case in (PATCH_CASES[1], ROW_CASES[0]):
             _, _, name = _run(member, case, 1)
             assert member in name, (member, name)
+    for member in (VARIANTS[0], VARIANTS[2]):       # dilated 3x3 with 40 couts: the 64-channel-wide tiles only
+        _, _, name = _run(member, PATCH_CASES[4], 1)
+        assert member in name, (member, name)
+    for member in ("conv_pgemm_i8<64x64,3x3,rs3", "conv_pgemm_i8<128x64,3x3,rs3"):      # the 3-slot ring
+        for case in (PATCH_CASES[1], PATCH_CASES[3]):
+            want, got, name = _run(member, case, 1)
+            assert member in name, (member, name)
+            assert np.array_equal(got, want), (name, case)
+    for member in KS2:       # two / four 64-channel chunks
+        for case in (PATCH_CASES[1], PATCH_CASES[8]):
+            _, _, name = _run(member, case, 1)
+            assert member in name, (member, name)
 
 
-@pytest.mark.parametrize("member", ["conv_pgemm_i8<128x64", "conv_pgemm_i8<64x128"])
+@pytest.mark.parametrize("member", ["conv_pgemm_i8<128x64", "conv_pgemm_i8<64x64"])
 def test_pgemm_fused_residual_tail(member):
     g, x = eltwise_relu_graph(77, 5, 64, 14, 14, True, tm2.ELT_SUM)
     want = oracle.run_graph(g, x)[0]

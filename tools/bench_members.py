@@ -23,6 +23,8 @@ SHAPES = {
                      (256, 28, 256, 1, 1, 0), (256, 14, 512, 1, 1, 0), (512, 14, 512, 1, 1, 0), (512, 7, 1024, 1, 1, 0),
                      (1024, 7, 1024, 1, 1, 0)],
     "custom": [(64, 56, 64, 3, 1, 1), (256, 14, 256, 3, 1, 1)],
+    "custom3": [(64, 56, 64, 3, 1, 1), (128, 28, 128, 3, 1, 1), (256, 14, 256, 3, 1, 1), (512, 7, 512, 3, 1, 1), (128, 56, 128, 3, 2, 1),
+                (256, 28, 256, 3, 2, 1), (512, 14, 512, 3, 2, 1)],
     # shallow-K pointwise layers (pw_stream / pw_rows territory): ResNet-50 2a / 2c / 3c, MobileNet-v1 2_1 .. 3_2
     "pw": [(64, 56, 64, 1, 1, 0), (64, 56, 256, 1, 1, 0), (128, 28, 512, 1, 1, 0), (32, 112, 64, 1, 1, 0), (64, 56, 128, 1, 1, 0),
            (128, 56, 128, 1, 1, 0), (128, 28, 256, 1, 1, 0)],
@@ -30,7 +32,7 @@ SHAPES = {
 MEMBERS = ["igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9", "gemm_direct",
            "pw_stream", "pw_rows", "conv_igemm2", "conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
 if os.environ.get("BENCH_MEMBERS"):
-    MEMBERS = os.environ["BENCH_MEMBERS"].split(",")
+    MEMBERS = os.environ["BENCH_MEMBERS"].split(";")
 
 
 def main():

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(r_)); exit(1); } } while (0)
@@ -49,7 +50,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
         conv_pgemm_prepare(ap, v);
         const int bn = conv_pgemm_bn(v), slot = bn == 128;
         if (!packed[slot]) {
-            std::vector<int8_t> wf(conv_pgemm_packed_bytes(ap, bn) + 256, 0);
+            std::vector<int8_t> wf(conv_pgemm_packed_bytes(ap, bn), 0);
             conv_pgemm_pack(ap, hw.data(), cout_pad, bn, wf.data());
             CK(hipMalloc(&packed[slot], wf.size()));
             CK(hipMemcpy(packed[slot], wf.data(), wf.size(), hipMemcpyHostToDevice));
@@ -58,7 +59,11 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
         const int bm = (v & 2) ? 64 : 128;
         const int tiles = ((ap.M + bm - 1) / bm) * ((CO + bn - 1) / bn);
         const int grid = (((ap.M + bm - 1) / bm + 7) / 8) * 8 * ((CO + bn - 1) / bn);
-        for (int flags : {0, 1, 2, 4, 3, 7}) {
+#ifdef TAMD_PG_ABLATE
+        for (int flags : {0, 2, 2 | 8, 2 | 16, 2 | 4, 2 | 32, 2 | 1, 63}) {
+#else
+        for (int flags : {0}) {
+#endif
             ap.dbg_flags = flags; ap.dbg_stamps = nullptr;
             for (int i = 0; i < 3; i++) CK(launch_conv_pgemm(ap, st));
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -89,7 +94,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             std::sort(ids.begin(), ids.end());
             cus = (int)(std::unique(ids.begin(), ids.end()) - ids.begin());
             printf("%-30s flags %d (%s%s%s) %7.2f us/launch %4d tiles ns %d | cycles med/max: setup %lld/%lld land %lld/%lld loop %lld/%lld (%.0f/stage) epi %lld/%lld total %lld/%lld | wall ns: start med/max %lld/%lld end med/max %lld/%lld\n",
-                   conv_pgemm_kernel_name(ap), flags, flags & 1 ? "noMFMA " : "", flags & 2 ? "noEPI " : "", flags & 4 ? "noALOAD" : "", 1e3 * ms / 20, tiles, ap.pg_ns,
+                   conv_pgemm_kernel_name(ap), flags, flags & 1 ? "noMFMA " : "", flags & 2 ? "noEPI " : "", (std::string(flags & 4 ? "noLOAD " : "") + (flags & 8 ? "noBAR " : "") + (flags & 16 ? "noLDSRD " : "") + (flags & 32 ? "noWAIT" : "")).c_str(), 1e3 * ms / 20, tiles, ap.pg_ns,
                    pct(setup, .5), pct(setup, 1), pct(land, .5), pct(land, 1), pct(loop, .5), pct(loop, 1), (double)pct(loop, .5) / ap.pg_ns, pct(epi, .5), pct(epi, 1),
                    pct(total, .5), pct(total, 1), pct(wstart, .5), pct(wstart, 1), pct(wend, .5), pct(wend, 1));
             hipEventDestroy(e0); hipEventDestroy(e1);
@@ -104,6 +109,7 @@ int main(int argc, char** argv)
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const int B = argc > 1 ? atoi(argv[1]) : 32;
     run_shape(B, 28, 128, 128, 3, 1, st);
+    if (argc > 2) return 0;
     run_shape(B, 14, 256, 256, 3, 1, st);
     run_shape(B, 56, 64, 64, 3, 1, st);
     run_shape(B, 14, 1024, 256, 1, 1, st);
