@@ -178,6 +178,9 @@ TAMD_API tamd_graph* tamd_graph_load_tm2(const void* mem, size_t size);
 TAMD_API int tamd_graph_set_batch(tamd_graph* g, int batch);
 
 /* ---- execution ----------------------------------------------------------------------------
+ * Threading: the library may be used from several host threads, each graph by ONE thread at a time (a graph's run state --
+ * I/O slots, runs in flight, its HSA queue, which is single-producer -- is not locked; the reference calls a subgraph's
+ * interface from one scheduler thread as well, scheduler.c:95-213).  Different graphs never share run state.
  * prerun  <- interface.pre_run   (device.h:46, called from scheduler.c:49-59; options may be NULL)
  * run     <- interface.run       (device.h:49, scheduler.c:134; must return with outputs complete)
  * destroy <- interface.post_run / release_graph (device.h:52-58, scheduler.c:201, subgraph.c:53-56) */
@@ -195,7 +198,9 @@ TAMD_API int tamd_graph_run(tamd_graph* g);
 /* asynchronous pair <- interface.async_run / async_wait (device.h:60-63; the reference's scheduler never issues them:
  * run_graph(graph, 0) is rejected, scheduler.c:75-79).  run_async stages the current input buffers, queues H2D -> kernels ->
  * D2H and returns; up to TWO runs may be in flight (a third submit fails); wait blocks for the OLDEST one and delivers its
- * outputs to the buffers that were set when it was submitted.  Same stream, same bytes as tamd_graph_run. */
+ * outputs to the buffers that were set when it was submitted.  Same bytes as tamd_graph_run; with direct dispatch each run is one
+ * burst on the graph's HSA queue (the second queues behind the first's closing packet), else both ride the graph's stream.
+ * While runs are in flight the other entry points that touch the I/O buffers (run, upload_inputs, download_outputs) fail. */
 TAMD_API int tamd_graph_run_async(tamd_graph* g);
 TAMD_API int tamd_graph_wait(tamd_graph* g);
 TAMD_API int tamd_graph_inflight(const tamd_graph* g);   /* runs submitted and not yet waited for */
@@ -209,6 +214,8 @@ TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
 /* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather) */
 TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);
 TAMD_API void* tamd_graph_stream(tamd_graph* g);          /* hipStream_t                           */
+/* wall time tamd_graph_prerun took (planning incl. the plan-time autotune, capture, direct-dispatch programs), milliseconds */
+TAMD_API double tamd_graph_prerun_ms(const tamd_graph* g);
 /* time `iters` back-to-back launches with HIP events on the graph's stream -> total ms */
 TAMD_API int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
     "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
     "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
-    "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_kernel_num", "tamd_graph_profile",
+    "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_prerun_ms", "tamd_graph_kernel_num", "tamd_graph_profile",
     "tamd_graph_read_tensor", "tamd_graph_tensor_num", "tamd_graph_tensor_desc", "tamd_graph_destroy",
 ]
 
@@ -61,6 +61,8 @@ def lib():
         L.tamd_graph_load_tm2.restype = vp
         L.tamd_graph_load_tm2.argtypes = [vp, C.c_size_t]
         L.tamd_graph_stream.restype = vp
+        L.tamd_graph_prerun_ms.restype = C.c_double
+        L.tamd_graph_prerun_ms.argtypes = [vp]
         for name, args in {
             "tamd_graph_set_batch": [vp, ci], "tamd_graph_prerun": [vp, C.POINTER(Options)],
             "tamd_graph_input_num": [vp], "tamd_graph_output_num": [vp],
@@ -181,6 +183,10 @@ class Graph:
 
     def stream(self):
         return lib().tamd_graph_stream(self._h)
+
+    def prerun_ms(self):
+        """wall milliseconds tamd_graph_prerun took (planning incl. autotune, capture, direct-dispatch programs)"""
+        return lib().tamd_graph_prerun_ms(self._h)
 
     def direct_packets(self):
         """AQL packets per launch() when direct dispatch is active, else 0"""

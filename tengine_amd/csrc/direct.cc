@@ -29,6 +29,8 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +43,7 @@
 namespace tamd {
 
 thread_local std::vector<LaunchRec>* g_launch_rec = nullptr;
+thread_local bool g_launch_coherent = false;
 
 namespace {
 
@@ -136,11 +139,38 @@ DeviceCtx* device_ctx(int gpu)
 struct DirectQueue {                                     // one HSA queue, shared by the programs of a graph
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};                                // counts bursts down from kStart
-    uint64_t bursts = 0;                                // closed by direct_wait
-    bool open = false;                                  // passes submitted since the last direct_wait
+    uint64_t bursts = 0;                                // closed so far (direct_close)
+    bool open = false;                                  // passes submitted since the last direct_close
     int refs = 0;
+    std::atomic<int> fault{0};                          // hsa_status_t handed to the queue's error callback (0: healthy)
     static constexpr hsa_signal_value_t kStart = (hsa_signal_value_t)1 << 40;
 };
+
+namespace {
+thread_local char g_direct_err[256] = "";
+void direct_err(const char* what, int code) { snprintf(g_direct_err, sizeof(g_direct_err), "%s (%d)", what, code); }
+
+// a kernel that faults (bad argument layout, scratch failure, memory violation) puts the queue into the error state: the read
+// index stops and no signal fires.  The runtime reports it here; every wait below looks at the flag instead of spinning forever
+void queue_fault(hsa_status_t status, hsa_queue_t*, void* data)
+{
+    ((DirectQueue*)data)->fault.store((int)status ? (int)status : -1);
+}
+
+double wait_limit_s()
+{
+    static const double lim = getenv("TAMD_DIRECT_TIMEOUT_S") ? atof(getenv("TAMD_DIRECT_TIMEOUT_S")) : 30.0;
+    return lim;
+}
+}  // namespace
+
+const char* direct_last_error() { return g_direct_err; }
+
+bool direct_probe(int gpu)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return device_ctx(gpu) != nullptr;
+}
 
 struct DirectProgram {
     DirectQueue* dq = nullptr;
@@ -197,9 +227,9 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         pk.group_segment_size = k.group + r.shmem;
         pk.kernel_object = k.object;
         p->pkts.push_back(pk);
-        // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores) announce it by name
+        // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores): flagged by their launcher
         static const bool allow_none = !(getenv("TAMD_DIRECT_COHERENT") && atoi(getenv("TAMD_DIRECT_COHERENT")) == 0);
-        coherent.push_back(allow_none && strstr(nm, "_coh_kernel") != nullptr);
+        coherent.push_back(allow_none && r.coherent);
     }
     if (hipMalloc(&p->kernargs, blob.size()) != hipSuccess || hipMemcpy(p->kernargs, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
@@ -218,7 +248,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         p->dq = new DirectQueue;
         uint32_t qsize = 1024;
         while (qsize < 8 * p->pkts.size()) qsize *= 2;
-        if (hsa_queue_create(ctx->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p->dq->q) != HSA_STATUS_SUCCESS) {
+        if (hsa_queue_create(ctx->agent, qsize, HSA_QUEUE_TYPE_SINGLE, queue_fault, p->dq, UINT32_MAX, UINT32_MAX, &p->dq->q) != HSA_STATUS_SUCCESS) {
             *why = "hsa_queue_create"; p->dq->q = nullptr; p->dq->refs = 1; direct_destroy(p); return nullptr;
         }
         if (hsa_signal_create(DirectQueue::kStart, 0, nullptr, &p->dq->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; p->dq->refs = 1; direct_destroy(p); return nullptr; }
@@ -250,8 +280,19 @@ int direct_submit(DirectProgram* p)
     const uint64_t n = p->pkts.size();
     DirectQueue* dq = p->dq;
     hsa_queue_t* q = dq->q;
+    if (dq->fault.load()) { direct_err("the HSA queue is in the error state (a dispatched kernel faulted)", dq->fault.load()); return -1; }
     const uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, n);
-    while (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size) {}      // ring full: the packet processor is behind
+    if (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size) {          // ring full: the packet processor is behind
+        const auto t0 = std::chrono::steady_clock::now();
+        while (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size) {
+            if (dq->fault.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s()) {
+                // the slots were reserved but never written: the queue is unusable from here on
+                if (!dq->fault.load()) dq->fault.store(-2);
+                direct_err("the HSA queue does not drain (faulted kernel or hung device)", dq->fault.load());
+                return -1;
+            }
+        }
+    }
     hsa_kernel_dispatch_packet_t* base = (hsa_kernel_dispatch_packet_t*)q->base_address;
     const uint64_t mask = q->size - 1;
     for (uint64_t i = 0; i < n; i++) {
@@ -276,15 +317,25 @@ int direct_submit(DirectProgram* p)
 }
 
 // closes the burst: one barrier packet behind everything submitted to the queue (barrier bit: it waits for the last kernel),
-// system-scope release, completion signal; returns when it has executed.  The host spins on the signal first (a blocking
-// run is a latency measurement: an interrupt-driven wake-up costs more than the pass) and only then sleeps on it.
-int direct_wait(DirectProgram* p)
+// system-scope release, completion signal.  The signal counts bursts down from kStart, so a burst number is a point on ONE
+// timeline: "burst b has completed" == signal <= kStart - b, and the asynchronous runs of a graph (two bursts in flight) need no
+// signal of their own.
+int direct_close(DirectProgram* p, unsigned long long* burst)
 {
     DirectQueue* dq = p->dq;
+    if (burst) *burst = dq->bursts;
     if (!dq->open) return 0;
+    if (dq->fault.load()) { direct_err("the HSA queue is in the error state (a dispatched kernel faulted)", dq->fault.load()); return -1; }
     hsa_queue_t* q = dq->q;
     const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
-    while (idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size) {}
+    const auto t0 = std::chrono::steady_clock::now();
+    while (idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size) {
+        if (dq->fault.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s()) {
+            if (!dq->fault.load()) dq->fault.store(-2);
+            direct_err("the HSA queue does not drain (faulted kernel or hung device)", dq->fault.load());
+            return -1;
+        }
+    }
     hsa_barrier_and_packet_t* b = (hsa_barrier_and_packet_t*)q->base_address + (idx & (q->size - 1));
     b->reserved0 = 0; b->reserved1 = 0; b->reserved2 = 0;
     for (int i = 0; i < 5; i++) b->dep_signal[i].handle = 0;
@@ -293,17 +344,44 @@ int direct_wait(DirectProgram* p)
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
     dq->bursts++;
     dq->open = false;
-    const hsa_signal_value_t target = DirectQueue::kStart - (hsa_signal_value_t)dq->bursts;
-    if (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, 2000000 /* timestamp ticks of spinning */, HSA_WAIT_STATE_ACTIVE) <= target) return 0;
-    while (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) > target) {}
+    if (burst) *burst = dq->bursts;
     return 0;
+}
+
+// The host spins on the signal first (a blocking run is a latency measurement: an interrupt-driven wake-up costs more than the
+// pass) and only then sleeps on it -- in slices, looking at the queue's fault flag between them, never forever.
+int direct_wait_burst(DirectProgram* p, unsigned long long burst)
+{
+    DirectQueue* dq = p->dq;
+    const hsa_signal_value_t target = DirectQueue::kStart - (hsa_signal_value_t)burst;
+    if (hsa_signal_load_scacquire(dq->done) <= target) return 0;
+    if (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, 2000000 /* timestamp ticks of spinning */, HSA_WAIT_STATE_ACTIVE) <= target) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        // ~50 ms slices (the timeout is in timestamp ticks of the system clock, 100 MHz here; only its order of magnitude matters)
+        if (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, 5000000, HSA_WAIT_STATE_BLOCKED) <= target) return 0;
+        if (dq->fault.load()) { direct_err("a dispatched kernel faulted: the HSA queue is in the error state", dq->fault.load()); return -1; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s()) {
+            dq->fault.store(-3);
+            direct_err("timeout waiting for a direct pass (TAMD_DIRECT_TIMEOUT_S)", -3);
+            return -1;
+        }
+    }
+}
+
+int direct_wait(DirectProgram* p)
+{
+    unsigned long long b = 0;
+    if (!p->dq->open) return 0;
+    if (direct_close(p, &b)) return -1;
+    return direct_wait_burst(p, b);
 }
 
 void direct_destroy(DirectProgram* p)
 {
     if (!p) return;
     if (p->dq) {
-        if (p->dq->q) (void)direct_wait(p);
+        if (p->dq->q && !p->dq->fault.load()) (void)direct_wait(p);
         if (--p->dq->refs <= 0) {
             if (p->dq->q) (void)hsa_queue_destroy(p->dq->q);
             if (p->dq->done.handle) (void)hsa_signal_destroy(p->dq->done);

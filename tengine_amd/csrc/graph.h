@@ -73,7 +73,9 @@ struct IOBind {
 struct Inflight {                    // one tamd_graph_run_async() that tamd_graph_wait() has not collected yet
     int slot = 0;
     std::vector<void*> host_out;     // where the caller wants this run's outputs (set_output at submit time)
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;       // hipGraph path
+    bool direct = false;             // direct path: the run is burst `burst` of the graph's HSA queue (direct.cc)
+    unsigned long long burst = 0;
 };
 
 struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
@@ -118,6 +120,8 @@ struct tamd_graph {
     int next_slot = 0;
     tamd::DirectProgram* direct = nullptr;     // tamd_options.direct_dispatch: the launch list as AQL packets (direct.cc)
     tamd::DirectProgram* direct_io = nullptr;  // .. the host-to-host list of I/O slot 0 (tamd_graph_run), same HSA queue
+    tamd::DirectProgram* direct_io2 = nullptr; // .. of I/O slot 1 (the second asynchronous run in flight)
+    double prerun_ms = 0;                      // wall time of tamd_graph_prerun (planning, autotune, capture)
     bool direct_busy = false;                  // passes submitted since the last wait
     tamd_options opt{};
     bool prepared = false;

@@ -1244,7 +1244,52 @@ static int launch_io(tamd_graph* g, int slot)
 
 using namespace tamd;
 
-// A graph lives on the device it was pre-run on; its entry points may be called from any host thread, whose current HIP
+// One direct pass against the eager pass of the same launch list, every graph output compared byte for byte.  Two pseudo-random
+// inputs: eager(A) -> want; eager(B) leaves B's results in every buffer; direct(A) must bring want back -- a pass that writes
+// nothing, or the wrong thing, shows up, and outputs that are prerun constants (PriorBox) are the same in all three.  0: identical.
+static int direct_selfcheck(tamd_graph* g)
+{
+    std::vector<std::vector<unsigned char>> want, got;
+    auto fill_inputs = [&](unsigned seed) -> int {
+        std::vector<unsigned char> noise;
+        unsigned lcg = seed;
+        for (auto& io : g->inputs) {
+            noise.resize(io.bytes);
+            if (g->tensors[io.tensor].dtype == TAMD_DT_FP32) {           // finite, moderate floats
+                float* f = (float*)noise.data();
+                for (size_t i = 0; i < io.bytes / 4; i++) { lcg = lcg * 1664525u + 1013904223u; f[i] = (float)((int)(lcg >> 20) - 2048) / 1024.f; }
+            } else
+                for (size_t i = 0; i < io.bytes; i++) { lcg = lcg * 1664525u + 1013904223u; noise[i] = (unsigned char)(lcg >> 24); }
+            HIPCHK(hipMemcpy(io.stage, noise.data(), io.bytes, hipMemcpyHostToDevice));
+        }
+        return 0;
+    };
+    auto snapshot = [&](std::vector<std::vector<unsigned char>>& dst) -> int {
+        dst.clear();
+        for (auto& io : g->outputs) {
+            dst.emplace_back(io.bytes);
+            HIPCHK(hipMemcpy(dst.back().data(), io.stage, io.bytes, hipMemcpyDeviceToHost));
+        }
+        return 0;
+    };
+    if (fill_inputs(0x5EED1234u) || run_steps(g, g->stream)) return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (snapshot(want)) return -1;
+    if (fill_inputs(0x0BADF00Du) || run_steps(g, g->stream)) return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (fill_inputs(0x5EED1234u)) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    if (direct_submit(g->direct) || direct_wait(g->direct)) { set_error("direct pass failed: %s", direct_last_error()); return -1; }
+    if (snapshot(got)) return -1;
+    for (auto& io : g->inputs) HIPCHK(hipMemset(io.stage, 0, io.bytes));
+    HIPCHK(hipDeviceSynchronize());
+    for (size_t i = 0; i < want.size(); i++)
+        if (want[i] != got[i]) { set_error("the direct pass does not reproduce the eager pass (output %zu differs)", i); return -1; }
+    return 0;
+}
+
+// A graph lives on the device it was pre-run on; its entry points may be called from any host thread -- ONE at a time per graph
+// (include/tengine_amd.h "Threading": run state and the single-producer HSA queue are not locked) -- whose current HIP
 // device is whatever that thread used last (events, eager launches and temporary allocations would land on the wrong
 // device otherwise).  hipSetDevice is a thread-local assignment when nothing changes.
 static int bind_device(tamd_graph* g)
@@ -1488,9 +1533,13 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         if (getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY") || (pre && strstr(pre, "rocprof"))) o.direct_dispatch = 0;
     }
     if (const char* dt = getenv("TG_DEBUG_TIME")) { if (atoi(dt) == 1) o.profile = 1; }     // cpu_define.h:41-43
+    const auto prerun_t0 = std::chrono::steady_clock::now();
     g->opt = o;
     if (infer_shapes(g) || validate_graph(g)) return -1;       // a malformed graph is refused before the device is touched
     if (tamd_init(o.gpu_index)) return -1;
+    // the planner picks the COHERENT kernel instances (agent-scope loads / write-through stores, slower under a hipGraph) only
+    // where direct dispatch can exist at all: HSA agent and loader extension are asked before anything is planned
+    if (o.direct_dispatch && !(o.use_hip_graph && direct_probe(o.gpu_index))) { o.direct_dispatch = 0; g->opt = o; }
     g->gpu = o.gpu_index;
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     // one quantisation scheme per device graph (the reference's splitter hands over homogeneous subgraphs)
@@ -1539,20 +1588,34 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
             HIPCHK(hipStreamSynchronize(g->stream));
             const char* why = "";
             g->direct = direct_build(g->gpu, g->stream, recs, &why);
-            if (!g->direct && getenv("TAMD_DEBUG")) fprintf(stderr, "tengine_amd: direct dispatch not used: %s\n", why);
-            if (g->direct && g->hexec_io[0][0]) {
-                // the host-to-host list of I/O slot 0 (upload launch, compute, download launch) on the same queue: tamd_graph_run
+            if (!g->direct) fprintf(stderr, "tengine_amd: direct dispatch not used (hipGraph replay instead): %s\n", why);
+            // the packets carry hand-built argument segments (hidden arguments at the code-object-v5 offsets) and hand-picked
+            // fence scopes: ONE direct pass must reproduce the eager pass byte for byte on a non-trivial input, or the graph
+            // keeps its hipGraph (a different ROCm, a renamed kernel, a stale line would otherwise be silently wrong outputs)
+            if (g->direct && direct_selfcheck(g)) {
+                fprintf(stderr, "tengine_amd: direct dispatch DISABLED for this graph: %s (hipGraph replay instead)\n", g_err);
+                direct_destroy(g->direct);
+                g->direct = nullptr;
+            }
+            for (int slot = 0; slot < 2 && g->direct && g->hexec_io[slot][0]; slot++) {
+                // the host-to-host list of I/O slot 0 | 1 (upload launch, compute, download launch) on the same queue:
+                // tamd_graph_run and the asynchronous pair
                 recs.clear();
                 g_launch_rec = &recs;
-                rc = run_steps(g, g->stream, 0);
+                rc = run_steps(g, g->stream, slot);
                 g_launch_rec = nullptr;
                 if (rc) return -1;
                 HIPCHK(hipStreamSynchronize(g->stream));
-                g->direct_io = direct_build(g->gpu, g->stream, recs, &why, g->direct);
-                if (!g->direct_io && getenv("TAMD_DEBUG")) fprintf(stderr, "tengine_amd: direct dispatch not used for host-to-host runs: %s\n", why);
+                DirectProgram* pio = direct_build(g->gpu, g->stream, recs, &why, g->direct);
+                if (!pio) fprintf(stderr, "tengine_amd: direct dispatch not used for host-to-host runs (slot %d): %s\n", slot, why);
+                (slot ? g->direct_io2 : g->direct_io) = pio;
+            }
+            if (!g->direct_io || !g->direct_io2) {          // both or none: the asynchronous pair alternates between them
+                if (g->direct_io2) { direct_destroy(g->direct_io2); g->direct_io2 = nullptr; }
             }
         }
     }
+    g->prerun_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - prerun_t0).count();
     g->prepared = true;
     return 0;
 }
@@ -1601,13 +1664,17 @@ int tamd_graph_set_output(tamd_graph* g, int idx, void* host, size_t bytes)
 // passes submitted by direct dispatch are not on the HIP stream: everything that touches the tensors waits for them first
 static int direct_drain(tamd_graph* g)
 {
-    if (g->direct && g->direct_busy) { if (direct_wait(g->direct)) return -1; g->direct_busy = false; }
+    if (g->direct && g->direct_busy) {
+        if (direct_wait(g->direct)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+        g->direct_busy = false;
+    }
     return 0;
 }
 
 int tamd_graph_upload_inputs(tamd_graph* g)
 {
     if (bind_device(g)) return -1;
+    if (!g->inflight.empty()) { set_error("tamd_graph_upload_inputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     for (auto& io : g->inputs) {
@@ -1626,7 +1693,8 @@ int tamd_graph_launch(tamd_graph* g)
         // the pass reads what the stream wrote (uploaded inputs): drain it before the first packet of a burst
         if (!g->direct_busy) HIPCHK(hipStreamSynchronize(g->stream));
         g->direct_busy = true;
-        return direct_submit(g->direct);
+        if (direct_submit(g->direct)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+        return 0;
     }
     if (g->hexec) {
         hipGraphExec_t e = g->hexecs[g->next_exec];
@@ -1638,12 +1706,14 @@ int tamd_graph_launch(tamd_graph* g)
 }
 
 int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->direct ? direct_packets(g->direct) : 0; }
+double tamd_graph_prerun_ms(const tamd_graph* g) { return g ? g->prerun_ms : 0.0; }
 
 int tamd_graph_sync(tamd_graph* g) { if (bind_device(g)) return -1; if (direct_drain(g)) return -1; HIPCHK(hipStreamSynchronize(g->stream)); return 0; }
 
 int tamd_graph_download_outputs(tamd_graph* g)
 {
     if (bind_device(g)) return -1;
+    if (!g->inflight.empty()) { set_error("tamd_graph_download_outputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     for (auto& io : g->outputs) HIPCHK(hipMemcpyAsync(io.pinned, io.stage, io.bytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
@@ -1664,7 +1734,7 @@ int tamd_graph_run(tamd_graph* g)
     }
     if (g->direct_io) {          // the same list as AQL packets: system-scope acquire in front, closing barrier packet behind
         HIPCHK(hipStreamSynchronize(g->stream));
-        if (direct_submit(g->direct_io) || direct_wait(g->direct_io)) return -1;
+        if (direct_submit(g->direct_io) || direct_wait(g->direct_io)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
     } else {
         if (launch_io(g, 0)) return -1;
         HIPCHK(hipStreamSynchronize(g->stream));
@@ -1686,16 +1756,28 @@ int tamd_graph_run_async(tamd_graph* g)
     if (g->inflight.size() >= 2) { set_error("two runs are already in flight: call tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     const int slot = g->next_slot;
-    if (!g->slot_done[slot]) HIPCHK(hipEventCreateWithFlags(&g->slot_done[slot], hipEventDisableTiming));
     for (auto& io : g->inputs) {
         if (!io.host_in) { set_error("input buffer not set"); return -1; }
         memcpy(slot ? io.pinned2 : io.pinned, io.host_in, io.bytes);
     }
-    if (launch_io(g, slot)) return -1;
     Inflight f;
-    f.slot = slot; f.done = g->slot_done[slot];
+    f.slot = slot;
     for (auto& io : g->outputs) f.host_out.push_back(io.host_out);
-    HIPCHK(hipEventRecord(f.done, g->stream));
+    if (g->direct_io && g->direct_io2) {
+        // the run is ONE burst on the graph's own HSA queue: the slot's host-to-host list (system-scope acquire in front: the
+        // pinned input was just written by the host), closed by a barrier packet that releases at system scope and counts the
+        // queue's completion signal down.  The second run's packets queue behind the first one's closing packet (barrier bit on
+        // every packet): the device goes from run k's download straight into run k+1's upload, the host is never in between.
+        DirectProgram* p = slot ? g->direct_io2 : g->direct_io;
+        if (g->inflight.empty()) HIPCHK(hipStreamSynchronize(g->stream));
+        if (direct_submit(p) || direct_close(p, &f.burst)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+        f.direct = true;
+    } else {
+        if (!g->slot_done[slot]) HIPCHK(hipEventCreateWithFlags(&g->slot_done[slot], hipEventDisableTiming));
+        if (launch_io(g, slot)) return -1;
+        f.done = g->slot_done[slot];
+        HIPCHK(hipEventRecord(f.done, g->stream));
+    }
     g->inflight.push_back(f);
     g->next_slot ^= 1;
     return 0;
@@ -1707,7 +1789,10 @@ int tamd_graph_wait(tamd_graph* g)
     if (!g || g->inflight.empty()) { set_error("tamd_graph_wait: no run in flight"); return -1; }
     if (bind_device(g)) return -1;
     const Inflight f = g->inflight.front();
-    HIPCHK(hipEventSynchronize(f.done));
+    if (f.direct) {
+        if (direct_wait_burst(g->direct_io, f.burst)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+    } else
+        HIPCHK(hipEventSynchronize(f.done));
     for (size_t i = 0; i < g->outputs.size(); i++)
         if (f.host_out[i]) memcpy(f.host_out[i], f.slot ? g->outputs[i].pinned2 : g->outputs[i].pinned, g->outputs[i].bytes);
     g->inflight.erase(g->inflight.begin());
@@ -1849,6 +1934,7 @@ void tamd_graph_destroy(tamd_graph* g)
     if (g->prepared && g->opt.profile) dump_profile(g);
     if (g->stream) hipStreamSynchronize(g->stream);
     std::lock_guard<std::mutex> lk(g_capture_mutex);      // hipFree is device-synchronous: not while another thread captures
+    if (g->direct_io2) { direct_destroy(g->direct_io2); g->direct_io2 = nullptr; }
     if (g->direct_io) { direct_destroy(g->direct_io); g->direct_io = nullptr; }
     if (g->direct) { direct_destroy(g->direct); g->direct = nullptr; }
     for (int i = 0; i < g->nexec; i++) if (g->hexecs[i]) hipGraphExecDestroy(g->hexecs[i]);

@@ -17,9 +17,14 @@ struct LaunchRec {
     dim3 grid, block;
     unsigned shmem;                     // dynamic LDS bytes
     std::vector<unsigned char> args;    // explicit kernel-argument segment
+    bool coherent = false;              // the kernel exchanges its tensors with agent-scope accesses (launch_rec_coherent): no fences
 };
 
 extern thread_local std::vector<LaunchRec>* g_launch_rec;       // direct.cc; non-null while a launch list is being recorded
+extern thread_local bool g_launch_coherent;                     // direct.cc; set by launch_rec_coherent() for the NEXT launch
+// a launcher calls this right before it launches a COHERENT kernel instance (pwdw.hip): the record says so explicitly -- the
+// packet's fence scopes do not hang on a naming convention
+inline void launch_rec_coherent() { g_launch_coherent = true; }
 
 template <typename T>
 inline void rec_pack(std::vector<unsigned char>& b, const T& v)
@@ -38,8 +43,10 @@ inline void launch_rec(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem
         r.func = reinterpret_cast<const void*>(kernel);
         r.grid = grid; r.block = block; r.shmem = (unsigned)shmem;
         (rec_pack<P>(r.args, static_cast<P>(a)), ...);
+        r.coherent = g_launch_coherent;
         g_launch_rec->push_back(std::move(r));
     }
+    g_launch_coherent = false;
     kernel<<<grid, block, shmem, s>>>(static_cast<P>(a)...);
 }
 
@@ -49,8 +56,13 @@ struct DirectProgram;
 // dispatched directly (a kernel that needs scratch memory, an unresolved symbol, no HSA queue): the caller keeps the hipGraph.
 // `share`: a program of the same graph whose HSA queue (and burst state) the new one uses as well.
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share = nullptr);
-int direct_submit(DirectProgram* p);        // one pass over the list: packets + one doorbell; returns without waiting
-int direct_wait(DirectProgram* p);          // until every submitted pass has completed
+bool direct_probe(int gpu);                 // HSA agent + loader extension present for HIP device `gpu` (cheap; asked before planning)
+int direct_submit(DirectProgram* p);        // one pass over the list: packets + one doorbell; returns without waiting; -1: queue fault / ring stuck
+int direct_close(DirectProgram* p, unsigned long long* burst);   // closes the burst with a barrier packet that carries the completion signal;
+                                                                 // does not wait.  *burst: ticket for direct_wait_burst
+int direct_wait_burst(DirectProgram* p, unsigned long long burst);   // until that burst (and everything before it) has completed; -1: queue fault / timeout
+int direct_wait(DirectProgram* p);          // direct_close + direct_wait_burst: until every submitted pass has completed
+const char* direct_last_error();            // what the last -1 of this thread was about
 int direct_packets(const DirectProgram* p);
 void direct_destroy(DirectProgram* p);
 

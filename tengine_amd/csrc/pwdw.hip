@@ -87,7 +87,11 @@ __device__ __forceinline__ void chain_wait(const ChainDep& d)
 
 __device__ __forceinline__ void chain_signal(const ChainDep& d)
 {
-    if (!d.my_counter) return;           // coherent stand-alone launch (pwdw_i8_coh_kernel): the kernel boundary orders the layers
+    // coherent stand-alone launch (pwdw_i8_coh_kernel): the kernel boundary orders the layers.  No explicit wait for the
+    // write-through stores here: S_ENDPGM does it ("the hardware implicitly executes S_WAITCNT 0 before executing this
+    // instruction", GCN3 / Vega / CDNA ISA manuals, SOPP S_ENDPGM; vmcnt counts stores until they are acknowledged, for sc1 stores by
+    // the memory side), a dispatch completes when its last wave has ended, and the next packet carries the barrier bit.
+    if (!d.my_counter) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have reached the memory side
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(d.my_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -502,7 +506,7 @@ int pwdw_steps(int nsteps)
 // plain or coherent instance of one variant
 #define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_)                                                                          \
     do {                                                                                                                     \
-        if (a.coherent) hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a); \
+        if (a.coherent) { launch_rec_coherent(); hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a); } \
         else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a);            \
     } while (0)
 

@@ -33,6 +33,7 @@ extern "C" {
 #include "module/module.h"
 #include "operator/op.h"
 #include "optimizer/split.h"
+#include "scheduler/scheduler.h"
 #include "utility/log.h"
 #include "utility/sys_port.h"
 #include "utility/vector.h"
@@ -599,10 +600,84 @@ void resplit_around_unsupported(struct graph* ir, struct device* hip)
     }
 }
 
+// ---- the scheduler half of asynchronous runs -----------------------------------------------------------------
+// The reference's only scheduler rejects run_graph(graph, 0) (scheduler.c:75-79) and has no wait (scheduler.c:186-189), so
+// interface.async_run / async_wait (device.h:60-63) are unreachable through its API.  The plugin therefore ships a scheduler of the
+// reference's own shape (struct scheduler, scheduler.h:34-43) and installs it on the context of every graph it splits:
+//   prerun / postrun / run(block = 1): the reference's sync scheduler, unchanged (find_default_scheduler());
+//   run(block = 0): a graph that is ONE subgraph on "HIP" is submitted with interface.async_run and the call returns -- up to two
+//                   runs in flight (the device pipelines run k+1's upload behind run k's download, csrc/graph.hip); any other
+//                   graph (CPU pieces in between) runs to completion right here, which keeps the API's promise trivially;
+//   wait:           interface.async_wait for the oldest run in flight; outputs land in the output tensors' buffers then.
+// Reference defect to know about: wait_graph() itself can never reach a scheduler -- its status test
+// `GRAPH_STAT_RUNNING != status || GRAPH_STAT_READY != status` (c_api.c:588) is always true, it returns -1.  The plugin exports
+// hip_wait_graph(graph, try_wait) with the body wait_graph was meant to have; INTEGRATION.md shows the one-token fix.
+struct HipSchedState { int inflight = 0; };
+
+HipSchedState* sched_state(struct graph* ir_graph)
+{
+    if (!ir_graph->attribute->scheduler_privacy) ir_graph->attribute->scheduler_privacy = new HipSchedState();
+    return (HipSchedState*)ir_graph->attribute->scheduler_privacy;
+}
+
+struct subgraph* single_hip_subgraph(struct graph* ir_graph)
+{
+    if (get_vector_num(ir_graph->subgraph_list) != 1) return nullptr;
+    struct subgraph* sg = get_ir_graph_subgraph(ir_graph, 0);
+    return (sg->device && 0 == strcmp(sg->device->name, HIP_DEV_NAME) && sg->device_graph) ? sg : nullptr;
+}
+
+int hip_sched_prerun(struct scheduler* s, struct graph* g) { (void)s; struct scheduler* d = find_default_scheduler(); return d->prerun(d, g); }
+
+int hip_sched_wait(struct scheduler* s, struct graph* ir_graph)
+{
+    (void)s;
+    HipSchedState* st = sched_state(ir_graph);
+    if (st->inflight == 0) { ir_graph->status = GRAPH_STAT_READY; return 0; }
+    struct subgraph* sg = single_hip_subgraph(ir_graph);
+    if (!sg || sg->device->interface->async_wait(sg->device, sg, 0) != 0) { ir_graph->status = GRAPH_STAT_ERROR; return -1; }
+    if (--st->inflight == 0) { sg->status = GRAPH_STAT_READY; ir_graph->status = GRAPH_STAT_READY; }
+    return 0;
+}
+
+int hip_sched_run(struct scheduler* s, struct graph* ir_graph, int block)
+{
+    struct scheduler* d = find_default_scheduler();
+    HipSchedState* st = sched_state(ir_graph);
+    if (block) {
+        while (st->inflight > 0)                         // a blocking run behind asynchronous ones: results stay in order
+            if (hip_sched_wait(s, ir_graph) != 0) return -1;
+        return d->run(d, ir_graph, 1);
+    }
+    struct subgraph* sg = single_hip_subgraph(ir_graph);
+    if (!sg) return d->run(d, ir_graph, 1);              // mixed placement: complete before returning (wait then has nothing to do)
+    if (st->inflight >= 2) { TLOG_ERR("Tengine HIP: two asynchronous runs are already in flight: wait_graph first\n"); return -1; }
+    sg->status = GRAPH_STAT_RUNNING;
+    if (sg->device->interface->async_run(sg->device, sg) != 0) { sg->status = GRAPH_STAT_ERROR; return -1; }
+    st->inflight++;
+    return 0;
+}
+
+int hip_sched_postrun(struct scheduler* s, struct graph* ir_graph)
+{
+    while (ir_graph->attribute->scheduler_privacy && sched_state(ir_graph)->inflight > 0)
+        if (hip_sched_wait(s, ir_graph) != 0) break;
+    struct scheduler* d = find_default_scheduler();
+    const int rc = d->postrun(d, ir_graph);
+    delete (HipSchedState*)ir_graph->attribute->scheduler_privacy;
+    ir_graph->attribute->scheduler_privacy = nullptr;
+    return rc;
+}
+
+struct scheduler hip_scheduler = {"hip_pipelined", hip_sched_prerun, hip_sched_run, hip_sched_wait, hip_sched_postrun, nullptr};
+
 int hip_split_graph(struct graph* ir_graph)
 {
     struct device* cur_dev = ir_graph->attribute->context->device;
     if (0 != strcmp(HIP_DEV_NAME, cur_dev->name)) return -1;
+    // split_graph runs inside prerun_graph, before the context's scheduler is asked to pre-run (c_api.c:468-530): from here on
+    // this context schedules through the plugin's scheduler (TG_HIP_SCHEDULER=0 keeps the reference's)
+    if (!(getenv("TG_HIP_SCHEDULER") && atoi(getenv("TG_HIP_SCHEDULER")) == 0)) ir_graph->attribute->context->scheduler = &hip_scheduler;
 
     struct vector* allowed_ops = create_vector(sizeof(int), nullptr);
     struct vector* blocked_ops = create_vector(sizeof(int), nullptr);
@@ -663,6 +738,16 @@ __attribute__((visibility("default"))) int register_hip_device(void)
     }
     TLOG_INFO("Tengine plugin device %s is registered.\n", hip_device.name);
     return 0;
+}
+
+// What the reference's wait_graph() was meant to do (its own status test makes it return -1 unconditionally, c_api.c:583-603):
+// 0 when the OLDEST asynchronous run_graph(graph, 0) has completed and its outputs are in the output tensors' buffers.
+__attribute__((visibility("default"))) int hip_wait_graph(void* graph, int try_wait)
+{
+    (void)try_wait;
+    struct graph* ir = (struct graph*)graph;
+    struct scheduler* sch = ir->attribute->context->scheduler;
+    return sch->wait(sch, ir);
 }
 
 // Introspection for tests and tools: where did the splitter put the nodes of a prerun graph?  One line per subgraph,

@@ -92,8 +92,8 @@ def test_variants_really_run():
             want, got, name = _run(member, case, 1)
             assert member in name, (member, name)
             assert np.array_equal(got, want), (name, case)
-    for member in KS2:       # two / four 64-channel chunks
-        for case in (PATCH_CASES[1], PATCH_CASES[8]):
+    for member in KS2:       # two / eight 64-channel chunks
+        for case in (PATCH_CASES[1], PATCH_CASES[10]):
             _, _, name = _run(member, case, 1)
             assert member in name, (member, name)
 

@@ -242,6 +242,54 @@ def test_int8_rescaling_concat_runs_on_the_device_and_matches_cpu(ref):
     assert np.array_equal(want, got)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["conv", "mobilenet_v1"])
+def test_async_run_graph_through_the_plugins_scheduler(ref, model):
+    """SURVEY 8(f)4, the scheduler half: the reference's own run_graph(graph, 0) reaches interface.async_run through the scheduler
+    the plugin installs on the context; two runs in flight, a third is refused; results in submission order, reference bytes.
+    wait_graph() itself cannot work in the unmodified reference (its status test is always true, c_api.c:588): asserted as is,
+    and hip_wait_graph() -- the body it was meant to have -- collects the runs."""
+    L = _load_plugin(ref)
+    P = C.CDLL(PLUGIN)
+    P.hip_wait_graph.restype = C.c_int
+    P.hip_wait_graph.argtypes = [C.c_void_p, C.c_int]
+    L.wait_graph.restype = C.c_int
+    L.wait_graph.argtypes = [C.c_void_p, C.c_int]
+    if model == "conv":
+        g, x1 = conv_graph(61, 2, 64, 14, 14, 96, 3, 1, 1)
+    else:
+        g = models.build("mobilenet_v1", "int8", 1)
+        x1 = models.synth_input(g, 7)
+    rng = np.random.default_rng(5)
+    x2 = rng.integers(-127, 128, size=x1.shape).astype(np.int8)
+    b = tm2.write_tm2(g)
+    want1 = ref.run_model(b, x1, ref.MODE_INT8, 4)[0]
+    want2 = ref.run_model(b, x2, ref.MODE_INT8, 4)[0]
+    assert not np.array_equal(want1, want2)
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
+    rg.set_input(x1)
+    rg.prerun()
+    assert_all_on_hip(rg)
+    buf = np.ascontiguousarray(x1).copy()           # ONE application buffer, refilled between submissions
+    t = L.get_graph_input_tensor(rg.g, 0, 0)
+    assert L.set_tensor_buffer(t, buf.ctypes.data, buf.nbytes) == 0
+    for rep in range(3):
+        buf[...] = x1
+        assert L.run_graph(rg.g, 0) == 0            # non-blocking: returns with the run in flight
+        buf[...] = x2                               # the input was staged at submission: the buffer is the application's again
+        assert L.run_graph(rg.g, 0) == 0
+        assert L.run_graph(rg.g, 0) != 0            # a third run in flight is refused
+        assert L.wait_graph(rg.g, 1) == -1          # the reference's own wait_graph: always -1 (c_api.c:588)
+        assert P.hip_wait_graph(rg.g, 1) == 0
+        assert np.array_equal(rg.outputs()[0], want1)
+        assert P.hip_wait_graph(rg.g, 1) == 0
+        assert np.array_equal(rg.outputs()[0], want2)
+    buf[...] = x1
+    assert L.run_graph(rg.g, 1) == 0                # and the blocking run still works on the same graph
+    assert np.array_equal(rg.outputs()[0], want1)
+    rg.close()
+
+
 class ShortOpt(C.Structure):     # an application that only knows the reference's convention: first field dev_name
     _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int)]
 
