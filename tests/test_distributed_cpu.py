@@ -108,6 +108,20 @@ def test_bench_gpus2_dry_run_spawns_two_ranks_and_gathers_every_output():
     assert line["config"]["gather_bytes_per_image"] == 255 * 13 * 13 + 255 * 26 * 26      # 215 475 B / image
 
 
+@pytest.mark.parametrize("model,total,per_image", [("yolov3_tiny", 64, 255 * 13 * 13 + 255 * 26 * 26), ("mssd", 128, None)])
+def test_bench_gpus8_dry_run_of_the_baseline_multi_gpu_configs(model, total, per_image):
+    """BASELINE configs[3] / [4] at the node's size: `python bench.py --gpus 8 --global-batch 64|128` -- eight ranks (gloo on CPU),
+    tmfile broadcast + integrity check on every rank, 8 / 16 images per rank, ONE gather of every output in global image order"""
+    r = _bench("--gpus", "8", "--dry-run", "--model", model, "--dtype", "uint8", "--global-batch", str(total), "--steps", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["shards"] == [total // 8] * 8 and line["config"]["global_batch"] == total
+    assert line["config"]["outputs"] >= 2
+    if per_image:
+        assert line["config"]["gather_bytes_per_image"] == per_image
+
+
 def test_bench_gpus2_without_two_devices_fails_loudly():
     r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
     assert r.returncode != 0

@@ -34,6 +34,17 @@ def test_bench_rccl_path_on_one_gpu(gather):
         assert line["ms_per_step"] < 1.5 * plain["ms_per_step"] + 0.02
 
 
+def test_bench_default_reports_both_gather_modes_and_the_same_path_at_n1():
+    """N > 1 default: two timed regions -- `value` = one overlapped all_gather per step, `gather_final` = no per-step
+    collective; N = 1 carries the hipGraph-replay figure too, the dispatch path of the per-step region (like for like curves)"""
+    line = _bench("--force-dist", "--steps", "60", "--warmup", "10", "--no-cpu-baseline")
+    assert "per step" in line["config"]["collectives"] and line["value"] > 1000
+    assert line["gather_final"]["value"] > 1000 and line["gather_final"]["ms_per_step"] > 0
+    plain = _bench("--steps", "60", "--warmup", "10", "--no-cpu-baseline")
+    assert plain["hipgraph_replay"]["value"] > 1000 and plain["output_checksum"] == line["output_checksum"]
+    assert plain["host_to_host_images_per_s"] > 1000 and plain["host_to_host"]["runs"] >= 200 and plain["prerun_ms"] > 0
+
+
 def test_bench_two_stream_yolo_gathers_both_heads():
     line = _bench("--force-dist", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--model", "yolov3_tiny", "--dtype", "uint8",
                   "--batch", "2", "--streams", "2", "--gather", "every")
