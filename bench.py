@@ -88,6 +88,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # every graph of this process (second timed region, concurrent streams) takes the plan the first one measured: the same kernels in
+    # every region, one plan-time autotune instead of one per graph (csrc/graph.hip: plan cache)
+    plan_tmp = None
+    if "TAMD_PLAN_CACHE" not in os.environ:
+        import tempfile
+        plan_tmp = os.path.join(tempfile.gettempdir(), "tamd_plan_%d_%d.txt" % (os.getpid(), rank))
+        os.environ["TAMD_PLAN_CACHE"] = plan_tmp
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d -- refusing to report a line for the wrong GPU count" % (args.gpus, world))
@@ -347,6 +354,8 @@ def main():
         except OSError:
             pass
 
+    if plan_tmp and os.path.exists(plan_tmp):
+        os.remove(plan_tmp)
     flush_c_stdio()
     if use_dist:
         dist.barrier()

@@ -119,14 +119,24 @@ static int plan_winograd_f32(tamd_graph* g, HNode& n, const HTensor& x, const HT
                 for (int j = 0; j < 4; j++)
                     U[((size_t)(4 * i + j) * a.Mpad + co) * a.Cpad + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
         }
+    // transformed weights, bias and the V / M workspaces (up to 1 GiB per layer) belong to the graph only if Winograd WINS the
+    // timing below: plain allocations until then, freed when the direct convolution is kept (they used to stay in dev_allocs --
+    // hundreds of MB of dead HBM per batched fp32 network)
     float* dU = nullptr; float* db = nullptr;
     void* dV = nullptr; void* dM = nullptr;
-    if (upload(g, U, &dU)) return -1;
+    std::vector<void*> mine;
+    auto drop = [&]() { for (void* q : mine) (void)hipFree(q); mine.clear(); };
+    auto grab = [&](void** q, size_t bytes) -> int {
+        if (hipMalloc(q, bytes + 1024) != hipSuccess) { (void)hipGetLastError(); set_error("winograd workspace: out of device memory"); drop(); return -1; }
+        mine.push_back(*q);
+        return 0;
+    };
+    if (grab((void**)&dU, U.size() * 4)) return -1;
+    if (hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { drop(); set_error("winograd weight upload failed"); return -1; }
     if (b) {
-        std::vector<float> hb((const float*)b->data.data(), (const float*)b->data.data() + y.c);
-        if (upload(g, hb, &db)) return -1;
+        if (grab((void**)&db, (size_t)y.c * 4) || hipMemcpy(db, b->data.data(), (size_t)y.c * 4, hipMemcpyHostToDevice) != hipSuccess) { drop(); return -1; }
     }
-    if (dev_alloc(g, &dV, 16ull * a.Cpad * a.Tpad * 4, false) || dev_alloc(g, &dM, 16ull * a.Mpad * a.Tpad * 4, false)) return -1;
+    if (grab(&dV, 16ull * a.Cpad * a.Tpad * 4) || grab(&dM, 16ull * a.Mpad * a.Tpad * 4)) return -1;
     a.x = (const float*)x.dptr; a.U = dU; a.bias = db; a.V = (float*)dV; a.M = (float*)dM; a.y = (float*)y.dptr;
     Step direct = g->steps.back();
     std::vector<std::function<hipError_t(hipStream_t)>> wino = {[a](hipStream_t s) { return launch_wino_in_f32(a, s); },
@@ -135,10 +145,12 @@ static int plan_winograd_f32(tamd_graph* g, HNode& n, const HTensor& x, const HT
     bool use = mode == 1;
     if (mode != 1) {
         float tw = 0, td = 0;
-        if (time_steps(g, wino, &tw) || time_steps(g, {direct.fn}, &td)) return -1;
+        if (time_steps(g, wino, &tw) || time_steps(g, {direct.fn}, &td)) { drop(); return -1; }
         use = tw * 3.f < td * 0.97f;                              // time_steps reports per launch: three against one
+        if (getenv("TAMD_DEBUG")) fprintf(stderr, "tengine_amd: %s: winograd F(2,3) %.2f us vs direct %.2f us -> %s\n", n.name.c_str(), 3e3f * tw, 1e3f * td, use ? "winograd" : "direct");
     }
-    if (!use) return 0;
+    if (!use) { HIPCHK(hipStreamSynchronize(g->stream)); drop(); return 0; }
+    for (void* q : mine) g->dev_allocs.push_back(q);           // from here on the graph owns them (freed by tamd_graph_destroy)
     g->steps.pop_back();
     const char* names[3] = {"wino_in_f32", "wino_gemm_f32<F(2,3)>", "wino_out_f32"};
     for (int k = 0; k < 3; k++) {

@@ -427,8 +427,17 @@ int plan_u8(tamd_graph* g)
             if (rc == 2 && pool) { pool = nullptr; rc = plan_conv_u8(g, n, relu, nullptr); }
             if (rc == 2) { relu = nullptr; rc = plan_conv_u8(g, n, nullptr); }       // kernel without the fused tail
             if (rc) return -1;
-            if (relu) fused[rj] = 1;
-            if (pool) fused[pj] = 1;
+            // tensors that now only exist inside the fused launch: tamd_graph_read_tensor must refuse them instead of returning the
+            // zeros of a buffer nobody writes (layer-by-layer parity tooling would be misled)
+            if (g->fused_away.size() != g->tensors.size()) g->fused_away.assign(g->tensors.size(), 0);
+            if (relu) { fused[rj] = 1; g->fused_away[n.out[0]] = 1; }
+            if (pool) {
+                fused[pj] = 1;
+                const int full = relu ? relu->out[0] : n.out[0];
+                bool written = count_consumers(g, full) > 1;           // == U8PoolFuse::write_full
+                for (auto& io : g->outputs) written = written || io.tensor == full;
+                if (!written) g->fused_away[full] = 1;
+            }
             break;
         }
         case TAMD_OP_FC:

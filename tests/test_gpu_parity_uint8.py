@@ -154,6 +154,33 @@ def test_concat_by_offset_u8(batch):
     gr.close()
 
 
+def test_fused_away_uint8_tensors_are_refused_by_read_tensor():
+    """conv -> leaky ReLU in one launch (and conv -> ReLU -> 2x2 max-pool): the conv's own bytes (and the unpooled map) never reach
+    memory -- read_tensor says so instead of returning the zeros of an unwritten buffer (graph_u8 fused_away)"""
+    from helpers import u8_conv_graph
+    g, x = u8_conv_graph(77, 1, 16, 16, 16, 24, 3, 1, 1, act=-1)
+    a = g.nodes[-1].outputs[0]
+    q = (g.tensors[a].scales[0], g.tensors[a].zero_points[0])
+    r = g.add_tensor("lk", [1, 24, 16, 16], tm2.DT_UINT8, tm2.TT_VAR, None, [q[0] * 0.8], [7])
+    g.add_node("lk", "ReLU", [a], [r], negative_slope=0.1)
+    pq = g.add_tensor("pool", [1, 24, 8, 8], tm2.DT_UINT8, tm2.TT_VAR, None, [q[0] * 0.8], [7])
+    ni = g.add_node("pool", "Pooling", [r], [pq], alg=0, kernel_h=2, kernel_w=2, stride_h=2, stride_w=2, **{"global": 0}, caffe_flavor=0,
+                    pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    g.output_nodes = [ni]
+    want = oracle.run_graph(g, x, keep_all=True)
+    gr = capi.Graph(tm2.write_tm2(g))
+    gr.set_input(x)
+    got = gr.run()[0]
+    assert np.array_equal(got.reshape(want[pq].shape), want[pq])
+    names = [k["kernel"] for k in gr.profile(1)]
+    assert len(names) == 1, names                    # conv + leaky ReLU + max-pool: one launch
+    for t in (a, r):
+        with pytest.raises(capi.TamdError):
+            gr.read_tensor(t)
+    assert np.array_equal(gr.read_tensor(pq).reshape(want[pq].shape), want[pq])
+    gr.close()
+
+
 def test_yolov3_tiny_uint8_bit_exact():
     """BASELINE configs[3] class: YOLOv3-tiny uint8 (13 convs up to K = 4608, leaky ReLU, max pools incl. the
     stride-1 'same' pool, upsample, concat with per-input rescale), whole graph on the device, layer by layer."""
