@@ -49,9 +49,13 @@ template <int N> struct pg_int { static constexpr int value = N; };
 
 // tools/exp/pgemm_anatomy.hip only: per-block device-clock stamps (wave 0) and ablation switches
 #ifdef TAMD_IGEMM_STAMPS
-#define PG_STAMP(i) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[(size_t)blockIdx.x * 8 + (i)] = ((i) == 0 || (i) == 6) ? (long long)wall_clock64() : (long long)clock64(); } while (0)
+#define PG_STAMP(i) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[((size_t)pg_rep * gridDim.x + blockIdx.x) * 8 + (i)] = ((i) == 0 || (i) == 6) ? (long long)wall_clock64() : (long long)clock64(); } while (0)
+// the whole tile computation pg_reps times in ONE launch (dbg_flags >> 8 extra passes): the second pass runs the same code with a
+// warm instruction cache -- how much of a block's time is instruction fetch?
+#define PG_REPS ((a.dbg_flags >> 8) + 1)
 #else
 #define PG_STAMP(i) do { } while (0)
+#define PG_REPS 1
 #endif
 #ifdef TAMD_PG_ABLATE            // run-time ablation switches (each costs a scalar branch where it is tested: only for A/B runs)
 #define PG_ON(bit) (!(a.dbg_flags & (bit)))
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
     // ONE LDS object (a second __shared__ makes hipcc drain vmcnt(0) in front of every ds_read of a glds pipeline)
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
 
+    [[maybe_unused]] const int pg_rep = 0;
     PG_STAMP(0);
     PG_STAMP(1);
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
@@ -330,6 +335,8 @@ __global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a
 
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
 
+    for (int pg_rep = 0; pg_rep < PG_REPS; pg_rep++) {
+    if (pg_rep) __syncthreads();
     PG_STAMP(0);
     PG_STAMP(1);
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
@@ -526,6 +533,7 @@ __global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a
     }
     PG_STAMP(5);
     PG_STAMP(6);
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -563,7 +571,7 @@ int conv_pgemm_stages(const ConvArgs& a) { return pg_kind(a) == PG_ROWS ? (a.ckp
 
 // variants: bit 0: BN 128 (else 64); bit 1: BM 64 (else 128); bit 2: KS 2 (512-thread blocks, intra-block split-K; 3x3 only)
 static constexpr int PG_LA = 4;            // ring depth of the generic kernels (the unrolled-taps kernel has 3 slots)
-int conv_pgemm_num_variants() { return 16; }
+int conv_pgemm_num_variants() { return 8; }        // (bit 3, the 3-slot ring, stays reachable through TAMD_PGEMM_RS3=1: measured slower everywhere)
 int conv_pgemm_bn(int variant) { return (variant & 1) ? 128 : 64; }
 static int pg_bm(int variant) { return (variant & 2) ? 64 : 128; }
 static int pg_ks(int variant) { return (variant & 4) ? 2 : 1; }

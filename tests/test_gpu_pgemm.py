@@ -87,15 +87,11 @@ def test_variants_really_run():
     for member in (VARIANTS[0], VARIANTS[2]):       # dilated 3x3 with 40 couts: the 64-channel-wide tiles only
         _, _, name = _run(member, PATCH_CASES[4], 1)
         assert member in name, (member, name)
-    for member in ("conv_pgemm_i8<64x64,3x3,rs3", "conv_pgemm_i8<128x64,3x3,rs3"):      # the 3-slot ring
-        for case in (PATCH_CASES[1], PATCH_CASES[3]):
-            want, got, name = _run(member, case, 1)
-            assert member in name, (member, name)
-            assert np.array_equal(got, want), (name, case)
-    for member, cases in ((KS2[0], (PATCH_CASES[1], PATCH_CASES[10])), (KS2[1], (PATCH_CASES[1],))):      # two / eight 64-channel chunks
-        for case in cases:       # (128 x 128 tiles over 7 x 7 images need more than 160 KB of LDS with two wave groups: not offered)
-            _, _, name = _run(member, case, 1)
-            assert member in name, (member, name)
+    for case in (PATCH_CASES[1], PATCH_CASES[10]):      # two / eight 64-channel chunks per wave group pair
+        _, _, name = _run(KS2[0], case, 1)
+        assert KS2[0] in name, (KS2[0], name)
+    # (128 x 128 tiles with two wave groups need 2 x (48 KB ring + two patch buffers): offered only where the patch is small --
+    #  single-image 14 x 14 tiles -- and covered by the parametrised exactness test where it applies)
 
 
 @pytest.mark.parametrize("member", ["conv_pgemm_i8<128x64", "conv_pgemm_i8<64x64"])

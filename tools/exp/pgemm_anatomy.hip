@@ -27,7 +27,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
     const size_t xb = (size_t)N * HW * HW * ckp + 4096;
     CK(hipMalloc(&x, xb)); CK(hipMalloc(&y, (size_t)N * OHW * OHW * cout_pad + 4096)); CK(hipMalloc(&z, 4096));
     CK(hipMalloc(&bias, cout_pad * 4 + 4096)); CK(hipMalloc(&sc, cout_pad * 4 + 4096));
-    const int max_blocks = 8192;
+    const int max_blocks = 16384;
     CK(hipMalloc(&ds, (size_t)max_blocks * 64));
     std::vector<int8_t> hx(xb), hw((size_t)cout_pad * kpad);
     srand(1);
@@ -62,7 +62,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
 #ifdef TAMD_PG_ABLATE
         for (int flags : {0, 2, 2 | 8, 2 | 16, 2 | 4, 2 | 32, 2 | 1, 63}) {
 #else
-        for (int flags : {0}) {
+        for (int flags : {0, 256}) {        // 256: the tile computation twice in one launch (second pass: warm instruction cache)
 #endif
             ap.dbg_flags = flags; ap.dbg_stamps = nullptr;
             for (int i = 0; i < 3; i++) CK(launch_conv_pgemm(ap, st));
@@ -77,8 +77,11 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             CK(hipMemsetAsync(ds, 0, (size_t)max_blocks * 64, st));
             CK(launch_conv_pgemm(ap, st));
             CK(hipStreamSynchronize(st));
-            std::vector<long long> h((size_t)grid * 8);
-            CK(hipMemcpy(h.data(), ds, h.size() * 8, hipMemcpyDeviceToHost));
+            const int reps = (flags >> 8) + 1;
+            std::vector<long long> hall((size_t)grid * 8 * reps);
+            CK(hipMemcpy(hall.data(), ds, hall.size() * 8, hipMemcpyDeviceToHost));
+            for (int rep = 0; rep < reps; rep++) {
+            std::vector<long long> h(hall.begin() + (size_t)rep * grid * 8, hall.begin() + (size_t)(rep + 1) * grid * 8);
             std::vector<long long> setup, land, loop, epi, total, wstart, wend;
             long long w0 = -1;
             for (int b = 0; b < grid; b++) if (h[b * 8 + 5]) w0 = (w0 < 0 || h[b * 8] < w0) ? h[b * 8] : w0;
@@ -93,10 +96,11 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             }
             std::sort(ids.begin(), ids.end());
             cus = (int)(std::unique(ids.begin(), ids.end()) - ids.begin());
-            printf("%-30s flags %d (%s%s%s) %7.2f us/launch %4d tiles ns %d | cycles med/max: setup %lld/%lld land %lld/%lld loop %lld/%lld (%.0f/stage) epi %lld/%lld total %lld/%lld | wall ns: start med/max %lld/%lld end med/max %lld/%lld\n",
-                   conv_pgemm_kernel_name(ap), flags, flags & 1 ? "noMFMA " : "", flags & 2 ? "noEPI " : "", (std::string(flags & 4 ? "noLOAD " : "") + (flags & 8 ? "noBAR " : "") + (flags & 16 ? "noLDSRD " : "") + (flags & 32 ? "noWAIT" : "")).c_str(), 1e3 * ms / 20, tiles, ap.pg_ns,
+            printf("%-30s pass %d flags %d (%s%s%s) %7.2f us/launch %4d tiles ns %d | cycles med/max: setup %lld/%lld land %lld/%lld loop %lld/%lld (%.0f/stage) epi %lld/%lld total %lld/%lld | wall ns: start med/max %lld/%lld end med/max %lld/%lld\n",
+                   conv_pgemm_kernel_name(ap), rep, flags, flags & 1 ? "noMFMA " : "", flags & 2 ? "noEPI " : "", (std::string(flags & 4 ? "noLOAD " : "") + (flags & 8 ? "noBAR " : "") + (flags & 16 ? "noLDSRD " : "") + (flags & 32 ? "noWAIT" : "")).c_str(), 1e3 * ms / 20, tiles, ap.pg_ns,
                    pct(setup, .5), pct(setup, 1), pct(land, .5), pct(land, 1), pct(loop, .5), pct(loop, 1), (double)pct(loop, .5) / ap.pg_ns, pct(epi, .5), pct(epi, 1),
                    pct(total, .5), pct(total, 1), pct(wstart, .5), pct(wstart, 1), pct(wend, .5), pct(wend, 1));
+            }
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
     }
