@@ -248,6 +248,13 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
         issue_a(sl, p);
         issue_b(sl, p);
     }
+    // the epilogue's per-channel vectors, fetched now instead of at the start of the epilogue (see the unrolled-taps kernel)
+    const int EOFF = RING + (PATCH ? 2 * npad * 64 + 4096 : 0);
+    if (wave == 0) {
+        const int gq = (lane & 31) % (BN / 4);
+        const int8_t* src = lane < 32 ? (const int8_t*)(a.bias + n0) + gq * 16 : (const int8_t*)(a.wscale + n0) + gq * 16;
+        PG_GLDS16(src, smem + EOFF);
+    }
     PG_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PG_STAMP(4);
 
-    if (PG_ON(2)) igemm_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi);       // gemm_epilogue.h
+    if (PG_ON(2)) igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});       // gemm_epilogue.h
     PG_STAMP(5);
     PG_STAMP(6);
 #ifdef TAMD_IGEMM_STAMPS
@@ -364,6 +371,15 @@ __global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a
     };
 #pragma unroll
     for (int p = 0; p < D; p++) issue_a(stage_off(p), p);
+    // .. and the epilogue's per-channel vectors (bias, multipliers: 8 bytes per cout, touched once per layer -- fetched from global
+    // memory at the START of the epilogue they were a cold round trip of ~1000 cycles in every block): one LDS-DMA piece by wave 0,
+    // lanes 0-31 the bias granules, lanes 32-63 the multipliers'
+    const int EOFF = KS * GRP + 64;
+    if (wave == 0) {
+        const int gq = (lane & 31) % (BN / 4);
+        const int8_t* src = lane < 32 ? (const int8_t*)(a.bias + n0) + gq * 16 : (const int8_t*)(a.wscale + n0) + gq * 16;
+        PG_GLDS16(src, smem + EOFF);
+    }
 
     // ---- the patch (see the generic kernel for the virtual padded input) ------------------------------------------------------
     const int ohw = a.OH * a.OW, Hp = a.pg_hp, Wp = a.pg_wp;
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a
     PG_STAMP(4);
 
     if constexpr (KS == 1) {
-        if (PG_ON(2)) igemm_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi);
+        if (PG_ON(2)) igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});
     } else {
         // partial sums of the two groups: group 0 keeps pixel columns [0,32) of each wave tile, group 1 keeps [32,64); the other
         // half goes to the partner wave (wave ^ 4) through LDS -- then each runs the epilogue on its half
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a
 #pragma unroll
                 for (int k = 0; k < 4; k++) fin[i][0][4 * q + k] = acc[i][0][4 * q + k] + v[k];
             }
-        if (PG_ON(2)) igemm_epilogue<1, TN>(a, fin, m0 + (wm + grp) * 32, n0, wm, wn, l31, hi);
+        if (PG_ON(2)) igemm_epilogue_src<1, TN>(a, fin, m0 + (wm + grp) * 32, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});
     }
     PG_STAMP(5);
     PG_STAMP(6);
@@ -588,9 +604,9 @@ static size_t pg_lds(const ConvArgs& a, int variant, int npad)
 {
     const int bn = conv_pgemm_bn(variant), bm = pg_bm(variant);
     switch (pg_kind(a)) {
-    case PG_ROWS: return (size_t)PG_LA * (bn + bm) * 64;
-    case PG_TAPS3: return (size_t)pg_ks(variant) * (pg_rs(variant) * (size_t)bn * 64 + 2 * (size_t)npad * 64) + 64;
-    default: return (size_t)PG_LA * bn * 64 + 2 * (size_t)npad * 64 + 4096;
+    case PG_ROWS: return (size_t)PG_LA * (bn + bm) * 64 + 1024;
+    case PG_TAPS3: return (size_t)pg_ks(variant) * (pg_rs(variant) * (size_t)bn * 64 + 2 * (size_t)npad * 64) + 64 + 1024;     // + zero unit, + bias / multipliers of the cout tile
+    default: return (size_t)PG_LA * bn * 64 + 2 * (size_t)npad * 64 + 4096 + 1024;
     }
 }
 

@@ -8,8 +8,21 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 
 // ---- fused epilogue shared by the 32x32-tile GEMM kernels: +bias, requantise (bit-exact, epilogue.h), pack 4 channels,
 // NHWC store.  acc[i][j]: 32x32 tile (cout tile i, pixel tile j) of wave (wm, wn) of the block tile at (m0, n0).
-template <int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi)
+// where the per-channel vectors of the epilogue come from: global memory (a cold round trip at the start of every block's
+// epilogue -- these 8 bytes per channel are touched once per layer) or an LDS copy the kernel fetched while it set itself up
+struct EpiFromGlobal {
+    const int32_t* b; const float* s;
+    __device__ __forceinline__ int4 bias4(int c) const { return *reinterpret_cast<const int4*>(b + c); }
+    __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(s + c); }
+};
+struct EpiFromLds {               // [BN ints of bias][BN floats of multipliers] of the block's cout tile, at `base`
+    const int8_t* base; int n0, bn;
+    __device__ __forceinline__ int4 bias4(int c) const { return *reinterpret_cast<const int4*>(base + (c - n0) * 4); }
+    __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(base + (bn + c - n0) * 4); }
+};
+
+template <int TM, int TN, typename Src>
+__device__ __forceinline__ void igemm_epilogue_src(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi, const Src src)
 {
     // C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
     const Rq rq = a.rq;
@@ -27,8 +40,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
             const int c = n0 + (wn * TN + i) * 32 + 8 * g4 + 4 * hi;
-            b4s[i][g4] = *reinterpret_cast<const int4*>(a.bias + c);
-            s4s[i][g4] = *reinterpret_cast<const float4*>(a.wscale + c);
+            b4s[i][g4] = src.bias4(c);
+            s4s[i][g4] = src.scale4(c);
         }
     static_for<0, TN>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -74,6 +87,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[
             }
         });
     });
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi)
+{
+    igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromGlobal{a.bias, a.wscale});
 }
 
 }  // namespace tamd

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
+#include <algorithm>
 
 #include "kernels.h"
 
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_u8_gemm_k(const U8ConvArgs 
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
     // x = (image, pixel tile): blocks that stream the same weight tile are neighbours in launch order (L2 reuse)
-    const int n = blockIdx.x / tpi, tile = blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
+    // tail_only: the main pixels went through conv_u8_patch_k; one block per (image, cout tile) for the tail pixels
+    const int n = a.tail_only ? blockIdx.x : blockIdx.x / tpi, tile = a.tail_only ? tiles : blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
     if (tile < tiles) conv_u8_body<WM, WN, TM, TN, KC, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
     else conv_u8_body<WM, WN, TM, TN, KC, true>(a, ws, xs, lut, n, N8, OHW, co0);
 }
@@ -397,7 +400,8 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
     const int bm = U8_CFGS[a.cfg].bm, bn = U8_CFGS[a.cfg].bn;
-    const dim3 grid(((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
+    const dim3 grid(a.tail_only ? a.N : ((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
+    if (a.tail_only && !ntail) return hipSuccess;
     const size_t lds = conv_u8_gemm_lds(a);
     auto go = [&](auto kern, int threads) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -414,6 +418,286 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
     case 7: return go(conv_u8_gemm_k<2, 2, 1, 1, 64>, 256);
     default: return go(conv_u8_gemm_k<2, 2, 1, 1, 32>, 256);
     }
+}
+
+// =================================================================================================================
+// The same GEMM for the MAIN pixels with the B operand read from an LDS-resident fp32 PATCH (round 3).
+//
+// conv_u8_body gathers and dequantises every im2col element -- a 3x3 layer touches each input byte nine times, ~14 VALU
+// instructions per touch (tap decode, bounds, byte load, (x - zp) * scale), ~150 per thread per 32 MFMAs -- and a wave issues one
+// instruction per 8-10 cycles: the kernels sat at 21-30 % of the fp32 MFMA rate on their staging.  Here the block keeps the input
+// patch of its pixel tile (every input row the tile touches, halo rows and columns included as real 0.0f, exactly the reference's
+// padding taps) for a chunk of channels in LDS, ALREADY dequantised, [channel][patch pixel] floats: each input byte is converted once per
+// block and chunk, and the B value of MFMA step s for lane (pixel l15, k%4 = kq) is ONE ds_read_b32 at a per-lane address computed
+// once in the prologue -- k = 4s + kq inside a super-step of 4*SS k decomposes into (channel, ky, kx) the same way in every
+// super-step (4*SS is a multiple of KH*KW), so the SS addresses per pixel tile are loop invariants; the super-step's channel
+// base is a scalar.  Summation order: unchanged -- accumulator tile (i, j) receives its k in ascending steps of 4, which
+// v_mfma_f32_16x16x4f32 adds as four fused multiply-adds in ascending k (conv_u8_body's header) -- so the bytes are the
+// reference's.  Weights: raw bytes as before, [cout tile][super-step][row][k%4][12 slots], dequantised while staged through a
+// register ring into LDS ([row][k%4][13-float groups]: conflict-free float4 fragment reads), one barrier per super-step
+// (36 MFMAs per wave for a 64 x 64 tile).  Tail pixels (OH*OW % 8) keep conv_u8_gemm's four-chain blocks (tail_only launch).
+// =================================================================================================================
+template <int TM, int TN, int KHW>
+__global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
+{
+    constexpr int WM = 2, WN = 2, BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int NTAPS = KHW * KHW;
+    constexpr int SS = KHW == 3 ? 9 : 8;                 // MFMA steps per super-step: 36 k = 4 channels x 9 taps | 32 k = 32 channels
+    constexpr int CSS = 4 * SS / NTAPS;                  // channels per super-step
+    constexpr int CPC = KHW == 3 ? 4 : 1;                // super-steps per patch chunk
+    constexpr int CC = CPC * CSS;                        // channels per patch chunk (16 | 32)
+    constexpr int LDA = 52;                              // floats per weight row in LDS: 4 classes x 13 (12 slots + 1 pad)
+    constexpr int NPS = KHW == 3 ? 2 : 1;                // patch pixels per thread per channel (npad <= 512 | 256)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wsm = smem;                                   // [2][BM][LDA]
+    float* patch = smem + 2 * BM * LDA;                  // [2][CC][npad]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM, l15 = lane & 15, kq = lane >> 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    const int tiles = (N8 + BN - 1) / BN;
+    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles, co0 = blockIdx.y * BM;
+    const int jbase = tile * BN, jlimit = N8;
+    const int npad = a.pk_npad, Wp = a.pk_wp;
+    const int KH = a.pk_kh, KW = a.pk_kw, DH = a.pk_dh, DW = a.pk_dw;
+
+    // ---- patch geometry of this pixel tile ---------------------------------------------------------------------------------
+    int oy_a, ox_a, oy_b, ox_b;
+    conv_pixel(a, jbase, &oy_a, &ox_a);
+    conv_pixel(a, (jbase + BN < jlimit ? jbase + BN : jlimit) - 1, &oy_b, &ox_b);
+    const int R0 = oy_a * a.SH - a.PH;                                       // input row of patch row 0
+    const int NP = ((oy_b - oy_a) * a.SH + (KH - 1) * DH + 1) * Wp;
+    const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
+    const int chw = a.H * a.W;
+    int soff[NPS];                                       // this thread's patch pixels: offset inside a channel plane, -1 outside the image
+#pragma unroll
+    for (int q = 0; q < NPS; q++) {
+        const int pp = tid + 256 * q;
+        const int prow = pp / Wp, pcol = pp - prow * Wp;
+        const int iy = R0 + prow, ix = pcol - a.PW;
+        soff[q] = (pp < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? iy * a.W + ix : -1;
+    }
+    const int nss = a.K / (4 * SS), nchunk = (a.C + CC - 1) / CC;
+    unsigned pregs[NPS][CC];                             // raw bytes of the chunk in flight (one register each: no wait until they are used)
+    auto pload = [&](int c) {
+        const int c0 = (c < nchunk ? c : nchunk - 1) * CC;                   // past the end: a harmless repeat
+#pragma unroll
+        for (int q = 0; q < NPS; q++)
+#pragma unroll
+            for (int cl = 0; cl < CC; cl++) {
+                const int ch = c0 + cl < a.C ? c0 + cl : a.C - 1;
+                pregs[q][cl] = xin[(size_t)ch * chw + (soff[q] >= 0 ? soff[q] : 0)];
+            }
+    };
+    auto pstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NPS; q++) {
+            const int pp = tid + 256 * q;
+            if (pp < npad) {
+#pragma unroll
+                for (int cl = 0; cl < CC; cl++)
+                    patch[(buf * CC + cl) * npad + pp] = soff[q] >= 0 ? dequant((uint8_t)pregs[q][cl], a.in_zp, a.in_scale) : 0.f;
+            }
+        }
+    };
+
+    // ---- weights: thread (row, class) stages 12 slots of its row per super-step through a 2-deep register ring ----------------
+    const int srow = tid >> 2, scls = tid & 3;
+    const bool sact = srow < BM;
+    const unsigned* wtile = reinterpret_cast<const unsigned*>(a.wpk + (size_t)(co0 / BM) * nss * (BM * 48)) + (sact ? (srow * 4 + scls) * 3 : 0);
+    unsigned wr[2][3];
+    auto wload = [&](int d, int ss) {
+        const unsigned* p = wtile + (size_t)(ss < nss ? ss : nss - 1) * (BM * 12);
+        wr[d][0] = p[0]; wr[d][1] = p[1]; wr[d][2] = p[2];
+    };
+    auto wstore = [&](int d, int buf) {
+        if (!sact) return;
+        float* q = wsm + (buf * BM + srow) * LDA + scls * 13;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            float4 w;
+            w.x = dequant((uint8_t)wr[d][v], a.w_zp, a.w_scale);
+            w.y = dequant((uint8_t)(wr[d][v] >> 8), a.w_zp, a.w_scale);
+            w.z = dequant((uint8_t)(wr[d][v] >> 16), a.w_zp, a.w_scale);
+            w.w = dequant((uint8_t)(wr[d][v] >> 24), a.w_zp, a.w_scale);
+            q[4 * v] = w.x; q[4 * v + 1] = w.y; q[4 * v + 2] = w.z; q[4 * v + 3] = w.w;      // 13-float groups: dword stores
+        }
+    };
+
+    // ---- per-lane B addresses (floats, relative to the chunk's first channel plane of the super-step) --------------------------
+    int baddr[TN][SS];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        int pj = jbase + (wn * TN + j) * 16 + l15;
+        pj = pj < jlimit ? pj : jlimit - 1;
+        int oy, ox;
+        conv_pixel(a, pj, &oy, &ox);
+        const int pp0 = ((oy - oy_a) * a.SH) * Wp + ox * a.SW;
+#pragma unroll
+        for (int s = 0; s < SS; s++) {
+            const int kl = 4 * s + kq, cl = kl / NTAPS, tap = kl - cl * NTAPS, ky = tap / KHW, kx = tap - ky * KHW;
+            baddr[j][s] = cl * npad + pp0 + ky * DH * Wp + kx * DW;
+        }
+    }
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: chunk 0 in patch buffer 0, chunk 1's bytes in flight, the first two super-steps of weights in the ring -----
+    wload(0, 0);
+    wload(1, 1);
+    pload(0);
+    pstore(0);
+    pload(1);
+    // one super-step; D: ring slot == weight buffer (compile-time: a dynamically indexed register array would live in scratch)
+    auto superstep = [&](int ss, auto D) {
+        constexpr int d = decltype(D)::value;
+        const int c = ss / CPC, u = ss - c * CPC;
+        __builtin_amdgcn_sched_barrier(0);
+        wstore(d, d);                                    // buffer d was last read two super-steps ago: every wave is past that barrier
+        wload(d, ss + 2);
+        __syncthreads();
+        if (u == CPC - 1) {
+            // the next chunk's patch, behind the barrier: every wave has finished the chunk that buffer held (with one super-step
+            // per chunk -- 1 x 1 -- that was the PREVIOUS super-step); its bytes were requested a chunk ago
+            pstore((c + 1) & 1);
+            pload(c + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* wsb = wsm + d * BM * LDA;
+        const float* pb = patch + ((c & 1) * CC + u * CSS) * npad;
+        float af[TM][SS];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const float* q = wsb + ((wm * TM + i) * 16 + l15) * LDA + kq * 13;
+#pragma unroll
+            for (int v = 0; v < SS; v++) af[i][v] = q[v];
+        }
+#pragma unroll
+        for (int s = 0; s < SS; s++) {
+            float bf[TN];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = pb[baddr[j][s]];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    for (int ss = 0; ss < nss; ss += 2) {
+        superstep(ss, std::integral_constant<int, 0>{});
+        if (ss + 1 < nss) superstep(ss + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue (conv_u8_body's, main pixels): D[row = 4*kq + e][col = l15] of each 16x16 tile ------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int pj = jbase + (wn * TN + j) * 16 + l15;
+        if (pj >= jlimit) continue;
+        int oy, ox;
+        conv_pixel(a, pj, &oy, &ox);
+        const int opix = oy * a.OW + ox;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int co = co0 + (wm * TM + i) * 16 + 4 * kq + e;
+                if (co >= a.cout) continue;
+                float s = acc[i][j][e];
+                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+                if (a.act == 0) s = s < 0.f ? 0.f : s;
+                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
+                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
+                if (a.pool.on) {
+                    const int m = quad_max((int)q);
+                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = pooled_byte(m, a.pool);
+                }
+            }
+    }
+}
+
+static const struct { int tm, tn; const char* n3; const char* n1; } U8P_CFGS[] = {
+    {2, 2, "conv_u8_patch_64x64<3x3>", "conv_u8_patch_64x64<1x1>"}, {1, 2, "conv_u8_patch_32x64<3x3>", "conv_u8_patch_32x64<1x1>"}};
+int conv_u8_patch_num_cfgs() { return 2; }
+int conv_u8_patch_bm(int cfg) { return U8P_CFGS[cfg].tm * 32; }
+int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 8 : 0; }
+const char* conv_u8_patch_kernel_name(const U8ConvArgs& a) { return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1; }
+
+static size_t u8p_lds(const U8ConvArgs& a)
+{
+    const int bm = conv_u8_patch_bm(a.pk_cfg), cc = a.pk_kh == 3 ? 16 : 32;
+    return (size_t)(2 * bm * 52 + 2 * cc * a.pk_npad) * 4;
+}
+
+// fills the patch fields of `a` for tile configuration cfg; false: this convolution does not go through the patch kernel
+bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
+{
+    static const bool off = getenv("TAMD_U8_PATCH") && atoi(getenv("TAMD_U8_PATCH")) == 0;
+    a.pk_cfg = -1;
+    a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
+    const int ss = conv_u8_patch_ss(a);
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = U8P_CFGS[cfg].tn * 32;
+    if (off || !ss || N8 == 0 || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 32) != 0 || a.PH < 0 || a.PW < 0) return false;
+    if ((size_t)a.C * a.H * a.W >= (1u << 31)) return false;
+    a.pk_wp = (a.OW - 1) * a.SW + (KW - 1) * DW + 1;
+    if (a.pk_wp < a.W + a.PW) a.pk_wp = a.W + a.PW;             // every column a tap can name: [-PW, max(W, last tap) )
+    // rows the worst pixel tile touches (window-major enumeration under a fused pool: two output rows per window row)
+    int worst = 0;
+    for (int j0 = 0; j0 < N8; j0 += bn) {
+        const int j1 = std::min(j0 + bn, N8) - 1;
+        int oy0, oy1;
+        if (a.pool.on) { const int half = a.OW >> 1; oy0 = 2 * ((j0 >> 2) / half); oy1 = 2 * ((j1 >> 2) / half) + 1; }
+        else { oy0 = j0 / a.OW; oy1 = j1 / a.OW; }
+        worst = std::max(worst, ((oy1 - oy0) * a.SH + (KH - 1) * DH + 1) * a.pk_wp);
+    }
+    a.pk_npad = (worst + 63) / 64 * 64;
+    a.pk_cfg = cfg;
+    if (a.pk_npad > (KH == 3 ? 512 : 256) || u8p_lds(a) > 150 * 1024) { a.pk_cfg = -1; return false; }
+    return true;
+}
+
+size_t conv_u8_patch_packed_bytes(const U8ConvArgs& a)
+{
+    const int bm = conv_u8_patch_bm(a.pk_cfg), ss = conv_u8_patch_ss(a);
+    return (size_t)((a.cout + bm - 1) / bm) * (a.K / (4 * ss) + 2) * bm * 48 + 64;        // + two super-steps the ring may prefetch past the end
+}
+
+void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, uint8_t* out)
+{
+    const int bm = conv_u8_patch_bm(a.pk_cfg), ss = conv_u8_patch_ss(a), nss = a.K / (4 * ss);
+    const size_t total = conv_u8_patch_packed_bytes(a);
+    for (size_t i = 0; i < total; i++) out[i] = w_zp;
+    for (int co = 0; co < a.cout; co++)
+        for (int k = 0; k < a.K; k++) {
+            const int st = k / (4 * ss), kl = k % (4 * ss), s = kl >> 2, cls = kl & 3;
+            out[((size_t)(co / bm) * nss + st) * (bm * 48) + ((co % bm) * 4 + cls) * 12 + s] = w[(size_t)co * a.K + k];
+        }
+}
+
+hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s)
+{
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    const int bm = conv_u8_patch_bm(a.pk_cfg), bn = U8P_CFGS[a.pk_cfg].tn * 32;
+    const dim3 grid(((N8 + bn - 1) / bn) * a.N, (a.cout + bm - 1) / bm, 1);
+    const size_t lds = u8p_lds(a);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return hipGetLastError();
+    };
+    const bool k3 = a.pk_kh == 3;
+    hipError_t e;
+    if (a.pk_cfg == 0) e = k3 ? go(conv_u8_patch_k<2, 2, 3>) : go(conv_u8_patch_k<2, 2, 1>);
+    else e = k3 ? go(conv_u8_patch_k<1, 2, 3>) : go(conv_u8_patch_k<1, 2, 1>);
+    if (e != hipSuccess || OHW == N8) return e;
+    U8ConvArgs t = a;                                    // the tail pixels of every image: conv_u8_gemm's four-chain blocks
+    t.tail_only = 1;
+    return launch_conv_u8_gemm(t, s);
 }
 
 // =================================================================================================================
