@@ -398,12 +398,14 @@ def main():
 
 def pmc_traffic(model, dtype, batch, family):
     """HBM bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC summary of this workload
-    (profiles/r02_traffic_<model>_<dtype>_b<batch>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
+    (profiles/rNN_traffic_<model>_<dtype>_b<batch>.json, the newest round's: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
     same-session streaming-copy calibration -- tools/collect_profiles.sh, tools/traffic_summary.py); None when this
     workload has no PMC pass (counters cannot be collected from inside the timed process)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic_%s_%s_b%d.json" % (model, dtype, batch))
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_%s_%s_b%d.json" % (model, dtype, batch))))
+    if not found:
         return None
+    path = found[-1]
     ks = json.load(open(path))["kernels"]
     tot, n = 0.0, 0
     import re

@@ -121,6 +121,7 @@ struct tamd_graph {
     tamd::DirectProgram* direct = nullptr;     // tamd_options.direct_dispatch: the launch list as AQL packets (direct.cc)
     tamd::DirectProgram* direct_io = nullptr;  // .. the host-to-host list of I/O slot 0 (tamd_graph_run), same HSA queue
     tamd::DirectProgram* direct_io2 = nullptr; // .. of I/O slot 1 (the second asynchronous run in flight)
+    int autotune_cold = -1;                    // plan-time timing mode, decided once (autotune_cold())
     double prerun_ms = 0;                      // wall time of tamd_graph_prerun (planning, autotune, capture)
     bool direct_busy = false;                  // passes submitted since the last wait
     tamd_options opt{};
@@ -133,6 +134,13 @@ namespace tamd {
 // planner helpers shared by graph.hip (int8, NHWC) and graph_u8.hip (uint8, NCHW)
 PoolGeom pool_geom(const tamd_pool_param& p, int h, int w);
 int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
+// plan-time autotune: candidates of a graph whose pass moves far more bytes than the L2s hold are timed COLD -- every timed
+// launch behind a fill of kL2FlushBytes (l2_flush_buffer(): one per device, kept for the life of the process) -- because that
+// is how they run inside a pass; small graphs (batch-1 classifiers live in the L2s from step to step) keep back-to-back timing
+constexpr size_t kL2FlushBytes = 64u << 20;
+void* l2_flush_buffer();
+bool autotune_cold(tamd_graph* g);
+int time_cold(tamd_graph* g, void* flush, const std::function<hipError_t()>& launch, float* ms_out);      // graph.hip
 void nhwc_geom(HTensor& t);
 int count_consumers(const tamd_graph* g, int tensor);
 int priorbox_count(const tamd_priorbox_param& p);

@@ -13,6 +13,8 @@
 #include <cstring>
 
 #include <functional>
+#include <map>
+#include <mutex>
 
 #include "graph.h"
 
@@ -169,15 +171,36 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         // plan-time autotune over the tile configurations (every one produces the same bytes: the chain order of an
         // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
+        // the patch kernel (3x3 / 1x1 with whole super-steps of channels): one more candidate of the same bytes.
+        // TAMD_U8_PATCH=0 never (conv_u8_patch_prepare), =1 whenever it applies (tests), otherwise it has to win the timing
+        const char* pk_env = getenv("TAMD_U8_PATCH");
+        const bool pk_force = pk_env && atoi(pk_env) == 1;
+        int pk_best = -1;
+        float* pk_w = nullptr;                     // dequantised weights in fragment order: one copy serves every tile configuration
+        auto patch_for = [&](U8ConvArgs& ac, int c) -> int {          // 1: ready, 0: not applicable, -1: error
+            if (!conv_u8_patch_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) return 0;
+            if (!pk_w) {
+                std::vector<float> wp(conv_u8_patch_packed_bytes(ac) / 4);
+                conv_u8_patch_pack(ac, w.data.data(), (uint8_t)qw.zp, qw.scale, wp.data());
+                if (upload(g, wp, &pk_w)) return -1;
+            }
+            ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
+            return 1;
+        };
         static const char* at_env = getenv("TAMD_AUTOTUNE");
         if (!(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG")) {
             hipEvent_t e0, e1;
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             float best_ms = 1e30f;
             int best_cfg = a.cfg;
-            // per-launch time of a candidate: a warm-up launch, then 5 back-to-back launches (25 when that is under 20 us)
+            // per-launch time of a candidate AS IT RUNS INSIDE A PASS (time_cold: weights evicted, input left by its producer);
+            // back-to-back launches of one layer flatter the latency-bound members by 30-60 % (profiles/r03_insitu_*).
+            // Small graphs / TAMD_AUTOTUNE_COLD=0: the
+            // warm timing (a warm-up launch, then 5 back-to-back launches, 25 when that is under 20 us)
+            void* flush = autotune_cold(g) ? l2_flush_buffer() : nullptr;
             auto time_of = [&](const std::function<hipError_t()>& launch, float* out) -> int {
                 if (launch() != hipSuccess) { (void)hipGetLastError(); *out = 1e30f; return 0; }
+                if (flush) return time_cold(g, flush, launch, out);
                 int reps = 5;
                 for (int round = 0; round < 2; round++) {
                     HIPCHK(hipEventRecord(e0, g->stream));
@@ -202,6 +225,19 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 float ms = 0;
                 if (time_of([&]() { return launch_conv_u8_gemm(ac, g->stream); }, &ms)) return -1;
                 if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best_cfg = c; }
+            }
+            {
+                float pk_ms = 1e30f;
+                for (int c = 0; c < conv_u8_patch_num_cfgs(); c++) {
+                    U8ConvArgs ac = a;
+                    const int r = patch_for(ac, c);
+                    if (r < 0) return -1;
+                    if (!r) continue;
+                    float ms = 0;
+                    if (time_of([&]() { return launch_conv_u8_patch(ac, g->stream); }, &ms)) return -1;
+                    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (gemm family best %.2f us)\n", n.name.c_str(), conv_u8_patch_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
+                    if (pk_force ? ms < pk_ms : ms < best_ms * 0.96f) { pk_best = c; pk_ms = ms; if (!pk_force) best_ms = ms; }
+                }
             }
             // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
             const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
@@ -230,8 +266,21 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
-        st.kernel = std::string(conv_u8_gemm_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
-        st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
+        if (pk_force && pk_best < 0)
+            for (int c = 0; c < conv_u8_patch_num_cfgs() && pk_best < 0; c++) {
+                U8ConvArgs ac = a;
+                const int r = patch_for(ac, c);
+                if (r < 0) return -1;
+                if (r) pk_best = c;
+            }
+        if (pk_best >= 0) {
+            if (patch_for(a, pk_best) != 1) return -1;
+            st.kernel = std::string(conv_u8_patch_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+            st.fn = [a](hipStream_t s) { return launch_conv_u8_patch(a, s); };
+        } else {
+            st.kernel = std::string(conv_u8_gemm_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+            st.fn = [a](hipStream_t s) { return launch_conv_u8_gemm(a, s); };
+        }
     } else {
         std::vector<float> wf((size_t)cout * K);
         for (size_t i = 0; i < wf.size(); i++) wf[i] = ((float)w.data[i] - (float)qw.zp) * qw.scale;

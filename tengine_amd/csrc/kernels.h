@@ -273,11 +273,10 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int wf_ld;
     U8PoolFuse pool;           // fused max-pool node (conv_u8_gemm main tiles and conv_u8_rgb3x3)
     // conv_u8_patch (u8_kernels.hip): the main pixels (j < (OH*OW)&~7) from an LDS-resident fp32 input patch
-    const uint8_t* wpk;        // raw weights, [cout tile of pk_bm][super-step of 4*SS k][row][k%4][12 slots: step s holds k = 4s + k%4]
+    const uint8_t* wpk;        // DEQUANTISED weights (floats) in MFMA A-fragment order, [16-row tile][super-step of 4*SS k][float4 group][lane]
     int pk_cfg;                // -1: not used; else tile configuration of launch_conv_u8_patch
-    int pk_npad, pk_wp;        // patch pixels of the worst pixel tile (multiple of 64) / patch row pitch (input columns incl. halo)
+    int pk_npad, pk_wp;        // floats per channel plane of the patch (3x3: 256 | 512, 1x1: the pixel tile) / patch row pitch (input columns incl. halo)
     int pk_kh, pk_kw, pk_dh, pk_dw;    // filter shape / dilation (the GEMM kernel gets them through klut)
-    int tail_only;             // conv_u8_gemm: run the tail-pixel blocks only (the main pixels went through conv_u8_patch)
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
@@ -339,14 +338,14 @@ int conv_u8_gemm_kc(int cfg);                      // K stage depth (weight pack
 int conv_u8_gemm_num_cfgs();
 size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the chosen configuration
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
-// main pixels from an LDS-resident fp32 patch (3x3 and 1x1, group 1); tail pixels, if any, by conv_u8_gemm with tail_only
+// main pixels from an LDS-resident fp32 patch (3x3 and 1x1, group 1); tail pixels, if any, on the VALU by extra blocks of the same launch
 int conv_u8_patch_num_cfgs();
 int conv_u8_patch_bm(int cfg);
 int conv_u8_patch_ss(const U8ConvArgs& a);                         // MFMA steps per super-step (9: 3x3, 8: 1x1); 0: shape not supported
 bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW);     // fills pk_*; false: not applicable
 const char* conv_u8_patch_kernel_name(const U8ConvArgs& a);
 size_t conv_u8_patch_packed_bytes(const U8ConvArgs& a);
-void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, uint8_t* out);       // w: [cout][K] as in the model
+void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, float w_scale, float* out);       // w: [cout][K] as in the model
 hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);

@@ -360,8 +360,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_u8_gemm_k(const U8ConvArgs 
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
     // x = (image, pixel tile): blocks that stream the same weight tile are neighbours in launch order (L2 reuse)
-    // tail_only: the main pixels went through conv_u8_patch_k; one block per (image, cout tile) for the tail pixels
-    const int n = a.tail_only ? blockIdx.x : blockIdx.x / tpi, tile = a.tail_only ? tiles : blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
+    const int n = blockIdx.x / tpi, tile = blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
     if (tile < tiles) conv_u8_body<WM, WN, TM, TN, KC, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
     else conv_u8_body<WM, WN, TM, TN, KC, true>(a, ws, xs, lut, n, N8, OHW, co0);
 }
@@ -400,8 +399,7 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, ntail = OHW - N8;
     const int bm = U8_CFGS[a.cfg].bm, bn = U8_CFGS[a.cfg].bn;
-    const dim3 grid(a.tail_only ? a.N : ((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
-    if (a.tail_only && !ntail) return hipSuccess;
+    const dim3 grid(((N8 + bn - 1) / bn + (ntail ? 1 : 0)) * a.N, (a.cout + bm - 1) / bm, 1);
     const size_t lds = conv_u8_gemm_lds(a);
     auto go = [&](auto kern, int threads) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -421,122 +419,255 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 }
 
 // =================================================================================================================
-// The same GEMM for the MAIN pixels with the B operand read from an LDS-resident fp32 PATCH (round 3).
+// The same GEMM for the MAIN pixels with both operands free of per-element staging (round 3).
 //
-// conv_u8_body gathers and dequantises every im2col element -- a 3x3 layer touches each input byte nine times, ~14 VALU
-// instructions per touch (tap decode, bounds, byte load, (x - zp) * scale), ~150 per thread per 32 MFMAs -- and a wave issues one
-// instruction per 8-10 cycles: the kernels sat at 21-30 % of the fp32 MFMA rate on their staging.  Here the block keeps the input
-// patch of its pixel tile (every input row the tile touches, halo rows and columns included as real 0.0f, exactly the reference's
-// padding taps) for a chunk of channels in LDS, ALREADY dequantised, [channel][patch pixel] floats: each input byte is converted once per
-// block and chunk, and the B value of MFMA step s for lane (pixel l15, k%4 = kq) is ONE ds_read_b32 at a per-lane address computed
-// once in the prologue -- k = 4s + kq inside a super-step of 4*SS k decomposes into (channel, ky, kx) the same way in every
-// super-step (4*SS is a multiple of KH*KW), so the SS addresses per pixel tile are loop invariants; the super-step's channel
-// base is a scalar.  Summation order: unchanged -- accumulator tile (i, j) receives its k in ascending steps of 4, which
-// v_mfma_f32_16x16x4f32 adds as four fused multiply-adds in ascending k (conv_u8_body's header) -- so the bytes are the
-// reference's.  Weights: raw bytes as before, [cout tile][super-step][row][k%4][12 slots], dequantised while staged through a
-// register ring into LDS ([row][k%4][13-float groups]: conflict-free float4 fragment reads), one barrier per super-step
-// (36 MFMAs per wave for a 64 x 64 tile).  Tail pixels (OH*OW % 8) keep conv_u8_gemm's four-chain blocks (tail_only launch).
+// conv_u8_body gathers and dequantises every im2col element and every weight -- a 3x3 layer touches each input byte nine times,
+// ~14 VALU instructions per touch (tap decode, bounds, byte load, (x - zp) * scale), ~150 per thread per 32 MFMAs -- and a wave
+// issues one instruction per 8-10 cycles: the kernels sat at 21-30 % of the fp32 MFMA rate on their staging.  Here
+//   B (input):  the block keeps the input patch of its pixel tile (3x3: every input row the tile touches, halo rows and columns
+//     included as real 0.0f -- the reference's padding taps; 1x1: the tile's own pixels) for a chunk of channels in LDS, ALREADY
+//     dequantised, [channel][patch pixel] floats with a compile-time plane stride: each input byte is converted once per block
+//     and chunk, and the B value of MFMA step s for lane (pixel l15, k%4 = kq) is ONE ds_read_b32 at a per-lane address computed
+//     once in the prologue plus an immediate -- k = 4s + kq inside a super-step of 4*SS k decomposes into (channel, ky, kx) the
+//     same way in every super-step (4*SS is a multiple of KH*KW), so the SS addresses per pixel tile are loop invariants;
+//   A (weights): dequantised ONCE at plan time on the host -- ((float)w - zp) * scale in fp32 is the same IEEE value wherever it
+//     is computed -- and stored in the MFMA A-fragment order, [16-row tile][super-step][float4 group][lane]: a wave fetches its
+//     fragments of the NEXT super-step straight from global memory (L2-resident, shared by every pixel tile) into registers,
+//     no LDS, no conversion, no barrier.
+// One barrier per patch chunk (4 super-steps of a 3x3 layer).  Summation order: unchanged -- accumulator tile (i, j) receives its
+// k in ascending steps of 4, which v_mfma_f32_16x16x4f32 adds as four fused multiply-adds in ascending k (conv_u8_body's
+// header) -- so the bytes are the reference's.  Tail pixels (OH*OW % 8): conv_u8_patch_tail, extra blocks of the same launch.
+// Blocks are numbered so that the eight XCDs split the cout tiles between them (each L2 holds its own slice of the weights).
 // =================================================================================================================
-template <int TM, int TN, int KHW>
+// The tail pixels (j >= (OH*OW)&~7) of the patch kernel's layers, on the VALU in the same launch: a lane owns one of the
+// reference's four k%4 chains of one output -- lane (row l15, chain r = lane/16) of a wave walks k = r, r+4, r+8, .. with fmaf
+// (what the MFMA does inside its step, conv_u8_body's header), reading its weights from the SAME fragment stream a main wave
+// fetches (lane (l15, r) of the MFMA A operand holds exactly row l15, k%4 = r) and the dequantised im2col column of its pixel
+// from LDS, class-major; the four chains meet in lanes 0..15 and are combined as the reference combines them
+// (conv_u8_body: rows inside an 8-/4-row block ((0+(s0+s1))+(s2+s3)), the last cout%4 rows ((s0+s1)+s2)+s3).  K%4 == 0 here
+// (the patch kernel takes whole super-steps only), so there is no scalar remainder.  A block = (image, tail pixel, 64 channels).
+template <int KHW>
+__device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* xs, int tb)
+{
+    constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 8, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64, RING = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, r = lane >> 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, T = OHW - N8, slices = (a.cout + 63) / 64;
+    const int slice = tb % slices, nt = tb / slices, t = nt % T, n = nt / T;
+    const int opix = N8 + t, oy = opix / a.OW, ox = opix - oy * a.OW;          // no fused pool on a layer with tail pixels
+    const int K4 = a.K >> 2, chw = a.H * a.W;
+    const uint8_t* xin = a.x + (size_t)n * a.C * chw;
+    for (int k = tid; k < a.K; k += 256) {
+        const int c = k / NTAPS, tap = k - c * NTAPS, ky = tap / KHW, kx = tap - ky * KHW;
+        const int iy = oy * a.SH - a.PH + ky * a.pk_dh, ix = ox * a.SW - a.PW + kx * a.pk_dw;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = dequant(xin[(size_t)c * chw + iy * a.W + ix], a.in_zp, a.in_scale);
+        xs[(k & 3) * K4 + (k >> 2)] = v;
+    }
+    __syncthreads();
+    const int tile16 = slice * 4 + wave;
+    if (tile16 * 16 >= a.cout) return;
+    const int nss = a.K / (4 * SS);
+    const float* wb = reinterpret_cast<const float*>(a.wpk) + (size_t)tile16 * nss * FRAG;
+    const float* xr = xs + r * K4;
+    float4 w4[RING][G4];
+    float wr[RING][REM > 0 ? REM : 1];
+    auto wload = [&](auto D, int ss) {
+        constexpr int d = decltype(D)::value;
+        const size_t o = (size_t)(ss < nss ? ss : nss - 1) * FRAG;
+#pragma unroll
+        for (int v = 0; v < G4; v++) w4[d][v] = *reinterpret_cast<const float4*>(wb + o + v * 256 + lane * 4);
+#pragma unroll
+        for (int v = 0; v < REM; v++) wr[d][v] = wb[o + G4 * 256 + lane * REM + v];
+    };
+    float acc = 0.f;
+    auto sstep = [&](auto D, int ss) {
+        constexpr int d = decltype(D)::value;
+        wload(std::integral_constant<int, (d + RING - 1) % RING>{}, ss + RING - 1);
+        const float* xp = xr + ss * SS;
+#pragma unroll
+        for (int v = 0; v < G4; v++) {
+            acc = __builtin_fmaf(w4[d][v].x, xp[4 * v], acc);
+            acc = __builtin_fmaf(w4[d][v].y, xp[4 * v + 1], acc);
+            acc = __builtin_fmaf(w4[d][v].z, xp[4 * v + 2], acc);
+            acc = __builtin_fmaf(w4[d][v].w, xp[4 * v + 3], acc);
+        }
+#pragma unroll
+        for (int v = 0; v < REM; v++) acc = __builtin_fmaf(wr[d][v], xp[4 * G4 + v], acc);
+    };
+    wload(std::integral_constant<int, 0>{}, 0);
+    wload(std::integral_constant<int, 1>{}, 1);
+    wload(std::integral_constant<int, 2>{}, 2);
+    for (int ss = 0; ss < nss; ss += RING) {
+        sstep(std::integral_constant<int, 0>{}, ss);
+        if (ss + 1 < nss) sstep(std::integral_constant<int, 1>{}, ss + 1);
+        if (ss + 2 < nss) sstep(std::integral_constant<int, 2>{}, ss + 2);
+        if (ss + 3 < nss) sstep(std::integral_constant<int, 3>{}, ss + 3);
+    }
+    const float s1 = __shfl(acc, l15 + 16), s2 = __shfl(acc, l15 + 32), s3 = __shfl(acc, l15 + 48);
+    const int co = tile16 * 16 + l15;
+    if (r != 0 || co >= a.cout) return;
+    float s = co < a.m_blocked ? (0.f + (acc + s1)) + (s2 + s3) : ((acc + s1) + s2) + s3;
+    if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+    if (a.act == 0) s = s < 0.f ? 0.f : s;
+    if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
+    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
+}
+
+#ifndef TAMD_U8P_ABLATE
+#define TAMD_U8P_ABLATE 0          // tools/exp/u8_patch_anatomy.hip: 1 no MFMA, 2 no B reads, 4 no fragment fetch, 8 no patch refresh, 16 no stores
+#endif
+template <int WM, int WN, int TM, int TN, int KHW, int NPSTR>
 __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
 {
-    constexpr int WM = 2, WN = 2, BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int ABL = TAMD_U8P_ABLATE;
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int NTAPS = KHW * KHW;
     constexpr int SS = KHW == 3 ? 9 : 8;                 // MFMA steps per super-step: 36 k = 4 channels x 9 taps | 32 k = 32 channels
     constexpr int CSS = 4 * SS / NTAPS;                  // channels per super-step
-    constexpr int CPC = KHW == 3 ? 4 : 1;                // super-steps per patch chunk
-    constexpr int CC = CPC * CSS;                        // channels per patch chunk (16 | 32)
-    constexpr int LDA = 52;                              // floats per weight row in LDS: 4 classes x 13 (12 slots + 1 pad)
-    constexpr int NPS = KHW == 3 ? 2 : 1;                // patch pixels per thread per channel (npad <= 512 | 256)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wsm = smem;                                   // [2][BM][LDA]
-    float* patch = smem + 2 * BM * LDA;                  // [2][CC][npad]
+    constexpr int CPC = 4;                               // super-steps per patch chunk == fragment register slots
+    constexpr int CC = CPC * CSS;                        // channels per patch chunk (16 | 128)
+    constexpr int NP = KHW == 3 ? NPSTR : BN;            // floats per channel plane of the patch
+    constexpr int PG = NP >= 256 ? 1 : 256 / NP;         // thread groups along the chunk's channels
+    constexpr int NPS = NP >= 256 ? NP / 256 : 1;        // patch pixels per thread
+    constexpr int CPT = CC / PG;                         // channels per thread
+    constexpr int G4 = SS / 4, REM = SS - 4 * G4;        // float4 groups / single floats of a lane's fragment per super-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // patch [2][CC][NP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM, l15 = lane & 15, kq = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    const int tiles = (N8 + BN - 1) / BN;
-    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles, co0 = blockIdx.y * BM;
+    const int tiles = (N8 + BN - 1) / BN, PT = tiles * a.N, CT = (a.cout + BM - 1) / BM;
+    if ((int)blockIdx.x >= PT * CT) {                    // the blocks behind the main grid: tail pixels
+        conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - PT * CT);
+        return;
+    }
+    int pt, ct;
+    if ((CT & 7) == 0) { const int lin = blockIdx.x, idx = lin >> 3; ct = (lin & 7) + 8 * (idx / PT); pt = idx % PT; }
+    else { pt = blockIdx.x % PT; ct = blockIdx.x / PT; }
+    const int n = pt / tiles, tile = pt - n * tiles, co0 = ct * BM;
     const int jbase = tile * BN, jlimit = N8;
-    const int npad = a.pk_npad, Wp = a.pk_wp;
-    const int KH = a.pk_kh, KW = a.pk_kw, DH = a.pk_dh, DW = a.pk_dw;
+    const int Wp = a.pk_wp;
+    const int DH = a.pk_dh, DW = a.pk_dw;
 
     // ---- patch geometry of this pixel tile ---------------------------------------------------------------------------------
     int oy_a, ox_a, oy_b, ox_b;
     conv_pixel(a, jbase, &oy_a, &ox_a);
     conv_pixel(a, (jbase + BN < jlimit ? jbase + BN : jlimit) - 1, &oy_b, &ox_b);
-    const int R0 = oy_a * a.SH - a.PH;                                       // input row of patch row 0
-    const int NP = ((oy_b - oy_a) * a.SH + (KH - 1) * DH + 1) * Wp;
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int chw = a.H * a.W;
-    int soff[NPS];                                       // this thread's patch pixels: offset inside a channel plane, -1 outside the image
+    const int pg = PG > 1 ? tid / NP : 0, ppix = PG > 1 ? tid % NP : tid;
+    int soff[NPS];                                       // this thread's patch pixels: offset inside a channel plane, -1: a zero
 #pragma unroll
     for (int q = 0; q < NPS; q++) {
-        const int pp = tid + 256 * q;
-        const int prow = pp / Wp, pcol = pp - prow * Wp;
-        const int iy = R0 + prow, ix = pcol - a.PW;
-        soff[q] = (pp < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? iy * a.W + ix : -1;
+        const int pp = ppix + 256 * q;
+        if (KHW == 3) {
+            const int NPX = ((oy_b - oy_a) * a.SH + (KHW - 1) * DH + 1) * Wp;
+            const int prow = pp / Wp, pcol = pp - prow * Wp;
+            const int iy = oy_a * a.SH - a.PH + prow, ix = pcol - a.PW;
+            soff[q] = (pp < NPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? iy * a.W + ix : -1;
+        } else {
+            const int pj = jbase + pp;
+            int oy, ox;
+            conv_pixel(a, pj < jlimit ? pj : jlimit - 1, &oy, &ox);
+            const int iy = oy * a.SH - a.PH, ix = ox * a.SW - a.PW;
+            soff[q] = (pj < jlimit && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? iy * a.W + ix : -1;
+        }
     }
+    float pmask[NPS];                                    // clamp bound of the patch pixel: +inf inside the image, 0 outside (branch-free zero)
+#pragma unroll
+    for (int q = 0; q < NPS; q++) pmask[q] = soff[q] >= 0 ? __builtin_inff() : 0.f;
     const int nss = a.K / (4 * SS), nchunk = (a.C + CC - 1) / CC;
-    unsigned pregs[NPS][CC];                             // raw bytes of the chunk in flight (one register each: no wait until they are used)
+    unsigned pregs[NPS][CPT];                            // raw bytes of the chunk in flight (one register each: no wait until they are used)
     auto pload = [&](int c) {
-        const int c0 = (c < nchunk ? c : nchunk - 1) * CC;                   // past the end: a harmless repeat
+        const int c0 = (c < nchunk ? c : nchunk - 1) * CC + pg * CPT;        // past the end: a harmless repeat
 #pragma unroll
         for (int q = 0; q < NPS; q++)
 #pragma unroll
-            for (int cl = 0; cl < CC; cl++) {
+            for (int cl = 0; cl < CPT; cl++) {
                 const int ch = c0 + cl < a.C ? c0 + cl : a.C - 1;
                 pregs[q][cl] = xin[(size_t)ch * chw + (soff[q] >= 0 ? soff[q] : 0)];
             }
     };
     auto pstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NPS; q++) {
-            const int pp = tid + 256 * q;
-            if (pp < npad) {
+        for (int q = 0; q < NPS; q++)
 #pragma unroll
-                for (int cl = 0; cl < CC; cl++)
-                    patch[(buf * CC + cl) * npad + pp] = soff[q] >= 0 ? dequant((uint8_t)pregs[q][cl], a.in_zp, a.in_scale) : 0.f;
+            for (int cl = 0; cl < CPT; cl++)
+            {
+                const float v = dequant((uint8_t)pregs[q][cl], a.in_zp, a.in_scale);
+                smem[(buf * CC + pg * CPT + cl) * NP + ppix + 256 * q] = __builtin_amdgcn_fmed3f(v, pmask[q], -pmask[q]);      // inside: v, outside: 0.f
             }
-        }
     };
 
-    // ---- weights: thread (row, class) stages 12 slots of its row per super-step through a 2-deep register ring ----------------
-    const int srow = tid >> 2, scls = tid & 3;
-    const bool sact = srow < BM;
-    const unsigned* wtile = reinterpret_cast<const unsigned*>(a.wpk + (size_t)(co0 / BM) * nss * (BM * 48)) + (sact ? (srow * 4 + scls) * 3 : 0);
-    unsigned wr[2][3];
-    auto wload = [&](int d, int ss) {
-        const unsigned* p = wtile + (size_t)(ss < nss ? ss : nss - 1) * (BM * 12);
-        wr[d][0] = p[0]; wr[d][1] = p[1]; wr[d][2] = p[2];
-    };
-    auto wstore = [&](int d, int buf) {
-        if (!sact) return;
-        float* q = wsm + (buf * BM + srow) * LDA + scls * 13;
+    // the refresh of the OTHER patch buffer, spread over the chunk's MFMA steps: element e of part u is converted and stored, and
+    // its register immediately re-requested for the chunk after (every byte flies for one whole chunk)
+    constexpr int EPP = NPS * CPT / CPC, EPS = (EPP + SS - 1) / SS;      // elements per super-step / per MFMA step
+    auto refresh = [&](auto BUF, auto U, auto S, int c) {
+        constexpr int buf = decltype(BUF)::value, u = decltype(U)::value, st = decltype(S)::value;
+        if (ABL & 8) return;
 #pragma unroll
-        for (int v = 0; v < 3; v++) {
-            float4 w;
-            w.x = dequant((uint8_t)wr[d][v], a.w_zp, a.w_scale);
-            w.y = dequant((uint8_t)(wr[d][v] >> 8), a.w_zp, a.w_scale);
-            w.z = dequant((uint8_t)(wr[d][v] >> 16), a.w_zp, a.w_scale);
-            w.w = dequant((uint8_t)(wr[d][v] >> 24), a.w_zp, a.w_scale);
-            q[4 * v] = w.x; q[4 * v + 1] = w.y; q[4 * v + 2] = w.z; q[4 * v + 3] = w.w;      // 13-float groups: dword stores
+        for (int e = st * EPS; e < (st + 1) * EPS && e < EPP; e++) {
+            const int idx = u * EPP + e, q = idx / CPT, cl = idx % CPT;
+            const float v = dequant((uint8_t)pregs[q][cl], a.in_zp, a.in_scale);
+            smem[((buf ^ 1) * CC + pg * CPT + cl) * NP + ppix + 256 * q] = __builtin_amdgcn_fmed3f(v, pmask[q], -pmask[q]);
+            const int c0 = (c + 2 < nchunk ? c + 2 : nchunk - 1) * CC + pg * CPT;
+            const int ch = c0 + cl < a.C ? c0 + cl : a.C - 1;
+            pregs[q][cl] = xin[(size_t)ch * chw + (soff[q] >= 0 ? soff[q] : 0)];
         }
     };
 
-    // ---- per-lane B addresses (floats, relative to the chunk's first channel plane of the super-step) --------------------------
+    // ---- weights: this wave's TM fragment streams, [tile16][super-step][G4 x (64 lanes x float4)][64 lanes x REM floats] ---------
+    constexpr int FRAG = SS * 64;                        // floats per (16-row tile, super-step)
+    const float* wbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) wbase[i] = reinterpret_cast<const float*>(a.wpk) + (size_t)(co0 / 16 + wm * TM + i) * nss * FRAG;
+    // fragment registers, a ring of RA super-steps (the loaded tuples are used where they land).  In a real pass the weights come
+    // from HBM / the infinity cache (2-3 us), not from an L2 that the previous launch of the same layer warmed: the narrow
+    // configurations look seven super-steps (~3.5 us of MFMA) ahead, the wide ones (36 address registers) three
+    constexpr int RA = TN <= 2 ? 2 * CPC : CPC;
+    float4 af4[RA][TM][G4];
+    float afr[RA][TM][REM > 0 ? REM : 1];
+    auto aload = [&](auto D, int ss) {
+        constexpr int d = decltype(D)::value;
+        const size_t o = (size_t)(ss < nss ? ss : nss - 1) * FRAG;
+        if (ABL & 4) { if (ss >= RA - 1) return; }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int v = 0; v < G4; v++) af4[d][i][v] = *reinterpret_cast<const float4*>(wbase[i] + o + v * 256 + lane * 4);
+#pragma unroll
+            for (int v = 0; v < REM; v++) afr[d][i][v] = wbase[i][o + G4 * 256 + lane * REM + v];
+        }
+    };
+    auto afrag = [&](auto D, int i, auto S) -> float {
+        constexpr int d = decltype(D)::value, s = decltype(S)::value;
+        if constexpr (s >= 4 * G4) return afr[d][i][s - 4 * G4];
+        else if constexpr ((s & 3) == 0) return af4[d][i][s >> 2].x;
+        else if constexpr ((s & 3) == 1) return af4[d][i][s >> 2].y;
+        else if constexpr ((s & 3) == 2) return af4[d][i][s >> 2].z;
+        else return af4[d][i][s >> 2].w;
+    };
+
+    // ---- per-lane B addresses (floats, relative to the first channel plane of the super-step) ---------------------------------
     int baddr[TN][SS];
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-        int pj = jbase + (wn * TN + j) * 16 + l15;
-        pj = pj < jlimit ? pj : jlimit - 1;
-        int oy, ox;
-        conv_pixel(a, pj, &oy, &ox);
-        const int pp0 = ((oy - oy_a) * a.SH) * Wp + ox * a.SW;
+        const int pl = (wn * TN + j) * 16 + l15;
+        int pp0 = pl;
+        if (KHW == 3) {
+            int pj = jbase + pl;
+            pj = pj < jlimit ? pj : jlimit - 1;
+            int oy, ox;
+            conv_pixel(a, pj, &oy, &ox);
+            pp0 = ((oy - oy_a) * a.SH) * Wp + ox * a.SW;
+        }
 #pragma unroll
         for (int s = 0; s < SS; s++) {
             const int kl = 4 * s + kq, cl = kl / NTAPS, tap = kl - cl * NTAPS, ky = tap / KHW, kx = tap - ky * KHW;
-            baddr[j][s] = cl * npad + pp0 + ky * DH * Wp + kx * DW;
+            baddr[j][s] = cl * NP + pp0 + ky * DH * Wp + kx * DW;
         }
     }
 
@@ -546,53 +677,86 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: chunk 0 in patch buffer 0, chunk 1's bytes in flight, the first two super-steps of weights in the ring -----
-    wload(0, 0);
-    wload(1, 1);
+    // ---- prologue: chunk 0 in patch buffer 0, chunk 1's bytes in flight, the fragments of super-steps 0..2 in slots 0..2 ---------
+    aload(std::integral_constant<int, 0>{}, 0);
+    aload(std::integral_constant<int, 1>{}, 1);
+    aload(std::integral_constant<int, 2>{}, 2);
+    if constexpr (RA > CPC) {
+        aload(std::integral_constant<int, 3>{}, 3);
+        aload(std::integral_constant<int, 4 % RA>{}, 4);
+        aload(std::integral_constant<int, 5 % RA>{}, 5);
+        aload(std::integral_constant<int, 6 % RA>{}, 6);
+    }
     pload(0);
     pstore(0);
     pload(1);
-    // one super-step; D: ring slot == weight buffer (compile-time: a dynamically indexed register array would live in scratch)
-    auto superstep = [&](int ss, auto D) {
-        constexpr int d = decltype(D)::value;
-        const int c = ss / CPC, u = ss - c * CPC;
-        __builtin_amdgcn_sched_barrier(0);
-        wstore(d, d);                                    // buffer d was last read two super-steps ago: every wave is past that barrier
-        wload(d, ss + 2);
-        __syncthreads();
-        if (u == CPC - 1) {
-            // the next chunk's patch, behind the barrier: every wave has finished the chunk that buffer held (with one super-step
-            // per chunk -- 1 x 1 -- that was the PREVIOUS super-step); its bytes were requested a chunk ago
-            pstore((c + 1) & 1);
-            pload(c + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float* wsb = wsm + d * BM * LDA;
-        const float* pb = patch + ((c & 1) * CC + u * CSS) * npad;
-        float af[TM][SS];
+    __syncthreads();
+    // one super-step: patch buffer BUF, super-step U of the chunk == fragment slot -- all compile time, so every LDS address is
+    // a loop-invariant register plus an immediate and no register array is indexed dynamically.  Global latency here is 1-2 us
+    // under load and a super-step is ~0.5 us of MFMA: the fragments are requested THREE super-steps ahead.
+    float bfr[3][TN];                                    // B values, read TWO MFMA steps ahead (an LDS read takes longer than a step's MFMAs)
+    auto bread = [&](auto BUF, auto U, auto S) {         // step S of super-step U (S may run past SS into the chunk's next super-step)
+        constexpr int buf = decltype(BUF)::value, sl = decltype(S)::value, u = decltype(U)::value + sl / SS, s = sl % SS;
+        constexpr int slot = (decltype(U)::value * SS + sl) % 3;
+        if constexpr (u < CPC) {
+            const float* pb = smem + (buf * CC + u * CSS) * NP;
+            if (ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const float* q = wsb + ((wm * TM + i) * 16 + l15) * LDA + kq * 13;
+                for (int j = 0; j < TN; j++) bfr[slot][j] = __builtin_bit_cast(float, baddr[j][s]);
+                return;
+            }
 #pragma unroll
-            for (int v = 0; v < SS; v++) af[i][v] = q[v];
-        }
-#pragma unroll
-        for (int s = 0; s < SS; s++) {
-            float bf[TN];
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = pb[baddr[j][s]];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; j++) bfr[slot][j] = pb[baddr[j][s]];
         }
     };
-    for (int ss = 0; ss < nss; ss += 2) {
-        superstep(ss, std::integral_constant<int, 0>{});
-        if (ss + 1 < nss) superstep(ss + 1, std::integral_constant<int, 1>{});
+    auto superstep = [&](auto BUF, auto U, int ss, int c) {
+        constexpr int u = decltype(U)::value, slot = (decltype(BUF)::value * CPC + u) % RA;
+        aload(std::integral_constant<int, (slot + RA - 1) % RA>{}, ss + RA - 1);
+        if constexpr (u == 0) { bread(BUF, U, std::integral_constant<int, 0>{}); bread(BUF, U, std::integral_constant<int, 1>{}); }
+        auto step = [&](auto S) {
+            constexpr int s = decltype(S)::value, bslot = (u * SS + s) % 3;
+            bread(BUF, U, std::integral_constant<int, s + 2>{});
+            __builtin_amdgcn_sched_barrier(0);           // the reads for step s + 2 go out BEFORE the MFMAs of step s
+            refresh(BUF, U, S, c);                       // (a few VALU + one LDS write + one byte load in the MFMAs' shadow)
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const float av = afrag(std::integral_constant<int, slot>{}, i, S);
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    if (ABL & 1) acc[i][j][0] += av * bfr[bslot][j];
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfr[bslot][j], acc[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        if constexpr (SS > 8) step(std::integral_constant<int, 8>{});
+    };
+    auto chunk = [&](auto BUF, int c) {
+        const int ss0 = c * CPC;
+        superstep(BUF, std::integral_constant<int, 0>{}, ss0, c);
+        if (ss0 + 1 < nss) superstep(BUF, std::integral_constant<int, 1>{}, ss0 + 1, c);
+        if (ss0 + 2 < nss) superstep(BUF, std::integral_constant<int, 2>{}, ss0 + 2, c);
+        if (ss0 + 3 < nss) superstep(BUF, std::integral_constant<int, 3>{}, ss0 + 3, c);
+        __syncthreads();                                 // the other buffer is complete, this one is free
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
 
     // ---- epilogue (conv_u8_body's, main pixels): D[row = 4*kq + e][col = l15] of each 16x16 tile ------------------------------
+    if (ABL & 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 1234.5f) a.y[tid] = 1;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int pj = jbase + (wn * TN + j) * 16 + l15;
@@ -621,29 +785,36 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     }
 }
 
-static const struct { int tm, tn; const char* n3; const char* n1; } U8P_CFGS[] = {
-    {2, 2, "conv_u8_patch_64x64<3x3>", "conv_u8_patch_64x64<1x1>"}, {1, 2, "conv_u8_patch_32x64<3x3>", "conv_u8_patch_32x64<1x1>"}};
-int conv_u8_patch_num_cfgs() { return 2; }
-int conv_u8_patch_bm(int cfg) { return U8P_CFGS[cfg].tm * 32; }
+// tile configurations: waves along cout x waves along pixels, 16x16 tiles per wave along cout x along pixels
+static const struct { int wm, wn, tm, tn; const char* n3; const char* n1; } U8P_CFGS[] = {
+    {2, 2, 2, 2, "conv_u8_patch_64x64<3x3>", "conv_u8_patch_64x64<1x1>"},
+    {4, 1, 2, 4, "conv_u8_patch_128x64<3x3>", "conv_u8_patch_128x64<1x1>"},
+    {2, 2, 2, 4, "conv_u8_patch_64x128<3x3>", "conv_u8_patch_64x128<1x1>"},
+    {1, 4, 2, 1, "conv_u8_patch_32x64<3x3>", "conv_u8_patch_32x64<1x1>"}};
+int conv_u8_patch_num_cfgs() { return 4; }
+int conv_u8_patch_bm(int cfg) { return U8P_CFGS[cfg].wm * U8P_CFGS[cfg].tm * 16; }
+static int u8p_bn(int cfg) { return U8P_CFGS[cfg].wn * U8P_CFGS[cfg].tn * 16; }
 int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 8 : 0; }
 const char* conv_u8_patch_kernel_name(const U8ConvArgs& a) { return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1; }
 
 static size_t u8p_lds(const U8ConvArgs& a)
 {
-    const int bm = conv_u8_patch_bm(a.pk_cfg), cc = a.pk_kh == 3 ? 16 : 32;
-    return (size_t)(2 * bm * 52 + 2 * cc * a.pk_npad) * 4;
+    const int cc = a.pk_kh == 3 ? 16 : 128;
+    return (size_t)(2 * cc * a.pk_npad) * 4;
 }
 
 // fills the patch fields of `a` for tile configuration cfg; false: this convolution does not go through the patch kernel
 bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
 {
-    static const bool off = getenv("TAMD_U8_PATCH") && atoi(getenv("TAMD_U8_PATCH")) == 0;
+    const char* env = getenv("TAMD_U8_PATCH");
+    const bool off = env && atoi(env) == 0;
     a.pk_cfg = -1;
     a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
     const int ss = conv_u8_patch_ss(a);
-    const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = U8P_CFGS[cfg].tn * 32;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = u8p_bn(cfg);
     if (off || !ss || N8 == 0 || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 32) != 0 || a.PH < 0 || a.PW < 0) return false;
-    if ((size_t)a.C * a.H * a.W >= (1u << 31)) return false;
+    if ((size_t)a.C * a.H * a.W >= (1u << 31) || (size_t)a.K * 4 > 150 * 1024) return false;      // (the tail blocks keep an im2col column in LDS)
+    if (KH == 1) { a.pk_wp = 0; a.pk_npad = bn; a.pk_cfg = cfg; return true; }      // the patch is the tile's own pixels
     a.pk_wp = (a.OW - 1) * a.SW + (KW - 1) * DW + 1;
     if (a.pk_wp < a.W + a.PW) a.pk_wp = a.W + a.PW;             // every column a tap can name: [-PW, max(W, last tap) )
     // rows the worst pixel tile touches (window-major enumeration under a fused pool: two output rows per window row)
@@ -655,49 +826,58 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
         else { oy0 = j0 / a.OW; oy1 = j1 / a.OW; }
         worst = std::max(worst, ((oy1 - oy0) * a.SH + (KH - 1) * DH + 1) * a.pk_wp);
     }
-    a.pk_npad = (worst + 63) / 64 * 64;
+    if (worst > 512) return false;
+    a.pk_npad = worst <= 256 ? 256 : 512;                        // the two plane strides the kernel is compiled for
     a.pk_cfg = cfg;
-    if (a.pk_npad > (KH == 3 ? 512 : 256) || u8p_lds(a) > 150 * 1024) { a.pk_cfg = -1; return false; }
     return true;
 }
 
+// the dequantised weights in A-fragment order: the same for every tile configuration
 size_t conv_u8_patch_packed_bytes(const U8ConvArgs& a)
 {
-    const int bm = conv_u8_patch_bm(a.pk_cfg), ss = conv_u8_patch_ss(a);
-    return (size_t)((a.cout + bm - 1) / bm) * (a.K / (4 * ss) + 2) * bm * 48 + 64;        // + two super-steps the ring may prefetch past the end
+    return (size_t)((a.cout + 15) / 16 + 8) * a.K * 16 * 4;        // + 8 tiles: the last block's waves may fetch rows past cout
 }
 
-void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, uint8_t* out)
+void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, float w_scale, float* out)
 {
-    const int bm = conv_u8_patch_bm(a.pk_cfg), ss = conv_u8_patch_ss(a), nss = a.K / (4 * ss);
-    const size_t total = conv_u8_patch_packed_bytes(a);
-    for (size_t i = 0; i < total; i++) out[i] = w_zp;
+    const int ss = conv_u8_patch_ss(a), nss = a.K / (4 * ss), g4 = ss / 4, rem = ss - 4 * g4, frag = ss * 64;
+    const size_t total = conv_u8_patch_packed_bytes(a) / 4;
+    for (size_t i = 0; i < total; i++) out[i] = 0.f;
     for (int co = 0; co < a.cout; co++)
         for (int k = 0; k < a.K; k++) {
-            const int st = k / (4 * ss), kl = k % (4 * ss), s = kl >> 2, cls = kl & 3;
-            out[((size_t)(co / bm) * nss + st) * (bm * 48) + ((co % bm) * 4 + cls) * 12 + s] = w[(size_t)co * a.K + k];
+            const int st = k / (4 * ss), kl = k % (4 * ss), s = kl >> 2, kq = kl & 3, lane = kq * 16 + (co & 15);
+            const size_t base = ((size_t)(co / 16) * nss + st) * frag;
+            const size_t at = s < 4 * g4 ? base + (size_t)(s / 4) * 256 + lane * 4 + (s & 3) : base + (size_t)g4 * 256 + lane * rem + (s - 4 * g4);
+            out[at] = ((float)w[(size_t)co * a.K + k] - (float)w_zp) * w_scale;      // conv_u8_body's dequant(), computed once
         }
 }
 
 hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
-    const int bm = conv_u8_patch_bm(a.pk_cfg), bn = U8P_CFGS[a.pk_cfg].tn * 32;
-    const dim3 grid(((N8 + bn - 1) / bn) * a.N, (a.cout + bm - 1) / bm, 1);
-    const size_t lds = u8p_lds(a);
+    const int bm = conv_u8_patch_bm(a.pk_cfg), bn = u8p_bn(a.pk_cfg);
+    const int main_blocks = ((N8 + bn - 1) / bn) * a.N * ((a.cout + bm - 1) / bm);
+    const int tail_blocks = (OHW - N8) * a.N * ((a.cout + 63) / 64);        // conv_u8_patch_tail: (image, tail pixel, 64 channels)
+    const dim3 grid(main_blocks + tail_blocks, 1, 1);
+    const size_t lds = std::max(u8p_lds(a), tail_blocks ? (size_t)a.K * 4 : (size_t)0);
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
         return hipGetLastError();
     };
-    const bool k3 = a.pk_kh == 3;
-    hipError_t e;
-    if (a.pk_cfg == 0) e = k3 ? go(conv_u8_patch_k<2, 2, 3>) : go(conv_u8_patch_k<2, 2, 1>);
-    else e = k3 ? go(conv_u8_patch_k<1, 2, 3>) : go(conv_u8_patch_k<1, 2, 1>);
-    if (e != hipSuccess || OHW == N8) return e;
-    U8ConvArgs t = a;                                    // the tail pixels of every image: conv_u8_gemm's four-chain blocks
-    t.tail_only = 1;
-    return launch_conv_u8_gemm(t, s);
+    hipError_t e = hipErrorInvalidValue;
+#define U8P_GO(WM, WN, TM, TN)                                                                                                   \
+    e = a.pk_kh == 1 ? go(conv_u8_patch_k<WM, WN, TM, TN, 1, 0>)                                                                  \
+                     : a.pk_npad == 256 ? go(conv_u8_patch_k<WM, WN, TM, TN, 3, 256>) : go(conv_u8_patch_k<WM, WN, TM, TN, 3, 512>)
+    switch (a.pk_cfg) {
+    case 0: U8P_GO(2, 2, 2, 2); break;
+    case 1: U8P_GO(4, 1, 2, 4); break;
+    case 2: U8P_GO(2, 2, 2, 4); break;
+    case 3: U8P_GO(1, 4, 2, 1); break;
+    default: break;
+    }
+#undef U8P_GO
+    return e;
 }
 
 // =================================================================================================================

@@ -1,0 +1,96 @@
+"""GPU parity of the uint8 patch convolution (u8_kernels.hip: conv_u8_patch_k) -- the 3x3 / 1x1 member that dequantises the
+input patch of a pixel tile once into LDS and walks the reference's k order (channel-major, tap-minor; conv_kernel_x86.c im2col)
+through the fp32 MFMA chain.  It is an autotune candidate next to conv_u8_mfma_*; here TAMD_U8_PATCH=1 pins it wherever it
+applies, and the bytes must equal the oracle's (pinned to the real reference by tests/test_uint8_oracle.py) and the GEMM member's."""
+import numpy as np
+import pytest
+
+from helpers import u8_conv_graph, u8_conv_pool_graph
+from oracle import oracle
+from tengine_amd import capi, models, tm2
+
+pytestmark = pytest.mark.gpu
+
+
+def run_with(g, x, patch, batch=None):
+    import os
+    old = os.environ.get("TAMD_U8_PATCH")
+    os.environ["TAMD_U8_PATCH"] = patch
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+        gr.set_input(x)
+        out = [o.copy() for o in gr.run()]
+        kernels = [k["kernel"] for k in gr.profile(1)]
+        gr.close()
+    finally:
+        if old is None:
+            del os.environ["TAMD_U8_PATCH"]
+        else:
+            os.environ["TAMD_U8_PATCH"] = old
+    return out, kernels
+
+
+CASES = [
+    # n, cin, h, w, cout, k, s, p, group, act, bias, dil
+    (1, 16, 40, 40, 32, 3, 1, 1, 1, -1, True, 1),       # one 32-row cout tile, 1600 px = 25 pixel tiles
+    (1, 64, 20, 20, 128, 3, 1, 1, 1, 0, True, 1),       # 400 px: ragged last pixel tile (16 px)
+    (2, 128, 13, 13, 255, 1, 1, 0, 1, -1, True, 1),     # 1x1, 169 px: 1 tail pixel (GEMM kernel's tail launch), cout 255
+    (1, 256, 13, 13, 512, 3, 1, 1, 1, 6, True, 1),      # K = 2304, relu6 (YOLO conv5 class)
+    (2, 32, 26, 26, 70, 3, 2, 1, 1, 0, False, 1),       # stride 2, no bias, cout % 4 == 2, 169 px
+    (3, 8, 9, 11, 13, 3, 1, 1, 1, 1, True, 1),          # small odd map: 99 px -> 96 main + 3 tail, K = 72
+    (1, 32, 12, 12, 16, 3, 1, 2, 1, 0, True, 2),        # dilation 2, pad 2
+    (1, 512, 7, 7, 64, 3, 1, 1, 1, 0, True, 1),         # K = 4608, 49 px: 48 main
+    (2, 64, 19, 19, 128, 1, 1, 0, 1, 0, True, 1),       # mssd pointwise class: 361 px, 1x1
+    (1, 96, 10, 10, 40, 1, 1, 0, 1, -1, True, 1),       # 1x1, C = 96 = 3 super-steps, cout 40
+    (1, 32, 19, 19, 48, 1, 2, 0, 1, 0, True, 1),        # 1x1 stride 2
+    (1, 4, 24, 24, 24, 3, 1, 1, 1, -1, True, 1),        # C = 4: one super-step in all (first-layer kernel also applies; patch pinned)
+    (1, 20, 16, 16, 32, 3, 1, 0, 1, 0, True, 1),        # pad 0, C = 20: five super-steps, odd chunk count
+    (1, 16, 8, 30, 32, 3, 1, 1, 1, 0, True, 1),         # wide rows
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_patch_conv_bytes_equal_oracle_and_gemm_member(case):
+    n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
+    g, x = u8_conv_graph(57 + cin + cout, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, "1")
+    assert any("conv_u8_patch" in kn for kn in kernels), kernels
+    ref, kernels0 = run_with(g, x, "0")
+    assert not any("conv_u8_patch" in kn for kn in kernels0), kernels0
+    for wv, a, b in zip(want, got, ref):
+        a = a.reshape(wv.shape)
+        bad = np.count_nonzero(a != wv)
+        assert bad == 0, "%d / %d bytes differ from the oracle (max |d| %d)" % (bad, wv.size, np.abs(a.astype(int) - wv.astype(int)).max())
+        assert np.array_equal(a, b.reshape(wv.shape))
+        assert len(np.unique(wv)) > 3
+
+
+POOL_CASES = [
+    ((1, 16, 16, 16, 32, 3, 1), dict()),                     # conv -> leaky -> 2x2/2 pool fused in the patch kernel's epilogue
+    ((2, 32, 12, 20, 70, 3, 1), dict(slope=0.0)),            # 240 px, cout 70
+    ((1, 32, 16, 16, 32, 1, 0), dict(relu=False)),           # 1x1 conv -> pool
+    ((1, 16, 16, 16, 32, 3, 1), dict(second_reader=True)),   # unpooled tensor stored too
+    ((1, 16, 52, 52, 32, 3, 1), dict()),                     # YOLO conv2 class: 2704 px, window-major tiles span 4 rows
+]
+
+
+@pytest.mark.parametrize("dims,kw", POOL_CASES, ids=[str(c[0]) + str(sorted(c[1].items())) for c in POOL_CASES])
+def test_patch_conv_with_fused_relu_and_pool(dims, kw):
+    g, x = u8_conv_pool_graph(190 + dims[1] + dims[2], *dims, **kw)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, "1")
+    assert any("conv_u8_patch" in kn and "+maxpool" in kn for kn in kernels), kernels
+    for wv, a in zip(want, got):
+        assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
+
+
+@pytest.mark.parametrize("name,batch,res", [("yolov3_tiny", 2, 416), ("mssd", 2, 300), ("yolov3_tiny", 1, 160)])
+def test_models_with_the_patch_member_pinned(name, batch, res):
+    g = models.build(name, "uint8", batch, res=res)
+    x = models.synth_input(g, 5, tm2.DT_UINT8)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, "1")
+    assert sum("conv_u8_patch" in kn for kn in kernels) >= 5, kernels
+    for wv, a in zip(want, got):
+        assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
