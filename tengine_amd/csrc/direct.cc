@@ -44,6 +44,7 @@ namespace tamd {
 
 thread_local std::vector<LaunchRec>* g_launch_rec = nullptr;
 thread_local bool g_launch_coherent = false;
+thread_local bool g_launch_beside = false;
 
 namespace {
 
@@ -255,8 +256,8 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
     }
     p->dq->refs++;
     if (p->pkts.size() * 2 > p->dq->q->size) { *why = "launch list longer than the shared queue"; direct_destroy(p); return nullptr; }
-    auto header = [](int type, int acq, int rel) {
-        return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) | (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)
+    auto header = [](int type, int acq, int rel, bool barrier = true) {
+        return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) | (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)
                           | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     };
     // fences inside a burst.  An ordinary launch acquires and releases at agent scope.  A coherent launch reads what other
@@ -264,10 +265,18 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
     // nothing to invalidate in front of it -- unless its predecessor is an ordinary launch: the first convolution reads the
     // graph input with ordinary loads, and in the host-to-host list that input was just written by the upload launch.
     const int K = HSA_PACKET_TYPE_KERNEL_DISPATCH;
+    int n_beside = 0;
     for (size_t i = 0; i < p->pkts.size(); i++) {
-        if (!coherent[i]) p->hdr.push_back(header(K, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT));
+        // a launch the graph marked independent of its predecessors (LaunchRec::beside) carries no barrier bit: the packet
+        // processor starts it while they run; whatever depends on it comes later with the bit set and waits for ALL of them
+        // -- and no acquire either: what it reads was released before the last ordered launch began, and that launch's acquire
+        // already dropped every stale line; nothing it reads has been written since (or it would not be independent)
+        const bool beside = i > 0 && recs[i].beside;
+        n_beside += beside;
+        if (!coherent[i]) p->hdr.push_back(header(K, beside ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, !beside));
         else p->hdr.push_back(header(K, (i > 0 && !coherent[i - 1]) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE));
     }
+    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] direct: %zu packets, %d without the barrier bit\n", p->pkts.size(), n_beside);
     p->h_open = header(K, HSA_FENCE_SCOPE_SYSTEM, coherent[0] ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT);
     p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     return p;

@@ -53,12 +53,48 @@ struct HNode {
     std::string name;
 };
 
+// what a step touches, for the dependency-aware barrier bits of the direct path: bytes [base, base + size) and, when period > 0,
+// only the slice [off, off + len) of every `period` bytes (a concat input's slot, a channel range of an NCHW concat buffer)
+struct Access {
+    const char* base = nullptr;
+    size_t size = 0, off = 0, len = 0, period = 0;
+};
+inline bool access_overlap(const Access& a, const Access& b)
+{
+    if (a.base + a.size <= b.base || b.base + b.size <= a.base) return false;
+    if (a.base == b.base && a.size == b.size && a.period > 0 && a.period == b.period) return !(a.off + a.len <= b.off || b.off + b.len <= a.off);
+    return true;
+}
+
 struct Step {                  // one device launch of the compiled plan
     std::string node, kernel;
     double macs = 0, bytes = 0;
     std::function<hipError_t(hipStream_t)> fn;
     bool once = false;         // every input is a prerun constant (PriorBox outputs): launched once at the end of prerun
+    // rd / wr list EVERYTHING the step's launch reads / writes in device memory that another step may write (constants left
+    // out) -- only then is deps set, and only a step with deps may run beside its predecessors (graph.hip run_steps)
+    bool deps = false;
+    std::vector<Access> rd, wr;
 };
+inline bool step_conflict(const Step& a, const Step& b)          // RAW, WAR or WAW between two steps that both carry deps
+{
+    for (auto& w : a.wr) { for (auto& x : b.wr) if (access_overlap(w, x)) return true; for (auto& x : b.rd) if (access_overlap(w, x)) return true; }
+    for (auto& r : a.rd) for (auto& x : b.wr) if (access_overlap(r, x)) return true;
+    return false;
+}
+inline Access access_of(const HTensor& t)                         // dense tensor, or the channel slice of the concat buffer it lives in
+{
+    Access a;
+    a.base = (const char*)t.dptr;
+    const size_t esz = t.dtype == TAMD_DT_FP32 ? 4 : 1;
+    if (t.is_view && t.cs > 0) {
+        a.period = (size_t)t.cs * t.h * t.w * esz; a.off = (size_t)t.c_off * t.h * t.w * esz; a.len = (size_t)t.c * t.h * t.w * esz;
+        a.size = a.period * (size_t)t.n;
+    } else {
+        a.size = t.elems() * esz; a.len = a.size;
+    }
+    return a;
+}
 
 struct IOBind {
     int tensor = -1;
@@ -140,6 +176,9 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
 constexpr size_t kL2FlushBytes = 64u << 20;
 void* l2_flush_buffer();
 bool autotune_cold(tamd_graph* g);
+// TAMD_PLAN_CACHE=<file>: "<site>|<node>|<shape>" -> what the plan-time autotune chose (graph.hip)
+bool plan_cache_get(const std::string& key, std::string* v);
+void plan_cache_put(const std::string& key, const std::string& v);
 int time_cold(tamd_graph* g, void* flush, const std::function<hipError_t()>& launch, float* ms_out);      // graph.hip
 void nhwc_geom(HTensor& t);
 int count_consumers(const tamd_graph* g, int tensor);

@@ -187,16 +187,46 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
             return 1;
         };
+        // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
+        const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
+        const bool rgb_ok = conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
+                            && !(rgb_env && atoi(rgb_env) == 0);
+        U8ConvArgs rgb = a;
+        auto rgb_ready = [&]() -> int {
+            if (rgb.wf) return 0;
+            rgb.wf_ld = rup(K, 4);
+            std::vector<float> wf((size_t)cout * rgb.wf_ld, 0.f);
+            for (int co = 0; co < cout; co++)
+                for (int k = 0; k < K; k++) wf[(size_t)co * rgb.wf_ld + k] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
+            float* dwf = nullptr;
+            if (upload(g, wf, &dwf)) return -1;
+            rgb.wf = dwf;
+            return 0;
+        };
+        bool use_rgb = false;
         static const char* at_env = getenv("TAMD_AUTOTUNE");
-        if (!(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG")) {
+        const bool tune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG");
+        // what the autotune decided last time (TAMD_PLAN_CACHE): "g<cfg>" GEMM family, "p<cfg>" patch kernel, "rgb"
+        char ckey[256];
+        snprintf(ckey, sizeof(ckey), "u8conv|%s|%dx%dx%dx%d>%d k%dx%d s%d d%d%s%s", n.name.c_str(), x.n, x.c, x.h, x.w, cout, p.kernel_h, p.kernel_w,
+                 p.stride_h, p.dilation_h, relu ? "+relu" : "", pool ? "+pool" : "");
+        std::string cached;
+        bool from_cache = false;
+        if (tune && !pk_force && !rgb_env && !pk_env && plan_cache_get(ckey, &cached) && cached.size() >= 2) {
+            const int c = atoi(cached.c_str() + 1);
+            if (cached == "rgb" && rgb_ok) { use_rgb = true; from_cache = true; }
+            else if (cached[0] == 'g' && c >= 0 && c < conv_u8_gemm_num_cfgs()) { a.cfg = c; from_cache = true; }
+            else if (cached[0] == 'p' && c >= 0 && c < conv_u8_patch_num_cfgs()) { U8ConvArgs ac = a; if (patch_for(ac, c) == 1) { pk_best = c; from_cache = true; } }
+        }
+        if (tune && !from_cache) {
             hipEvent_t e0, e1;
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             float best_ms = 1e30f;
             int best_cfg = a.cfg;
             // per-launch time of a candidate AS IT RUNS INSIDE A PASS (time_cold: weights evicted, input left by its producer);
             // back-to-back launches of one layer flatter the latency-bound members by 30-60 % (profiles/r03_insitu_*).
-            // Small graphs / TAMD_AUTOTUNE_COLD=0: the
-            // warm timing (a warm-up launch, then 5 back-to-back launches, 25 when that is under 20 us)
+            // Small graphs / TAMD_AUTOTUNE_COLD=0: warm timing (a warm-up launch, then 5 back-to-back launches, 25 when that is
+            // under 20 us)
             void* flush = autotune_cold(g) ? l2_flush_buffer() : nullptr;
             auto time_of = [&](const std::function<hipError_t()>& launch, float* out) -> int {
                 if (launch() != hipSuccess) { (void)hipGetLastError(); *out = 1e30f; return 0; }
@@ -226,43 +256,39 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 if (time_of([&]() { return launch_conv_u8_gemm(ac, g->stream); }, &ms)) return -1;
                 if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best_cfg = c; }
             }
-            {
-                float pk_ms = 1e30f;
-                for (int c = 0; c < conv_u8_patch_num_cfgs(); c++) {
-                    U8ConvArgs ac = a;
-                    const int r = patch_for(ac, c);
-                    if (r < 0) return -1;
-                    if (!r) continue;
-                    float ms = 0;
-                    if (time_of([&]() { return launch_conv_u8_patch(ac, g->stream); }, &ms)) return -1;
-                    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (gemm family best %.2f us)\n", n.name.c_str(), conv_u8_patch_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
-                    if (pk_force ? ms < pk_ms : ms < best_ms * 0.96f) { pk_best = c; pk_ms = ms; if (!pk_force) best_ms = ms; }
-                }
-            }
-            // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
-            const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
-            if (conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
-                && !(rgb_env && atoi(rgb_env) == 0)) {
+            float pk_ms = 1e30f;
+            for (int c = 0; c < conv_u8_patch_num_cfgs(); c++) {
                 U8ConvArgs ac = a;
-                ac.wf_ld = rup(K, 4);
-                std::vector<float> wf((size_t)cout * ac.wf_ld, 0.f);
-                for (int co = 0; co < cout; co++)
-                    for (int k = 0; k < K; k++) wf[(size_t)co * ac.wf_ld + k] = ((float)w.data[(size_t)co * K + k] - (float)qw.zp) * qw.scale;
-                float* dwf = nullptr;
-                if (upload(g, wf, &dwf)) return -1;
-                ac.wf = dwf;
+                const int r = patch_for(ac, c);
+                if (r < 0) return -1;
+                if (!r) continue;
+                float ms = 0;
+                if (time_of([&]() { return launch_conv_u8_patch(ac, g->stream); }, &ms)) return -1;
+                if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (gemm family best %.2f us)\n", n.name.c_str(), conv_u8_patch_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
+                if (pk_force ? ms < pk_ms : ms < best_ms * 0.96f) { pk_best = c; pk_ms = ms; if (!pk_force) best_ms = ms; }
+            }
+            if (rgb_ok) {
+                if (rgb_ready()) return -1;
                 float ms = 1e30f;
-                if (time_of([&]() { return launch_conv_u8_rgb3x3(ac, g->stream); }, &ms)) return -1;
-                if (ms < best_ms * 0.96f || (rgb_env && atoi(rgb_env) == 1)) {
-                    hipEventDestroy(e0); hipEventDestroy(e1);
-                    st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
-                    st.fn = [ac](hipStream_t s) { return launch_conv_u8_rgb3x3(ac, s); };
-                    g->steps.push_back(st);
-                    return 0;
-                }
+                if (time_of([&]() { return launch_conv_u8_rgb3x3(rgb, g->stream); }, &ms)) return -1;
+                use_rgb = ms < best_ms * 0.96f;
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;
+            plan_cache_put(ckey, use_rgb ? std::string("rgb") : pk_best >= 0 ? "p" + std::to_string(pk_best) : "g" + std::to_string(best_cfg));
+        }
+        if (rgb_ok && rgb_env && atoi(rgb_env) == 1) use_rgb = true;
+        // everything this launch touches besides constants: the input, the output (a concat slice when it is a view), the pooled output
+        st.rd.push_back(access_of(x));
+        st.wr.push_back(access_of(y));
+        if (pool) st.wr.push_back(access_of(g->tensors[pool->out[0]]));
+        st.deps = true;
+        if (use_rgb) {
+            if (rgb_ready()) return -1;
+            st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+            st.fn = [rgb](hipStream_t s) { return launch_conv_u8_rgb3x3(rgb, s); };
+            g->steps.push_back(st);
+            return 0;
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
@@ -589,6 +615,11 @@ int plan_u8(tamd_graph* g)
                 }
                 Step st; st.node = n.name; st.kernel = kname; st.bytes = 2.0 * x.elems();
                 st.once = all_const;                                     // e.g. mbox_priorbox: PriorBox outputs only
+                {                                                        // reads its source, writes ITS slot of every outer slice
+                    Access r = access_of(perm_src[i] >= 0 ? g->tensors[perm_src[i]] : x), wa;
+                    wa.base = (const char*)y.dptr; wa.size = y.elems(); wa.period = (size_t)out_img; wa.off = (size_t)off; wa.len = (size_t)in_img;
+                    st.rd.push_back(r); st.wr.push_back(wa); st.deps = !y.is_view;
+                }
                 st.fn = [a](hipStream_t s) { return launch_flatcat_u8(a, s); };
                 g->steps.push_back(st);
                 off += in_img;

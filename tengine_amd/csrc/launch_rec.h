@@ -18,6 +18,7 @@ struct LaunchRec {
     unsigned shmem;                     // dynamic LDS bytes
     std::vector<unsigned char> args;    // explicit kernel-argument segment
     bool coherent = false;              // the kernel exchanges its tensors with agent-scope accesses (launch_rec_coherent): no fences
+    bool beside = false;                // independent of every launch since the last ordered one (launch_rec_beside): no barrier bit
 };
 
 extern thread_local std::vector<LaunchRec>* g_launch_rec;       // direct.cc; non-null while a launch list is being recorded
@@ -25,6 +26,10 @@ extern thread_local bool g_launch_coherent;                     // direct.cc; se
 // a launcher calls this right before it launches a COHERENT kernel instance (pwdw.hip): the record says so explicitly -- the
 // packet's fence scopes do not hang on a naming convention
 inline void launch_rec_coherent() { g_launch_coherent = true; }
+extern thread_local bool g_launch_beside;                       // direct.cc; set by launch_rec_beside() for the NEXT launch
+// the graph calls this before a step whose reads and writes touch nothing the launches since the last ordered launch write or
+// read (graph.hip run_steps): its first launch may start while they still run -- its packet goes out without the barrier bit
+inline void launch_rec_beside() { g_launch_beside = true; }
 
 template <typename T>
 inline void rec_pack(std::vector<unsigned char>& b, const T& v)
@@ -44,9 +49,11 @@ inline void launch_rec(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem
         r.grid = grid; r.block = block; r.shmem = (unsigned)shmem;
         (rec_pack<P>(r.args, static_cast<P>(a)), ...);
         r.coherent = g_launch_coherent;
+        r.beside = g_launch_beside;
         g_launch_rec->push_back(std::move(r));
     }
     g_launch_coherent = false;
+    g_launch_beside = false;
     kernel<<<grid, block, shmem, s>>>(static_cast<P>(a)...);
 }
 

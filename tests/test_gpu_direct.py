@@ -119,3 +119,27 @@ def test_direct_dispatch_coherent_kernels_with_fences_kept(monkeypatch):
     gr.close()
     for w, o in zip(want, got):
         assert np.array_equal(o.reshape(w.shape), w)
+
+
+def test_direct_overlap_of_independent_launches_keeps_the_bytes(monkeypatch):
+    """TAMD_DIRECT_OVERLAP=1: launches that touch nothing their predecessors touch (the SSD head convolutions, the concat copies)
+    go out without the AQL barrier bit; the results must be the ordered pass's, run after run"""
+    import numpy as np
+    from tengine_amd import capi, models, tm2
+    g = models.build("mssd", "uint8", 2)
+    x = models.synth_input(g, 11, tm2.DT_UINT8)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TAMD_DIRECT_OVERLAP", mode)
+        gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True)
+        gr.set_input(x)
+        first = [o.copy() for o in gr.run()]
+        for _ in range(20):
+            again = gr.run()
+            for a, b in zip(first, again):
+                assert np.array_equal(a, b)
+        outs[mode] = first
+        assert gr.direct_packets() > 0
+        gr.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b)
