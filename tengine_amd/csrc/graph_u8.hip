@@ -292,13 +292,17 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
-        if (pk_force && pk_best < 0)
-            for (int c = 0; c < conv_u8_patch_num_cfgs() && pk_best < 0; c++) {
+        if (pk_force && pk_best < 0) {
+            const char* pc = getenv("TAMD_U8_PATCH_CFG");          // tests / fuzzing: the tile configuration to try first
+            const int first = pc ? atoi(pc) % conv_u8_patch_num_cfgs() : 0;
+            for (int k = 0; k < conv_u8_patch_num_cfgs() && pk_best < 0; k++) {
+                const int c = (first + k) % conv_u8_patch_num_cfgs();
                 U8ConvArgs ac = a;
                 const int r = patch_for(ac, c);
                 if (r < 0) return -1;
                 if (r) pk_best = c;
             }
+        }
         if (pk_best >= 0) {
             if (patch_for(a, pk_best) != 1) return -1;
             st.kernel = std::string(conv_u8_patch_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
@@ -597,6 +601,10 @@ int plan_u8(tamd_graph* g)
             bool all_const = true;
             for (int i : n.in) all_const &= g->tensors[i].prerun_const;
             int off = 0;
+            // two to eight copied inputs (the SSD heads: six per concat): one launch for all of them (TAMD_FUSE_CONCAT=0: one each)
+            const char* fc_env = getenv("TAMD_FUSE_CONCAT");
+            U8CatMulti multi{};
+            const size_t first_step = g->steps.size();
             for (int i : n.in) {
                 HTensor& x = g->tensors[i];
                 const int in_img = (int)(x.dims[ax] * inner);
@@ -622,7 +630,23 @@ int plan_u8(tamd_graph* g)
                 }
                 st.fn = [a](hipStream_t s) { return launch_flatcat_u8(a, s); };
                 g->steps.push_back(st);
+                if (multi.count < 8) { multi.src[multi.count] = a; multi.rescale[multi.count] = a.in.scale / a.out.scale; }
+                multi.count++;
                 off += in_img;
+            }
+            if (multi.count >= 2 && multi.count <= 8 && !all_const && !y.is_view && !(fc_env && atoi(fc_env) == 0)) {
+                Step st = g->steps[first_step];
+                st.kernel = g->steps[first_step].kernel + "<x" + std::to_string(multi.count) + ">";
+                st.bytes = 0; st.rd.clear(); st.wr.clear();
+                for (size_t k = first_step; k < g->steps.size(); k++) {
+                    st.bytes += g->steps[k].bytes;
+                    st.rd.insert(st.rd.end(), g->steps[k].rd.begin(), g->steps[k].rd.end());
+                    st.wr.insert(st.wr.end(), g->steps[k].wr.begin(), g->steps[k].wr.end());
+                    if (g->steps[k].kernel != g->steps[first_step].kernel) st.kernel = "concat_u8<x" + std::to_string(multi.count) + ">";
+                }
+                st.fn = [multi](hipStream_t s) { return launch_flatcat_multi_u8(multi, s); };
+                g->steps.resize(first_step);
+                g->steps.push_back(st);
             }
             y.prerun_const = all_const;
             break;

@@ -321,6 +321,13 @@ struct U8CatArgs {             // flat per-image slice copy: concat on axis 1 of
     U8Q in, out;
 };
 
+struct U8CatMulti {            // every input of one concat node in ONE launch (blockIdx.z = input): MobileNet-SSD's mbox_loc / mbox_conf
+    U8CatArgs src[8];
+    float rescale[8];
+    int count;
+};
+hipError_t launch_flatcat_multi_u8(const U8CatMulti& m, hipStream_t s);
+
 struct U8SoftmaxArgs {         // softmax over the middle axis of [outer][on][inner]
     const uint8_t* x; uint8_t* y;
     int outer, on, inner;

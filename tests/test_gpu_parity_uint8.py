@@ -256,7 +256,22 @@ def test_ssd_head_plumbing_u8(fuse, same_q):
     assert np.array_equal(got.reshape(want.shape), want)
     assert len(np.unique(want)) > 3
     assert ("permute_u8" in kernels) == (not fuse), kernels
-    assert ("permute_concat_u8" in kernels) == fuse, kernels
+    assert any(k.startswith("permute_concat_u8<x") for k in kernels) == fuse, kernels      # one launch for both heads
+
+
+def test_concat_inputs_in_one_launch_or_one_each(monkeypatch):
+    """all copied inputs of a concat node go through ONE launch (six per concat in MobileNet-SSD); TAMD_FUSE_CONCAT=0: one each"""
+    g, x = u8_ssd_head_graph(37, 2, 24, 10, 6)
+    want = oracle.run_graph(g, x)[0]
+    for mode, launches in (("1", 1), ("0", 2)):
+        monkeypatch.setenv("TAMD_FUSE_CONCAT", mode)
+        gr = capi.Graph(tm2.write_tm2(g))
+        gr.set_input(x)
+        got = gr.run()[0]
+        kernels = [k["kernel"] for k in gr.profile(1)]
+        gr.close()
+        assert np.array_equal(got.reshape(want.shape), want)
+        assert sum(k.startswith("permute_concat_u8") for k in kernels) == launches, kernels
 
 
 def test_permute_standalone_u8():

@@ -1,7 +1,7 @@
 """Randomised device-vs-oracle campaign (runs ON THE GPU BOX; the oracle is the checker, nothing under test uses it).
 
 Same random single-op graphs as tools/fuzz_oracle.py, run through the C ABI on the GPU with a randomly pinned member
-of the kernel family (TAMD_FORCE_GEMM / TAMD_U8_CFG / TAMD_U8_RGB3X3 / TAMD_FIRST_ROWS) and compared byte for byte with
+of the kernel family (TAMD_FORCE_GEMM / TAMD_U8_CFG / TAMD_U8_PATCH / TAMD_U8_RGB3X3 / TAMD_FIRST_ROWS) and compared byte for byte with
 oracle/tg_oracle.c (itself pinned to the real reference by fuzz_oracle.py).
 
     python tools/fuzz_device.py --dtype uint8 --seconds 50 --seed 1"""
@@ -34,8 +34,9 @@ def main():
     os.environ["TAMD_AUTOTUNE"] = "0"          # the pinned member decides, not the clock
     t0, graphs, tot, bad, kernels = time.time(), 0, 0, 0, {}
     while time.time() - t0 < a.seconds:
-        g, x = random_graph(rng, a.dtype)
-        for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS"):
+        patch = a.dtype == "uint8" and rng.random() < 0.6
+        g, x = random_graph(rng, a.dtype, int(rng.choice([4, 4, 32])) if patch else 1)
+        for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS", "TAMD_U8_PATCH", "TAMD_U8_PATCH_CFG"):
             os.environ.pop(k, None)
         if a.dtype == "int8":
             m = I8_MEMBERS[int(rng.integers(len(I8_MEMBERS)))]
@@ -46,6 +47,9 @@ def main():
         else:
             if rng.random() < 0.8:
                 os.environ["TAMD_U8_CFG"] = str(int(rng.integers(8)))
+            if patch:                              # the patch convolution wherever it applies, a random tile configuration first
+                os.environ["TAMD_U8_PATCH"] = "1"
+                os.environ["TAMD_U8_PATCH_CFG"] = str(int(rng.integers(4)))
         want = oracle.run_graph(g, x)
         try:
             gr = capi.Graph(tm2.write_tm2(g))

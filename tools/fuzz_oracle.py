@@ -26,13 +26,14 @@ from oracle import oracle, ref_capi  # noqa: E402
 from tengine_amd import tm2  # noqa: E402
 
 
-def random_graph(rng, dtype):
+def random_graph(rng, dtype, cin_mult=1):
     u8 = dtype == "uint8"
     seed = int(rng.integers(1 << 30))
     kind = int(rng.integers(0, 10))
     if kind < 6:
         k = int(rng.choice([1, 1, 3, 3, 5, 7]))
         cin, cout = int(rng.integers(2, 200 if k < 7 else 24)), int(rng.integers(2, 130))
+        cin = (cin + cin_mult - 1) // cin_mult * cin_mult      # (fuzz_device: channel counts the pinned kernel member applies to)
         dil = int(rng.choice([1, 1, 1, 2])) if k == 3 else 1
         ext = dil * (k - 1) + 1
         h, w, n = int(rng.integers(ext, 40)), int(rng.integers(ext, 40)), int(rng.integers(1, 4))
