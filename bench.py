@@ -27,6 +27,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -299,7 +300,9 @@ def main():
         fam = {}
         for k in prof:
             # family = the kernel's base name: template variants (tile shapes, K splits) of one kernel count together
-            f = fam.setdefault(k["kernel"].split("<")[0].split("+")[0], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            # family = the kernel name without its template / fusion suffixes and without the tile shape (conv_u8_patch_32x64<3x3>+relu)
+            name = re.sub(r"_\d+x\d+(x\d+)?(k\d+)?$", "", k["kernel"].split("<")[0].split("+")[0])
+            f = fam.setdefault(name, {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
             f["ms"] += k["ms"]; f["bytes"] += k["bytes"]; f["macs"] += k["macs"]; f["launches"] += 1
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
@@ -417,7 +420,9 @@ def pmc_traffic(model, dtype, batch, family):
             mode, prod = int(m.group(1)), int(m.group(2))
             fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"
             return fam == family
-        return family in name
+        # step names vs kernel symbols where they differ
+        alias = {"conv_u8_mfma": "conv_u8_gemm_k", "conv_u8_patch": "conv_u8_patch_k", "conv_pgemm_i8": "conv_pgemm", "conv_igemm_i8": "conv_igemm"}
+        return alias.get(family, family) in name
 
     for name, v in ks.items():
         if member(name) and v["hbm_read_bytes_per_launch"] is not None:

@@ -348,7 +348,7 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 // main pixels from an LDS-resident fp32 patch (3x3 and 1x1, group 1); tail pixels, if any, on the VALU by extra blocks of the same launch
 int conv_u8_patch_num_cfgs();
 int conv_u8_patch_bm(int cfg);
-int conv_u8_patch_ss(const U8ConvArgs& a);                         // MFMA steps per super-step (9: 3x3, 8: 1x1); 0: shape not supported
+int conv_u8_patch_ss(const U8ConvArgs& a);                         // MFMA steps per super-step (9: 3x3, 4: 1x1); 0: shape not supported
 bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW);     // fills pk_*; false: not applicable
 const char* conv_u8_patch_kernel_name(const U8ConvArgs& a);
 size_t conv_u8_patch_packed_bytes(const U8ConvArgs& a);

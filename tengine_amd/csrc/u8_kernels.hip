@@ -449,7 +449,7 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 template <int KHW>
 __device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* xs, int tb)
 {
-    constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 8, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64, RING = 4;
+    constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 4, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64, RING = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, r = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, T = OHW - N8, slices = (a.cout + 63) / 64;
     const int slice = tb % slices, nt = tb / slices, t = nt % T, n = nt / T;
@@ -525,10 +525,10 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int NTAPS = KHW * KHW;
-    constexpr int SS = KHW == 3 ? 9 : 8;                 // MFMA steps per super-step: 36 k = 4 channels x 9 taps | 32 k = 32 channels
+    constexpr int SS = KHW == 3 ? 9 : 4;                 // MFMA steps per super-step: 36 k = 4 channels x 9 taps | 16 k = 16 channels
     constexpr int CSS = 4 * SS / NTAPS;                  // channels per super-step
     constexpr int CPC = 4;                               // super-steps per patch chunk == fragment register slots
-    constexpr int CC = CPC * CSS;                        // channels per patch chunk (16 | 128)
+    constexpr int CC = CPC * CSS;                        // channels per patch chunk (16 | 64)
     constexpr int NP = KHW == 3 ? NPSTR : BN;            // floats per channel plane of the patch
     constexpr int PG = NP >= 256 ? 1 : 256 / NP;         // thread groups along the chunk's channels
     constexpr int NPS = NP >= 256 ? NP / 256 : 1;        // patch pixels per thread
@@ -730,9 +730,11 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-        if constexpr (SS > 8) step(std::integral_constant<int, 8>{});
+        step(std::integral_constant<int, 3>{});
+        if constexpr (SS > 4) {
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{});
+            step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+        }
     };
     auto chunk = [&](auto BUF, int c) {
         const int ss0 = c * CPC;
@@ -794,12 +796,12 @@ static const struct { int wm, wn, tm, tn; const char* n3; const char* n1; } U8P_
 int conv_u8_patch_num_cfgs() { return 4; }
 int conv_u8_patch_bm(int cfg) { return U8P_CFGS[cfg].wm * U8P_CFGS[cfg].tm * 16; }
 static int u8p_bn(int cfg) { return U8P_CFGS[cfg].wn * U8P_CFGS[cfg].tn * 16; }
-int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 8 : 0; }
+int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 4 : 0; }
 const char* conv_u8_patch_kernel_name(const U8ConvArgs& a) { return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1; }
 
 static size_t u8p_lds(const U8ConvArgs& a)
 {
-    const int cc = a.pk_kh == 3 ? 16 : 128;
+    const int cc = a.pk_kh == 3 ? 16 : 64;
     return (size_t)(2 * cc * a.pk_npad) * 4;
 }
 
@@ -812,7 +814,7 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
     a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
     const int ss = conv_u8_patch_ss(a);
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = u8p_bn(cfg);
-    if (off || !ss || N8 == 0 || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 32) != 0 || a.PH < 0 || a.PW < 0) return false;
+    if (off || !ss || N8 == 0 || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 16) != 0 || a.PH < 0 || a.PW < 0) return false;
     if ((size_t)a.C * a.H * a.W >= (1u << 31) || (size_t)a.K * 4 > 150 * 1024) return false;      // (the tail blocks keep an im2col column in LDS)
     if (KH == 1) { a.pk_wp = 0; a.pk_npad = bn; a.pk_cfg = cfg; return true; }      // the patch is the tile's own pixels
     a.pk_wp = (a.OW - 1) * a.SW + (KW - 1) * DW + 1;

@@ -41,8 +41,9 @@ CASES = [
     (1, 32, 12, 12, 16, 3, 1, 2, 1, 0, True, 2),        # dilation 2, pad 2
     (1, 512, 7, 7, 64, 3, 1, 1, 1, 0, True, 1),         # K = 4608, 49 px: 48 main
     (2, 64, 19, 19, 128, 1, 1, 0, 1, 0, True, 1),       # mssd pointwise class: 361 px, 1x1
-    (1, 96, 10, 10, 40, 1, 1, 0, 1, -1, True, 1),       # 1x1, C = 96 = 3 super-steps, cout 40
+    (1, 96, 10, 10, 40, 1, 1, 0, 1, -1, True, 1),       # 1x1, C = 96 = 6 super-steps (a chunk and a half), cout 40
     (1, 32, 19, 19, 48, 1, 2, 0, 1, 0, True, 1),        # 1x1 stride 2
+    (2, 48, 13, 13, 100, 1, 1, 0, 1, 6, True, 1),       # 1x1, C = 48 = three 16-channel super-steps (one partial chunk), 1 tail pixel
     (1, 4, 24, 24, 24, 3, 1, 1, 1, -1, True, 1),        # C = 4: one super-step in all (first-layer kernel also applies; patch pinned)
     (1, 20, 16, 16, 32, 3, 1, 0, 1, 0, True, 1),        # pad 0, C = 20: five super-steps, odd chunk count
     (1, 16, 8, 30, 32, 3, 1, 1, 1, 0, True, 1),         # wide rows

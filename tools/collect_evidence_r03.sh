@@ -57,5 +57,24 @@ for cfg in "mobilenet_v1 1 int8" "resnet50 32 int8" "mobilenet_v1 64 int8" "yolo
   unset TAMD_PLAN_CACHE
   echo "$cfg: $(wc -l < $O/traffic_$1_$3_b$2.txt) traffic lines, $(wc -l < $O/pmc_mfma_$1_$3_b$2.csv) pmc lines"
 done
+# ---- 5. inside a pass: per-position kernel durations of hipGraph replays (uint8 configs), and the patch kernel's ablation anatomy
+cd /tmp
+for cfg in "yolov3_tiny 8" "mssd 16"; do
+  set -- $cfg
+  export TAMD_PLAN_CACHE=$O/plan_$1_uint8_b$2.txt
+  rm -rf $O/trace_is
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_is -- python $R/tools/replay_model.py $1 $2 30 uint8 > $O/replay_$1.txt 2> $O/trace_is.err
+  T=$(find $O/trace_is -name "*kernel_trace.csv" | head -1)
+  N=$(grep -o "launches_per_replay [0-9]*" $O/replay_$1.txt | cut -d' ' -f2)
+  python $R/tools/trace_gaps.py $T $N 30 > $O/insitu_trace_$1_uint8_b$2.txt 2>&1
+  unset TAMD_PLAN_CACHE
+  python $R/tools/replay_model.py $1 $2 30 uint8 >> $O/insitu_trace_$1_uint8_b$2.txt 2>&1      # the same replays without the tracer
+done
+rm -rf $O/trace_is
+if ls $R/tools/exp/u8_patch_anatomy_0.bin > /dev/null 2>&1; then
+  cd $R/tools/exp
+  for m in 0 1 2 4 8 16 3 7 15 31; do timeout 120 ./u8_patch_anatomy_$m.bin; done 2>&1 | sort -s -k1,1 > $O/u8_patch_anatomy_ablation.txt
+fi
+cd /tmp
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*counter_collection.csv" -delete; rm -rf $O/trace $O/calib_FETCH_SIZE $O/calib_WRITE_SIZE
 ls $O | head -60
