@@ -12,6 +12,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -522,19 +523,29 @@ static bool autotune_enabled()
 // A first prerun measures as usual and writes the file; later preruns of the same model take the recorded choices WITHOUT
 // launching anything -- a profiler then sees the run's own launches only (round 2's rocprofv3 CSVs were 99 % autotune
 // dispatches), the plan no longer depends on one box's timing noise, and prerun drops from seconds to the packing time.
+// The table is process-wide (graphs of one process share it) and guarded by a mutex; a file that changed on disk since it was
+// read (size or modification time) is read again at the next lookup.
 struct PlanCache {
     bool loaded = false, dirty = false;
     std::string path;
+    long long stamp = 0;                                  // size ^ mtime of the file as read / written
     std::map<std::string, std::string> kv;
 };
-static PlanCache& plan_cache()
+static std::mutex g_plan_cache_mu;
+static long long file_stamp(const std::string& path)
+{
+    struct stat st;
+    if (path.empty() || stat(path.c_str(), &st) != 0) return 0;
+    return (long long)st.st_size * 1000003ll ^ (long long)st.st_mtim.tv_sec * 1000000007ll ^ (long long)st.st_mtim.tv_nsec;
+}
+static PlanCache& plan_cache_locked()                     // call with g_plan_cache_mu held
 {
     static PlanCache pc;
     const char* p = getenv("TAMD_PLAN_CACHE");
     const std::string want = p ? p : "";
-    if (!pc.loaded || pc.path != want) {
+    if (!pc.loaded || pc.path != want || (!pc.dirty && file_stamp(want) != pc.stamp)) {
         pc = PlanCache();
-        pc.loaded = true; pc.path = want;
+        pc.loaded = true; pc.path = want; pc.stamp = file_stamp(want);
         if (FILE* f = want.empty() ? nullptr : fopen(want.c_str(), "r")) {
             char line[512];
             while (fgets(line, sizeof(line), f)) {
@@ -552,7 +563,8 @@ static PlanCache& plan_cache()
 }
 bool plan_cache_get(const std::string& key, std::string* v)
 {
-    PlanCache& pc = plan_cache();
+    std::lock_guard<std::mutex> lk(g_plan_cache_mu);
+    PlanCache& pc = plan_cache_locked();
     auto it = pc.kv.find(key);
     if (pc.path.empty() || it == pc.kv.end()) return false;
     *v = it->second;
@@ -560,20 +572,23 @@ bool plan_cache_get(const std::string& key, std::string* v)
 }
 void plan_cache_put(const std::string& key, const std::string& v)
 {
-    PlanCache& pc = plan_cache();
+    std::lock_guard<std::mutex> lk(g_plan_cache_mu);
+    PlanCache& pc = plan_cache_locked();
     if (pc.path.empty()) return;
     pc.kv[key] = v;
     pc.dirty = true;
 }
 static void plan_cache_flush()
 {
-    PlanCache& pc = plan_cache();
+    std::lock_guard<std::mutex> lk(g_plan_cache_mu);
+    PlanCache& pc = plan_cache_locked();
     if (pc.path.empty() || !pc.dirty) return;
     if (FILE* f = fopen(pc.path.c_str(), "w")) {
         for (auto& e : pc.kv) fprintf(f, "%s\t%s\n", e.first.c_str(), e.second.c_str());
         fclose(f);
     }
     pc.dirty = false;
+    pc.stamp = file_stamp(pc.path);
 }
 
 // pointwise weight panel in MFMA fragment order: [16-channel slice][64-deep K step][lane = (k block of 16) * 16 + channel][16 B];
