@@ -179,7 +179,7 @@ struct DirectProgram {
     std::vector<hsa_kernel_dispatch_packet_t> pkts;     // bodies; headers are written last, per pass
     std::vector<uint16_t> hdr;                          // header of packet i inside a burst (the first packet of a burst: h_open)
     void* kernargs = nullptr;
-    uint16_t h_open = 0, h_close = 0;
+    uint16_t h_open = 0, h_close = 0, h_wrap = 0;        // first packet of a burst / closing barrier packet / first packet of a later pass
 };
 
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share)
@@ -279,6 +279,12 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
     if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] direct: %zu packets, %d without the barrier bit\n", p->pkts.size(), n_beside);
     p->h_open = header(K, HSA_FENCE_SCOPE_SYSTEM, coherent[0] ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT);
     p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
+    // a pass queued right behind another pass of the same burst: when the graph found the first launch independent of the
+    // previous pass's last launches (LaunchRec::wrap), its packet carries no barrier bit -- it starts while they finish; the
+    // second packet has the bit again and waits for both.  The fences stay what they are (the input may have been rewritten in
+    // between; a coherent first launch reads it with agent-scope loads as before).
+    p->h_wrap = (!recs.empty() && recs[0].wrap) ? (uint16_t)(p->hdr[0] & ~(1u << HSA_PACKET_HEADER_BARRIER)) : p->hdr[0];      // same fences, no barrier bit
+    if (getenv("TAMD_DEBUG") && p->h_wrap != p->hdr[0]) fprintf(stderr, "[tamd] direct: the first launch of a pass runs beside the end of the previous pass\n");
     return p;
 }
 
@@ -314,7 +320,7 @@ int direct_submit(DirectProgram* p)
         d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
         d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
         d->completion_signal.handle = 0;
-        __atomic_store_n(&d->header, (i == 0 && !dq->open) ? p->h_open : p->hdr[i], __ATOMIC_RELEASE);
+        __atomic_store_n(&d->header, i == 0 ? (dq->open ? p->h_wrap : p->h_open) : p->hdr[i], __ATOMIC_RELEASE);
     }
     // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor is never handed
     // a batch that is not contiguous in memory

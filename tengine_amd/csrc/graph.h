@@ -87,11 +87,17 @@ inline Access access_of(const HTensor& t)                         // dense tenso
     Access a;
     a.base = (const char*)t.dptr;
     const size_t esz = t.dtype == TAMD_DT_FP32 ? 4 : 1;
-    if (t.is_view && t.cs > 0) {
-        a.period = (size_t)t.cs * t.h * t.w * esz; a.off = (size_t)t.c_off * t.h * t.w * esz; a.len = (size_t)t.c * t.h * t.w * esz;
-        a.size = a.period * (size_t)t.n;
-    } else {
-        a.size = t.elems() * esz; a.len = a.size;
+    if (t.nchw_raw || t.cs <= 0) {                                // NCHW bytes (uint8 / fp32 graphs, raw graph inputs)
+        if (t.is_view && t.cs > 0) {
+            a.period = (size_t)t.cs * t.h * t.w * esz; a.off = (size_t)t.c_off * t.h * t.w * esz; a.len = (size_t)t.c * t.h * t.w * esz;
+            a.size = a.period * (size_t)t.n;
+        } else {
+            a.size = t.elems() * esz; a.len = a.size;
+        }
+    } else {                                                      // NHWC int8 buffer, cs bytes per pixel; a view owns channels [c_off, c_off + c)
+        a.size = (size_t)t.n * t.h * t.w * t.cs;
+        if (t.is_view) { a.period = (size_t)t.cs; a.off = (size_t)t.c_off; a.len = (size_t)t.c; }
+        else a.len = a.size;
     }
     return a;
 }

@@ -19,6 +19,7 @@ struct LaunchRec {
     std::vector<unsigned char> args;    // explicit kernel-argument segment
     bool coherent = false;              // the kernel exchanges its tensors with agent-scope accesses (launch_rec_coherent): no fences
     bool beside = false;                // independent of every launch since the last ordered one (launch_rec_beside): no barrier bit
+    bool wrap = false;                  // (first record only) independent of the END of the previous pass: in a burst of passes it starts beside it
 };
 
 extern thread_local std::vector<LaunchRec>* g_launch_rec;       // direct.cc; non-null while a launch list is being recorded

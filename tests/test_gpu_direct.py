@@ -143,3 +143,27 @@ def test_direct_overlap_of_independent_launches_keeps_the_bytes(monkeypatch):
         gr.close()
     for a, b in zip(outs["0"], outs["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 1), ("mobilenet_v1", "int8", 4), ("yolov3_tiny", "uint8", 1)])
+def test_back_to_back_passes_overlap_at_the_seam_and_keep_the_bytes(name, dtype, batch, monkeypatch):
+    """a burst of passes on the direct path: the first launch of pass k+1 carries no barrier bit when it touches nothing the last
+    launch of pass k touches (TAMD_DIRECT_WRAP=1; off by default, it buys nothing on this stack); hundreds of queued passes, a changed input in between, and the
+    results are those of the ordered list"""
+    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
+    b = tm2.write_tm2(g)
+    xs = [models.synth_input(g, s, NP[dtype]) for s in (31, 32)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TAMD_DIRECT_WRAP", mode)
+        gr = capi.Graph(b, direct_dispatch=True)
+        assert gr.direct_packets() > 0
+        outs = []
+        for x in xs:
+            outs.append([o.copy() for o in _resident(gr, x, 300)])            # 300 passes queued behind each other, one wait
+        res[mode] = outs
+        gr.close()
+    for a, c in zip(res["0"], res["1"]):
+        for u, v in zip(a, c):
+            assert np.array_equal(u, v)
+    assert any(not np.array_equal(u, v) for u, v in zip(res["1"][0], res["1"][1]))
