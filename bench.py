@@ -300,9 +300,7 @@ def main():
         fam = {}
         for k in prof:
             # family = the kernel's base name: template variants (tile shapes, K splits) of one kernel count together
-            # family = the kernel name without its template / fusion suffixes and without the tile shape (conv_u8_patch_32x64<3x3>+relu)
-            name = re.sub(r"_\d+x\d+(x\d+)?(k\d+)?$", "", k["kernel"].split("<")[0].split("+")[0])
-            f = fam.setdefault(name, {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            f = fam.setdefault(kernel_family(k["kernel"]), {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
             f["ms"] += k["ms"]; f["bytes"] += k["bytes"]; f["macs"] += k["macs"]; f["launches"] += 1
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
@@ -397,6 +395,13 @@ def main():
         if cpu:
             line["speedup_vs_cpu_reference"] = value / cpu["value"] if cpu["value"] else None
         print(json.dumps(line), flush=True)
+
+
+def kernel_family(step_kernel):
+    """the family a launch is booked under in `roofline`: the step's kernel name without its template / fusion suffixes and
+    without the tile shape -- conv_u8_patch_32x64<3x3>+relu -> conv_u8_patch, conv_u8_mfma_64x64k64+relu+maxpool -> conv_u8_mfma,
+    pwdw_i8<s1,7x14,512> -> pwdw_i8"""
+    return re.sub(r"_\d+x\d+(x\d+)?(k\d+)?$", "", step_kernel.split("<")[0].split("+")[0])
 
 
 def pmc_traffic(model, dtype, batch, family):

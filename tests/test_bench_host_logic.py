@@ -1,0 +1,66 @@
+"""Host-side pieces of bench.py and the evidence tooling that need no GPU: how launches are grouped into kernel families for the
+`roofline` object, how the committed PMC summaries are matched to a family, and that the per-config table of profiles/README.md
+can be re-derived from the committed files."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_families():
+    b = _bench()
+    assert b.kernel_family("conv_u8_patch_32x64<3x3>+relu") == "conv_u8_patch"
+    assert b.kernel_family("conv_u8_patch_128x64<1x1>") == "conv_u8_patch"
+    assert b.kernel_family("conv_u8_mfma_64x64k64+relu+maxpool") == "conv_u8_mfma"
+    assert b.kernel_family("conv_u8_rgb3x3+relu+maxpool") == "conv_u8_rgb3x3"
+    assert b.kernel_family("pwdw_i8<s1,7x14,512>") == "pwdw_i8"
+    assert b.kernel_family("conv_pgemm_i8<128x64,3x3,ks2>") == "conv_pgemm_i8"
+    assert b.kernel_family("conv_igemm_i8<64x64x64>") == "conv_igemm_i8"
+    assert b.kernel_family("permute_concat_u8<x6>") == "permute_concat_u8"
+
+
+def test_pmc_traffic_reads_the_newest_committed_summary():
+    b = _bench()
+    # the headline workload has a committed PMC pass; bytes per launch of the dominant family are a sane number
+    t = b.pmc_traffic("mobilenet_v1", "int8", 1, "pwdw_i8")
+    assert t is not None and 2e5 < t < 2e7
+    # the uint8 configs of round 3 as well (step name conv_u8_patch -> kernel symbol conv_u8_patch_k)
+    t = b.pmc_traffic("yolov3_tiny", "uint8", 8, "conv_u8_patch")
+    assert t is not None and t > 1e5
+    assert b.pmc_traffic("no_such_model", "int8", 1, "pwdw_i8") is None
+
+
+def test_evidence_table_is_rederivable_from_profiles():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "r03"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("| ") and "ms / step" not in ln]
+    assert len(rows) == 5, r.stdout
+    readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    for ln in rows:
+        assert ln in readme, "profiles/README.md is out of date with the committed evidence: " + ln
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    for f in ("r03_bench_b1.json", "r03_bench_b1_driver_invocation.json"):
+        j = json.loads(open(os.path.join(ROOT, "profiles", f)).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                  "config", "roofline", "cpu_baseline", "host_to_host_images_per_s", "prerun_ms", "value_definition"):
+            assert k in j, (f, k)
+        assert j["vs_baseline"] is None and j["n_gpus"] == 1 and j["dtype"] == "int8" and "workload" in j["config"]
+        r = j["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        c = j["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c
