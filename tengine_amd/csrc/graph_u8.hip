@@ -187,6 +187,17 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
             return 1;
         };
+        // conv_u8_pw shares the 1x1 fragment-order weights and the tail blocks with the patch kernel, not its switches
+        auto pw_ready = [&](U8ConvArgs& ac) -> int {
+            ac.pk_kh = ac.pk_kw = 1; ac.pk_dh = ac.pk_dw = 1; ac.pk_wp = 0; ac.pk_cfg = 0; ac.pk_npad = 64;
+            if (!pk_w) {
+                std::vector<float> wp(conv_u8_patch_packed_bytes(ac) / 4);
+                conv_u8_patch_pack(ac, w.data.data(), (uint8_t)qw.zp, qw.scale, wp.data());
+                if (upload(g, wp, &pk_w)) return -1;
+            }
+            ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
+            return 0;
+        };
         // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
         const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
         const bool rgb_ok = conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
@@ -203,7 +214,8 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             rgb.wf = dwf;
             return 0;
         };
-        bool use_rgb = false;
+        bool use_rgb = false, use_pw = false;           // conv_u8_rgb3x3 / conv_u8_pw (shallow pointwise layers of large maps)
+        const char* pw_env = getenv("TAMD_U8_PW");                     // 0: never, 1: wherever it applies (tests)
         static const char* at_env = getenv("TAMD_AUTOTUNE");
         const bool tune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG");
         // what the autotune decided last time (TAMD_PLAN_CACHE): "g<cfg>" GEMM family, "p<cfg>" patch kernel, "rgb"
@@ -212,9 +224,10 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                  p.stride_h, p.dilation_h, relu ? "+relu" : "", pool ? "+pool" : "");
         std::string cached;
         bool from_cache = false;
-        if (tune && !pk_force && !rgb_env && !pk_env && plan_cache_get(ckey, &cached) && cached.size() >= 2) {
+        if (tune && !pk_force && !rgb_env && !pk_env && !pw_env && plan_cache_get(ckey, &cached) && cached.size() >= 2) {
             const int c = atoi(cached.c_str() + 1);
             if (cached == "rgb" && rgb_ok) { use_rgb = true; from_cache = true; }
+            else if (cached == "pw" && conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) { use_pw = true; from_cache = true; }
             else if (cached[0] == 'g' && c >= 0 && c < conv_u8_gemm_num_cfgs()) { a.cfg = c; from_cache = true; }
             else if (cached[0] == 'p' && c >= 0 && c < conv_u8_patch_num_cfgs()) { U8ConvArgs ac = a; if (patch_for(ac, c) == 1) { pk_best = c; from_cache = true; } }
         }
@@ -267,6 +280,16 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (gemm family best %.2f us)\n", n.name.c_str(), conv_u8_patch_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
                 if (pk_force ? ms < pk_ms : ms < best_ms * 0.96f) { pk_best = c; pk_ms = ms; if (!pk_force) best_ms = ms; }
             }
+            if (conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) {
+                U8ConvArgs ac = a;
+                if (pw_ready(ac)) return -1;
+                {
+                    float ms = 1e30f;
+                    if (time_of([&]() { return launch_conv_u8_pw(ac, g->stream); }, &ms)) return -1;
+                    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (best so far %.2f us)\n", n.name.c_str(), conv_u8_pw_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
+                    if (ms < best_ms * 0.96f) { use_pw = true; best_ms = ms; }
+                }
+            }
             if (rgb_ok) {
                 if (rgb_ready()) return -1;
                 float ms = 1e30f;
@@ -275,9 +298,17 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;
-            plan_cache_put(ckey, use_rgb ? std::string("rgb") : pk_best >= 0 ? "p" + std::to_string(pk_best) : "g" + std::to_string(best_cfg));
+            plan_cache_put(ckey, use_rgb ? std::string("rgb") : use_pw ? std::string("pw") : pk_best >= 0 ? "p" + std::to_string(pk_best) : "g" + std::to_string(best_cfg));
         }
         if (rgb_ok && rgb_env && atoi(rgb_env) == 1) use_rgb = true;
+        if (pw_env && atoi(pw_env) == 1 && conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) use_pw = true;
+        if (use_pw && !use_rgb) {
+            if (pw_ready(a)) return -1;
+            st.kernel = std::string(conv_u8_pw_kernel_name(a)) + (relu ? "+relu" : "");
+            st.fn = [a](hipStream_t s) { return launch_conv_u8_pw(a, s); };
+            g->steps.push_back(st);
+            return 0;
+        }
         // everything this launch touches besides constants: the input, the output (a concat slice when it is a view), the pooled output
         st.rd.push_back(access_of(x));
         st.wr.push_back(access_of(y));

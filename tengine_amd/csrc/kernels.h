@@ -354,6 +354,10 @@ const char* conv_u8_patch_kernel_name(const U8ConvArgs& a);
 size_t conv_u8_patch_packed_bytes(const U8ConvArgs& a);
 void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, float w_scale, float* out);       // w: [cout][K] as in the model
 hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s);
+// shallow pointwise layers of large maps (K = 32 | 64): weights resident in registers, B straight from the NCHW input, one wave per tile
+bool conv_u8_pw_applicable(const U8ConvArgs& a, int KH, int KW);
+const char* conv_u8_pw_kernel_name(const U8ConvArgs& a);
+hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);

@@ -883,6 +883,122 @@ hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s)
 }
 
 // =================================================================================================================
+// Shallow pointwise layers of large maps (MobileNet-SSD conv1 / conv2: 1x1, stride 1, K = 32 | 64 on 150^2 / 75^2 maps):
+// K is one or two patch chunks, so a conv_u8_patch block is all prologue and epilogue there.  Here a WAVE is the unit: it keeps
+// the weight fragments of its 16*TM output channels for the WHOLE K in registers (the conv_u8_patch fragment stream, read once),
+// walks 16-pixel column tiles of the batch grid-stride, reads the B operand straight from the NCHW input -- lane (pixel l15,
+// k%4 = kq) needs the bytes of channels 4s + kq of its pixel: KS byte loads per tile, requested one tile ahead -- converts them in
+// the shadow of the previous MFMAs and issues the chain in ascending k (the reference's order, conv_u8_body's header).  No LDS, no
+// barrier, no block-level cooperation.  Tail pixels: conv_u8_patch_tail blocks behind the main grid, as in conv_u8_patch.
+// =================================================================================================================
+template <int TM, int KS>
+__global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // used by the tail blocks only
+    if ((int)blockIdx.x >= main_blocks) {
+        conv_u8_patch_tail<1>(a, smem, blockIdx.x - main_blocks);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, PTI = (N8 + 15) / 16, CT = (a.cout + 16 * TM - 1) / (16 * TM);
+    const int nwaves = main_blocks * 4, gw = blockIdx.x * 4 + wave;
+    const int ct = gw % CT, lanes_of_ct = (nwaves - ct + CT - 1) / CT;        // waves that share this cout tile stride over the pixel tiles
+    const int co0 = ct * 16 * TM;
+    // ---- the weights of this wave: [tile16][super-step of 4 MFMA steps][lane][float4] (conv_u8_patch_pack, 1x1) -------------------
+    constexpr int NSS = KS / 4;
+    float4 af[TM][NSS];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const float* wb = reinterpret_cast<const float*>(a.wpk) + (size_t)(co0 / 16 + i) * NSS * 256;
+#pragma unroll
+        for (int ss = 0; ss < NSS; ss++) af[i][ss] = *reinterpret_cast<const float4*>(wb + ss * 256 + lane * 4);
+    }
+    const int total = a.N * PTI;
+    auto tile_ptr = [&](int t, int* n, int* pj) __attribute__((always_inline)) {
+        *n = t / PTI;
+        *pj = (t - *n * PTI) * 16 + l15;
+    };
+    unsigned bq[2][KS];                                  // raw bytes of the tile in flight / the tile being computed
+    auto bload = [&](auto D, int t) __attribute__((always_inline)) {
+        constexpr int d = decltype(D)::value;
+        int n, pj;
+        tile_ptr(t < total ? t : total - 1, &n, &pj);
+        const uint8_t* xp = a.x + (size_t)n * a.C * OHW + (size_t)kq * OHW + (pj < N8 ? pj : N8 - 1);
+#pragma unroll
+        for (int s = 0; s < KS; s++) bq[d][s] = xp[(size_t)(4 * s) * OHW];
+    };
+    auto compute = [&](auto D, int t) __attribute__((always_inline)) {
+        constexpr int d = decltype(D)::value;
+        v4f acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const float bf = dequant((uint8_t)bq[d][s], a.in_zp, a.in_scale);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const float4 f = af[i][s >> 2];
+                const float av = (s & 3) == 0 ? f.x : (s & 3) == 1 ? f.y : (s & 3) == 2 ? f.z : f.w;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf, acc[i], 0, 0, 0);
+            }
+        }
+        int n, pj;
+        tile_ptr(t, &n, &pj);
+        if (pj >= N8) return;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int co = co0 + i * 16 + 4 * kq + e;
+                if (co >= a.cout) continue;
+                float s = acc[i][e];
+                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+                if (a.act == 0) s = s < 0.f ? 0.f : s;
+                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
+                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = q;
+            }
+    };
+    int t = gw / CT;                                     // this wave's first pixel tile; the next ones follow at a stride of lanes_of_ct
+    if (t >= total) return;
+    bload(std::integral_constant<int, 0>{}, t);
+    for (; t < total; t += 2 * lanes_of_ct) {
+        bload(std::integral_constant<int, 1>{}, t + lanes_of_ct);
+        compute(std::integral_constant<int, 0>{}, t);
+        if (t + lanes_of_ct >= total) break;
+        bload(std::integral_constant<int, 0>{}, t + 2 * lanes_of_ct);
+        compute(std::integral_constant<int, 1>{}, t + lanes_of_ct);
+    }
+}
+
+// shallow pointwise layers: 1x1, stride 1, no padding, K in {32, 64} (at K = 128 the patch kernel and the staging GEMM are faster), no fused pool; the patch fields (pk_kh = 1, wpk in the
+// 1x1 fragment order) must be prepared (conv_u8_patch_prepare with any configuration)
+bool conv_u8_pw_applicable(const U8ConvArgs& a, int KH, int KW)
+{
+    const char* env = getenv("TAMD_U8_PW");
+    if (env && atoi(env) == 0) return false;
+    return KH == 1 && KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0 && a.H == a.OH && a.W == a.OW && !a.pool.on
+           && (a.K == 32 || a.K == 64) && (a.OH * a.OW & ~7) >= 16 && (size_t)a.C * a.H * a.W < (1u << 31);
+}
+
+const char* conv_u8_pw_kernel_name(const U8ConvArgs& a) { return a.K == 32 ? "conv_u8_pw<k32>" : "conv_u8_pw<k64>"; }
+
+hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s)
+{
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, PTI = (N8 + 15) / 16;
+    const int tm = 4, CT = (a.cout + 16 * tm - 1) / (16 * tm);
+    const long items = (long)a.N * PTI * CT;             // (pixel tile, cout tile) pairs: four per block, at most ~8 blocks per CU
+    const int main_blocks = (int)std::min<long>((items + 3) / 4, 2048);
+    const int tail_blocks = (OHW - N8) * a.N * ((a.cout + 63) / 64);
+    const size_t lds = tail_blocks ? (size_t)a.K * 4 : 0;
+    const dim3 grid(main_blocks + tail_blocks, 1, 1);
+    if (a.K == 32) hipLaunchKernelGGL((conv_u8_pw_k<4, 8>), grid, dim3(256), lds, s, a, main_blocks);
+    else hipLaunchKernelGGL((conv_u8_pw_k<4, 16>), grid, dim3(256), lds, s, a, main_blocks);
+    return hipGetLastError();
+}
+
+// =================================================================================================================
 // First layers (3x3, <= 4 input channels, dilation 1: YOLOv3-tiny conv0, MobileNet / SSD conv0): K = 9*C is one
 // MFMA stage at most, so the GEMM kernel above is all set-up and epilogue there.  Here a thread owns one pixel, keeps
 // its K dequantised taps in registers and walks the output channels: weights are LDS broadcasts, each

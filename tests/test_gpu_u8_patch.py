@@ -95,3 +95,46 @@ def test_models_with_the_patch_member_pinned(name, batch, res):
     assert sum("conv_u8_patch" in kn for kn in kernels) >= 5, kernels
     for wv, a in zip(want, got):
         assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
+
+
+PW_CASES = [
+    # n, cin, h, w, cout, act, bias      (1x1, stride 1, pad 0; K = cin in {32, 64})
+    (2, 32, 20, 20, 64, 0, True),        # K = 32, 400 px: 25 column tiles, no tail
+    (1, 32, 13, 13, 13, -1, True),       # 169 px: 168 main (half a tile at the end) + 1 tail pixel; cout 13 (one partial row tile)
+    (3, 64, 10, 10, 100, 6, True),       # K = 64, 100 px: 96 main + 4 tail; relu6; cout 100 (two 64-row wave tiles, the second ragged)
+    (1, 64, 38, 38, 128, 0, False),      # MobileNet-SSD conv2 class, no bias
+    (2, 64, 19, 19, 255, 1, True),       # cout 255 (four wave tiles, the last ragged), 361 px: 360 main + 1 tail, relu1 clamp
+    (1, 32, 8, 8, 32, -1, True),         # 64 px: four tiles in all
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[str(c) for c in PW_CASES])
+def test_shallow_pointwise_kernel_bytes_equal_oracle(case, monkeypatch):
+    """conv_u8_pw: a wave keeps the weights of its output rows for the whole K in registers and reads B straight from the NCHW
+    input -- TAMD_U8_PW=1 pins it where it applies; bytes == oracle == the other members"""
+    n, cin, h, w, cout, act, bias = case
+    g, x = u8_conv_graph(77 + cin + cout, n, cin, h, w, cout, 1, 1, 0, 1, act, bias, 1)
+    want = oracle.run_graph(g, x)
+    monkeypatch.setenv("TAMD_U8_PW", "1")
+    got, kernels = run_with(g, x, "0")
+    assert any(kn.startswith("conv_u8_pw<") for kn in kernels), kernels
+    monkeypatch.setenv("TAMD_U8_PW", "0")
+    ref, kernels0 = run_with(g, x, "0")
+    assert not any("conv_u8_pw" in kn for kn in kernels0), kernels0
+    for wv, a, b in zip(want, got, ref):
+        a = a.reshape(wv.shape)
+        bad = np.count_nonzero(a != wv)
+        assert bad == 0, "%d / %d bytes differ from the oracle (max |d| %d)" % (bad, wv.size, np.abs(a.astype(int) - wv.astype(int)).max())
+        assert np.array_equal(a, b.reshape(wv.shape))
+        assert len(np.unique(wv)) > 3
+
+
+def test_mssd_with_the_shallow_pointwise_kernel_pinned(monkeypatch):
+    monkeypatch.setenv("TAMD_U8_PW", "1")
+    g = models.build("mssd", "uint8", 2)
+    x = models.synth_input(g, 6, tm2.DT_UINT8)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, "1")
+    assert sum(kn.startswith("conv_u8_pw<") for kn in kernels) >= 2, kernels
+    for wv, a in zip(want, got):
+        assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
