@@ -444,7 +444,21 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
     import numpy as np
     logical = os.cpu_count() or 1
     physical = physical_cores() or logical
-    sweep = sorted({t for t in (1, 8, 32, physical, logical) if 1 <= t <= logical})
+    # The reference takes omp_get_max_threads() as its core count the first time it is asked (source/system/cpu.c:110, cached),
+    # caps it at 64 and builds the all-cores mask as ((size_t)1 << count) - 1 -- zero for 64, and then every kernel runs on one
+    # thread whatever options.num_thread says (the flat sweep below).  Asking OpenMP for fewer threads BEFORE the reference's first
+    # graph (what OMP_NUM_THREADS=<n> in the environment does) keeps the mask valid with the sources untouched:
+    # TAMD_BENCH_REF_THREADS=<n <= 63> does that and sweeps up to n.  It is opt-in until it has been timed on the 256-CPU box with
+    # its 16-CPU cgroup allowance (n = 63 there spun for more than a minute; n = the allowance is the setting to try).
+    cap = logical
+    cap_env = os.environ.get("TAMD_BENCH_REF_THREADS")
+    if cap_env and cap_env.isdigit() and 1 <= int(cap_env) <= 63:
+        cap = min(int(cap_env), logical)
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cap)
+        except (OSError, AttributeError):
+            pass
+    sweep = sorted({min(t, cap) for t in (1, 8, 32, physical, logical) if t >= 1})
     try:
         from oracle import ref_capi
         if not ref_capi.available():
