@@ -432,9 +432,11 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 //     same way in every super-step (4*SS is a multiple of KH*KW), so the SS addresses per pixel tile are loop invariants;
 //   A (weights): dequantised ONCE at plan time on the host -- ((float)w - zp) * scale in fp32 is the same IEEE value wherever it
 //     is computed -- and stored in the MFMA A-fragment order, [16-row tile][super-step][float4 group][lane]: a wave fetches its
-//     fragments of the NEXT super-step straight from global memory (L2-resident, shared by every pixel tile) into registers,
+//     fragments three to seven super-steps AHEAD straight from global memory (shared by every pixel tile) into a register ring,
 //     no LDS, no conversion, no barrier.
-// One barrier per patch chunk (4 super-steps of a 3x3 layer).  Summation order: unchanged -- accumulator tile (i, j) receives its
+// A super-step is 36 k (4 channels x 9 taps, 9 MFMA steps) for 3x3 and 16 k (16 channels, 4 MFMA steps) for 1x1; a patch chunk
+// is 4 super-steps; one barrier per chunk; the B reads run two MFMA steps ahead; the refresh of the other patch buffer (convert,
+// store, re-request) is spread over the chunk's MFMA steps.  Summation order: unchanged -- accumulator tile (i, j) receives its
 // k in ascending steps of 4, which v_mfma_f32_16x16x4f32 adds as four fused multiply-adds in ascending k (conv_u8_body's
 // header) -- so the bytes are the reference's.  Tail pixels (OH*OW % 8): conv_u8_patch_tail, extra blocks of the same launch.
 // Blocks are numbered so that the eight XCDs split the cout tiles between them (each L2 holds its own slice of the weights).
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     __syncthreads();
     // one super-step: patch buffer BUF, super-step U of the chunk == fragment slot -- all compile time, so every LDS address is
     // a loop-invariant register plus an immediate and no register array is indexed dynamically.  Global latency here is 1-2 us
-    // under load and a super-step is ~0.5 us of MFMA: the fragments are requested THREE super-steps ahead.
+    // under load and a super-step is ~0.5 us of MFMA: the fragments are requested RA - 1 super-steps ahead.
     float bfr[3][TN];                                    // B values, read TWO MFMA steps ahead (an LDS read takes longer than a step's MFMAs)
     auto bread = [&](auto BUF, auto U, auto S) {         // step S of super-step U (S may run past SS into the chunk's next super-step)
         constexpr int buf = decltype(BUF)::value, sl = decltype(S)::value, u = decltype(U)::value + sl / SS, s = sl % SS;
