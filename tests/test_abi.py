@@ -175,6 +175,22 @@ def test_launch_recorder_packs_arguments_like_the_code_object(tmp_path):
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
 
 
+def test_dependency_test_of_the_barrier_free_launches(tmp_path):
+    """which launch may run beside which (tengine_amd/csrc/graph.h: access_of / access_overlap / step_conflict -- NCHW tensors,
+    uint8 concat slices, int8 NHWC channel views, concat slots; RAW / WAR / WAW): checked on the host, no device involved
+    (tests/csrc/step_conflict_check.cc)"""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "step_conflict_check")
+    subprocess.check_call([hipcc, "-std=c++17", "-I", os.path.join(ROOT, "tengine_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "csrc", "step_conflict_check.cc"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 failures" in out.stdout, out.stdout
+
+
 def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
     """tamd_options grew a field (direct_dispatch): a caller compiled against the older, shorter struct still passes its own
     `size`, and the binding's struct matches the header's field order."""
