@@ -145,6 +145,11 @@ typedef struct tamd_options {
                            * passes are ordered among themselves and observed by tamd_graph_sync / _download_outputs /
                            * _run; work on tamd_graph_stream() is NOT ordered behind them.  TAMD_DIRECT_DISPATCH=0|1
                            * overrides.  Falls back to the hipGraph silently when the list cannot be dispatched directly. */
+    int keep_tensors;     /* 1: every intermediate tensor keeps a buffer of its own, so tamd_graph_read_tensor can return any of
+                           * them after a run (the TG_DEBUG_DATA analogue).  0 (default): tensors whose lifetimes do not overlap
+                           * share device memory -- a pass then touches a fraction of the bytes, which is what keeps the batched
+                           * configs inside the device's last-level cache; read_tensor refuses such tensors.  TAMD_POOL=0|1
+                           * overrides (0 = keep). */
 } tamd_options;
 
 typedef struct tamd_graph tamd_graph;

@@ -290,7 +290,10 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
 
 int direct_packets(const DirectProgram* p) { return p ? (int)p->pkts.size() : 0; }
 
-int direct_submit(DirectProgram* p)
+// close_burst: this pass is the last of its burst and its LAST packet closes it -- it releases at system scope and carries the
+// queue's completion signal itself, so no barrier packet follows (one packet less for the packet processor to walk: what a
+// blocking host-to-host run waits for is the end of that kernel, not the retirement of an empty packet behind it)
+int direct_submit(DirectProgram* p, bool close_burst, unsigned long long* burst)
 {
     const uint64_t n = p->pkts.size();
     DirectQueue* dq = p->dq;
@@ -320,14 +323,24 @@ int direct_submit(DirectProgram* p)
         d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
         d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
         d->completion_signal.handle = 0;
-        __atomic_store_n(&d->header, i == 0 ? (dq->open ? p->h_wrap : p->h_open) : p->hdr[i], __ATOMIC_RELEASE);
+        uint16_t h = i == 0 ? (dq->open ? p->h_wrap : p->h_open) : p->hdr[i];
+        if (close_burst && i + 1 == n) {
+            d->completion_signal = dq->done;
+            h = (uint16_t)((h & ~(3u << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        }
+        __atomic_store_n(&d->header, h, __ATOMIC_RELEASE);
     }
     // one doorbell per pass -- two when the pass wraps around the end of the ring, so that a queue interceptor is never handed
     // a batch that is not contiguous in memory
     const uint64_t to_end = q->size - (idx0 & mask);
     if (to_end < n) hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + to_end - 1));
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + n - 1));
-    dq->open = true;
+    if (close_burst) {
+        dq->bursts++;
+        dq->open = false;
+        if (burst) *burst = dq->bursts;
+    } else
+        dq->open = true;
     return 0;
 }
 
@@ -377,7 +390,8 @@ int direct_wait_burst(DirectProgram* p, unsigned long long burst)
         if (hsa_signal_wait_scacquire(dq->done, HSA_SIGNAL_CONDITION_LT, target + 1, 5000000, HSA_WAIT_STATE_BLOCKED) <= target) return 0;
         if (dq->fault.load()) { direct_err("a dispatched kernel faulted: the HSA queue is in the error state", dq->fault.load()); return -1; }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit_s()) {
-            dq->fault.store(-3);
+            // a pass that is merely slow is an error for THIS wait, not a dead queue: only the runtime's fault callback marks the
+            // queue unusable (a later wait on the same burst may still succeed)
             direct_err("timeout waiting for a direct pass (TAMD_DIRECT_TIMEOUT_S)", -3);
             return -1;
         }
@@ -392,11 +406,21 @@ int direct_wait(DirectProgram* p)
     return direct_wait_burst(p, b);
 }
 
+// everything ever submitted to the program's queue: the open burst (closed here) AND the bursts that were closed at submit
+// time and never collected (asynchronous runs: direct_close without a wait)
+int direct_wait_all(DirectProgram* p)
+{
+    if (direct_wait(p)) return -1;
+    return direct_wait_burst(p, p->dq->bursts);
+}
+
 void direct_destroy(DirectProgram* p)
 {
     if (!p) return;
     if (p->dq) {
-        if (p->dq->q && !p->dq->fault.load()) (void)direct_wait(p);
+        // packets may still be running: the open burst, and bursts closed at submit time that nobody waited for (asynchronous
+        // runs) -- kernel arguments, tensors and the queue itself must outlive them
+        if (p->dq->q && !p->dq->fault.load()) (void)direct_wait_all(p);
         if (--p->dq->refs <= 0) {
             if (p->dq->q) (void)hsa_queue_destroy(p->dq->q);
             if (p->dq->done.handle) (void)hsa_signal_destroy(p->dq->done);

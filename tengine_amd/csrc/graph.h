@@ -122,6 +122,11 @@ struct Inflight {                    // one tamd_graph_run_async() that tamd_gra
 
 struct PoolGeom { int oh, ow, kh, kw, sh, sw, ph0, pw0; };
 
+// device memory of a graph comes out of a few large allocations (bump-allocated, 256-byte granules): one hipMalloc per tensor /
+// weight blob scatters a model over hundreds of separately mapped ranges, and inside a pass every launch then starts with
+// translation misses on pages it last touched a whole step ago
+struct DevArena { char* base = nullptr; size_t cap = 0, used = 0; };
+
 }  // namespace tamd
 
 #define HIPCHK(expr)                                                                              \
@@ -141,6 +146,9 @@ struct tamd_graph {
     std::vector<tamd::Step> in_steps;   // input layout launches (after H2D)
     std::vector<tamd::Step> out_steps;  // output layout launches (before D2H)
     std::vector<void*> dev_allocs;
+    std::vector<tamd::DevArena> arenas;       // dev_alloc(): bump allocation out of these (each is also in dev_allocs)
+    std::vector<char> pooled;           // tensors whose buffer is shared with other tensors of disjoint lifetime (read_tensor refuses them)
+    size_t pool_bytes = 0, unpooled_bytes = 0;     // activation arena with / without lifetime sharing (TAMD_DEBUG prints both)
     std::map<int, float*> f32_copy;     // uint8 tensor -> its dequantised fp32 copy (input of the fp32 MFMA conv kernel)
     std::vector<char> fused_away;       // tensors that only exist inside a fused launch (read_tensor refuses them)
     void* zero_page = nullptr;          // 256 zero bytes (out-of-image taps of the LDS-DMA conv kernel)
@@ -166,6 +174,12 @@ struct tamd_graph {
     int autotune_cold = -1;                    // plan-time timing mode, decided once (autotune_cold())
     double prerun_ms = 0;                      // wall time of tamd_graph_prerun (planning, autotune, capture)
     bool direct_busy = false;                  // passes submitted since the last wait
+    bool stream_dirty = true;                  // something may be pending on `stream` (uploads, eager launches): drain it before a direct burst
+    bool stream_exposed = false;               // tamd_graph_stream() handed the stream out: the caller may queue work this library cannot see
+    bool io_zero_copy = false;                 // the host-to-host lists store graph outputs straight into the pinned host buffers
+    // TAMD_H2H_TRACE=1: where a blocking tamd_graph_run spends its time on the host (ns): copy in, stream drain, submit, wait, copy out
+    long long h2h_ns[5] = {0, 0, 0, 0, 0};
+    long long h2h_runs = 0;
     tamd_options opt{};
     bool prepared = false;
     int gpu = 0;

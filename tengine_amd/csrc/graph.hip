@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -316,9 +317,31 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
     // slack: the pointwise kernels read whole 64-byte K steps, up to 8 of them past a pixel row's last channel (those
     // bytes meet zero weights, but must be readable behind the last pixel of a buffer too)
     const size_t slack = 1024;
-    HIPCHK(hipMalloc(p, bytes + slack));
-    g->dev_allocs.push_back(*p);
-    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes + slack, g->stream));    // never the legacy stream: it would collide with another thread's capture
+    const char* ae = getenv("TAMD_ARENA");                       // 0: one hipMalloc per buffer (round 1-3 behaviour; A/B runs)
+    if (ae && atoi(ae) == 0) {
+        HIPCHK(hipMalloc(p, bytes + slack));
+        g->dev_allocs.push_back(*p);
+        if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes + slack, g->stream));    // never the legacy stream: it would collide with another thread's capture
+        return 0;
+    }
+    // bump allocation out of a few large chunks: a model's tensors, weights and per-channel vectors are hundreds of buffers, and
+    // as separate hipMalloc ranges each brings its own page-table fragment -- inside a pass every launch then begins with
+    // translation misses on memory it last touched a step ago.  One contiguous range per 32 MB .. 1 GB maps with large fragments.
+    const size_t need = (bytes + slack + 255) & ~(size_t)255;
+    DevArena* a = g->arenas.empty() ? nullptr : &g->arenas.back();
+    if (!a || a->used + need > a->cap) {
+        size_t cap = g->arenas.empty() ? ((size_t)32 << 20) : std::min<size_t>(2 * g->arenas.back().cap, (size_t)1 << 30);
+        cap = (std::max(cap, need) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        DevArena na;
+        HIPCHK(hipMalloc((void**)&na.base, cap));
+        na.cap = cap;
+        g->dev_allocs.push_back(na.base);
+        g->arenas.push_back(na);
+        a = &g->arenas.back();
+    }
+    *p = a->base + a->used;
+    a->used += need;
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes + slack, g->stream));
     return 0;
 }
 
@@ -529,7 +552,8 @@ struct PlanCache {
     bool loaded = false, dirty = false;
     std::string path;
     long long stamp = 0;                                  // size ^ mtime of the file as read / written
-    std::map<std::string, std::string> kv;
+    std::map<std::string, std::string> kv;     // the file's entries + this process's
+    std::map<std::string, std::string> mine;   // what THIS process decided since the file was read (merged over the file at flush)
 };
 static std::mutex g_plan_cache_mu;
 static long long file_stamp(const std::string& path)
@@ -537,6 +561,31 @@ static long long file_stamp(const std::string& path)
     struct stat st;
     if (path.empty() || stat(path.c_str(), &st) != 0) return 0;
     return (long long)st.st_size * 1000003ll ^ (long long)st.st_mtim.tv_sec * 1000000007ll ^ (long long)st.st_mtim.tv_nsec;
+}
+// first line of a plan file: what the choices were made FOR.  A file written by another library version, for another
+// architecture or with another candidate list is ignored as a whole (and overwritten at the next flush): a stale choice
+// could name a configuration this build no longer launches
+static std::string plan_cache_header()
+{
+    return std::string("#tamd-plan v2 gfx950 ") + tamd_version() + " gemm" + std::to_string(conv_igemm_num_cfgs()) + "/" + std::to_string(conv_pgemm_num_variants())
+           + " u8" + std::to_string(conv_u8_gemm_num_cfgs()) + "/" + std::to_string(conv_u8_patch_num_cfgs());
+}
+static void plan_cache_read(const std::string& path, std::map<std::string, std::string>* kv)
+{
+    FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[512];
+    bool first = true, ok = false;
+    while (fgets(line, sizeof(line), f)) {
+        std::string l = line;
+        while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+        if (first) { first = false; ok = l == plan_cache_header(); if (!ok) break; continue; }
+        const size_t tab = l.find('\t');
+        if (tab == std::string::npos) continue;
+        (*kv)[l.substr(0, tab)] = l.substr(tab + 1);
+    }
+    fclose(f);
+    if (!ok) kv->clear();
 }
 static PlanCache& plan_cache_locked()                     // call with g_plan_cache_mu held
 {
@@ -546,18 +595,7 @@ static PlanCache& plan_cache_locked()                     // call with g_plan_ca
     if (!pc.loaded || pc.path != want || (!pc.dirty && file_stamp(want) != pc.stamp)) {
         pc = PlanCache();
         pc.loaded = true; pc.path = want; pc.stamp = file_stamp(want);
-        if (FILE* f = want.empty() ? nullptr : fopen(want.c_str(), "r")) {
-            char line[512];
-            while (fgets(line, sizeof(line), f)) {
-                char* tab = strchr(line, '\t');
-                if (!tab) continue;
-                *tab = 0;
-                std::string v = tab + 1;
-                while (!v.empty() && (v.back() == '\n' || v.back() == '\r')) v.pop_back();
-                pc.kv[line] = v;
-            }
-            fclose(f);
-        }
+        plan_cache_read(want, &pc.kv);
     }
     return pc;
 }
@@ -576,17 +614,28 @@ void plan_cache_put(const std::string& key, const std::string& v)
     PlanCache& pc = plan_cache_locked();
     if (pc.path.empty()) return;
     pc.kv[key] = v;
+    pc.mine[key] = v;
     pc.dirty = true;
 }
+// Several processes may share one file (the ranks of a multi-GPU job): the entries on disk are merged with this process's own
+// decisions (ours win), written to a temporary file and renamed over the old one -- a reader sees the old file or the new one,
+// never half of either.
 static void plan_cache_flush()
 {
     std::lock_guard<std::mutex> lk(g_plan_cache_mu);
     PlanCache& pc = plan_cache_locked();
     if (pc.path.empty() || !pc.dirty) return;
-    if (FILE* f = fopen(pc.path.c_str(), "w")) {
-        for (auto& e : pc.kv) fprintf(f, "%s\t%s\n", e.first.c_str(), e.second.c_str());
+    std::map<std::string, std::string> merged;
+    plan_cache_read(pc.path, &merged);
+    for (auto& e : pc.mine) merged[e.first] = e.second;
+    const std::string tmp = pc.path + ".tmp." + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "w")) {
+        fprintf(f, "%s\n", plan_cache_header().c_str());
+        for (auto& e : merged) fprintf(f, "%s\t%s\n", e.first.c_str(), e.second.c_str());
         fclose(f);
+        if (rename(tmp.c_str(), pc.path.c_str()) != 0) (void)remove(tmp.c_str());
     }
+    pc.kv = merged;
     pc.dirty = false;
     pc.stamp = file_stamp(pc.path);
 }
@@ -1075,8 +1124,14 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     snprintf(ckey, sizeof(ckey), "pwdw|%s|n%d %dx%d k%d m%d f%d c%zu", sa.node.c_str(), a.N, a.H, a.W, a.ktot, tmode, fmode, cfgs.size());
     std::string cached;
     int cf = 0, cb = 0;
+    bool from_cache = false;
     if (autotune && plan_cache_get(ckey, &cached) && sscanf(cached.c_str(), "%d,%d", &cf, &cb) == 2 && cb >= 0 && cb < (int)cfgs.size()) {
-        fuse = cf != 0; best = (size_t)cb;
+        // a cached index is only as good as the file it came from: the configuration must still launch here
+        const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[cb].th, cfgs[cb].tw) : a;
+        if (!cf || launch_pwdw(v, cfgs[cb].threads, g->stream) == hipSuccess) { fuse = cf != 0; best = (size_t)cb; from_cache = true; }
+        else (void)hipGetLastError();
+    }
+    if (from_cache) {
     } else if (autotune) {
         float best_ms = 1e30f;
         for (size_t c = 0; c < cfgs.size(); c++) {
@@ -1175,6 +1230,7 @@ static int plan(tamd_graph* g)
         }
         if (direct) { t.nchw_raw = true; t.dptr = io.stage; t.cs = 0; }
     }
+    std::vector<size_t> own;                     // tensors that own a buffer (not a constant, a raw input, a view or an alias)
     for (size_t i = 0; i < g->tensors.size(); i++) {
         HTensor& t = g->tensors[i];
         if (t.ttype == TAMD_TT_CONST || t.nchw_raw) continue;
@@ -1190,7 +1246,71 @@ static int plan(tamd_graph* g)
                 if (!n.out.empty() && n.out[0] == (int)i) dword_producer = (n.op == TAMD_OP_CONV || n.op == TAMD_OP_FC || n.op == TAMD_OP_POOL);
             if (is_out && dword_producer) t.cs = t.c;
         }
-        if (dev_alloc(g, &t.dptr, (size_t)t.n * t.h * t.w * t.cs, true)) return -1;
+        own.push_back(i);
+    }
+    // ---- activation buffers.  Tensors whose lifetimes cannot overlap share device memory (tamd_options.keep_tensors = 0, the
+    // default): a pass then touches a fraction of the bytes -- ResNet-50 at batch 32 owns 345 MB of activations one by one, more
+    // than the 256 MB last-level cache, but never has more than ~65 MB of them alive.  Lifetime of a buffer, in node positions
+    // (the launch list follows the node order, except that a fused tail runs at ITS PRODUCER's position and a fused
+    // eltwise / ReLU at the position of the convolution that absorbs it): written from `birth` = the earliest producer within two
+    // hops above the node that produces it (covers both exceptions, conservatively), read until `death` = the last node that
+    // names it (or a view / alias of it) as an input.  A launch reads and writes in one go, so buffers with birth == death of
+    // another never share.  Graph inputs / outputs and tensors with padding channels (cs != c: their padding bytes are zero from
+    // the allocation on and stay zero) keep their own buffers.
+    g->pooled.assign(g->tensors.size(), 0);
+    {
+        const char* pe = getenv("TAMD_POOL");
+        const bool pool = pe ? atoi(pe) != 0 : !g->opt.keep_tensors;
+        const int NN = (int)g->nodes.size();
+        auto root_of = [&](int t) { for (int hop = 0; hop < 8; hop++) { if (view_of[t] >= 0) t = view_of[t]; else if (alias_of[t] >= 0) t = alias_of[t]; else break; } return t; };
+        std::vector<int> prod(g->tensors.size(), -1), birth(g->tensors.size(), NN), death(g->tensors.size(), -1);
+        for (int ni = 0; ni < NN; ni++)
+            for (int o : g->nodes[ni].out) prod[o] = ni;
+        auto up = [&](int ni) { int e = ni; for (int i : g->nodes[ni].in) if (g->tensors[i].ttype != TAMD_TT_CONST && prod[i] >= 0) e = std::min(e, prod[i]); return e; };
+        for (int ni = 0; ni < NN; ni++) {
+            const HNode& n = g->nodes[ni];
+            if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST) continue;
+            int e = ni;
+            for (int i : n.in) if (g->tensors[i].ttype != TAMD_TT_CONST && prod[i] >= 0) e = std::min(e, up(prod[i]));
+            for (int o : n.out) { const int r = root_of(o); birth[r] = std::min(birth[r], e); death[r] = std::max(death[r], ni); }
+            for (int i : n.in) if (g->tensors[i].ttype != TAMD_TT_CONST) { const int r = root_of(i); death[r] = std::max(death[r], ni); }
+        }
+        std::vector<char> pinned(g->tensors.size(), 0);
+        for (auto& io : g->inputs) pinned[root_of(io.tensor)] = 1;
+        for (auto& io : g->outputs) pinned[root_of(io.tensor)] = 1;
+        struct Blk { size_t t, bytes, off; int b, d; };
+        std::vector<Blk> blks;
+        auto bytes_of = [&](const HTensor& t) { return ((size_t)t.n * t.h * t.w * t.cs + 1024 + 255) & ~(size_t)255; };
+        for (size_t i : own) {
+            HTensor& t = g->tensors[i];
+            g->unpooled_bytes += bytes_of(t);
+            if (pool && !pinned[i] && t.cs == t.c && death[i] >= 0 && birth[i] <= death[i]) blks.push_back({i, bytes_of(t), 0, birth[i], death[i]});
+            else if (dev_alloc(g, &t.dptr, (size_t)t.n * t.h * t.w * t.cs, true)) return -1;
+        }
+        // greedy by size: the largest buffers first, each at the lowest offset that is free over its whole lifetime
+        std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.bytes != b.bytes ? a.bytes > b.bytes : a.t < b.t; });
+        size_t total = 0;
+        for (size_t k = 0; k < blks.size(); k++) {
+            std::vector<std::pair<size_t, size_t>> busy;           // [offset, end) of placed buffers alive at the same time
+            for (size_t j = 0; j < k; j++)
+                if (blks[j].b <= blks[k].d && blks[k].b <= blks[j].d) busy.push_back({blks[j].off, blks[j].off + blks[j].bytes});
+            std::sort(busy.begin(), busy.end());
+            size_t off = 0;
+            for (auto& r : busy) { if (off + blks[k].bytes <= r.first) break; off = std::max(off, r.second); }
+            blks[k].off = off;
+            total = std::max(total, off + blks[k].bytes);
+        }
+        if (!blks.empty()) {
+            void* base = nullptr;
+            if (dev_alloc(g, &base, total, true)) return -1;
+            for (const Blk& b : blks) { g->tensors[b.t].dptr = (char*)base + b.off; g->pooled[b.t] = 1; }
+            g->pool_bytes = total;
+        }
+        for (size_t i = 0; i < g->tensors.size(); i++)                 // views / aliases of a shared buffer are shared too
+            if (g->tensors[i].ttype != TAMD_TT_CONST && (view_of[i] >= 0 || alias_of[i] >= 0) && g->pooled[root_of((int)i)]) g->pooled[i] = 1;
+        if (getenv("TAMD_DEBUG"))
+            fprintf(stderr, "[tamd] activations: %.1f MB one buffer per tensor, %zu of %zu buffers share %.1f MB\n", g->unpooled_bytes / 1048576.0, blks.size(),
+                    own.size(), g->pool_bytes / 1048576.0);
     }
     // resolve views / aliases (nodes are in topological order; resolve chains iteratively)
     for (int pass = 0; pass < 4; pass++)
@@ -1400,6 +1520,7 @@ static int run_steps(tamd_graph* g, hipStream_t s, int io_slot = -1)
             }
             const size_t before = g_launch_rec ? g_launch_rec->size() : 0;
             hipError_t e = st.fn(s);
+            launch_rec_clear_flags();          // a step that launched nothing must not leave its flags to the next step's launch
             if (e != hipSuccess) { set_error("launch %s (%s) failed: %s", st.kernel.c_str(), st.node.c_str(), hipGetErrorString(e)); return -1; }
             if (!first_step) first_step = &st;
             last_step = &st;
@@ -1436,6 +1557,18 @@ using namespace tamd;
 // One direct pass against the eager pass of the same launch list, every graph output compared byte for byte.  Two pseudo-random
 // inputs: eager(A) -> want; eager(B) leaves B's results in every buffer; direct(A) must bring want back -- a pass that writes
 // nothing, or the wrong thing, shows up, and outputs that are prerun constants (PriorBox) are the same in all three.  0: identical.
+static void selfcheck_noise(const tamd_graph* g, const IOBind& io, unsigned* lcg_state, std::vector<unsigned char>* noise)
+{
+    unsigned lcg = *lcg_state;
+    noise->resize(io.bytes);
+    if (g->tensors[io.tensor].dtype == TAMD_DT_FP32) {           // finite, moderate floats
+        float* f = (float*)noise->data();
+        for (size_t i = 0; i < io.bytes / 4; i++) { lcg = lcg * 1664525u + 1013904223u; f[i] = (float)((int)(lcg >> 20) - 2048) / 1024.f; }
+    } else
+        for (size_t i = 0; i < io.bytes; i++) { lcg = lcg * 1664525u + 1013904223u; (*noise)[i] = (unsigned char)(lcg >> 24); }
+    *lcg_state = lcg;
+}
+
 static int direct_selfcheck(tamd_graph* g)
 {
     std::vector<std::vector<unsigned char>> want, got;
@@ -1443,12 +1576,7 @@ static int direct_selfcheck(tamd_graph* g)
         std::vector<unsigned char> noise;
         unsigned lcg = seed;
         for (auto& io : g->inputs) {
-            noise.resize(io.bytes);
-            if (g->tensors[io.tensor].dtype == TAMD_DT_FP32) {           // finite, moderate floats
-                float* f = (float*)noise.data();
-                for (size_t i = 0; i < io.bytes / 4; i++) { lcg = lcg * 1664525u + 1013904223u; f[i] = (float)((int)(lcg >> 20) - 2048) / 1024.f; }
-            } else
-                for (size_t i = 0; i < io.bytes; i++) { lcg = lcg * 1664525u + 1013904223u; noise[i] = (unsigned char)(lcg >> 24); }
+            selfcheck_noise(g, io, &lcg, &noise);
             HIPCHK(hipMemcpy(io.stage, noise.data(), io.bytes, hipMemcpyHostToDevice));
         }
         return 0;
@@ -1474,6 +1602,82 @@ static int direct_selfcheck(tamd_graph* g)
     HIPCHK(hipDeviceSynchronize());
     for (size_t i = 0; i < want.size(); i++)
         if (want[i] != got[i]) { set_error("the direct pass does not reproduce the eager pass (output %zu differs)", i); return -1; }
+    return 0;
+}
+
+// ---- host-to-host lists: graph outputs stored straight into the pinned host buffers ---------------------------------------------
+// A blocking run_graph is upload kernel -> launch list -> download kernel -> closing packet.  The download kernel copies a few
+// hundred bytes (MobileNet: 1000) that the last compute launch has just written; it costs a launch boundary, a kernel and an
+// HBM round trip for nothing.  In the RECORDED list of an I/O slot every kernel argument that holds an output's device staging
+// address is re-pointed at the slot's pinned host buffer (device-mapped: the download kernel already writes there), and the
+// download launch is dropped; the closing packet's system-scope release makes the stores visible to the host as before.  Only
+// outputs nobody else reads on the device qualify (a consumer would otherwise read host memory), and only when at least one
+// argument matched; the patched program must then reproduce the eager list byte for byte (direct_io_selfcheck) or it is rebuilt
+// with its download launches.
+static bool io_zero_copy_wanted()
+{
+    const char* e = getenv("TAMD_IO_ZERO_COPY");
+    return !(e && atoi(e) == 0);
+}
+
+static int patch_pointer(std::vector<LaunchRec>& recs, size_t nrecs, const void* from, const void* to)
+{
+    int hits = 0;
+    for (size_t r = 0; r < nrecs; r++)
+        for (size_t off = 0; off + 8 <= recs[r].args.size(); off += 8) {
+            const void* v;
+            memcpy(&v, recs[r].args.data() + off, 8);
+            if (v == from) { memcpy(recs[r].args.data() + off, &to, 8); hits++; }
+        }
+    return hits;
+}
+
+// recs = the recorded host-to-host list of `slot`: [uploads][in_steps, steps, out_steps][one download launch per output].
+// Returns true when every download launch could be dropped.
+static bool zero_copy_outputs(tamd_graph* g, std::vector<LaunchRec>& recs, int slot)
+{
+    const size_t nout = g->outputs.size();
+    if (nout == 0 || recs.size() <= nout + g->inputs.size()) return false;
+    const size_t body = recs.size() - nout;
+    std::vector<LaunchRec> trial(recs.begin(), recs.begin() + body);
+    for (auto& io : g->outputs) {
+        const HTensor& t = g->tensors[io.tensor];
+        if (io.stage == t.dptr && count_consumers(g, io.tensor) != 1) return false;      // read again on the device
+        if (t.prerun_const) return false;                                                  // written once at prerun, not by the list
+        void* dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, slot ? io.pinned2 : io.pinned, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (patch_pointer(trial, body, io.stage, dev) < 1) return false;
+    }
+    recs.swap(trial);
+    return true;
+}
+
+// the host-to-host program of `slot` against the eager list of the same slot (upload and download launches included), every
+// pinned output compared byte for byte.  0: identical.
+static int direct_io_selfcheck(tamd_graph* g, DirectProgram* pio, int slot)
+{
+    std::vector<unsigned char> noise;
+    std::vector<std::vector<unsigned char>> want;
+    unsigned lcg = 0xC0FFEE11u + (unsigned)slot;
+    for (auto& io : g->inputs) {
+        selfcheck_noise(g, io, &lcg, &noise);
+        memcpy(slot ? io.pinned2 : io.pinned, noise.data(), io.bytes);
+    }
+    if (run_steps(g, g->stream, slot)) return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    for (auto& io : g->outputs) {
+        unsigned char* pin = (unsigned char*)(slot ? io.pinned2 : io.pinned);
+        want.emplace_back(pin, pin + io.bytes);
+        memset(pin, 0xA5, io.bytes);
+    }
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long b = 0;
+    if (direct_submit(pio, true, &b) || direct_wait_burst(pio, b)) { set_error("direct host-to-host pass failed: %s", direct_last_error()); return -1; }
+    for (size_t i = 0; i < g->outputs.size(); i++)
+        if (memcmp(want[i].data(), slot ? g->outputs[i].pinned2 : g->outputs[i].pinned, g->outputs[i].bytes) != 0) {
+            set_error("the direct host-to-host pass does not reproduce the eager list (output %zu differs)", i);
+            return -1;
+        }
     return 0;
 }
 
@@ -1527,7 +1731,7 @@ int tamd_init(int gpu_index)
 
 int tamd_shutdown(void) { return 0; }
 const char* tamd_last_error(void) { return g_err; }
-const char* tamd_version(void) { return "tengine_amd 0.1 (gfx950)"; }
+const char* tamd_version(void) { return "tengine_amd 0.4 (gfx950)"; }
 
 int tamd_op_supported(int op, int dtype)
 {
@@ -1712,6 +1916,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         if (have >= (int)(offsetof(tamd_options, use_hip_graph) + sizeof(int))) o.use_hip_graph = opt->use_hip_graph;
         if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) o.profile = opt->profile;
         if (have >= (int)(offsetof(tamd_options, direct_dispatch) + sizeof(int))) o.direct_dispatch = opt->direct_dispatch;
+        if (have >= (int)(offsetof(tamd_options, keep_tensors) + sizeof(int))) o.keep_tensors = opt->keep_tensors;
     }
     if (const char* dd = getenv("TAMD_DIRECT_DISPATCH")) o.direct_dispatch = atoi(dd) != 0;
     // a tool that intercepts HSA queues (rocprofv3) crashes in its doorbell handler on packets it did not see HIP write
@@ -1795,13 +2000,29 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
                 g_launch_rec = nullptr;
                 if (rc) return -1;
                 HIPCHK(hipStreamSynchronize(g->stream));
+                // outputs straight into the pinned host buffers (no download launch) where the list allows it
+                std::vector<LaunchRec> with_downloads = recs;
+                const bool zc = io_zero_copy_wanted() && zero_copy_outputs(g, recs, slot);
                 DirectProgram* pio = direct_build(g->gpu, g->stream, recs, &why, g->direct);
+                bool zc_ok = zc && pio;
+                if (pio && direct_io_selfcheck(g, pio, slot)) {
+                    if (zc) fprintf(stderr, "tengine_amd: zero-copy outputs DISABLED for this graph: %s\n", g_err);
+                    direct_destroy(pio);
+                    pio = nullptr; zc_ok = false; why = g_err;
+                    if (zc) {                                // once more with the download launches
+                        pio = direct_build(g->gpu, g->stream, with_downloads, &why, g->direct);
+                        if (pio && direct_io_selfcheck(g, pio, slot)) { direct_destroy(pio); pio = nullptr; why = g_err; }
+                    }
+                }
+                if (slot == 0) g->io_zero_copy = zc_ok;
                 if (!pio) fprintf(stderr, "tengine_amd: direct dispatch not used for host-to-host runs (slot %d): %s\n", slot, why);
                 (slot ? g->direct_io2 : g->direct_io) = pio;
             }
             if (!g->direct_io || !g->direct_io2) {          // both or none: the asynchronous pair alternates between them
                 if (g->direct_io2) { direct_destroy(g->direct_io2); g->direct_io2 = nullptr; }
             }
+            if (getenv("TAMD_DEBUG") && g->direct_io)
+                fprintf(stderr, "[tamd] host-to-host list: %d packets%s\n", direct_packets(g->direct_io), g->io_zero_copy ? ", outputs stored straight into the pinned host buffers" : "");
         }
     }
     plan_cache_flush();
@@ -1861,6 +2082,26 @@ static int direct_drain(tamd_graph* g)
     return 0;
 }
 
+// the direct path of this graph is unusable (queue fault, a burst that never completed): forget the runs in flight -- their
+// results are lost, the caller has been told -- and go back to the hipGraph executables, which every entry point still has
+static void direct_abandon(tamd_graph* g, const char* why)
+{
+    fprintf(stderr, "tengine_amd: direct dispatch abandoned for this graph (%s): hipGraph replay from here on\n", why);
+    g->inflight.erase(std::remove_if(g->inflight.begin(), g->inflight.end(), [](const Inflight& f) { return f.direct; }), g->inflight.end());
+    // direct_destroy waits for what is still running unless the queue has faulted; a hung burst is bounded by TAMD_DIRECT_TIMEOUT_S
+    if (g->direct_io2) { direct_destroy(g->direct_io2); g->direct_io2 = nullptr; }
+    if (g->direct_io) { direct_destroy(g->direct_io); g->direct_io = nullptr; }
+    if (g->direct) { direct_destroy(g->direct); g->direct = nullptr; }
+    g->direct_busy = false;
+}
+
+static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool close_on_last_packet()
+{
+    const char* e = getenv("TAMD_DIRECT_CLOSE_ON_LAST");          // 0: a separate barrier packet closes the burst (round 2-3 behaviour)
+    return !(e && atoi(e) == 0);
+}
+
 int tamd_graph_upload_inputs(tamd_graph* g)
 {
     if (bind_device(g)) return -1;
@@ -1872,6 +2113,7 @@ int tamd_graph_upload_inputs(tamd_graph* g)
         memcpy(io.pinned, io.host_in, io.bytes);
         HIPCHK(hipMemcpyAsync(io.stage, io.pinned, io.bytes, hipMemcpyHostToDevice, g->stream));
     }
+    g->stream_dirty = true;
     return 0;
 }
 
@@ -1881,11 +2123,12 @@ int tamd_graph_launch(tamd_graph* g)
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     if (g->direct) {
         // the pass reads what the stream wrote (uploaded inputs): drain it before the first packet of a burst
-        if (!g->direct_busy) HIPCHK(hipStreamSynchronize(g->stream));
+        if (!g->direct_busy) { HIPCHK(hipStreamSynchronize(g->stream)); g->stream_dirty = false; }
         g->direct_busy = true;
         if (direct_submit(g->direct)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
         return 0;
     }
+    g->stream_dirty = true;
     if (g->hexec) {
         hipGraphExec_t e = g->hexecs[g->next_exec];
         g->next_exec = (g->next_exec + 1) % g->nexec;
@@ -1898,7 +2141,17 @@ int tamd_graph_launch(tamd_graph* g)
 int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->direct ? direct_packets(g->direct) : 0; }
 double tamd_graph_prerun_ms(const tamd_graph* g) { return g ? g->prerun_ms : 0.0; }
 
-int tamd_graph_sync(tamd_graph* g) { if (bind_device(g)) return -1; if (direct_drain(g)) return -1; HIPCHK(hipStreamSynchronize(g->stream)); return 0; }
+int tamd_graph_sync(tamd_graph* g)
+{
+    if (bind_device(g)) return -1;
+    if (direct_drain(g)) return -1;
+    // asynchronous runs that were submitted and not collected yet are device work too (their outputs stay in the pinned slots
+    // until tamd_graph_wait delivers them)
+    if (g->direct_io && !g->inflight.empty() && direct_wait_all(g->direct_io)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->stream_dirty = false;
+    return 0;
+}
 
 int tamd_graph_download_outputs(tamd_graph* g)
 {
@@ -1918,19 +2171,42 @@ int tamd_graph_run(tamd_graph* g)
     if (!g->inflight.empty()) { set_error("tamd_graph_run while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
     if (bind_device(g)) return -1;
     if (direct_drain(g)) return -1;
+    static const bool trace = getenv("TAMD_H2H_TRACE") && atoi(getenv("TAMD_H2H_TRACE")) == 1;
+    long long t[6] = {0, 0, 0, 0, 0, 0};
+    if (trace) t[0] = now_ns();
     for (auto& io : g->inputs) {
         if (!io.host_in) { set_error("input buffer not set"); return -1; }
         memcpy(io.pinned, io.host_in, io.bytes);
     }
-    if (g->direct_io) {          // the same list as AQL packets: system-scope acquire in front, closing barrier packet behind
-        HIPCHK(hipStreamSynchronize(g->stream));
-        if (direct_submit(g->direct_io) || direct_wait(g->direct_io)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+    if (trace) t[1] = now_ns();
+    if (g->direct_io) {
+        // the same list as AQL packets: system-scope acquire in front; the burst is closed by the list's last packet (or a barrier
+        // packet behind it).  The graph's HIP stream is drained only when something may be pending on it: what the pass reads was
+        // either written by the pass itself (the upload launch) or by stream work this library knows about
+        if (g->stream_dirty || g->stream_exposed) { HIPCHK(hipStreamSynchronize(g->stream)); g->stream_dirty = false; }
+        if (trace) t[2] = now_ns();
+        unsigned long long b = 0;
+        int rc = close_on_last_packet() ? direct_submit(g->direct_io, true, &b) : (direct_submit(g->direct_io) || direct_close(g->direct_io, &b));
+        if (trace) t[3] = now_ns();
+        if (!rc) rc = direct_wait_burst(g->direct_io, b);
+        if (rc) {
+            set_error("direct dispatch: %s", direct_last_error());
+            direct_abandon(g, g_err);
+            return -1;
+        }
     } else {
+        if (trace) t[2] = t[3] = now_ns();
         if (launch_io(g, 0)) return -1;
         HIPCHK(hipStreamSynchronize(g->stream));
     }
+    if (trace) t[4] = now_ns();
     for (auto& io : g->outputs)
         if (io.host_out) memcpy(io.host_out, io.pinned, io.bytes);
+    if (trace) {
+        t[5] = now_ns();
+        for (int i = 0; i < 5; i++) g->h2h_ns[i] += t[i + 1] - t[i];
+        g->h2h_runs++;
+    }
     return 0;
 }
 
@@ -1959,11 +2235,18 @@ int tamd_graph_run_async(tamd_graph* g)
         // queue's completion signal down.  The second run's packets queue behind the first one's closing packet (barrier bit on
         // every packet): the device goes from run k's download straight into run k+1's upload, the host is never in between.
         DirectProgram* p = slot ? g->direct_io2 : g->direct_io;
-        if (g->inflight.empty()) HIPCHK(hipStreamSynchronize(g->stream));
-        if (direct_submit(p) || direct_close(p, &f.burst)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+        if (g->inflight.empty() && (g->stream_dirty || g->stream_exposed)) { HIPCHK(hipStreamSynchronize(g->stream)); g->stream_dirty = false; }
+        const int rc = close_on_last_packet() ? direct_submit(p, true, &f.burst) : (direct_submit(p) || direct_close(p, &f.burst));
+        if (rc) {
+            // packets may be in the ring without a closing packet: the queue cannot be trusted any more
+            set_error("direct dispatch: %s", direct_last_error());
+            direct_abandon(g, g_err);
+            return -1;
+        }
         f.direct = true;
     } else {
         if (!g->slot_done[slot]) HIPCHK(hipEventCreateWithFlags(&g->slot_done[slot], hipEventDisableTiming));
+        g->stream_dirty = true;
         if (launch_io(g, slot)) return -1;
         f.done = g->slot_done[slot];
         HIPCHK(hipEventRecord(f.done, g->stream));
@@ -1980,7 +2263,13 @@ int tamd_graph_wait(tamd_graph* g)
     if (bind_device(g)) return -1;
     const Inflight f = g->inflight.front();
     if (f.direct) {
-        if (direct_wait_burst(g->direct_io, f.burst)) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+        if (direct_wait_burst(g->direct_io, f.burst)) {
+            // the run is lost; so is everything queued behind it.  Drop the bookkeeping (the graph would otherwise refuse every
+            // entry point with "runs in flight" until it is destroyed) and leave the direct path
+            set_error("direct dispatch: %s", direct_last_error());
+            direct_abandon(g, g_err);
+            return -1;
+        }
     } else
         HIPCHK(hipEventSynchronize(f.done));
     for (size_t i = 0; i < g->outputs.size(); i++)
@@ -1999,7 +2288,8 @@ int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
     return 0;
 }
 
-void* tamd_graph_stream(tamd_graph* g) { return (void*)g->stream; }
+// once the caller holds the stream it may queue work there that this library cannot see: every direct burst drains it first again
+void* tamd_graph_stream(tamd_graph* g) { g->stream_exposed = true; g->stream_dirty = true; return (void*)g->stream; }
 
 int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms)
 {
@@ -2090,6 +2380,11 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
                   "TAMD_FUSE_ELTWISE=0 / TAMD_FUSE_RELU=0 at prerun materialise it)", t.name.c_str());
         return -1;
     }
+    if ((size_t)idx < g->pooled.size() && g->pooled[idx]) {
+        set_error("read_tensor: %s shares its device memory with tensors of other lifetimes and does not survive the pass "
+                  "(tamd_options.keep_tensors = 1 / TAMD_POOL=0 at prerun gives every tensor its own buffer)", t.name.c_str());
+        return -1;
+    }
     size_t need = t.elems() * esize(t.dtype);
     if (bytes != need) { set_error("read_tensor: %zu bytes given, %zu needed", bytes, need); return -1; }
     if (direct_drain(g)) return -1;
@@ -2122,6 +2417,13 @@ void tamd_graph_destroy(tamd_graph* g)
     if (!g) return;
     if (g->prepared) (void)bind_device(g);
     if (g->prepared && g->opt.profile) dump_profile(g);
+    if (g->h2h_runs > 0)
+        fprintf(stderr, "[tamd] blocking run, host side, mean of %lld runs (us): copy in %.2f | stream drain %.2f | submit %.2f | wait %.2f | copy out %.2f\n", g->h2h_runs,
+                1e-3 * g->h2h_ns[0] / g->h2h_runs, 1e-3 * g->h2h_ns[1] / g->h2h_runs, 1e-3 * g->h2h_ns[2] / g->h2h_runs, 1e-3 * g->h2h_ns[3] / g->h2h_runs,
+                1e-3 * g->h2h_ns[4] / g->h2h_runs);
+    // runs submitted and never collected are still device work: direct_destroy below waits for every closed burst before the
+    // queue, the kernel arguments and the tensors go away
+    g->inflight.clear();
     if (g->stream) hipStreamSynchronize(g->stream);
     std::lock_guard<std::mutex> lk(g_capture_mutex);      // hipFree is device-synchronous: not while another thread captures
     if (g->direct_io2) { direct_destroy(g->direct_io2); g->direct_io2 = nullptr; }

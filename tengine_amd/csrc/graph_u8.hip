@@ -228,7 +228,10 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             const int c = atoi(cached.c_str() + 1);
             if (cached == "rgb" && rgb_ok) { use_rgb = true; from_cache = true; }
             else if (cached == "pw" && conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) { use_pw = true; from_cache = true; }
-            else if (cached[0] == 'g' && c >= 0 && c < conv_u8_gemm_num_cfgs()) { a.cfg = c; from_cache = true; }
+            else if (cached[0] == 'g' && c >= 0 && c < conv_u8_gemm_num_cfgs()) {
+                U8ConvArgs ac = a; ac.cfg = c; ac.Kpad = rup(K, conv_u8_gemm_kc(c));
+                if (conv_u8_gemm_lds(ac) <= 150 * 1024) { a.cfg = c; from_cache = true; }      // the same filter the autotune applies
+            }
             else if (cached[0] == 'p' && c >= 0 && c < conv_u8_patch_num_cfgs()) { U8ConvArgs ac = a; if (patch_for(ac, c) == 1) { pk_best = c; from_cache = true; } }
         }
         if (tune && !from_cache) {

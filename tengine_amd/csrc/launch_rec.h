@@ -31,6 +31,8 @@ extern thread_local bool g_launch_beside;                       // direct.cc; se
 // the graph calls this before a step whose reads and writes touch nothing the launches since the last ordered launch write or
 // read (graph.hip run_steps): its first launch may start while they still run -- its packet goes out without the barrier bit
 inline void launch_rec_beside() { g_launch_beside = true; }
+// both flags belong to ONE step: a step that launched nothing (or failed before its launch) must not hand them to the next one
+inline void launch_rec_clear_flags() { g_launch_coherent = false; g_launch_beside = false; }
 
 template <typename T>
 inline void rec_pack(std::vector<unsigned char>& b, const T& v)
@@ -65,11 +67,14 @@ struct DirectProgram;
 // `share`: a program of the same graph whose HSA queue (and burst state) the new one uses as well.
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share = nullptr);
 bool direct_probe(int gpu);                 // HSA agent + loader extension present for HIP device `gpu` (cheap; asked before planning)
-int direct_submit(DirectProgram* p);        // one pass over the list: packets + one doorbell; returns without waiting; -1: queue fault / ring stuck
+// one pass over the list: packets + one doorbell; returns without waiting; -1: queue fault / ring stuck.  close_burst: the pass's
+// last packet closes the burst itself (system-scope release + the completion signal), *burst = ticket for direct_wait_burst
+int direct_submit(DirectProgram* p, bool close_burst = false, unsigned long long* burst = nullptr);
 int direct_close(DirectProgram* p, unsigned long long* burst);   // closes the burst with a barrier packet that carries the completion signal;
                                                                  // does not wait.  *burst: ticket for direct_wait_burst
 int direct_wait_burst(DirectProgram* p, unsigned long long burst);   // until that burst (and everything before it) has completed; -1: queue fault / timeout
-int direct_wait(DirectProgram* p);          // direct_close + direct_wait_burst: until every submitted pass has completed
+int direct_wait(DirectProgram* p);          // direct_close + direct_wait_burst: until every pass of the OPEN burst has completed
+int direct_wait_all(DirectProgram* p);      // .. and every burst closed earlier without a wait (asynchronous runs)
 const char* direct_last_error();            // what the last -1 of this thread was about
 int direct_packets(const DirectProgram* p);
 void direct_destroy(DirectProgram* p);

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -267,6 +268,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
 
     tamd_options opt;
     opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    opt.keep_tensors = 0;         // tensors of disjoint lifetimes share device memory (only subgraph outputs are visible to Tengine)
     opt.direct_dispatch = 1;      // the blocking host-to-host run as one AQL pass on the subgraph's own HSA queue (csrc/direct.cc:
                                   // MobileNet-v1 batch 1 81.6 -> 68.7 us per run); TAMD_DIRECT_DISPATCH=0 keeps the hipGraph
     if (options) {   // options may be NULL (scheduler.c:49-59); else the blob of set_context_device, whose byte count the core
@@ -278,6 +280,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
             if (have >= (int)(offsetof(tamd_options, use_hip_graph) + sizeof(int))) opt.use_hip_graph = o->use_hip_graph;
             if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) opt.profile = o->profile;
             if (have >= (int)(offsetof(tamd_options, direct_dispatch) + sizeof(int))) opt.direct_dispatch = o->direct_dispatch;
+            if (have >= (int)(offsetof(tamd_options, keep_tensors) + sizeof(int))) opt.keep_tensors = o->keep_tensors;
         }
     }
     const char* env = getenv("TG_HIP_DEVICE");
@@ -612,30 +615,119 @@ void resplit_around_unsupported(struct graph* ir, struct device* hip)
 // Reference defect to know about: wait_graph() itself can never reach a scheduler -- its status test
 // `GRAPH_STAT_RUNNING != status || GRAPH_STAT_READY != status` (c_api.c:588) is always true, it returns -1.  The plugin exports
 // hip_wait_graph(graph, try_wait) with the body wait_graph was meant to have; INTEGRATION.md shows the one-token fix.
-struct HipSchedState { int inflight = 0; };
+// State per graph lives in attribute->scheduler_privacy, which the reference releases with sys_free when a graph is destroyed
+// without postrun (executer.c:51-53): it is allocated with sys_malloc, a plain struct.
+struct HipSchedState { int inflight; };
 
 HipSchedState* sched_state(struct graph* ir_graph)
 {
-    if (!ir_graph->attribute->scheduler_privacy) ir_graph->attribute->scheduler_privacy = new HipSchedState();
+    if (!ir_graph->attribute->scheduler_privacy) {
+        HipSchedState* st = (HipSchedState*)sys_malloc(sizeof(HipSchedState));
+        if (!st) return nullptr;
+        st->inflight = 0;
+        ir_graph->attribute->scheduler_privacy = st;
+    }
     return (HipSchedState*)ir_graph->attribute->scheduler_privacy;
 }
 
-struct subgraph* single_hip_subgraph(struct graph* ir_graph)
+// A context schedules through hip_scheduler only while graphs that the plugin split are alive on it: the count per context is kept
+// here, and the reference's own scheduler goes back onto the context when the last such graph is post-run (or the plugin is
+// unregistered) -- a context must never be left pointing at a scheduler of a library that may be unloaded.
+std::mutex g_sched_mu;
+std::map<struct context*, int> g_sched_live;
+
+void sched_attach(struct context* ctx)
 {
-    if (get_vector_num(ir_graph->subgraph_list) != 1) return nullptr;
-    struct subgraph* sg = get_ir_graph_subgraph(ir_graph, 0);
-    return (sg->device && 0 == strcmp(sg->device->name, HIP_DEV_NAME) && sg->device_graph) ? sg : nullptr;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    g_sched_live[ctx]++;
 }
 
-int hip_sched_prerun(struct scheduler* s, struct graph* g) { (void)s; struct scheduler* d = find_default_scheduler(); return d->prerun(d, g); }
+void sched_detach(struct context* ctx);
+
+// The one subgraph asynchronous runs are built around: the graph's ONLY subgraph on "HIP", fed by graph inputs alone (nothing
+// another subgraph produces).  Everything else of the graph -- the CPU pieces behind it: DetectionOutput of an SSD model, an
+// unsupported tail -- runs on the host when the run is collected.  nullptr: the graph cannot be pipelined.
+struct subgraph* pipelined_hip_subgraph(struct graph* ir_graph)
+{
+    struct subgraph* hip = nullptr;
+    const int count = get_vector_num(ir_graph->subgraph_list);
+    for (int i = 0; i < count; i++) {
+        struct subgraph* sg = get_ir_graph_subgraph(ir_graph, i);
+        if (sg->device && 0 == strcmp(sg->device->name, HIP_DEV_NAME)) {
+            if (hip || !sg->device_graph) return nullptr;
+            hip = sg;
+        }
+    }
+    if (!hip) return nullptr;
+    for (int i = 0; i < count; i++) {                     // the HIP piece must not wait for anybody
+        struct subgraph* sg = get_ir_graph_subgraph(ir_graph, i);
+        if (sg == hip) continue;
+        for (int k = 0; k < sg->output_num; k++)
+            for (int m = 0; m < hip->input_num; m++)
+                if (sg->output_tensor_list[k] == hip->input_tensor_list[m]) return nullptr;
+    }
+    return hip;
+}
+
+// the subgraphs behind `done` (everything but the HIP piece), each once all of its producers have run: what the reference's
+// scheduler does for the whole graph (scheduler.c:72-181), restated over tensor indices
+int run_remaining_subgraphs(struct graph* ir_graph, struct subgraph* done)
+{
+    const int count = get_vector_num(ir_graph->subgraph_list);
+    std::vector<char> ran(count, 0);
+    int left = 0;
+    for (int i = 0; i < count; i++) {
+        if (get_ir_graph_subgraph(ir_graph, i) == done) ran[i] = 1;
+        else left++;
+    }
+    while (left > 0) {
+        bool progress = false;
+        for (int i = 0; i < count; i++) {
+            if (ran[i]) continue;
+            struct subgraph* sg = get_ir_graph_subgraph(ir_graph, i);
+            bool ready = true;
+            for (int j = 0; j < count && ready; j++) {
+                if (ran[j] || j == i) continue;
+                struct subgraph* other = get_ir_graph_subgraph(ir_graph, j);
+                for (int k = 0; k < other->output_num && ready; k++)
+                    for (int m = 0; m < sg->input_num; m++)
+                        if (other->output_tensor_list[k] == sg->input_tensor_list[m]) { ready = false; break; }
+            }
+            if (!ready) continue;
+            sg->status = GRAPH_STAT_RUNNING;
+            if (sg->device->interface->run(sg->device, sg) < 0) {
+                TLOG_ERR("Tengine HIP scheduler: run subgraph %d error!\n", sg->index);
+                sg->status = GRAPH_STAT_ERROR;
+                return -1;
+            }
+            sg->status = GRAPH_STAT_READY;
+            ran[i] = 1; left--; progress = true;
+        }
+        if (!progress) { TLOG_ERR("Tengine HIP scheduler: no subgraph is ready, %d still waiting\n", left); return -1; }
+    }
+    return 0;
+}
+
+int hip_sched_prerun(struct scheduler* s, struct graph* g)
+{
+    (void)s;
+    struct scheduler* d = find_default_scheduler();
+    const int rc = d->prerun(d, g);
+    if (rc == 0) sched_attach(g->attribute->context);
+    return rc;
+}
 
 int hip_sched_wait(struct scheduler* s, struct graph* ir_graph)
 {
     (void)s;
     HipSchedState* st = sched_state(ir_graph);
+    if (!st) return -1;
     if (st->inflight == 0) { ir_graph->status = GRAPH_STAT_READY; return 0; }
-    struct subgraph* sg = single_hip_subgraph(ir_graph);
+    struct subgraph* sg = pipelined_hip_subgraph(ir_graph);
     if (!sg || sg->device->interface->async_wait(sg->device, sg, 0) != 0) { ir_graph->status = GRAPH_STAT_ERROR; return -1; }
+    // the device part of the OLDEST run is in the subgraph's output tensors now: the host pieces behind it consume them here,
+    // before the next wait delivers the next run's
+    if (run_remaining_subgraphs(ir_graph, sg) != 0) { ir_graph->status = GRAPH_STAT_ERROR; return -1; }
     if (--st->inflight == 0) { sg->status = GRAPH_STAT_READY; ir_graph->status = GRAPH_STAT_READY; }
     return 0;
 }
@@ -644,13 +736,14 @@ int hip_sched_run(struct scheduler* s, struct graph* ir_graph, int block)
 {
     struct scheduler* d = find_default_scheduler();
     HipSchedState* st = sched_state(ir_graph);
+    if (!st) return -1;
     if (block) {
         while (st->inflight > 0)                         // a blocking run behind asynchronous ones: results stay in order
             if (hip_sched_wait(s, ir_graph) != 0) return -1;
         return d->run(d, ir_graph, 1);
     }
-    struct subgraph* sg = single_hip_subgraph(ir_graph);
-    if (!sg) return d->run(d, ir_graph, 1);              // mixed placement: complete before returning (wait then has nothing to do)
+    struct subgraph* sg = pipelined_hip_subgraph(ir_graph);
+    if (!sg) return d->run(d, ir_graph, 1);              // no single leading HIP piece: complete before returning (wait then has nothing to do)
     if (st->inflight >= 2) { TLOG_ERR("Tengine HIP: two asynchronous runs are already in flight: wait_graph first\n"); return -1; }
     sg->status = GRAPH_STAT_RUNNING;
     if (sg->device->interface->async_run(sg->device, sg) != 0) { sg->status = GRAPH_STAT_ERROR; return -1; }
@@ -664,12 +757,26 @@ int hip_sched_postrun(struct scheduler* s, struct graph* ir_graph)
         if (hip_sched_wait(s, ir_graph) != 0) break;
     struct scheduler* d = find_default_scheduler();
     const int rc = d->postrun(d, ir_graph);
-    delete (HipSchedState*)ir_graph->attribute->scheduler_privacy;
-    ir_graph->attribute->scheduler_privacy = nullptr;
+    if (ir_graph->attribute->scheduler_privacy) {
+        sys_free(ir_graph->attribute->scheduler_privacy);
+        ir_graph->attribute->scheduler_privacy = nullptr;
+    }
+    sched_detach(ir_graph->attribute->context);
     return rc;
 }
 
 struct scheduler hip_scheduler = {"hip_pipelined", hip_sched_prerun, hip_sched_run, hip_sched_wait, hip_sched_postrun, nullptr};
+
+void sched_detach(struct context* ctx)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    auto it = g_sched_live.find(ctx);
+    if (it == g_sched_live.end()) return;
+    if (--it->second <= 0) {
+        g_sched_live.erase(it);
+        if (ctx->scheduler == &hip_scheduler) ctx->scheduler = find_default_scheduler();
+    }
+}
 
 int hip_split_graph(struct graph* ir_graph)
 {
@@ -677,7 +784,11 @@ int hip_split_graph(struct graph* ir_graph)
     if (0 != strcmp(HIP_DEV_NAME, cur_dev->name)) return -1;
     // split_graph runs inside prerun_graph, before the context's scheduler is asked to pre-run (c_api.c:468-530): from here on
     // this context schedules through the plugin's scheduler (TG_HIP_SCHEDULER=0 keeps the reference's)
-    if (!(getenv("TG_HIP_SCHEDULER") && atoi(getenv("TG_HIP_SCHEDULER")) == 0)) ir_graph->attribute->context->scheduler = &hip_scheduler;
+    if (!(getenv("TG_HIP_SCHEDULER") && atoi(getenv("TG_HIP_SCHEDULER")) == 0)) {
+        ir_graph->attribute->context->scheduler = &hip_scheduler;
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        g_sched_live.insert({ir_graph->attribute->context, 0});      // known from now on: unregister_hip_device restores it
+    }
 
     struct vector* allowed_ops = create_vector(sizeof(int), nullptr);
     struct vector* blocked_ops = create_vector(sizeof(int), nullptr);
@@ -778,6 +889,12 @@ __attribute__((visibility("default"))) int hip_device_placement(void* graph, cha
 
 __attribute__((visibility("default"))) int unregister_hip_device(void)
 {
+    {   // no context may keep pointing at this library's scheduler once the device is gone
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        for (auto& e : g_sched_live)
+            if (e.first->scheduler == &hip_scheduler) e.first->scheduler = find_default_scheduler();
+        g_sched_live.clear();
+    }
     int ret = unregister_device(&hip_device);
     if (0 != ret) {
         TLOG_INFO("Tengine plugin %s unregister failed.\n", hip_device.name);

@@ -199,4 +199,4 @@ def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
     body = hdr[hdr.index("typedef struct tamd_options {"):hdr.index("} tamd_options;")]
     fields = re.findall(r"^\s+(?:const\s+)?\w+\*?\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in capi.Options._fields_], (fields, capi.Options._fields_)
-    assert fields[-1] == "direct_dispatch" and ctypes.sizeof(capi.Options) == 32
+    assert fields[-2:] == ["direct_dispatch", "keep_tensors"] and ctypes.sizeof(capi.Options) == 32

@@ -151,7 +151,8 @@ def test_mobilenet_v1_int8_batch1_bit_exact():
         if fuse is not None:
             os.environ["TAMD_FUSE_PWDW"] = fuse
         try:
-            gr = capi.Graph(tm2.write_tm2(g))
+            # layer by layer: every tensor keeps its own buffer (the default shares memory between disjoint lifetimes)
+            gr = capi.Graph(tm2.write_tm2(g), keep_tensors=(fuse == "0"))
         finally:
             os.environ.pop("TAMD_FUSE_PWDW", None)
         gr.set_input(x)
@@ -205,6 +206,10 @@ def test_resnet50_int8_batch2_bit_exact():
     got = gr.run()[0]
     out_t = g.nodes[g.output_nodes[0]].outputs[0]
     if not np.array_equal(got.reshape(want[out_t].shape), want[out_t]):
+        gr.close()
+        gr = capi.Graph(tm2.write_tm2(g), keep_tensors=True)      # again with one buffer per tensor, to read the layers back
+        gr.set_input(x)
+        gr.run()
         for n in g.nodes:                      # pinpoint the first differing layer
             if n.op in ("Const", "InputOp"):
                 continue

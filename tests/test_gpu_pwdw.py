@@ -127,7 +127,7 @@ def test_fused_equals_unfused_on_device_and_intermediate_is_refused():
     # the intermediate tensor only exists in LDS: reading it must fail loudly, not return the memset zeros
     os.environ["TAMD_FUSE_PWDW"] = "2"
     try:
-        gr = capi.Graph(tm2.write_tm2(g))
+        gr = capi.Graph(tm2.write_tm2(g), keep_tensors=True)
     finally:
         del os.environ["TAMD_FUSE_PWDW"]
     gr.set_input(x)
