@@ -167,7 +167,8 @@ def main():
         for b in per_image:
             slot_off.append(slot_bytes)
             slot_bytes += b * max_shard
-        slots, gathered, works = None, None, {}
+        slots, gathered, works, slot_done, stalls = None, None, {}, {}, [0]
+        sides = [torch.cuda.Stream(device=torch.device("cuda", local_rank)) for _ in range(S)] if mode == "every" else None
         if mode != "none":
             slots = [[torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
             gathered = [[torch.empty(slot_bytes * world, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
@@ -184,8 +185,21 @@ def main():
                 s_ = (k // S) & 1
                 with torch.cuda.stream(exts[i]):
                     if works.get((i, s_)) is not None:
-                        works[(i, s_)].wait()         # slot free again (gather issued two rounds ago is done)
+                        # the slot's previous gather (two steps ago) must be complete before the slot is refilled: the HOST waits
+                        # here when it is not -- at most two gathers are ever outstanding, the compute queue cannot run away from
+                        # the collectives, and every such wait is counted (`gather_stalls` in the line)
+                        ev = slot_done.get((i, s_))
+                        if ev is not None and not ev.query():
+                            stalls[0] += 1
+                            ev.synchronize()
+                        works[(i, s_)].wait()
                     gather(i, s_)
+                # the slot's completion event, recorded behind the collective on a SIDE stream: the graph's own stream must not
+                # wait for this step's gather (it overlaps the next step)
+                with torch.cuda.stream(sides[i]):
+                    works[(i, s_)].wait()
+                    ev = slot_done.setdefault((i, s_), torch.cuda.Event())
+                    ev.record()
 
         def drain():
             if mode == "final":                          # the last step's outputs of every stream, one collective each
@@ -220,7 +234,8 @@ def main():
             t = torch.tensor([el_], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_ = float(t.item())
-        info = {"el": el_, "n_out": n_out, "per_image": per_image, "out_sizes": out_sizes, "direct_packets": gr.direct_packets(), "mode": mode}
+        info = {"el": el_, "n_out": n_out, "per_image": per_image, "out_sizes": out_sizes, "direct_packets": gr.direct_packets(), "mode": mode,
+                "gather_stalls": stalls[0]}
         if keep:
             return info, grs
         for q in grs:
@@ -236,6 +251,12 @@ def main():
         main_info, grs = region("none", args.direct, keep=True)
     elif args.gather == "both":
         main_info, _ = region("every", 0)
+        # the same K steps on the SAME dispatch path (hipGraph replay) without any collective: what the N GPUs do when nothing is
+        # gathered -- the like-for-like reference of `value` inside this very job (N x the N = 1 line's `hipgraph_replay`)
+        rep_info, _ = region("none", 0)
+        side["no_collective_hipgraph"] = {"value": total_images * args.steps / rep_info["el"], "ms_per_step": 1e3 * rep_info["el"] / args.steps,
+                                          "what": "K steps as hipGraph replays on every rank, no collective: value / this = what the per-step gather costs; "
+                                                  "compare with n_gpus x the N = 1 line's hipgraph_replay.value"}
         fin_info, grs = region("final", args.direct, keep=True)
         side["gather_final"] = {"value": total_images * args.steps / fin_info["el"], "ms_per_step": 1e3 * fin_info["el"] / args.steps,
                                 "what": "same K steps, no per-step collective (direct AQL dispatch, %d packets per step): every output of the LAST step "
@@ -389,6 +410,10 @@ def main():
             "host_to_host_images_per_s": host_to_host["images_per_s_median"] if host_to_host else None,
             "host_to_host_pipelined_images_per_s": host_to_host["pipelined_images_per_s"] if host_to_host else None,
             "prerun_ms": prerun_ms,
+            # which N = 1 figure a scaling curve of `value` has to be read against: at N > 1 the per-step-gather region replays
+            # hipGraphs (it needs the stream order), so its N = 1 counterpart is `hipgraph_replay`, not the direct-dispatch `value`
+            "scaling_baseline_key": "hipgraph_replay" if (use_dist and gather_mode == "every") or (not use_dist and "hipgraph_replay" in side) else "value",
+            "gather_stalls": main_info.get("gather_stalls", 0) if use_dist else None,
             **side,
             "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
         }
@@ -446,19 +471,19 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
     physical = physical_cores() or logical
     # The reference takes omp_get_max_threads() as its core count the first time it is asked (source/system/cpu.c:110, cached),
     # caps it at 64 and builds the all-cores mask as ((size_t)1 << count) - 1 -- zero for 64, and then every kernel runs on one
-    # thread whatever options.num_thread says (the flat sweep below).  Asking OpenMP for fewer threads BEFORE the reference's first
-    # graph (what OMP_NUM_THREADS=<n> in the environment does) keeps the mask valid with the sources untouched:
-    # TAMD_BENCH_REF_THREADS=<n <= 63> does that and sweeps up to n.  It is opt-in until it has been timed on the 256-CPU box with
-    # its 16-CPU cgroup allowance (n = 63 there spun for more than a minute; n = the allowance is the setting to try).
-    cap = logical
-    cap_env = os.environ.get("TAMD_BENCH_REF_THREADS")
-    if cap_env and cap_env.isdigit() and 1 <= int(cap_env) <= 63:
-        cap = min(int(cap_env), logical)
+    # thread whatever options.num_thread says (a flat sweep).  Asking OpenMP for fewer threads BEFORE the reference's first graph
+    # (what OMP_NUM_THREADS=<n> in the environment does) keeps the mask valid with the sources untouched.  Default cap: the
+    # smallest of the container's CPU allowance (cgroup cpu.max), the physical cores and 63; TAMD_BENCH_REF_THREADS=<n> pins it,
+    # =0 switches the cap off (the reference as it probes this host by itself).
+    cap, cap_why = ref_thread_cap(logical, physical)
+    if cap < logical:
         try:
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cap)
         except (OSError, AttributeError):
-            pass
-    sweep = sorted({min(t, cap) for t in (1, 8, 32, physical, logical) if t >= 1})
+            cap, cap_why = logical, "libgomp not reachable: no cap"
+    sweep = sorted({min(t, cap) for t in (1, 4, 8, 16, 32, physical, logical) if t >= 1})
+    if len(sweep) > 5:
+        sweep = sorted(set(sweep[:2] + sweep[-3:]))
     try:
         from oracle import ref_capi
         if not ref_capi.available():
@@ -482,15 +507,15 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
             pts.append((threads, min(ts), float(np.mean(ts)), len(ts)))
         best = min(pts, key=lambda p: p[1])
         flat = max(p[1] for p in pts) < 1.08 * min(p[1] for p in pts) and len(pts) > 2
-        note = ""
+        note = "; OpenMP capped at %d threads before the reference's first graph (%s): works around source/system/cpu.c:110-121,269" % (cap, cap_why) if cap < logical else ""
         if flat and logical >= 64:
             # source/system/cpu.c:120-121,269: core_count is capped at 64 and the all-cores mask is ((size_t)1 << core_count) - 1,
             # which is 0 on x86-64 for 64 -> get_cpu_mask_count() = 0 -> num_thread = 0: on a >= 64-CPU host the reference
             # runs its kernels single-threaded whatever options.num_thread says (the sweep is flat)
-            note = ("; the sweep is flat because the reference's own CPU probing (source/system/cpu.c:120-121,269) yields a zero core "
+            note += ("; the sweep is flat because the reference's own CPU probing (source/system/cpu.c:120-121,269) yields a zero core "
                     "mask on a host with >= 64 logical CPUs and its kernels run single-threaded here")
         out = {"value": batch / best[1], "unit": "images/s", "cores": 1 if (flat and logical >= 64) else best[0], "kind": "reference",
-               "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_max": cgroup_cpu_max(),
+               "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_max": cgroup_cpu_max(), "openmp_cap": cap if cap < logical else None,
                "sweep": [{"threads": p[0], "min_ms": 1e3 * p[1], "mean_ms": 1e3 * p[2], "runs": p[3]} for p in pts],
                "sample": "timed run_graph() calls of the same tmfile/input (batch %d) at each requested thread count of the sweep (%s), "
                          "%.0f s of CPU work in total; value = best point (min %.1f ms); reference CPU backend built -O3 -mfma "
@@ -530,6 +555,34 @@ def cpu_baseline(tm_bytes, g, x, batch, budget_s, u8=False):
             ts.append(time.perf_counter() - t0)
         return {"value": batch / min(ts), "unit": "images/s", "cores": logical, "kind": "port",
                 "sample": "%d timed oracle passes (batch %d), min %.1f ms" % (len(ts), batch, 1e3 * min(ts))}
+
+
+def cgroup_cpus():
+    """whole CPUs of the container's cgroup allowance ("quota period" in cpu.max), None when unlimited / unreadable"""
+    cm = cgroup_cpu_max()
+    if cm:
+        f = cm.split()
+        if len(f) == 2 and f[0].isdigit() and f[1].isdigit() and int(f[1]) > 0:
+            return max(1, -(-int(f[0]) // int(f[1])))
+    return None
+
+
+def ref_thread_cap(logical, physical, env=None):
+    """(threads OpenMP is limited to before the reference library's first graph, why).  See cpu_baseline."""
+    env = os.environ.get("TAMD_BENCH_REF_THREADS") if env is None else env
+    if env is not None and env.strip().isdigit():
+        n = int(env)
+        if n == 0:
+            return logical, "TAMD_BENCH_REF_THREADS=0: no cap"
+        return max(1, min(n, 63, logical)), "TAMD_BENCH_REF_THREADS"
+    allow = cgroup_cpus()
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = logical
+    cands = [("cgroup cpu.max allowance", allow), ("physical cores", physical), ("scheduler affinity", aff), ("the reference's 63-core limit", 63)]
+    why, cap = min(((w, c) for w, c in cands if c), key=lambda e: e[1])
+    return max(1, min(cap, logical)), why
 
 
 def cgroup_cpu_max():
@@ -623,8 +676,14 @@ def dry_run(args, rank, world):
         if int(flag.item()) != 1:
             raise SystemExit("bench.py --dry-run: gathered outputs are not in global image order")
         if rank == 0:
+            multi = world > 1
             print(json.dumps({"metric": "images/sec %s %s" % (args.dtype, args.model), "value": None, "unit": "images/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "scaling": "strong" if args.global_batch else "weak",
+                              # the keys a measured N > 1 line carries (null here: nothing was measured)
+                              "scaling_baseline_key": "hipgraph_replay", "gather_stalls": None,
+                              "gather_final": {"value": None} if multi and args.gather == "both" else None,
+                              "no_collective_hipgraph": {"value": None} if multi and args.gather == "both" else None,
                               "config": {"workload": "%s %s: gloo plumbing check only, no device work" % (args.model, args.dtype),
                                          "global_batch": total, "shards": counts, "outputs": len(per_image),
                                          "gather_bytes_per_image": sum(per_image), "tmfile_bytes": len(tm_bytes),

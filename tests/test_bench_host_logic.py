@@ -64,3 +64,22 @@ def test_committed_bench_lines_carry_the_contract_fields():
         c = j["cpu_baseline"]
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in c
+
+
+def test_reference_thread_cap_defaults_to_the_smallest_allowance(monkeypatch):
+    """the reference CPU baseline must be its real multi-thread number.  The reference breaks on >= 64 logical
+    CPUs (source/system/cpu.c:110-121,269: zero core mask); bench.py limits OpenMP BEFORE the reference's first graph to
+    min(cgroup allowance, physical cores, affinity, 63); TAMD_BENCH_REF_THREADS pins or disables the cap."""
+    import bench
+    monkeypatch.setattr(bench, "cgroup_cpu_max", lambda: "1600000 100000")
+    monkeypatch.setattr(bench.os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    assert bench.cgroup_cpus() == 16
+    assert bench.ref_thread_cap(256, 128, env="") == (16, "cgroup cpu.max allowance")
+    monkeypatch.setattr(bench, "cgroup_cpu_max", lambda: "max 100000")
+    assert bench.cgroup_cpus() is None
+    assert bench.ref_thread_cap(256, 128, env="") == (63, "the reference's 63-core limit")
+    assert bench.ref_thread_cap(256, 32, env="") == (32, "physical cores")
+    assert bench.ref_thread_cap(256, 128, env="0")[0] == 256
+    assert bench.ref_thread_cap(256, 128, env="40") == (40, "TAMD_BENCH_REF_THREADS")
+    assert bench.ref_thread_cap(256, 128, env="200")[0] == 63
+    assert bench.ref_thread_cap(8, 4, env="") == (4, "physical cores")

@@ -120,6 +120,26 @@ def test_bench_gpus8_dry_run_of_the_baseline_multi_gpu_configs(model, total, per
     assert line["config"]["outputs"] >= 2
     if per_image:
         assert line["config"]["gather_bytes_per_image"] == per_image
+    _check_multi_gpu_keys(line, 8)
+
+
+def _check_multi_gpu_keys(line, n):
+    """what an N > 1 line must carry so that a scaling curve can be read like for like -- the judged `value`
+    (per-step gather), `gather_final`, the same-dispatch-path figure without a collective, the name of the N = 1 key the curve is
+    read against, the stall counter of the bounded gather -- with a consistent GPU count / parallelism tag"""
+    for key in ("value", "gather_final", "no_collective_hipgraph", "scaling_baseline_key", "gather_stalls", "scaling"):
+        assert key in line, key
+    assert line["scaling_baseline_key"] == "hipgraph_replay"
+    assert line["n_gpus"] == n and line["config"]["parallelism"] == "dp%d" % n and sum(line["config"]["shards"]) == line["config"]["global_batch"]
+
+
+def test_bench_gpus2_dry_run_of_the_headline_config_carries_the_multi_gpu_keys():
+    """BASELINE configs[1] (int8 MobileNet-v1, batch 1 per GPU) at N = 2: weak scaling, one image per rank"""
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["config"]["shards"] == [1, 1]
+    _check_multi_gpu_keys(line, 2)
 
 
 def test_bench_gpus2_without_two_devices_fails_loudly():

@@ -53,3 +53,65 @@ def test_async_protocol_errors():
     gr.wait()
     gr.run()
     gr.close()
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_destroy_and_sync_with_uncollected_runs(direct):
+    """asynchronous runs on the direct path are closed at submit time; destroying (or syncing) the graph while
+    they are still executing must wait for them -- the queue, the kernel arguments and the pinned buffers outlive the packets."""
+    g = models.build("mobilenet_v1", "int8", 1)
+    tmb = tm2.write_tm2(g)
+    x = models.synth_input(g, 11)
+    ref = capi.Graph(tmb)
+    ref.set_input(x)
+    want = ref.run()[0].copy()
+    ref.close()
+    for _ in range(20):                       # many short-lived graphs: a use-after-free would fault or corrupt sooner or later
+        gr = capi.Graph(tmb, direct_dispatch=direct)
+        gr.set_input(x)
+        gr.run_async()
+        gr.run_async()
+        gr.close()                            # nothing collected
+    gr = capi.Graph(tmb, direct_dispatch=direct)
+    gr.set_input(x)
+    out = gr.output_like()
+    gr.run_async(out)
+    gr.sync()                                 # device work of the uncollected run is complete after this ...
+    gr.wait()                                 # ... and wait() only delivers it
+    assert np.array_equal(out[0], want)
+    gr.bind_default_outputs()
+    assert np.array_equal(gr.run()[0], want)
+    gr.close()
+
+
+def test_blocking_run_variants_agree(monkeypatch):
+    """the host-to-host list with outputs stored straight into the pinned host buffer and the burst closed by its last packet
+    (defaults) == the round-3 form (download launch, barrier packet) == the hipGraph form, for a 1x1-map output (MobileNet) and
+    for outputs that pass through a layout launch (a conv graph whose output is a map)."""
+    from helpers import conv_graph
+    cases = [models.build("mobilenet_v1", "int8", 1)]
+    xs = [models.synth_input(cases[0], 5)]
+    g2, x2 = conv_graph(21, 2, 32, 14, 14, 48, 3, 1, 1)
+    cases.append(g2)
+    xs.append(x2)
+    for g, x in zip(cases, xs):
+        tmb = tm2.write_tm2(g)
+        outs = []
+        for env in ({}, {"TAMD_IO_ZERO_COPY": "0"}, {"TAMD_DIRECT_CLOSE_ON_LAST": "0"}, {"TAMD_IO_ZERO_COPY": "0", "TAMD_DIRECT_CLOSE_ON_LAST": "0"}, None):
+            for k, v in (env or {}).items():
+                monkeypatch.setenv(k, v)
+            gr = capi.Graph(tmb, direct_dispatch=env is not None)
+            for k in (env or {}):
+                monkeypatch.delenv(k)
+            gr.set_input(x)
+            a = gr.run()[0].copy()
+            b = gr.run()[0].copy()
+            o2 = gr.output_like()
+            gr.run_async(o2)
+            gr.wait()
+            gr.close()
+            assert np.array_equal(a, b) and np.array_equal(a, o2[0])
+            outs.append(a)
+        for o in outs[1:]:
+            assert np.array_equal(outs[0], o)
+        assert np.array_equal(outs[0].reshape(-1), oracle.run_graph(g, x)[0].reshape(-1))

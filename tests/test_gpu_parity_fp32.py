@@ -1,6 +1,8 @@
 """GPU parity, fp32: the HIP backend through the C ABI against the CPU oracle (double-accumulated
-restatement, itself within 1e-5 of the real reference: tests/test_fp32_oracle.py).  Tolerance 1e-4, written here:
-|device - oracle| <= 1e-4 + 1e-4 * |oracle|."""
+restatement: tests/test_fp32_oracle.py pins it to the real reference, whose own Winograd path carries most of THAT test's
+budget).  Tolerance, written here: ABSOLUTE, max |device - oracle| <= 1e-4 (north_star: "fp32 within 1e-4"; the reference's own
+conformance bar is absolute too, tests/op/test_onnx_op.h:173-188) -- every tensor in these tests is O(1..20), where binary32
+accumulation sits around 1e-6.  The max |d| of every comparison is printed (pytest -s / the captured log)."""
 import numpy as np
 import pytest
 
@@ -9,7 +11,13 @@ from tengine_amd import capi, models, tm2
 from tengine_amd.tm2 import DT_FP32, Graph
 
 pytestmark = pytest.mark.gpu
-TOL = dict(rtol=1e-4, atol=1e-4)
+ATOL = 1e-4
+
+
+def close(got, want, what=""):
+    d = float(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)).max()) if np.size(want) else 0.0
+    print("fp32 parity %s: max |d| = %.3g (|ref| max %.3g)" % (what, d, float(np.abs(want).max()) if np.size(want) else 0.0))
+    return d <= ATOL
 
 
 def run_hip(g, x):
@@ -58,7 +66,7 @@ def test_conv_f32(case):
     want = oracle.run_graph(g, x)[0]
     got = run_hip(g, x)[0].reshape(want.shape)
     assert got.dtype == np.float32
-    assert np.allclose(got, want, **TOL), "max |d| %g" % np.abs(got - want).max()
+    assert close(got, want), "max |d| %g" % np.abs(got - want).max()
 
 
 @pytest.mark.parametrize("name,batch", [("squeezenet_v1.1", 1), ("squeezenet_v1.1", 4), ("mobilenet_v1", 2)])
@@ -70,7 +78,7 @@ def test_fp32_models(name, batch):
     want = oracle.run_graph(g, x)
     got = run_hip(g, x)
     for w, o in zip(want, got):
-        assert np.allclose(o.reshape(w.shape), w, **TOL), "max |d| %g" % np.abs(o.reshape(w.shape) - w).max()
+        assert close(o.reshape(w.shape), w, "%s b%d" % (name, batch)), "max |d| %g" % np.abs(o.reshape(w.shape) - w).max()
         assert np.abs(w).max() > 1e-3
 
 
@@ -120,7 +128,7 @@ def test_conv_f32_winograd_forced(case, monkeypatch):
     names = [k["kernel"] for k in gr.profile(1)]
     gr.close()
     assert names == ["wino_in_f32", "wino_gemm_f32<F(2,3)>", "wino_out_f32"], names
-    assert np.allclose(got, want, **TOL), "max |d| %g" % np.abs(got - want).max()
+    assert close(got, want), "max |d| %g" % np.abs(got - want).max()
     monkeypatch.setenv("TAMD_F32_WINOGRAD", "0")
     direct = run_hip(g, x)[0].reshape(want.shape)
     assert np.abs(direct - got).max() <= 2e-4 * max(1.0, np.abs(want).max())
@@ -140,4 +148,4 @@ def test_squeezenet_fp32_winograd_modes(mode, monkeypatch):
     gr.close()
     assert any(k.startswith("wino_gemm") for k in names) == (mode == "1"), names
     for w_, o in zip(want, got):
-        assert np.allclose(o.reshape(w_.shape), w_, **TOL), "max |d| %g" % np.abs(o.reshape(w_.shape) - w_).max()
+        assert close(o.reshape(w_.shape), w_), "max |d| %g" % np.abs(o.reshape(w_.shape) - w_).max()
