@@ -17,7 +17,7 @@ _NP = {DT_FP32: np.float32, DT_FP16: np.float16, DT_INT8: np.int8, DT_UINT8: np.
 
 class Options(C.Structure):           # tamd_options
     _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int),
-                ("direct_dispatch", C.c_int), ("keep_tensors", C.c_int)]
+                ("direct_dispatch", C.c_int), ("keep_tensors", C.c_int), ("u8_integer", C.c_int)]
 
 
 class KernelInfo(C.Structure):        # tamd_kernel_info
@@ -98,7 +98,7 @@ def device_count():
 class Graph:
     """A device graph loaded from tmfile bytes (same bytes the reference's `tengine:m` loader takes)."""
 
-    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False, direct_dispatch=False, keep_tensors=False):
+    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False, direct_dispatch=False, keep_tensors=False, u8_integer=False):
         L = lib()
         self._h = L.tamd_graph_load_tm2(tm_bytes, len(tm_bytes))
         if not self._h:
@@ -106,7 +106,7 @@ class Graph:
         if batch is not None:
             _check(L.tamd_graph_set_batch(self._h, batch), "set_batch")
         opt = Options(b"HIP", C.sizeof(Options), gpu_index, 1 if use_hip_graph else 0, 1 if profile else 0, 1 if direct_dispatch else 0,
-                      1 if keep_tensors else 0)
+                      1 if keep_tensors else 0, 1 if u8_integer else 0)
         _check(L.tamd_graph_prerun(self._h, C.byref(opt)), "prerun")
         self._in, self._out = [], []
         for i in range(L.tamd_graph_output_num(self._h)):

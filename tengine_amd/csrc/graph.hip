@@ -1652,6 +1652,24 @@ static bool zero_copy_outputs(tamd_graph* g, std::vector<LaunchRec>& recs, int s
     return true;
 }
 
+// The mirror image for graph inputs (TAMD_IO_ZERO_COPY_IN=1; off by default until it measures faster): the first compute launch
+// reads the slot's pinned host buffer itself (device-mapped, uncached on the device side) and the upload launches are dropped.
+// recs = [one upload launch per input][the rest]; every later argument that holds an input's staging address is re-pointed.
+static bool zero_copy_inputs(tamd_graph* g, std::vector<LaunchRec>& recs, int slot)
+{
+    const char* e = getenv("TAMD_IO_ZERO_COPY_IN");
+    const size_t nin = g->inputs.size();
+    if (!(e && atoi(e) == 1) || nin == 0 || recs.size() <= nin) return false;
+    std::vector<LaunchRec> trial(recs.begin() + nin, recs.end());
+    for (auto& io : g->inputs) {
+        void* dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, slot ? io.pinned2 : io.pinned, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (patch_pointer(trial, trial.size(), io.stage, dev) < 1) return false;
+    }
+    recs.swap(trial);
+    return true;
+}
+
 // the host-to-host program of `slot` against the eager list of the same slot (upload and download launches included), every
 // pinned output compared byte for byte.  0: identical.
 static int direct_io_selfcheck(tamd_graph* g, DirectProgram* pio, int slot)
@@ -1917,7 +1935,9 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) o.profile = opt->profile;
         if (have >= (int)(offsetof(tamd_options, direct_dispatch) + sizeof(int))) o.direct_dispatch = opt->direct_dispatch;
         if (have >= (int)(offsetof(tamd_options, keep_tensors) + sizeof(int))) o.keep_tensors = opt->keep_tensors;
+        if (have >= (int)(offsetof(tamd_options, u8_integer) + sizeof(int))) o.u8_integer = opt->u8_integer;
     }
+    if (const char* ui = getenv("TAMD_U8_INT")) o.u8_integer = atoi(ui) != 0;
     if (const char* dd = getenv("TAMD_DIRECT_DISPATCH")) o.direct_dispatch = atoi(dd) != 0;
     // a tool that intercepts HSA queues (rocprofv3) crashes in its doorbell handler on packets it did not see HIP write
     // (ROCm 7.2: SIGSEGV inside the interceptor on the first pass, profiles/r02_direct_dispatch.txt): under such a tool the graph
@@ -2002,7 +2022,8 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
                 HIPCHK(hipStreamSynchronize(g->stream));
                 // outputs straight into the pinned host buffers (no download launch) where the list allows it
                 std::vector<LaunchRec> with_downloads = recs;
-                const bool zc = io_zero_copy_wanted() && zero_copy_outputs(g, recs, slot);
+                bool zc = io_zero_copy_wanted() && zero_copy_outputs(g, recs, slot);
+                if (zero_copy_inputs(g, recs, slot)) zc = true;        // (a failed self-check below falls back to the full list)
                 DirectProgram* pio = direct_build(g->gpu, g->stream, recs, &why, g->direct);
                 bool zc_ok = zc && pio;
                 if (pio && direct_io_selfcheck(g, pio, slot)) {

@@ -169,6 +169,114 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             for (auto& io : g->outputs) a.pool.write_full |= (io.tensor == pool->in[0]);
             st.bytes += (double)yp.elems() - (a.pool.write_full ? 0.0 : (double)y.elems());
         }
+        // ---- the opt-in INTEGER path (tamd_options.u8_integer; u8i_kernels.hip): exact int32 sums on the int8 MFMA, one rounding,
+        // then the reference's own requantisation -- within one quantisation step of the reference's bytes, not identical.
+        // Everything of this node that is not the convolution proper (fused ReLU / max-pool tails, concat-by-offset placement)
+        // is shared with the byte-exact kernels.  Layers the kernel does not take (maps narrower than 4 columns, patches beyond
+        // 512 pixels) fall through to the byte-exact family, whose bytes are inside the bar by definition.
+        // (first layers -- 3 or 4 input channels against the kernel's 32-channel K step -- stay on conv_u8_rgb3x3 / the staging GEMM)
+        const char* imc = getenv("TAMD_U8_INT_MIN_C");
+        if (g->opt.u8_integer && x.c >= (imc ? atoi(imc) : 8)) {
+            a.i_alpha = qx.zp - 128; a.i_beta = qw.zp - 128;
+            std::vector<int> cands;
+            for (int c = 0; c < conv_u8i_num_cfgs(); c++) {
+                U8ConvArgs ac = a;
+                if (conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) cands.push_back(c);
+            }
+            const char* ic = getenv("TAMD_U8I_CFG");                 // tests / fuzzing: pin one tile shape where it applies
+            if (ic && *ic) {
+                const int want = atoi(ic) % conv_u8i_num_cfgs();
+                if (std::find(cands.begin(), cands.end(), want) != cands.end()) cands.assign(1, want);
+            }
+            if (!cands.empty()) {
+                std::map<int, std::pair<int8_t*, int32_t*>> ipacked;      // cout tile height -> packed weights + per-channel constants
+                auto iready = [&](U8ConvArgs& ac, int c) -> int {
+                    if (!conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) return -1;
+                    const int bm = conv_u8i_bm(c);
+                    auto it = ipacked.find(bm);
+                    if (it == ipacked.end()) {
+                        std::vector<int8_t> wp(conv_u8i_packed_bytes(ac));
+                        std::vector<int32_t> cv((size_t)rup(cout, bm) + 4);
+                        conv_u8i_pack(ac, w.data.data(), qw.zp, qx.zp, b ? (const int32_t*)b->data.data() : nullptr, wp.data(), cv.data());
+                        int8_t* dw = nullptr; int32_t* dc = nullptr;
+                        if (upload(g, wp, &dw) || upload(g, cv, &dc)) return -1;
+                        it = ipacked.emplace(bm, std::make_pair(dw, dc)).first;
+                    }
+                    ac.iw = it->second.first; ac.icv = it->second.second;
+                    return 0;
+                };
+                // geometry heuristic: the largest tile that still gives every CU a block; the plan-time timing then decides
+                auto blocks_of = [&](int c) {
+                    U8ConvArgs ac = a;
+                    conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w);
+                    static const int bns[] = {64, 64, 128, 128, 128, 256};
+                    const int bm = conv_u8i_bm(c), bn = bns[c];
+                    const long tiles = ac.i_tw ? (long)((y.w + ac.i_tw - 1) / ac.i_tw) * ((y.h + bn / ac.i_tw - 1) / (bn / ac.i_tw)) : (y.h * y.w + bn - 1) / bn;
+                    return tiles * x.n * ((cout + bm - 1) / bm);
+                };
+                int pick = cands[0];
+                {
+                    static const int pref[] = {3, 1, 2, 0, 5, 4};
+                    long most = -1;
+                    bool done = false;
+                    for (int c : pref) {
+                        if (std::find(cands.begin(), cands.end(), c) == cands.end()) continue;
+                        const long bl = blocks_of(c);
+                        if (!done && bl >= 256) { pick = c; done = true; }
+                        if (!done && bl > most) { most = bl; pick = c; }
+                    }
+                }
+                static const char* iat_env = getenv("TAMD_AUTOTUNE");
+                char ikey[256];
+                snprintf(ikey, sizeof(ikey), "u8iconv|%s|%dx%dx%dx%d>%d k%dx%d s%d d%d%s%s", n.name.c_str(), x.n, x.c, x.h, x.w, cout, p.kernel_h, p.kernel_w,
+                         p.stride_h, p.dilation_h, relu ? "+relu" : "", pool ? "+pool" : "");
+                std::string icached;
+                const bool itune = !(iat_env && atoi(iat_env) == 0) && st.macs >= 4e6 && cands.size() > 1;
+                bool ifrom_cache = false;
+                if (itune && plan_cache_get(ikey, &icached) && icached.size() >= 2 && icached[0] == 'i') {
+                    const int c = atoi(icached.c_str() + 1);
+                    if (std::find(cands.begin(), cands.end(), c) != cands.end()) { pick = c; ifrom_cache = true; }
+                }
+                if (itune && !ifrom_cache) {
+                    hipEvent_t e0, e1;
+                    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+                    void* flush = autotune_cold(g) ? l2_flush_buffer() : nullptr;
+                    float best_ms = 1e30f;
+                    std::vector<int> order{pick};
+                    for (int c : cands) if (c != pick) order.push_back(c);
+                    for (int c : order) {
+                        U8ConvArgs ac = a;
+                        if (iready(ac, c)) return -1;
+                        auto launch = [&]() { return launch_conv_u8i(ac, g->stream); };
+                        float ms = 1e30f;
+                        if (launch() != hipSuccess) { (void)hipGetLastError(); continue; }
+                        if (flush) { if (time_cold(g, flush, launch, &ms)) return -1; }
+                        else {
+                            const int reps = 10;
+                            HIPCHK(hipEventRecord(e0, g->stream));
+                            for (int it = 0; it < reps; it++) (void)launch();
+                            HIPCHK(hipEventRecord(e1, g->stream));
+                            HIPCHK(hipEventSynchronize(e1));
+                            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                            ms /= reps;
+                        }
+                        if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us\n", n.name.c_str(), conv_u8i_kernel_name(ac), 1e3 * ms);
+                        if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; pick = c; }
+                    }
+                    hipEventDestroy(e0); hipEventDestroy(e1);
+                    plan_cache_put(ikey, "i" + std::to_string(pick));
+                }
+                if (iready(a, pick)) return -1;
+                st.rd.push_back(access_of(x));
+                st.wr.push_back(access_of(y));
+                if (pool) st.wr.push_back(access_of(g->tensors[pool->out[0]]));
+                st.deps = true;
+                st.kernel = std::string(conv_u8i_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+                st.fn = [a](hipStream_t s) { return launch_conv_u8i(a, s); };
+                g->steps.push_back(st);
+                return 0;
+            }
+        }
         // plan-time autotune over the tile configurations (every one produces the same bytes: the chain order of an
         // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
         // the patch kernel (3x3 / 1x1 with whole super-steps of channels): one more candidate of the same bytes.

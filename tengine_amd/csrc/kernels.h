@@ -277,6 +277,13 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int pk_cfg;                // -1: not used; else tile configuration of launch_conv_u8_patch
     int pk_npad, pk_wp;        // floats per channel plane of the patch (3x3: 256 | 512, 1x1: the pixel tile) / patch row pitch (input columns incl. halo)
     int pk_kh, pk_kw, pk_dh, pk_dw;    // filter shape / dilation (the GEMM kernel gets them through klut)
+    // conv_u8i (u8i_kernels.hip): the opt-in INTEGER path -- exact int32 sums on the int8 MFMA, results within one step of the reference
+    const int8_t* iw;          // (w ^ 0x80) in MFMA A-fragment order [cout tile][step = (32-channel chunk, tap)][32-row fragment][lane][16 B]
+    const int32_t* icv;        // per output channel: bias - alpha * sum_k w'_k + Kp * alpha * beta, padded to the cout tile
+    int i_cfg, i_npad, i_nchunks;      // tile configuration / pixels per patch granule plane (128 | 256 | 512) / 32-channel chunks
+    int i_cgs;                 // log2 of the 32-channel groups a chunk (= one barrier) holds: 0 | 1 | 2
+    int i_tw;                  // 0: linear pixel tiles; 8 | 16: 2-D tiles of this width (maps too wide for a linear tile's bounding box)
+    int i_alpha, i_beta;       // in_zp - 128, w_zp - 128
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
@@ -358,6 +365,14 @@ hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_pw_applicable(const U8ConvArgs& a, int KH, int KW);
 const char* conv_u8_pw_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s);
+// the integer path (u8i_kernels.hip); shares U8ConvArgs (geometry, fused ReLU / max-pool tails) with the byte-exact kernels
+int conv_u8i_num_cfgs();
+int conv_u8i_bm(int cfg);
+bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW);          // fills i_cfg / i_npad / i_nchunks / pk_k*; false: not applicable
+size_t conv_u8i_packed_bytes(const U8ConvArgs& a);
+void conv_u8i_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec);    // w: [cout][K] as in the model
+const char* conv_u8i_kernel_name(const U8ConvArgs& a);
+hipError_t launch_conv_u8i(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);

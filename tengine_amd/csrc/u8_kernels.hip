@@ -19,97 +19,9 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "u8_epilogue.h"
 
 namespace tamd {
-
-// (int)(round(s / out_scale) + zp), clamp [0,255] -- conv_kernel_x86.c:1783-1788, conv_kernel_ref_uint8.c:177-182,
-// fc_ref.c:196-202, eltwise_ref.c:571-578
-__device__ __forceinline__ int quant_round_div(float s, float out_scale, int zp)
-{
-    float r = roundf(__fdiv_rn(s, out_scale));
-    r = fminf(fmaxf(r, -65536.f), 65536.f);
-    return (int)r + zp;
-}
-__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
-
-// sat_u8(quant_round_div(s, out_scale, zp)) without the IEEE division on the common path (it was a third of the VALU work of
-// a depthwise output).  y = fma(s, fl(1/out_scale), copysign(0.5 + e, s)), e = 2^-13: for |d| < 300, d = fl(s / out_scale),
-// |s * inv - d| <= 2 |d| 2^-24 and y rounds within 2^-16, together < 5.1e-5 < e, so trunc(y) = round_half_away(d) unless
-// fract(|y|) < 2e -- those ~2.4e-4 of the values take the reference expression.  Beyond |y| = 300 the byte is saturated
-// whatever the rounding did (0 <= zp <= 255), so nothing there is handed over.  Only for SATURATING call sites: the pooling
-// node has no lower clamp (pooled_byte wraps), it keeps quant_round_div.  tests/csrc/u8_round_check.c replays this on the host.
-__device__ __forceinline__ uint8_t quant_round_sat_u8(float s, float out_scale, int zp)
-{
-    if ((unsigned)zp > 255u) return sat_u8(quant_round_div(s, out_scale, zp));       // uniform; never taken for a uint8 tensor
-    const float inv = __fdiv_rn(1.0f, out_scale);                                    // uniform: hoisted out of the pixel loops
-    const float y = __fmaf_rn(s, inv, copysignf(0.5f + 0x1p-13f, s));
-    const float ay = fabsf(y);
-    int r = (int)fminf(fmaxf(y, -65536.f), 65536.f);                                 // truncates
-    if (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f) r = (int)fminf(fmaxf(roundf(__fdiv_rn(s, out_scale)), -65536.f), 65536.f);
-    return sat_u8(r + zp);
-}
-
-// round(f / out_scale + zp), clamp -- relu_kernel_ref_uint8.c:83-89, upsample_ref.c:118-125 (zero point INSIDE the round)
-__device__ __forceinline__ uint8_t quant_round_in_exact(float f, U8Q q)
-{
-    float r = roundf(__fdiv_rn(f, q.scale) + (float)q.zp);
-    r = fminf(fmaxf(r, -65536.f), 65536.f);
-    return sat_u8((int)r);
-}
-// The same without the division on the common path (the fused ReLU of every uint8 conv output goes through here).  The
-// reference rounds x = fl(fl(f / s) + zp); y = fma(f, fl(1/s), zp) is within 2|d| 2^-24 + 2 * 2^-16 < 6.6e-5 of it for |x| < 300
-// (the quotient's rounding, the sum's, the fma's), the half is added with one more rounding (2^-16): 8.1e-5 < e = 2^-13, so
-// trunc(y + copysign(0.5 + e, y)) is round_half_away(x) unless its fraction is below 2e -- then the reference expression
-// decides; beyond 300 the byte is saturated either way.  tests/csrc/u8_round_check.c replays it.
-__device__ __forceinline__ uint8_t quant_round_in(float f, U8Q q)
-{
-    if ((unsigned)q.zp > 255u) return quant_round_in_exact(f, q);                     // uniform; never taken for a uint8 tensor
-    const float inv = __fdiv_rn(1.0f, q.scale);
-    const float y = __fmaf_rn(f, inv, (float)q.zp);
-    const float y2 = y + copysignf(0.5f + 0x1p-13f, y);
-    const float ay = fabsf(y2);
-    if (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f) return quant_round_in_exact(f, q);
-    return sat_u8((int)fminf(fmaxf(y2, -65536.f), 65536.f));
-}
-__device__ __forceinline__ float dequant(uint8_t u, float zp, float scale) { return ((float)u - zp) * scale; }
-
-// ReLU / leaky ReLU node applied to a conv's own uint8 result: relu_kernel_ref_uint8.c:48-95 on that byte
-__device__ __forceinline__ uint8_t fused_relu(uint8_t q, float scale, int zp, const U8Relu& r)
-{
-    float f = dequant(q, (float)zp, scale);
-    if (f < 0.f) f = (r.slope == 0.f) ? 0.f : f * r.slope;
-    return quant_round_in(f, r.out);
-}
-
-// Output pixel j of a conv launch -> (oy, ox).  Row-major normally; with a fused 2x2 max-pool (U8PoolFuse) window-major, so
-// that lanes 4w..4w+3 of a pixel column group hold the window w = (py, px): j = 4 * (py * OW/2 + px) + 2 * dy + dx.
-// The reference's main / tail split of a pixel (j < (OH*OW)&~7) is a property of its ROW-MAJOR index; the planner only
-// fuses when OH*OW % 8 == 0, where every pixel is a main pixel whatever the order.
-__device__ __forceinline__ void conv_pixel(const U8ConvArgs& a, int j, int* oy, int* ox)
-{
-    if (a.pool.on) {
-        const int half = a.OW >> 1, w = j >> 2, py = w / half, px = w - py * half;
-        *oy = 2 * py + ((j >> 1) & 1); *ox = 2 * px + (j & 1);
-    } else {
-        *oy = j / a.OW; *ox = j - *oy * a.OW;
-    }
-}
-
-// max over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1])
-__device__ __forceinline__ int quad_max(int v)
-{
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
-    return max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
-}
-
-// the pool node on the window maximum m: pooling_kernel_ref_uint8.c:91-200 dequantises every byte, takes the fp32 max (the
-// dequantisation is monotone: that is the dequantised max byte), then round(f / out_scale) + out_zp with ONLY the upper clamp
-__device__ __forceinline__ uint8_t pooled_byte(int m, const U8PoolFuse& p)
-{
-    const float f = ((float)(m - p.in.zp)) * p.in.scale;
-    const int od = quant_round_div(f, p.out.scale, p.out.zp);
-    return (uint8_t)(od > 255 ? 255 : od);
-}
 
 // =================================================================================================================
 // group == 1 convolution: conv/x86/conv_kernel_x86.c:68-80 (weights -> fp32), :126-185 (im2col_uint8, k = (c,ky,kx),

@@ -1,0 +1,412 @@
+// uint8 convolution on the INT8 matrix cores -- the opt-in integer path (tamd_options.u8_integer / TAMD_U8_INT=1).
+//
+// The reference simulates uint8 in fp32 (conv_kernel_x86.c:68-80 weights -> fp32, :126-185 im2col_uint8, :322-960 sgemm_fp,
+// :1703-1794 requantise), so its bytes carry the rounding of an fp32 summation; the byte-exact path (u8_kernels.hip) repeats
+// that chain on the fp32 MFMA (157 TFLOP/s peak).  BASELINE.md section 2 / SURVEY section 7 step 5 state the policy for a faster
+// uint8 form: results within ONE quantisation step of the reference, mismatch histogram reported.  This file is that form:
+//
+//   sum_k (x_k - zx)(w_k - zw)        exactly, in int32, on v_mfma_i32_32x32x32_i8 (32x the fp32 MFMA rate)
+//   f = (float)(sum + bias) * (in_scale * w_scale)                       one rounding instead of K of them
+//   then the reference's own tail: activation clamp, (int)(round(f / out_scale) + zp), clamp [0,255]  (:1746-1790), the fused
+//   ReLU / leaky ReLU node and the fused 2x2 max-pool node exactly as the byte-exact kernels apply them (u8_epilogue.h).
+//
+// Operands: x' = x - 128 and w' = w - 128 are int8 (a byte XOR 0x80).  With alpha = zx - 128, beta = zw - 128:
+//   sum_k (x'_k - alpha)(w'_k - beta) = sum x'w'  -  beta * sum_k x'_k  -  alpha * sum_k w'_k  +  Kp * alpha * beta
+// `sum x'w'` is the MFMA; `sum_k w'_k` and the constant are folded into a per-channel int32 vector at plan time (cvec); the one
+// data-dependent term, the sum of the pixel's im2col column, is accumulated beside the MFMAs with v_dot4_i32_i8 on the B
+// fragments the lane holds anyway (skipped when zw == 128).  Out-of-image taps hold x' = alpha (the reference's im2col writes
+// 0.0f there = the dequantised zero point) and padded channels hold w' = beta: both contribute exactly 0.
+//
+// Integer accumulation is order-free, so K is ordered for the hardware: k = (32-channel chunk, ky, kx, channel) -- an MFMA K
+// step is 32 channels of one tap.  Layout in HBM stays the reference's dense NCHW bytes on both sides (the glue kernels of the
+// uint8 planner are shared with the byte-exact path), so the kernel transposes while it stages:
+//   B: the block keeps the input PATCH of its pixel tile (bounding box of every input row / column the tile's taps touch, pad
+//      bytes outside the image) for 32 channels in LDS, [16-channel granule][patch pixel][16 B]; a thread loads 4 channels x 4
+//      consecutive patch columns as four (unaligned) dwords, fixes the columns that fall outside the image with one v_perm_b32,
+//      4x4 byte-transposes (8 v_perm_b32) and writes four dwords.  A tap is then a scalar offset on the lane's ds_read_b128
+//      address -- each input byte enters the CU once per block instead of KH*KW times.  Two patch buffers: the next chunk's
+//      global loads are issued before the current chunk's MFMAs and stored behind them; one barrier per chunk.
+//   A: weights packed at plan time in MFMA fragment order [cout tile][step = (chunk, tap)][32-row fragment][lane][16 B],
+//      fetched from global straight into a 3-deep register ring (shared by every pixel tile through the L2s).
+//   D: lanes run along pixels = along NCHW rows; 16 output channels per lane and 32x32 tile.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "dw_common.h"
+#include "kernels.h"
+#include "u8_epilogue.h"
+
+namespace tamd {
+
+typedef int v4i_q __attribute__((ext_vector_type(4)));
+typedef int v16i_q __attribute__((ext_vector_type(16)));
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_u8i(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_u8i<I + 1, N>(f);
+    }
+}
+
+// bounding box of the output pixels j0..jl (conv_pixel order: row-major, or window-major under a fused 2x2 max-pool)
+__host__ __device__ inline void u8i_box(int OW, int pool_on, int j0, int jl, int* oy0, int* oy1, int* ox0, int* ox1)
+{
+    if (pool_on) {
+        const int half = OW >> 1, w0 = j0 >> 2, w1 = jl >> 2, py0 = w0 / half, py1 = w1 / half;
+        *oy0 = 2 * py0; *oy1 = 2 * py1 + 1;
+        if (py0 == py1) { *ox0 = 2 * (w0 - py0 * half); *ox1 = 2 * (w1 - py1 * half) + 1; }
+        else { *ox0 = 0; *ox1 = OW - 1; }
+    } else {
+        *oy0 = j0 / OW; *oy1 = jl / OW;
+        if (*oy0 == *oy1) { *ox0 = j0 - *oy0 * OW; *ox1 = jl - *oy1 * OW; }
+        else { *ox0 = 0; *ox1 = OW - 1; }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int NU>
+__global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
+{
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int OHW = a.OH * a.OW, HW = a.H * a.W;
+    // pixel tiles: LINEAR (i_tw == 0): BN consecutive pixels of the image in conv_pixel order -- every lane useful on small maps;
+    // 2-D (i_tw = tile width 8 | 16): a TH x TW window of the output map, so the patch stays small on maps too wide for a
+    // linear tile's bounding box (the launcher picks: conv_u8i_prepare)
+    const int TW = a.i_tw, TH = TW ? BN / TW : 0;
+    const int tiles_x = TW ? (a.OW + TW - 1) / TW : 0;
+    const int tiles = TW ? tiles_x * ((a.OH + TH - 1) / TH) : (OHW + BN - 1) / BN;
+    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles;
+    const int co0 = blockIdx.y * BM;
+    const int j0 = tile * BN, jl = min(j0 + BN, OHW) - 1;                 // linear tiles
+    const int oyb = TW ? (tile / tiles_x) * TH : 0, oxb = TW ? (tile - (tile / tiles_x) * tiles_x) * TW : 0;      // 2-D tiles
+    const int KH = a.pk_kh, KW = a.pk_kw, DH = a.pk_dh, DW = a.pk_dw, ntaps = KH * KW;
+    // local pixel index (0 .. BN-1) -> output coordinates (clamped into the map for lanes past the tile's last pixel) and whether
+    // the lane holds a real pixel.  Under a fused 2x2 max-pool both tile forms enumerate window-major (u8_epilogue.h conv_pixel)
+    auto pixel_of = [&](int jloc, int* oy, int* ox) -> bool {
+        if (TW == 0) {
+            const int j = j0 + jloc;
+            conv_pixel(a, min(j, jl), oy, ox);
+            return j <= jl;
+        }
+        int dy, dx;
+        if (a.pool.on) { const int w = jloc >> 2, hw = TW >> 1, wy = w / hw, wx = w - wy * hw; dy = 2 * wy + ((jloc >> 1) & 1); dx = 2 * wx + (jloc & 1); }
+        else { dy = jloc / TW; dx = jloc - dy * TW; }
+        const bool live = oyb + dy < a.OH && oxb + dx < a.OW;
+        *oy = min(oyb + dy, a.OH - 1); *ox = min(oxb + dx, a.OW - 1);
+        return live;
+    };
+
+    // ---- the patch: input rows [RY0, RY0 + rows), columns [XA, XA + Wp4) -- out-of-image positions hold the pad byte -----------
+    int oy0, oy1, ox0, ox1;
+    if (TW == 0) u8i_box(a.OW, a.pool.on, j0, jl, &oy0, &oy1, &ox0, &ox1);
+    else { oy0 = oyb; oy1 = min(oyb + TH, a.OH) - 1; ox0 = oxb; ox1 = min(oxb + TW, a.OW) - 1; }
+    const int RY0 = oy0 * a.SH - a.PH, XA = ox0 * a.SW - a.PW;
+    const int Wp4 = ((ox1 - ox0) * a.SW + (KW - 1) * DW + 1 + 3) & ~3, W4q = Wp4 >> 2;
+    const int rows = (oy1 - oy0) * a.SH + (KH - 1) * DH + 1;
+    const int P = rows * Wp4;                                // <= NPAD (the launcher checked the worst tile)
+    const int NPAD = a.i_npad;                               // pixels per granule plane
+    const unsigned padw = (unsigned)(a.i_alpha & 0xff) * 0x01010101u;
+
+    // A chunk = CG groups of 32 channels (CG = 1 | 2 | 4: small patches take more channels per barrier; 1x1 layers would otherwise
+    // see a barrier per MFMA step).  Staging units: (channel quad cq of the chunk, patch pixel quad q); surplus threads repeat
+    // the last unit (same bytes to the same place)
+    const int CGS = a.i_cgs, CG = 1 << CGS;                  // log2 / groups per chunk
+    const int BUFB = 2 * CG * NPAD * 16;                     // bytes of a patch buffer: 2 * CG granule planes
+    const uint8_t* xin = a.x + (size_t)n * a.C * HW;
+    int goff[NU], ldst[NU], cq4[NU];
+    unsigned sel[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) {
+        const int u = min(t + 256 * i, 2 * CG * P - 1);
+        const int cq = u & (8 * CG - 1), q = u >> (3 + CGS), r = q / W4q, xq = q - r * W4q;
+        const int iy = RY0 + r, ix0 = XA + 4 * xq;
+        const bool rowok = (unsigned)iy < (unsigned)a.H;
+        const int ixc = min(max(ix0, 0), a.W - 4);
+        unsigned sl = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = ix0 + j;
+            const bool ok = rowok && (unsigned)col < (unsigned)a.W;
+            sl |= (unsigned)(ok ? col - ixc : 4) << (8 * j);
+        }
+        sel[i] = sl;
+        goff[i] = rowok ? iy * a.W + ixc : 0;
+        cq4[i] = cq * 4;
+        ldst[i] = ((cq >> 2) * NPAD + 4 * q) * 16 + (cq & 3) * 4;
+    }
+    unsigned sv[NU][4];
+    auto stage_load = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NU; i++)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                const int c = min(cc * (32 * CG) + cq4[i] + c4, a.C - 1);      // padded channels re-read the last one: they meet w' = beta
+                __builtin_memcpy(&sv[i][c4], xin + (size_t)c * HW + goff[i], 4);
+            }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            unsigned d[4], x[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) d[c4] = __builtin_amdgcn_perm(padw, sv[i][c4] ^ 0x80808080u, sel[i]);
+            transpose4x4(d, x);                                         // d[c] = channel c at 4 pixels -> x[p] = pixel p's 4 channels
+#pragma unroll
+            for (int p = 0; p < 4; p++) *reinterpret_cast<unsigned*>(smem + buf * BUFB + ldst[i] + 16 * p) = x[p];
+        }
+    };
+
+    // ---- B fragment addresses: lane (pixel l31 of tile jn, k half hi) ------------------------------------------------------------
+    int bfr[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; jn++) {
+        int oy, ox;
+        (void)pixel_of((wn * TN + jn) * 32 + l31, &oy, &ox);              // lanes past the last pixel read a real one; never stored
+        const int pp0 = (oy * a.SH - a.PH - RY0) * Wp4 + (ox * a.SW - a.PW - XA);
+        bfr[jn] = (hi * NPAD + pp0) * 16;
+    }
+    const int row_step = (DH * Wp4 - KW * DW) * 16, grp_step = 2 * NPAD * 16;
+
+    // ---- A: fragments of this wave's TM 32-row tiles, one step = (BM / 32) KB; a register ring D steps deep: with one or two
+    // waves per SIMD a fragment requested two steps ahead (~200 cycles) is not there yet, eight steps are ----------------------------
+    constexpr int D = 8;
+    const int ngroups = a.i_nchunks, ns = ngroups * ntaps, nchunks = (ngroups + CG - 1) >> CGS;
+    const int8_t* wt = a.iw + ((size_t)blockIdx.y * ns * (BM / 32) + wm * TM) * 1024 + lane * 16;
+    // (a running pointer, no clamp: the packed weights carry D + 1 steps of readable slack behind the last one)
+    auto load_a = [&](v4i_q (&f)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) f[i] = *reinterpret_cast<const v4i_q*>(wt + i * 1024);
+        wt += (BM / 32) * 1024;
+    };
+
+    v16i_q acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int jn = 0; jn < TN; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0;
+    int ssum[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; jn++) ssum[jn] = 0;
+    const bool need_sum = a.i_beta != 0;
+
+    v4i_q ar[D][TM];
+#pragma unroll
+    for (int d = 0; d < D; d++) load_a(ar[d]);
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    if (nchunks > 1) stage_load(1);
+
+    // read position = the step whose B fragments are fetched next (one step ahead of the MFMAs): chunk, group inside it, tap
+    int r_chunk = 0, r_grp = 0, r_tap = 0, r_kx = 0, r_off = 0;          // r_off: byte offset inside the patch buffer (group plane + tap)
+    int r_ngrp = min(CG, ngroups);                                       // groups of the read chunk
+    v4i_q bf[TN], bfn[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; jn++) bf[jn] = *reinterpret_cast<const v4i_q*>(smem + bfr[jn]);
+    for (int s0 = 0; s0 < ns; s0 += D) {
+        static_for_u8i<0, D>([&](auto Dd) {
+            constexpr int d = decltype(Dd)::value;
+            const int st = s0 + d;
+            if (st < ns) {                                               // uniform
+                // advance the read position to step st + 1
+                bool wrap = false;
+                r_tap++; r_kx++; r_off += DW * 16;
+                if (r_kx == KW) { r_kx = 0; r_off += row_step; }
+                if (r_tap == ntaps) {
+                    r_tap = 0; r_kx = 0; r_grp++;
+                    r_off = r_grp * grp_step;
+                    if (r_grp == r_ngrp) { r_grp = 0; r_off = 0; r_chunk++; r_ngrp = min(CG, ngroups - r_chunk * CG); wrap = true; }
+                }
+                const bool more = st + 1 < ns;
+                if (more && !wrap) {
+                    const uint8_t* pb = smem + (r_chunk & 1) * BUFB + r_off;
+#pragma unroll
+                    for (int jn = 0; jn < TN; jn++) bfn[jn] = *reinterpret_cast<const v4i_q*>(pb + bfr[jn]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int jn = 0; jn < TN; jn++) acc[i][jn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ar[d][i], bf[jn], acc[i][jn], 0, 0, 0);
+                if (need_sum) {
+#pragma unroll
+                    for (int jn = 0; jn < TN; jn++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) ssum[jn] = __builtin_amdgcn_sdot4(bf[jn][e], 0x01010101, ssum[jn], false);
+                }
+                load_a(ar[d]);
+                if (more && wrap) {
+                    // the next chunk: its bytes were requested when this one started; everyone is past the other buffer's last read
+                    // (that chunk ended at the previous barrier)
+                    stage_store(r_chunk & 1);
+                    __syncthreads();
+                    if (r_chunk + 1 < nchunks) stage_load(r_chunk + 1);
+                    const uint8_t* pb = smem + (r_chunk & 1) * BUFB;
+#pragma unroll
+                    for (int jn = 0; jn < TN; jn++) bfn[jn] = *reinterpret_cast<const v4i_q*>(pb + bfr[jn]);
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; jn++) bf[jn] = bfn[jn];
+            }
+        });
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (pixel), row = (e & 3) + 8 * (e >> 2) + 4 * hi (channel) ------
+#pragma unroll
+    for (int jn = 0; jn < TN; jn++) {
+        // the column sum of the pixel: the two k halves of a step sit in lanes l31 and l31 + 32
+        const int colsum = ssum[jn] + __shfl_xor(ssum[jn], 32);
+        int oy, ox;
+        const bool live = pixel_of((wn * TN + jn) * 32 + l31, &oy, &ox);
+        const int opix = oy * a.OW + ox, ppix = (oy >> 1) * (a.OW >> 1) + (ox >> 1);
+        const int corr = a.i_beta * colsum;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int cb = co0 + (wm * TM + i) * 32 + 8 * g4 + 4 * hi;
+                const int4 cv = *reinterpret_cast<const int4*>(a.icv + cb);         // icv is padded to the cout tile
+                const int cvs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int co = cb + e;
+                    if (co >= a.cout) continue;                                      // uniform over a quad of lanes (hi is)
+                    float s = (float)(acc[i][jn][4 * g4 + e] - corr + cvs[e]) * a.bias_scale;
+                    if (a.act == 0) s = s < 0.f ? 0.f : s;
+                    if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+                    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
+                    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                    if (live && (!a.pool.on || a.pool.write_full)) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
+                    if (a.pool.on) {             // OH, OW even under a fused pool: a window's four pixels are four neighbouring lanes, live together
+                        const int m = quad_max((int)q);
+                        if (live && (l31 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = pooled_byte(m, a.pool);
+                    }
+                }
+            }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+static const struct { int wm, wn, tm, tn; const char* name; } U8I_CFGS[] = {
+    {2, 2, 1, 1, "conv_u8i_64x64"}, {2, 2, 2, 1, "conv_u8i_128x64"}, {2, 2, 1, 2, "conv_u8i_64x128"}, {2, 2, 2, 2, "conv_u8i_128x128"},
+    {1, 4, 1, 1, "conv_u8i_32x128"}, {1, 4, 1, 2, "conv_u8i_32x256"}};
+int conv_u8i_num_cfgs() { return 6; }
+int conv_u8i_bm(int cfg) { return U8I_CFGS[cfg].wm * U8I_CFGS[cfg].tm * 32; }
+static int u8i_bn(int cfg) { return U8I_CFGS[cfg].wn * U8I_CFGS[cfg].tn * 32; }
+const char* conv_u8i_kernel_name(const U8ConvArgs& a) { return U8I_CFGS[a.i_cfg].name; }
+
+// patch pixels of the worst pixel tile of `bn` outputs (rows x pitch rounded to 4)
+static int u8i_patch_pixels(const U8ConvArgs& a, int bn)
+{
+    const int OHW = a.OH * a.OW;
+    int worst = 0;
+    for (int j0 = 0; j0 < OHW; j0 += bn) {
+        const int jl = std::min(j0 + bn, OHW) - 1;
+        int oy0, oy1, ox0, ox1;
+        u8i_box(a.OW, a.pool.on, j0, jl, &oy0, &oy1, &ox0, &ox1);
+        const int wp4 = ((ox1 - ox0) * a.SW + (a.pk_kw - 1) * a.pk_dw + 1 + 3) & ~3;
+        const int rows = (oy1 - oy0) * a.SH + (a.pk_kh - 1) * a.pk_dh + 1;
+        worst = std::max(worst, rows * wp4);
+    }
+    return worst;
+}
+
+// fills i_cfg / i_npad / i_nchunks and the filter shape; false: this tile configuration cannot take the layer
+bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
+{
+    if (cfg < 0 || cfg >= conv_u8i_num_cfgs()) return false;
+    if (a.W < 4 || a.C < 1 || (size_t)a.C * a.H * a.W >= (1u << 30)) return false;      // the staging loads are dwords inside an image row
+    if (a.pool.on && ((a.OH | a.OW) & 1)) return false;
+    a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
+    const int bm = conv_u8i_bm(cfg), bn = u8i_bn(cfg);
+    if (bm > 32 && a.cout <= bm / 2) return false;                                   // a tile half empty: the narrower shape exists
+    if (a.pool.on && (a.OH * a.OW) % 8 != 0) return false;                           // what the planner promises the fused pool
+    // linear tiles where their worst bounding box fits (at most 4 staging units per thread = 512 patch pixels), else 2-D tiles
+    int worst = u8i_patch_pixels(a, bn);
+    a.i_tw = 0;
+    const char* tm = getenv("TAMD_U8I_TILES");                                       // tests: 2 = 2-D tiles wherever they fit
+    if (worst > 512 || (tm && atoi(tm) == 2)) {
+        const int tw = bn >= 128 ? 16 : 8, th = bn / tw;
+        const int w2 = ((th - 1) * a.SH + (KH - 1) * DH + 1) * (((tw - 1) * a.SW + (KW - 1) * DW + 1 + 3) & ~3);
+        if (w2 > 512) { if (worst > 512) return false; }
+        else { worst = w2; a.i_tw = tw; }
+    }
+    a.i_npad = worst <= 128 ? 128 : worst <= 256 ? 256 : 512;
+    a.i_nchunks = (a.C + 31) / 32;                                                   // 32-channel groups
+    // groups per chunk (1 | 2 | 4): as many as the staging budget (4 units per thread = 512 patch pixels x groups) and the layer hold
+    a.i_cgs = 0;
+    while (a.i_cgs < 2 && (2 << a.i_cgs) * a.i_npad <= 512 && (2 << a.i_cgs) <= a.i_nchunks) a.i_cgs++;
+    if (const char* cg = getenv("TAMD_U8I_CG")) a.i_cgs = std::min(a.i_cgs, atoi(cg) >= 4 ? 2 : atoi(cg) >= 2 ? 1 : 0);
+    a.i_cfg = cfg;
+    return true;
+}
+
+// (w ^ 0x80) in fragment order, padded with the weight zero point (w' = beta); cvec[co] = bias - alpha * sum_k w'_k + Kp * alpha * beta
+size_t conv_u8i_packed_bytes(const U8ConvArgs& a)
+{
+    const int bm = conv_u8i_bm(a.i_cfg), ntile = (a.cout + bm - 1) / bm;
+    return ((size_t)ntile * a.i_nchunks * a.pk_kh * a.pk_kw + 10) * bm * 32;         // + readable slack for the ring's last prefetches (D + 1 steps)
+}
+void conv_u8i_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec)
+{
+    const int bm = conv_u8i_bm(a.i_cfg), ntile = (a.cout + bm - 1) / bm, ntaps = a.pk_kh * a.pk_kw, ns = a.i_nchunks * ntaps;
+    const int alpha = in_zp - 128, beta = w_zp - 128;
+    const int8_t padb = (int8_t)(uint8_t)(w_zp ^ 0x80);
+    std::fill(out, out + conv_u8i_packed_bytes(a), padb);
+    for (int co = 0; co < ntile * bm; co++) {
+        long w1 = 0;
+        for (int s = 0; s < ns; s++) {
+            const int cc = s / ntaps, tap = s % ntaps;
+            int8_t* frag = out + (((size_t)(co / bm) * ns + s) * (bm / 32) + (co % bm) / 32) * 1024;
+            for (int kb = 0; kb < 32; kb++) {
+                const int c = cc * 32 + kb;
+                int8_t v = padb;
+                if (co < a.cout && c < a.C) v = (int8_t)(uint8_t)(w[((size_t)co * a.C + c) * ntaps + tap] ^ 0x80);
+                frag[((kb >> 4) * 32 + (co & 31)) * 16 + (kb & 15)] = v;
+                w1 += v;
+            }
+        }
+        cvec[co] = (int32_t)((co < a.cout && bias ? (long)bias[co] : 0L) - (long)alpha * w1 + (long)ns * 32 * alpha * beta);
+    }
+}
+
+hipError_t launch_conv_u8i(const U8ConvArgs& a, hipStream_t s)
+{
+    const int bm = conv_u8i_bm(a.i_cfg), bn = u8i_bn(a.i_cfg), OHW = a.OH * a.OW;
+    const int tiles = a.i_tw ? ((a.OW + a.i_tw - 1) / a.i_tw) * ((a.OH + bn / a.i_tw - 1) / (bn / a.i_tw)) : (OHW + bn - 1) / bn;
+    const dim3 grid(tiles * a.N, (a.cout + bm - 1) / bm, 1);
+    const size_t lds = (size_t)2 * (2 << a.i_cgs) * a.i_npad * 16;
+    const int units = (a.i_npad << a.i_cgs) / 128;                                  // staging units per thread: 1 | 2 | 4
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return hipGetLastError();
+    };
+#define U8I_NU(WM, WN, TM, TN)                                                      \
+    switch (units) {                                                                \
+    case 1: return go(conv_u8i_k<WM, WN, TM, TN, 1>);                               \
+    case 2: return go(conv_u8i_k<WM, WN, TM, TN, 2>);                               \
+    default: return go(conv_u8i_k<WM, WN, TM, TN, 4>);                              \
+    }
+    switch (a.i_cfg) {
+    case 0: U8I_NU(2, 2, 1, 1)
+    case 1: U8I_NU(2, 2, 2, 1)
+    case 2: U8I_NU(2, 2, 1, 2)
+    case 3: U8I_NU(2, 2, 2, 2)
+    case 4: U8I_NU(1, 4, 1, 1)
+    default: U8I_NU(1, 4, 1, 2)
+    }
+#undef U8I_NU
+}
+
+}  // namespace tamd

@@ -268,6 +268,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
 
     tamd_options opt;
     opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    opt.u8_integer = 0;           // byte-exact uint8 unless the application asks for the integer form
     opt.keep_tensors = 0;         // tensors of disjoint lifetimes share device memory (only subgraph outputs are visible to Tengine)
     opt.direct_dispatch = 1;      // the blocking host-to-host run as one AQL pass on the subgraph's own HSA queue (csrc/direct.cc:
                                   // MobileNet-v1 batch 1 81.6 -> 68.7 us per run); TAMD_DIRECT_DISPATCH=0 keeps the hipGraph
@@ -281,6 +282,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
             if (have >= (int)(offsetof(tamd_options, profile) + sizeof(int))) opt.profile = o->profile;
             if (have >= (int)(offsetof(tamd_options, direct_dispatch) + sizeof(int))) opt.direct_dispatch = o->direct_dispatch;
             if (have >= (int)(offsetof(tamd_options, keep_tensors) + sizeof(int))) opt.keep_tensors = o->keep_tensors;
+            if (have >= (int)(offsetof(tamd_options, u8_integer) + sizeof(int))) opt.u8_integer = o->u8_integer;
         }
     }
     const char* env = getenv("TG_HIP_DEVICE");

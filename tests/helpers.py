@@ -421,3 +421,44 @@ def u8_conv_pool_graph(seed, n, cin, h, w, cout, k=3, p=1, slope=0.1, relu=True,
         outs.append(g.add_node("side_relu", "ReLU", [cur], [r2], negative_slope=0.0))
     g.output_nodes = outs
     return g, x
+
+
+# ---- the opt-in integer uint8 path (tamd_options.u8_integer; csrc/u8i_kernels.hip) ---------------------------------------------
+def u8_conv_int_model(g, x):
+    """What the integer path computes for a single group-1 uint8 Convolution graph (u8_conv_graph), operation for operation:
+    exact integer sum of (x - zx)(w - zw) + bias, ONE float32 product with fl(in_scale * w_scale), the conv's activation clamp,
+    then the reference's requantisation (int)(round(f / out_scale) + zp) -> [0, 255] (conv_kernel_x86.c:1746-1790).  Not the
+    reference's bytes (its fp32 simulation rounds K times): the bar against the reference is one quantisation step."""
+    node = g.nodes[-1]
+    assert node.op == "Convolution"
+    p = node.params
+    xt = g.tensors[node.inputs[0]]
+    wt = g.tensors[node.inputs[1]]
+    yt = g.tensors[node.outputs[0]]
+    w = np.asarray(wt.data).astype(np.int64) - int(wt.zero_points[0])
+    xv = x.astype(np.int64) - int(xt.zero_points[0])
+    n, cin, h, wd = x.shape
+    cout, _, kh, kw = w.shape
+    s, dil, pad = p["stride_h"], p["dilation_h"], p["pad_h0"]
+    oh, ow = yt.dims[2], yt.dims[3]
+    xp = np.zeros((n, cin, h + 2 * pad, wd + 2 * pad), np.int64)       # out-of-image taps contribute (zx - zx) = 0
+    xp[:, :, pad:pad + h, pad:pad + wd] = xv
+    acc = np.zeros((n, cout, oh, ow), np.int64)
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, :, ky * dil:ky * dil + (oh - 1) * s + 1:s, kx * dil:kx * dil + (ow - 1) * s + 1:s]
+            acc += np.einsum("nchw,oc->nohw", patch, w[:, :, ky, kx])
+    if len(node.inputs) > 2:
+        acc += np.asarray(g.tensors[node.inputs[2]].data).astype(np.int64).reshape(1, cout, 1, 1)
+    assert np.abs(acc).max() < 2 ** 31
+    bs = np.float32(np.float32(xt.scales[0]) * np.float32(wt.scales[0]))
+    f = acc.astype(np.float32) * bs
+    act = p["activation"]
+    if act == 0:
+        f = np.maximum(f, np.float32(0))
+    if act > 0:
+        f = np.minimum(np.maximum(f, np.float32(0)), np.float32(6))
+    d = (f / np.float32(yt.scales[0])).astype(np.float64)
+    r = np.sign(d) * np.floor(np.abs(d) + 0.5)
+    q = np.clip(r, -65536, 65536).astype(np.int64) + int(yt.zero_points[0])
+    return np.clip(q, 0, 255).astype(np.uint8)

@@ -20,10 +20,11 @@ g = models.build(name, "int8", batch, device_only=(name != "mobilenet_v1"))
 tmb = tm2.write_tm2(g)
 x = models.synth_input(g, 3)
 VARIANTS = [("round-3 list (download launch, barrier packet)", {"TAMD_IO_ZERO_COPY": "0", "TAMD_DIRECT_CLOSE_ON_LAST": "0"}),
-            ("outputs straight to pinned host", {"TAMD_DIRECT_CLOSE_ON_LAST": "0"}),
-            ("burst closed by the last packet", {"TAMD_IO_ZERO_COPY": "0"}),
-            ("both (default)", {}),
+            ("outputs to pinned host + close on last (default)", {}),
+            ("+ first launch reads the pinned input (no upload)", {"TAMD_IO_ZERO_COPY_IN": "1"}),
             ("hipGraph", None)]
+if os.environ.get("H2H_ONLY"):
+    VARIANTS = [v for i, v in enumerate(VARIANTS) if str(i) in os.environ["H2H_ONLY"].split(",")]
 graphs, ref = [], None
 for nm, env in VARIANTS:
     for k, v in (env or {}).items():
