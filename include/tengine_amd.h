@@ -219,6 +219,9 @@ TAMD_API int tamd_graph_launch(tamd_graph* g);            /* async on the graph'
 TAMD_API int tamd_graph_sync(tamd_graph* g);
 /* packets per pass when tamd_graph_launch dispatches directly (tamd_options.direct_dispatch took effect), else 0 */
 TAMD_API int tamd_graph_direct_packets(const tamd_graph* g);
+/* of those packets, how many carry hidden arguments placed at the offsets the kernel's own code-object metadata lists (the rest
+ * use the code-object-v5 default layout, vouched for by the prerun self-check) */
+TAMD_API int tamd_graph_direct_meta_packets(const tamd_graph* g);
 TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
 /* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather) */
 TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);

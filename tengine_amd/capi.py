@@ -31,7 +31,7 @@ EXPORTS = [
     "tamd_graph_set_outputs", "tamd_graph_load_tm2", "tamd_graph_set_batch", "tamd_graph_prerun",
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
     "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
-    "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
+    "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_direct_meta_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
     "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_prerun_ms", "tamd_graph_kernel_num", "tamd_graph_profile",
     "tamd_graph_read_tensor", "tamd_graph_tensor_num", "tamd_graph_tensor_desc", "tamd_graph_destroy",
 ]
@@ -71,7 +71,7 @@ def lib():
             "tamd_graph_set_input": [vp, ci, vp, C.c_size_t], "tamd_graph_set_output": [vp, ci, vp, C.c_size_t],
             "tamd_graph_run": [vp], "tamd_graph_run_async": [vp], "tamd_graph_wait": [vp], "tamd_graph_inflight": [vp],
             "tamd_graph_upload_inputs": [vp], "tamd_graph_launch": [vp],
-            "tamd_graph_sync": [vp], "tamd_graph_direct_packets": [vp], "tamd_graph_download_outputs": [vp],
+            "tamd_graph_sync": [vp], "tamd_graph_direct_packets": [vp], "tamd_graph_direct_meta_packets": [vp], "tamd_graph_download_outputs": [vp],
             "tamd_graph_output_device": [vp, ci, C.POINTER(vp), C.POINTER(C.c_size_t)],
             "tamd_graph_stream": [vp], "tamd_graph_time_launches": [vp, ci, C.POINTER(C.c_float)],
             "tamd_graph_kernel_num": [vp], "tamd_graph_profile": [vp, ci, C.POINTER(KernelInfo), ci],
@@ -192,6 +192,9 @@ class Graph:
     def direct_packets(self):
         """AQL packets per launch() when direct dispatch is active, else 0"""
         return lib().tamd_graph_direct_packets(self._h)
+
+    def direct_meta_packets(self):
+        return lib().tamd_graph_direct_meta_packets(self._h)
 
     def kernel_num(self):
         """number of compute launches of one forward pass"""

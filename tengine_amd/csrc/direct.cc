@@ -38,6 +38,7 @@
 #include <mutex>
 #include <string>
 
+#include "codeobj_meta.h"
 #include "launch_rec.h"
 
 namespace tamd {
@@ -55,6 +56,8 @@ struct DeviceCtx {
     hsa_agent_t agent{}, cpu{};
     bool have_cpu = false;
     std::map<std::string, KernelSym> syms;
+    std::map<std::string, HiddenLayout> layouts;        // "<kernel>.kd" -> hidden-argument offsets from the code objects' metadata notes
+    std::map<uint64_t, bool> seen_objects;              // storage base of the code objects already parsed
 };
 std::mutex g_mu;
 std::map<int, DeviceCtx> g_ctx;
@@ -98,10 +101,31 @@ hsa_status_t scan_symbol(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t 
     return HSA_STATUS_SUCCESS;
 }
 
+// the code object a loaded code object came from, when the loader still holds it in host memory (HIP's fat-binary images do):
+// its AMDGPU metadata note lists every kernel's arguments, hidden ones included (codeobj_meta.h)
+hsa_status_t scan_code_object(hsa_executable_t, hsa_loaded_code_object_t lco, void* data)
+{
+    DeviceCtx* ctx = ((SymScan*)data)->ctx;
+    if (!g_loader.hsa_ven_amd_loader_loaded_code_object_get_info) return HSA_STATUS_SUCCESS;
+    uint32_t st = 0;
+    if (g_loader.hsa_ven_amd_loader_loaded_code_object_get_info(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_TYPE, &st) != HSA_STATUS_SUCCESS
+        || st != HSA_VEN_AMD_LOADER_CODE_OBJECT_STORAGE_TYPE_MEMORY) return HSA_STATUS_SUCCESS;
+    uint64_t base = 0, size = 0;
+    if (g_loader.hsa_ven_amd_loader_loaded_code_object_get_info(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_MEMORY_BASE, &base) != HSA_STATUS_SUCCESS
+        || g_loader.hsa_ven_amd_loader_loaded_code_object_get_info(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_MEMORY_SIZE, &size) != HSA_STATUS_SUCCESS
+        || !base || !size) return HSA_STATUS_SUCCESS;
+    if (ctx->seen_objects.count(base)) return HSA_STATUS_SUCCESS;
+    ctx->seen_objects[base] = true;
+    (void)codeobj_hidden_layouts((const void*)(uintptr_t)base, (size_t)size, ctx->layouts);
+    return HSA_STATUS_SUCCESS;
+}
+
 hsa_status_t scan_executable(hsa_executable_t exe, void* data)
 {
     DeviceCtx* ctx = ((SymScan*)data)->ctx;
     (void)hsa_executable_iterate_agent_symbols(exe, ctx->agent, scan_symbol, data);
+    if (g_loader.hsa_ven_amd_loader_executable_iterate_loaded_code_objects)
+        (void)g_loader.hsa_ven_amd_loader_executable_iterate_loaded_code_objects(exe, scan_code_object, data);
     return HSA_STATUS_SUCCESS;
 }
 
@@ -180,6 +204,7 @@ struct DirectProgram {
     std::vector<uint16_t> hdr;                          // header of packet i inside a burst (the first packet of a burst: h_open)
     void* kernargs = nullptr;
     uint16_t h_open = 0, h_close = 0, h_wrap = 0;        // first packet of a burst / closing barrier packet / first packet of a later pass
+    int n_meta = 0;                                      // packets whose hidden-argument offsets were read from code-object metadata
 };
 
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share)
@@ -195,6 +220,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
     std::vector<size_t> offs;
     std::vector<char> coherent;                         // packet i is a coherent launch (pwdw.hip)
     bool scanned = false;
+    int n_meta = 0;                                     // launches whose hidden-argument offsets came from the code object's metadata
     for (const LaunchRec& r : recs) {
         const char* nm = hipKernelNameRefByPtr(r.func, stream);
         if (!nm) { *why = "kernel without a name"; delete p; return nullptr; }
@@ -207,18 +233,42 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         // runtime backs the queue's scratch on demand, as it does for HIP's own queues; TAMD_DIRECT_SCRATCH=0 refuses instead
         static const bool allow_scratch = !(getenv("TAMD_DIRECT_SCRATCH") && atoi(getenv("TAMD_DIRECT_SCRATCH")) == 0);
         if (k.priv != 0 && !allow_scratch) { *why = "a kernel of the list uses scratch memory"; delete p; return nullptr; }
-        const size_t hid = (r.args.size() + 7) & ~(size_t)7;
         if (r.args.size() > k.kernarg) { *why = "recorded arguments exceed the kernel's argument segment"; delete p; return nullptr; }
-        const size_t seg = std::max<size_t>(k.kernarg, hid + 72);
+        // hidden arguments: at the offsets the kernel's own metadata lists (codeobj_meta.h).  Only where the code object is no
+        // longer readable (or carries no note) the code-object-v5 defaults stand in -- block counts at the first 8-byte boundary
+        // behind the explicit arguments, group sizes at +12, grid dimensionality at +64 -- and the prerun self-check
+        // (graph.hip direct_selfcheck) is what then vouches for them.  TAMD_DIRECT_META=0 forces the defaults (tests).
+        HiddenLayout hl;
+        {
+            static const bool use_meta = !(getenv("TAMD_DIRECT_META") && atoi(getenv("TAMD_DIRECT_META")) == 0);
+            auto lt = ctx->layouts.find(key);
+            if (use_meta && lt != ctx->layouts.end()) {
+                hl = lt->second;
+                if ((size_t)hl.explicit_end > ((r.args.size() + 7) & ~(size_t)7) || (size_t)hl.explicit_end + 8 < r.args.size()) {
+                    *why = "recorded arguments do not match the kernel's metadata"; delete p; return nullptr;
+                }
+                n_meta++;
+            } else {
+                const int hid = (int)((r.args.size() + 7) & ~(size_t)7);
+                for (int a3 = 0; a3 < 3; a3++) { hl.block_count[a3] = hid + 4 * a3; hl.group_size[a3] = hid + 12 + 2 * a3; hl.remainder[a3] = hid + 18 + 2 * a3; }
+                hl.grid_dims = hid + 64;
+            }
+        }
+        size_t seg = k.kernarg;
+        for (int a3 = 0; a3 < 3; a3++) seg = std::max<size_t>(seg, std::max(hl.block_count[a3] + 4, std::max(hl.group_size[a3], hl.remainder[a3]) + 2));
+        seg = std::max<size_t>(seg, std::max<size_t>(hl.grid_dims + 2, r.args.size()));
         const size_t off = (blob.size() + 255) & ~(size_t)255;
         blob.resize(off + seg, 0);
         memcpy(blob.data() + off, r.args.data(), r.args.size());
         const uint32_t bc[3] = {r.grid.x, r.grid.y, r.grid.z};
         const uint16_t gs[3] = {(uint16_t)r.block.x, (uint16_t)r.block.y, (uint16_t)r.block.z};
-        const uint16_t dims = r.grid.z * r.block.z > 1 ? 3 : (r.grid.y * r.block.y > 1 ? 2 : 1);
-        memcpy(blob.data() + off + hid, bc, 12);
-        memcpy(blob.data() + off + hid + 12, gs, 6);
-        memcpy(blob.data() + off + hid + 64, &dims, 2);
+        const uint16_t dims = r.grid.z * r.block.z > 1 ? 3 : (r.grid.y * r.block.y > 1 ? 2 : 1), zero16 = 0;
+        for (int a3 = 0; a3 < 3; a3++) {
+            if (hl.block_count[a3] >= 0) memcpy(blob.data() + off + hl.block_count[a3], &bc[a3], 4);
+            if (hl.group_size[a3] >= 0) memcpy(blob.data() + off + hl.group_size[a3], &gs[a3], 2);
+            if (hl.remainder[a3] >= 0) memcpy(blob.data() + off + hl.remainder[a3], &zero16, 2);       // grids are whole multiples of the group
+        }
+        if (hl.grid_dims >= 0) memcpy(blob.data() + off + hl.grid_dims, &dims, 2);
         offs.push_back(off);
         hsa_kernel_dispatch_packet_t pk{};
         pk.setup = (uint16_t)(dims << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
@@ -253,6 +303,19 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
             *why = "hsa_queue_create"; p->dq->q = nullptr; p->dq->refs = 1; direct_destroy(p); return nullptr;
         }
         if (hsa_signal_create(DirectQueue::kStart, 0, nullptr, &p->dq->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; p->dq->refs = 1; direct_destroy(p); return nullptr; }
+        // experiment (tools/exp): run the whole list on a subset of the CUs -- "first32" = mask bits 0..31,
+        // "stride8" = every 8th bit (tools/exp/cumask_probe.hip tells which of the two is one XCD on this stack)
+        if (const char* cm = getenv("TAMD_DIRECT_CU_MASK")) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (!strcmp(cm, "first32")) mask[0] = 0xffffffffu;
+            else if (!strcmp(cm, "stride8")) for (int i = 0; i < 8; i++) mask[i] = 0x01010101u;
+            else if (!strcmp(cm, "first64")) mask[0] = mask[1] = 0xffffffffu;
+            else if (!strcmp(cm, "stride4")) for (int i = 0; i < 8; i++) mask[i] = 0x11111111u;
+            if (mask[0]) {
+                const hsa_status_t st = hsa_amd_queue_cu_set_mask(p->dq->q, 256, mask);
+                if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] direct queue CU mask %s: %s\n", cm, st == HSA_STATUS_SUCCESS ? "set" : "REFUSED");
+            }
+        }
     }
     p->dq->refs++;
     if (p->pkts.size() * 2 > p->dq->q->size) { *why = "launch list longer than the shared queue"; direct_destroy(p); return nullptr; }
@@ -273,10 +336,13 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         // already dropped every stale line; nothing it reads has been written since (or it would not be independent)
         const bool beside = i > 0 && recs[i].beside;
         n_beside += beside;
-        if (!coherent[i]) p->hdr.push_back(header(K, beside ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, !beside));
+        static const bool exp_nofence = getenv("TAMD_EXP_NOFENCE") != nullptr;        // timing experiment: bytes not trustworthy (graph.hip)
+        if (!coherent[i] && exp_nofence) p->hdr.push_back(header(K, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, !beside));
+        else if (!coherent[i]) p->hdr.push_back(header(K, beside ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, !beside));
         else p->hdr.push_back(header(K, (i > 0 && !coherent[i - 1]) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE));
     }
-    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] direct: %zu packets, %d without the barrier bit\n", p->pkts.size(), n_beside);
+    if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] direct: %zu packets, %d without the barrier bit, hidden arguments of %d from code-object metadata\n", p->pkts.size(), n_beside, n_meta);
+    p->n_meta = n_meta;
     p->h_open = header(K, HSA_FENCE_SCOPE_SYSTEM, coherent[0] ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT);
     p->h_close = header(HSA_PACKET_TYPE_BARRIER_AND, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM);
     // a pass queued right behind another pass of the same burst: when the graph found the first launch independent of the
@@ -289,6 +355,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
 }
 
 int direct_packets(const DirectProgram* p) { return p ? (int)p->pkts.size() : 0; }
+int direct_meta_packets(const DirectProgram* p) { return p ? p->n_meta : 0; }
 
 // close_burst: this pass is the last of its burst and its LAST packet closes it -- it releases at system scope and carries the
 // queue's completion signal itself, so no barrier packet follows (one packet less for the packet processor to walk: what a

@@ -433,6 +433,11 @@ static RqArgs host_rq(const RqFold& r, int cpad, std::vector<float>* mf, std::ve
     q.yhi = ok ? 128.f + (float)host_q(q.hi, r.out_scale) + 0.75f : 255.75f;
     return q;
 }
+// timing experiments only (tools/exp/xcd_local.sh): TAMD_EXP_PLAIN_KERNELS=1 plans the ordinary (non-coherent) kernel
+// instances under direct dispatch; TAMD_EXP_NOFENCE=1 strips the fences of ordinary launches AND skips the self-check -- the bytes
+// of such a graph are NOT trustworthy (stale L1 lines), only its clock is looked at
+static bool exp_plain_kernels() { const char* e = getenv("TAMD_EXP_PLAIN_KERNELS"); return e && atoi(e) == 1; }
+
 // uploads both per-channel vectors; *wscale = the fast-path multipliers, rq->m2 = the chain's factors
 static int upload_rq(tamd_graph* g, const RqFold& r, int cpad, const float** wscale, RqArgs* rq)
 {
@@ -853,7 +858,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             v.wf = d0; v.bias = d1;
             v.x = a.x; v.N = x.n; v.H = x.h; v.W = x.w; v.cs_in = x.cs; v.ktot = ckp; v.nsteps = nsteps; v.steps = steps;
             v.mode = 2; v.prod = 0; v.slices = slices; v.cw = cws;
-            v.coherent = g->opt.direct_dispatch ? 1 : 0;
+            v.coherent = (g->opt.direct_dispatch && !exp_plain_kernels()) ? 1 : 0;
             v.tile_major = (double)x.h * x.w * x.cs > (double)cout * ckp && slices <= 65535 ? 1 : 0;
             v.y = a.y; v.ldc = a.ldc; v.c_off = a.c_off; v.c_limit = a.c_limit;
             v.S = 1; v.OH = x.h; v.OW = x.w; v.TW = x.w; v.tiles_x = 1; v.RH = 1; v.RW = x.w;
@@ -1029,7 +1034,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         a.wf = d0; a.bias = d1;
     }
     a.prod = prod;
-    a.coherent = g->opt.direct_dispatch ? 1 : 0;
+    a.coherent = (g->opt.direct_dispatch && !exp_plain_kernels()) ? 1 : 0;
     // the larger operand is the one every XCD should fetch only its share of (pwdw.hip: block -> XCD mapping)
     a.tile_major = (double)x.h * x.w * (prod == 1 ? x.c : x.cs) * (slices >= 8 ? 8 : slices) > (double)C * ktot * 8.0 ? 1 : 0;
     if (slices > 65535) a.tile_major = 0;
@@ -2006,7 +2011,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
             // the packets carry hand-built argument segments (hidden arguments at the code-object-v5 offsets) and hand-picked
             // fence scopes: ONE direct pass must reproduce the eager pass byte for byte on a non-trivial input, or the graph
             // keeps its hipGraph (a different ROCm, a renamed kernel, a stale line would otherwise be silently wrong outputs)
-            if (g->direct && direct_selfcheck(g)) {
+            if (g->direct && !getenv("TAMD_EXP_NOFENCE") && direct_selfcheck(g)) {
                 fprintf(stderr, "tengine_amd: direct dispatch DISABLED for this graph: %s (hipGraph replay instead)\n", g_err);
                 direct_destroy(g->direct);
                 g->direct = nullptr;
@@ -2160,6 +2165,7 @@ int tamd_graph_launch(tamd_graph* g)
 }
 
 int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->direct ? direct_packets(g->direct) : 0; }
+int tamd_graph_direct_meta_packets(const tamd_graph* g) { return g && g->direct ? direct_meta_packets(g->direct) : 0; }
 double tamd_graph_prerun_ms(const tamd_graph* g) { return g ? g->prerun_ms : 0.0; }
 
 int tamd_graph_sync(tamd_graph* g)

@@ -77,6 +77,7 @@ int direct_wait(DirectProgram* p);          // direct_close + direct_wait_burst:
 int direct_wait_all(DirectProgram* p);      // .. and every burst closed earlier without a wait (asynchronous runs)
 const char* direct_last_error();            // what the last -1 of this thread was about
 int direct_packets(const DirectProgram* p);
+int direct_meta_packets(const DirectProgram* p);      // of those, how many took their hidden-argument offsets from code-object metadata
 void direct_destroy(DirectProgram* p);
 
 }  // namespace tamd

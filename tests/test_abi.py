@@ -175,6 +175,57 @@ def test_launch_recorder_packs_arguments_like_the_code_object(tmp_path):
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
 
 
+def test_hidden_argument_offsets_are_read_from_code_object_metadata(tmp_path):
+    """Direct dispatch places the hidden arguments (block counts, group sizes, grid dimensionality) where the kernel's own
+    NT_AMDGPU_METADATA note lists them (tengine_amd/csrc/codeobj_meta.h: ELF note walk + MessagePack reader).
+    Checked on the host: hipcc compiles two kernels for gfx950, the parser's offsets must be the ones `llvm-readelf --notes`
+    prints, and truncated objects are refused without reading out of bounds (the check is built with the address sanitizer)."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)) or not os.path.exists(readelf) or not shutil.which("g++"):
+        pytest.skip("hipcc / llvm-readelf / g++ not available")
+    src = tmp_path / "k.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n"
+                   "struct A { const float* x; float* y; int n; short s; };\n"
+                   "__global__ void k1(A a) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < a.n) a.y[i] = a.x[i] * a.s; }\n"
+                   "__global__ void k2(const int* p, int* q, int n, float f, double d, char c) { int i = blockIdx.y * gridDim.x * blockDim.x + blockIdx.x * blockDim.x"
+                   " + threadIdx.x; if (i < n) q[i] = p[i] + (int)f + (int)d + c; }\n")
+    co = str(tmp_path / "k.co")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "--cuda-device-only", "--no-gpu-bundle-output", "-c", str(src), "-o", co],
+                          stderr=subprocess.DEVNULL)
+    exe = str(tmp_path / "codeobj_meta_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fsanitize=address,undefined", os.path.join(ROOT, "tests", "csrc", "codeobj_meta_test.cc"), "-o", exe])
+    out = subprocess.run([exe, co], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        w = line.split()
+        got[w[0]] = {w[i]: [int(v) for v in w[i + 1:i + (4 if w[i] in ("block_count", "group_size", "remainder") else 2)]] for i in range(1, len(w)) if not w[i].lstrip("-").isdigit()}
+    notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True).stdout
+    # the note, kernel by kernel: offsets by value_kind
+    want, cur, off = {}, None, None
+    for line in notes.splitlines():
+        t = line.strip()
+        if t.startswith("- .offset:") or t.startswith(".offset:"):
+            off = int(t.split()[-1])
+        elif t.startswith(".value_kind:"):
+            cur = cur if cur is not None else {}
+            cur.setdefault(t.split()[-1], []).append(off)
+        elif t.startswith(".symbol:"):
+            want[t.split()[-1]] = cur or {}
+            cur = None
+    assert len(got) == 2 and set(got) == set(want), (got.keys(), want.keys())
+    for sym, g_ in got.items():
+        w_ = want[sym]
+        assert g_["block_count"] == [w_["hidden_block_count_" + a][0] for a in "xyz"]
+        assert g_["group_size"] == [w_["hidden_group_size_" + a][0] for a in "xyz"]
+        assert g_["remainder"] == [w_["hidden_remainder_" + a][0] for a in "xyz"]
+        assert g_["grid_dims"] == w_["hidden_grid_dims"]
+        assert g_["unknown_pointer"] == [0]
+
+
 def test_dependency_test_of_the_barrier_free_launches(tmp_path):
     """which launch may run beside which (tengine_amd/csrc/graph.h: access_of / access_overlap / step_conflict -- NCHW tensors,
     uint8 concat slices, int8 NHWC channel views, concat slots; RAW / WAR / WAW): checked on the host, no device involved
@@ -199,4 +250,4 @@ def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
     body = hdr[hdr.index("typedef struct tamd_options {"):hdr.index("} tamd_options;")]
     fields = re.findall(r"^\s+(?:const\s+)?\w+\*?\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in capi.Options._fields_], (fields, capi.Options._fields_)
-    assert fields[-2:] == ["direct_dispatch", "keep_tensors"] and ctypes.sizeof(capi.Options) == 32
+    assert fields[-3:] == ["direct_dispatch", "keep_tensors", "u8_integer"] and ctypes.sizeof(capi.Options) == 40

@@ -33,6 +33,8 @@ def test_direct_dispatch_same_bytes_as_graph_replay(name, dtype, batch):
     ref.close()
     gr = capi.Graph(b, direct_dispatch=True)
     assert gr.direct_packets() >= gr.kernel_num() > 0, "direct dispatch did not take effect"
+    # every packet's hidden arguments sit where the kernel's own code-object metadata says (csrc/codeobj_meta.h), not at assumed offsets
+    assert gr.direct_meta_packets() == gr.direct_packets(), (gr.direct_meta_packets(), gr.direct_packets())
     got = _resident(gr, x, 3)
     for w, o in zip(want, got):
         assert np.array_equal(w, o)
