@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--model", default="mobilenet_v1")
     ap.add_argument("--dtype", default="int8", choices=["int8", "uint8"],
                     help="int8 = BASELINE metric; uint8 = the fp32-simulated configs (yolov3_tiny ...), side lines only")
+    ap.add_argument("--u8-integer", action="store_true",
+                    help="uint8 models on the opt-in integer path (tamd_options.u8_integer: exact int32 sums on the int8 MFMA, results within "
+                         "one quantisation step of the reference per layer instead of byte-identical); a side line, never the default")
     ap.add_argument("--streams", type=int, default=1, help="concurrent batch-1 graph instances (1 = sequential, tm_benchmark semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path with world_size 1 (test)")
@@ -76,6 +79,10 @@ def main():
                          "--gather every needs the stream order and always uses 0")
     ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args()
+    if args.u8_integer:
+        if args.dtype != "uint8":
+            raise SystemExit("bench.py: --u8-integer is a mode of the uint8 models")
+        os.environ["TAMD_U8_INT"] = "1"          # every graph of this job (and of the ranks it spawns)
 
     # `python bench.py --gpus N` run plainly: start the N ranks ourselves (one process per GPU) -- or fail
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -326,7 +333,7 @@ def main():
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
         t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
-        mfma_peak = MFMA_F32_PEAK_TOPS if u8 else MFMA_I8_PEAK_TOPS
+        mfma_peak = MFMA_F32_PEAK_TOPS if (u8 and not args.u8_integer) else MFMA_I8_PEAK_TOPS
         t_mfma = 2.0 * d["macs"] / (mfma_peak * 1e12)
         if t_hbm >= t_mfma:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
@@ -387,9 +394,10 @@ def main():
         value = total_images * args.steps / el
         line = {
             "metric": "images/sec int8 MobileNet-v1 224x224" if (args.model, args.dtype) == ("mobilenet_v1", "int8")
-            else "images/sec %s %s" % (args.dtype, args.model), "value": value, "unit": "images/s", "n_gpus": world,
+            else "images/sec %s %s%s" % (args.dtype, args.model, " (integer path, <= 1 LSB per layer)" if args.u8_integer else ""), "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32 (uint8 simulated in fp32, as the reference)" if u8 else "int8",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": ("int8 MFMA, int32 sums (uint8 integer path: within one step of the reference per layer, NOT byte-identical)" if args.u8_integer
+                                                                                else "f32 (uint8 simulated in fp32, as the reference)") if u8 else "int8",
             "data": "synthetic",
             "config": {"workload": "%s %s batch=%d per GPU%s, weights = seeded synthetic tmfile, input resident in HBM, "
                                    "%s, %d stream(s)" % (args.model, args.dtype, args.batch,

@@ -176,6 +176,26 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         // 512 pixels) fall through to the byte-exact family, whose bytes are inside the bar by definition.
         // (first layers -- 3 or 4 input channels against the kernel's 32-channel K step -- stay on conv_u8_rgb3x3 / the staging GEMM)
         const char* imc = getenv("TAMD_U8_INT_MIN_C");
+        if (g->opt.u8_integer && x.c <= 4 && !(getenv("TAMD_U8I_RGB") && atoi(getenv("TAMD_U8I_RGB")) == 0)) {
+            a.i_alpha = qx.zp - 128; a.i_beta = qw.zp - 128;
+            if (conv_u8i_rgb_applicable(a, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) {
+                conv_u8i_rgb_prepare(a);
+                std::vector<int8_t> wp(conv_u8i_rgb_packed_bytes(a));
+                std::vector<int32_t> cv((size_t)rup(cout, 16) + 4);
+                conv_u8i_rgb_pack(a, w.data.data(), qw.zp, qx.zp, b ? (const int32_t*)b->data.data() : nullptr, wp.data(), cv.data());
+                int8_t* dw = nullptr; int32_t* dc = nullptr;
+                if (upload(g, wp, &dw) || upload(g, cv, &dc)) return -1;
+                a.iw = dw; a.icv = dc;
+                st.rd.push_back(access_of(x));
+                st.wr.push_back(access_of(y));
+                if (pool) st.wr.push_back(access_of(g->tensors[pool->out[0]]));
+                st.deps = true;
+                st.kernel = std::string("conv_u8i_rgb3x3") + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+                st.fn = [a](hipStream_t s) { return launch_conv_u8i_rgb(a, s); };
+                g->steps.push_back(st);
+                return 0;
+            }
+        }
         if (g->opt.u8_integer && x.c >= (imc ? atoi(imc) : 8)) {
             a.i_alpha = qx.zp - 128; a.i_beta = qw.zp - 128;
             std::vector<int> cands;

@@ -282,6 +282,7 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     const int32_t* icv;        // per output channel: bias - alpha * sum_k w'_k + Kp * alpha * beta, padded to the cout tile
     int i_cfg, i_npad, i_nchunks;      // tile configuration / pixels per patch granule plane (128 | 256 | 512) / 32-channel chunks
     int i_cgs;                 // log2 of the 32-channel groups a chunk (= one barrier) holds: 0 | 1 | 2
+    int i_dbg;                 // anatomy runs only (TAMD_U8I_ABLATE): 1 no stores, 2 no requantisation, 4 no input loads -- wrong bytes by design
     int i_tw;                  // 0: linear pixel tiles; 8 | 16: 2-D tiles of this width (maps too wide for a linear tile's bounding box)
     int i_alpha, i_beta;       // in_zp - 128, w_zp - 128
 };
@@ -373,6 +374,12 @@ size_t conv_u8i_packed_bytes(const U8ConvArgs& a);
 void conv_u8i_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec);    // w: [cout][K] as in the model
 const char* conv_u8i_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8i(const U8ConvArgs& a, hipStream_t s);
+// first layers of the integer path (3x3, <= 4 input channels): the whole K in one v_mfma_i32_16x16x64_i8
+bool conv_u8i_rgb_applicable(const U8ConvArgs& a, int KH, int KW, int DH, int DW);
+void conv_u8i_rgb_prepare(U8ConvArgs& a);          // fills i_npad (patch pixels of a full 16x16 window)
+size_t conv_u8i_rgb_packed_bytes(const U8ConvArgs& a);
+void conv_u8i_rgb_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec);
+hipError_t launch_conv_u8i_rgb(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);

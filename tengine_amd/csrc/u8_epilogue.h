@@ -34,6 +34,22 @@ __device__ __forceinline__ uint8_t quant_round_sat_u8(float s, float out_scale, 
     return sat_u8(r + zp);
 }
 
+// The same function with the reciprocal handed in (one division per kernel, not per call site) and the rare hand-over to the
+// reference expression behind a WAVE-level test: the ~2.4e-4 of the values that need the IEEE division no longer make every lane
+// of every wave pay for it (left to the compiler the two-sided `if` is if-converted: the division runs always, predicated).
+// Identical results: the same y, the same test, the same fallback.
+__device__ __forceinline__ uint8_t quant_round_sat_u8_w(float s, float out_scale, float inv, int zp)
+{
+    const float y = __fmaf_rn(s, inv, copysignf(0.5f + 0x1p-13f, s));
+    const float ay = fabsf(y);
+    int r = (int)fminf(fmaxf(y, -65536.f), 65536.f);                                 // truncates
+    const bool rare = (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f) || (unsigned)zp > 255u;
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+        if (rare) r = (int)fminf(fmaxf(roundf(__fdiv_rn(s, out_scale)), -65536.f), 65536.f);
+    }
+    return sat_u8(r + zp);
+}
+
 // round(f / out_scale + zp), clamp -- relu_kernel_ref_uint8.c:83-89, upsample_ref.c:118-125 (zero point INSIDE the round)
 __device__ __forceinline__ uint8_t quant_round_in_exact(float f, U8Q q)
 {

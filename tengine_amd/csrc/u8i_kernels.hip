@@ -116,6 +116,13 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
     const int P = rows * Wp4;                                // <= NPAD (the launcher checked the worst tile)
     const int NPAD = a.i_npad;                               // pixels per granule plane
     const unsigned padw = (unsigned)(a.i_alpha & 0xff) * 0x01010101u;
+    // the fused ReLU node and the fused pool node are functions of ONE byte (u8_epilogue.h: fused_relu of the conv's own byte,
+    // pooled_byte of the window maximum): tabulated once per block (thread t: entry t), looked up per output -- the same bytes as
+    // evaluating them per output, at a thirtieth of the arithmetic
+    uint8_t* lut = smem + 2 * (2 << a.i_cgs) * NPAD * 16;        // [256] fused ReLU, [256] pooled byte
+    lut[t] = a.relu.on ? fused_relu((uint8_t)t, a.out_scale, a.out_zp, a.relu) : (uint8_t)t;
+    if (a.pool.on) lut[256 + t] = pooled_byte(t, a.pool);
+    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
 
     // A chunk = CG groups of 32 channels (CG = 1 | 2 | 4: small patches take more channels per barrier; 1x1 layers would otherwise
     // see a barrier per MFMA step).  Staging units: (channel quad cq of the chunk, patch pixel quad q); surplus threads repeat
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
 #pragma unroll
             for (int c4 = 0; c4 < 4; c4++) {
                 const int c = min(cc * (32 * CG) + cq4[i] + c4, a.C - 1);      // padded channels re-read the last one: they meet w' = beta
-                __builtin_memcpy(&sv[i][c4], xin + (size_t)c * HW + goff[i], 4);
+                if (a.i_dbg & 4) sv[i][c4] = 0x01020304u * (unsigned)(c + 1);   // anatomy runs only (TAMD_U8I_ABLATE): no input loads
+                else __builtin_memcpy(&sv[i][c4], xin + (size_t)c * HW + goff[i], 4);
             }
     };
     auto stage_store = [&](int buf) {
@@ -285,16 +293,175 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
                     float s = (float)(acc[i][jn][4 * g4 + e] - corr + cvs[e]) * a.bias_scale;
                     if (a.act == 0) s = s < 0.f ? 0.f : s;
                     if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-                    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                    uint8_t q;
+                    if (a.i_dbg & 2) q = (uint8_t)(acc[i][jn][4 * g4 + e] + cvs[e]);   // anatomy: no requantisation arithmetic
+                    else q = lut[quant_round_sat_u8_w(s, a.out_scale, inv_out, a.out_zp)];
+                    if ((a.i_dbg & 1) && q != 77) continue;                             // anatomy: (almost) no stores
                     if (live && (!a.pool.on || a.pool.write_full)) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
                     if (a.pool.on) {             // OH, OW even under a fused pool: a window's four pixels are four neighbouring lanes, live together
                         const int m = quad_max((int)q);
-                        if (live && (l31 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = pooled_byte(m, a.pool);
+                        if (live && (l31 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = lut[256 + m];
                     }
                 }
             }
     }
+}
+
+// =================================================================================================================
+// First layers (3x3, at most 4 input channels: YOLOv3-tiny / MobileNet / MobileNet-SSD conv0) on the same arithmetic.  The
+// 32-channel K step of conv_u8i_k would be nine tenths padding here; instead the whole K = 9 taps x 4 channel slots is ONE
+// v_mfma_i32_16x16x64_i8: k = tap * 4 + channel, lane (pixel l15, quarter q) supplies taps 4q .. 4q+3 (taps >= 9 and the 4th
+// channel slot are zero bytes on both operands).  The block's 16x16 output window keeps its input patch in LDS pixel-major, 4 bytes
+// per pixel {c0, c1, c2, 0} (staged from the three NCHW planes with dword loads + one 4x4 byte transpose), so a lane's 16-byte B
+// fragment is four ds_read_b32 at pp0 + tap offset -- no im2col, no per-byte gathers.  Weights: one 16-row fragment per 16 output
+// channels, in registers for the whole block.  Epilogue as conv_u8i_k (column sums over the REAL k only: the zero slots add
+// nothing to either side of the expansion).
+// =================================================================================================================
+template <int RT>
+__global__ __launch_bounds__(256) void conv_u8i_rgb_k(const U8ConvArgs a)
+{
+    constexpr int TH = 16, TW = 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, q = lane >> 4, wave = t >> 6;
+    const int OHW = a.OH * a.OW, HW = a.H * a.W;
+    const int tiles_x = (a.OW + TW - 1) / TW, tiles = tiles_x * ((a.OH + TH - 1) / TH);
+    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles;
+    const int oyb = (tile / tiles_x) * TH, oxb = (tile - (tile / tiles_x) * tiles_x) * TW;
+    const int oy1 = min(oyb + TH, a.OH) - 1, ox1 = min(oxb + TW, a.OW) - 1;
+    const int RY0 = oyb * a.SH - a.PH, XA = oxb * a.SW - a.PW;
+    const int Wp4 = ((ox1 - oxb) * a.SW + 3 + 3) & ~3, W4q = Wp4 >> 2, rows = (oy1 - oyb) * a.SH + 3;
+    const unsigned padw = (unsigned)(a.i_alpha & 0xff) * 0x01010101u;
+    const uint8_t* xin = a.x + (size_t)n * a.C * HW;
+    uint8_t* lut = smem + a.i_npad * 4;                         // byte tables of the fused ReLU / pool nodes (see conv_u8i_k), behind the patch
+    lut[t] = a.relu.on ? fused_relu((uint8_t)t, a.out_scale, a.out_zp, a.relu) : (uint8_t)t;
+    if (a.pool.on) lut[256 + t] = pooled_byte(t, a.pool);
+    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
+
+    // ---- weights of this block's output channels: RT fragments of 16 rows, lane (row l15, quarter q) ------------------------------
+    v4i_q af[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) af[r] = *reinterpret_cast<const v4i_q*>(a.iw + (size_t)r * 1024 + lane * 16);
+
+    // ---- stage the patch: unit = 4 consecutive patch columns of one row, all channels ------------------------------------------------
+    for (int u = t; u < rows * W4q; u += 256) {
+        const int r = u / W4q, xq = u - r * W4q;
+        const int iy = RY0 + r, ix0 = XA + 4 * xq;
+        const bool rowok = (unsigned)iy < (unsigned)a.H;
+        const int ixc = min(max(ix0, 0), a.W - 4);
+        unsigned sl = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = ix0 + j;
+            sl |= (unsigned)((rowok && (unsigned)col < (unsigned)a.W) ? col - ixc : 4) << (8 * j);
+        }
+        const int goff = rowok ? iy * a.W + ixc : 0;
+        unsigned d[4], x[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            d[c] = 0u;                                                 // the 4th (and any missing) channel slot: zero bytes
+            if (c < a.C) {
+                unsigned v;
+                __builtin_memcpy(&v, xin + (size_t)c * HW + goff, 4);
+                d[c] = __builtin_amdgcn_perm(padw, v ^ 0x80808080u, sl);
+            }
+        }
+        transpose4x4(d, x);
+        *reinterpret_cast<uint4*>(smem + (size_t)(r * Wp4 + 4 * xq) * 4) = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    __syncthreads();
+
+    // ---- per column tile of 16 pixels: fragment = taps 4q .. 4q+3 of the lane's pixel ------------------------------------------------
+    int toff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int tp = 4 * q + i; toff[i] = tp < 9 ? ((tp / 3) * Wp4 + tp % 3) * 4 : -1; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+        const int jloc = wave * 64 + ct * 16 + l15;
+        int dy, dx;
+        if (a.pool.on) { const int w = jloc >> 2, wy = w >> 3, wx = w & 7; dy = 2 * wy + ((jloc >> 1) & 1); dx = 2 * wx + (jloc & 1); }
+        else { dy = jloc >> 4; dx = jloc & 15; }
+        const bool live = oyb + dy <= oy1 && oxb + dx <= ox1;
+        const int oy = min(oyb + dy, oy1), ox = min(oxb + dx, ox1);
+        const int pp0 = ((oy - oyb) * a.SH * Wp4 + (ox - oxb) * a.SW) * 4;
+        v4i_q bf;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(smem + pp0 + (toff[i] < 0 ? 0 : toff[i]));
+            bf[i] = toff[i] < 0 ? 0 : (int)v;
+        }
+        int cs = 0;
+        if (a.i_beta != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cs = __builtin_amdgcn_sdot4(bf[i], 0x01010101, cs, false);
+            cs += __shfl_xor(cs, 16);
+            cs += __shfl_xor(cs, 32);
+        }
+        const int corr = a.i_beta * cs;
+        const int opix = oy * a.OW + ox, ppix = (oy >> 1) * (a.OW >> 1) + (ox >> 1);
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            v4i_q acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[r], bf, acc, 0, 0, 0);
+            const int cb = r * 16 + 4 * q;                               // D: col = l15 (pixel), rows 4q .. 4q+3 (channels)
+            const int4 cv = *reinterpret_cast<const int4*>(a.icv + cb);
+            const int cvs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int co = cb + e;
+                if (co >= a.cout) continue;
+                float sv = (float)(acc[e] - corr + cvs[e]) * a.bias_scale;
+                if (a.act == 0) sv = sv < 0.f ? 0.f : sv;
+                if (a.act > 0) { sv = sv < 0.f ? 0.f : sv; sv = sv > 6.f ? 6.f : sv; }
+                const uint8_t qv = lut[quant_round_sat_u8_w(sv, a.out_scale, inv_out, a.out_zp)];
+                if (live && (!a.pool.on || a.pool.write_full)) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = qv;
+                if (a.pool.on) {
+                    const int m = quad_max((int)qv);
+                    if (live && (l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = lut[256 + m];
+                }
+            }
+        }
+    }
+}
+
+bool conv_u8i_rgb_applicable(const U8ConvArgs& a, int KH, int KW, int DH, int DW)
+{
+    if (a.C < 1 || a.C > 4 || KH != 3 || KW != 3 || DH != 1 || DW != 1 || a.cout > 64 || a.W < 4) return false;
+    if (a.pool.on && (((a.OH | a.OW) & 1) || (a.OH * a.OW) % 8 != 0)) return false;
+    if (a.SH < 1 || a.SW < 1 || a.SH > 2 || a.SW > 2) return false;      // patch of a 16x16 window: at most 33 x 36 pixels
+    return true;
+}
+void conv_u8i_rgb_prepare(U8ConvArgs& a) { a.i_npad = (15 * a.SH + 3) * ((15 * a.SW + 3 + 3) & ~3); }      // patch pixels of a full window
+size_t conv_u8i_rgb_packed_bytes(const U8ConvArgs& a) { return (size_t)((a.cout + 15) / 16) * 1024; }
+// fragment r: lane (row l15, quarter q), byte i*4 + c = w'[16r + l15][c][tap 4q + i] (zero outside the real taps / channels);
+// cvec[co] = bias - alpha * sum_real w' + 9 * C * alpha * beta
+void conv_u8i_rgb_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec)
+{
+    const int rt = (a.cout + 15) / 16, alpha = in_zp - 128, beta = w_zp - 128;
+    std::fill(out, out + conv_u8i_rgb_packed_bytes(a), (int8_t)0);
+    for (int co = 0; co < rt * 16; co++) {
+        long w1 = 0;
+        if (co < a.cout)
+            for (int c = 0; c < a.C; c++)
+                for (int tp = 0; tp < 9; tp++) {
+                    const int8_t v = (int8_t)(uint8_t)(w[((size_t)co * a.C + c) * 9 + tp] ^ 0x80);
+                    out[(size_t)(co / 16) * 1024 + ((tp / 4) * 16 + (co & 15)) * 16 + (tp % 4) * 4 + c] = v;
+                    w1 += v;
+                }
+        cvec[co] = (int32_t)((co < a.cout && bias ? (long)bias[co] : 0L) - (long)alpha * w1 + (long)9 * a.C * alpha * beta);
+    }
+}
+hipError_t launch_conv_u8i_rgb(const U8ConvArgs& a, hipStream_t s)
+{
+    const int tiles = ((a.OW + 15) / 16) * ((a.OH + 15) / 16);
+    const size_t lds = (size_t)a.i_npad * 4 + 512;                 // the patch of a full 16x16 window + the two byte tables
+    const dim3 grid(tiles * a.N);
+    switch ((a.cout + 15) / 16) {
+    case 1: hipLaunchKernelGGL(conv_u8i_rgb_k<1>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(conv_u8i_rgb_k<2>, grid, dim3(256), lds, s, a); break;
+    case 3: hipLaunchKernelGGL(conv_u8i_rgb_k<3>, grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL(conv_u8i_rgb_k<4>, grid, dim3(256), lds, s, a); break;
+    }
+    return hipGetLastError();
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -344,10 +511,14 @@ bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
     }
     a.i_npad = worst <= 128 ? 128 : worst <= 256 ? 256 : 512;
     a.i_nchunks = (a.C + 31) / 32;                                                   // 32-channel groups
+    a.i_dbg = getenv("TAMD_U8I_ABLATE") ? atoi(getenv("TAMD_U8I_ABLATE")) : 0;       // anatomy runs (tools/exp): wrong bytes by design
     // groups per chunk (1 | 2 | 4): as many as the staging budget (4 units per thread = 512 patch pixels x groups) and the layer hold
+    // (default ONE: measured faster than 2 / 4 on both uint8 configs -- the larger staging burst stalls the MFMAs longer than the
+    // saved barriers cost; TAMD_U8I_CG=2|4 asks for more where the budget allows, tests run them)
+    int cg_max = 0;
+    while (cg_max < 2 && (2 << cg_max) * a.i_npad <= 512 && (2 << cg_max) <= a.i_nchunks) cg_max++;
     a.i_cgs = 0;
-    while (a.i_cgs < 2 && (2 << a.i_cgs) * a.i_npad <= 512 && (2 << a.i_cgs) <= a.i_nchunks) a.i_cgs++;
-    if (const char* cg = getenv("TAMD_U8I_CG")) a.i_cgs = std::min(a.i_cgs, atoi(cg) >= 4 ? 2 : atoi(cg) >= 2 ? 1 : 0);
+    if (const char* cg = getenv("TAMD_U8I_CG")) a.i_cgs = std::min(cg_max, atoi(cg) >= 4 ? 2 : atoi(cg) >= 2 ? 1 : 0);
     a.i_cfg = cfg;
     return true;
 }
@@ -386,7 +557,7 @@ hipError_t launch_conv_u8i(const U8ConvArgs& a, hipStream_t s)
     const int bm = conv_u8i_bm(a.i_cfg), bn = u8i_bn(a.i_cfg), OHW = a.OH * a.OW;
     const int tiles = a.i_tw ? ((a.OW + a.i_tw - 1) / a.i_tw) * ((a.OH + bn / a.i_tw - 1) / (bn / a.i_tw)) : (OHW + bn - 1) / bn;
     const dim3 grid(tiles * a.N, (a.cout + bm - 1) / bm, 1);
-    const size_t lds = (size_t)2 * (2 << a.i_cgs) * a.i_npad * 16;
+    const size_t lds = (size_t)2 * (2 << a.i_cgs) * a.i_npad * 16 + 512;          // two patch buffers + the two byte tables
     const int units = (a.i_npad << a.i_cgs) / 128;                                  // staging units per thread: 1 | 2 | 4
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
