@@ -159,6 +159,13 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         a.in_scale = qx.scale; a.in_zp = (float)qx.zp;
         a.bias_scale = qx.scale * qw.scale;           // conv_kernel_x86.c:1723
         a.act = p.activation; a.out_scale = qy.scale; a.out_zp = qy.zp; a.relu = fr;
+        {   // the integer path's requantisation constants (u8_epilogue.h: u8i_requant), binary32 like everything around them
+            const float bs = qx.scale * qw.scale;
+            a.i_m = bs / qy.scale;
+            a.i_qlo = 0; a.i_qhi = 255;
+            if (p.activation >= 0) a.i_qlo = std::min(std::max(qy.zp, 0), 255);
+            if (p.activation > 0) a.i_qhi = std::min(255, std::max(a.i_qlo, (int)roundf(6.0f / qy.scale) + qy.zp));
+        }
         if (pool) {
             HTensor& yp = g->tensors[pool->out[0]];
             a.pool.on = 1;
@@ -198,26 +205,40 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         if (g->opt.u8_integer && x.c >= (imc ? atoi(imc) : 8)) {
             a.i_alpha = qx.zp - 128; a.i_beta = qw.zp - 128;
+            // candidates: the general kernel's tile shapes (ids 0..5) and, for 1x1 / stride 1 / unpadded layers, the register-only
+            // pointwise kernel's (ids 6..11).  Every one computes the same bytes (exact integer sums, one epilogue)
+            const int NG = conv_u8i_num_cfgs(), NP = conv_u8i_pw_num_cfgs();
+            auto iprepare = [&](U8ConvArgs& ac, int c) -> bool {
+                return c < NG ? conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w) : conv_u8i_pw_prepare(ac, c - NG, p.kernel_h, p.kernel_w);
+            };
+            const char* pwe = getenv("TAMD_U8I_PW");                   // 0: never the pointwise kernel (tests), 1: only it where it applies
             std::vector<int> cands;
-            for (int c = 0; c < conv_u8i_num_cfgs(); c++) {
+            for (int c = 0; c < NG + NP; c++) {
+                if (c >= NG && pwe && atoi(pwe) == 0) continue;
                 U8ConvArgs ac = a;
-                if (conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) cands.push_back(c);
+                if (iprepare(ac, c)) cands.push_back(c);
+            }
+            if (pwe && atoi(pwe) == 1) {
+                std::vector<int> only;
+                for (int c : cands) if (c >= NG) only.push_back(c);
+                if (!only.empty()) cands.swap(only);
             }
             const char* ic = getenv("TAMD_U8I_CFG");                 // tests / fuzzing: pin one tile shape where it applies
             if (ic && *ic) {
-                const int want = atoi(ic) % conv_u8i_num_cfgs();
+                const int want = atoi(ic) % (NG + NP);
                 if (std::find(cands.begin(), cands.end(), want) != cands.end()) cands.assign(1, want);
             }
             if (!cands.empty()) {
                 std::map<int, std::pair<int8_t*, int32_t*>> ipacked;      // cout tile height -> packed weights + per-channel constants
+                auto bm_of = [&](int c) { return c < NG ? conv_u8i_bm(c) : conv_u8i_pw_bm(c - NG); };
                 auto iready = [&](U8ConvArgs& ac, int c) -> int {
-                    if (!conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) return -1;
-                    const int bm = conv_u8i_bm(c);
+                    if (!iprepare(ac, c)) return -1;
+                    const int bm = bm_of(c);
                     auto it = ipacked.find(bm);
                     if (it == ipacked.end()) {
-                        std::vector<int8_t> wp(conv_u8i_packed_bytes(ac));
+                        std::vector<int8_t> wp(conv_u8i_packed_bytes(ac, bm));
                         std::vector<int32_t> cv((size_t)rup(cout, bm) + 4);
-                        conv_u8i_pack(ac, w.data.data(), qw.zp, qx.zp, b ? (const int32_t*)b->data.data() : nullptr, wp.data(), cv.data());
+                        conv_u8i_pack(ac, bm, w.data.data(), qw.zp, qx.zp, b ? (const int32_t*)b->data.data() : nullptr, wp.data(), cv.data());
                         int8_t* dw = nullptr; int32_t* dc = nullptr;
                         if (upload(g, wp, &dw) || upload(g, cv, &dc)) return -1;
                         it = ipacked.emplace(bm, std::make_pair(dw, dc)).first;
@@ -225,18 +246,20 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                     ac.iw = it->second.first; ac.icv = it->second.second;
                     return 0;
                 };
+                auto ilaunch = [NG](const U8ConvArgs& ac, int c, hipStream_t s) { return c < NG ? launch_conv_u8i(ac, s) : launch_conv_u8i_pw(ac, s); };
+                auto iname = [NG](const U8ConvArgs& ac, int c) { return c < NG ? conv_u8i_kernel_name(ac) : conv_u8i_pw_kernel_name(ac); };
                 // geometry heuristic: the largest tile that still gives every CU a block; the plan-time timing then decides
                 auto blocks_of = [&](int c) {
                     U8ConvArgs ac = a;
-                    conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w);
+                    iprepare(ac, c);
                     static const int bns[] = {64, 64, 128, 128, 128, 256};
-                    const int bm = conv_u8i_bm(c), bn = bns[c];
+                    const int bm = bm_of(c), bn = c < NG ? bns[c] : conv_u8i_pw_bn(c - NG);
                     const long tiles = ac.i_tw ? (long)((y.w + ac.i_tw - 1) / ac.i_tw) * ((y.h + bn / ac.i_tw - 1) / (bn / ac.i_tw)) : (y.h * y.w + bn - 1) / bn;
                     return tiles * x.n * ((cout + bm - 1) / bm);
                 };
                 int pick = cands[0];
                 {
-                    static const int pref[] = {3, 1, 2, 0, 5, 4};
+                    static const int pref[] = {6, 7, 9, 8, 10, 11, 3, 1, 2, 0, 5, 4};
                     long most = -1;
                     bool done = false;
                     for (int c : pref) {
@@ -267,7 +290,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                     for (int c : order) {
                         U8ConvArgs ac = a;
                         if (iready(ac, c)) return -1;
-                        auto launch = [&]() { return launch_conv_u8i(ac, g->stream); };
+                        auto launch = [&]() { return ilaunch(ac, c, g->stream); };
                         float ms = 1e30f;
                         if (launch() != hipSuccess) { (void)hipGetLastError(); continue; }
                         if (flush) { if (time_cold(g, flush, launch, &ms)) return -1; }
@@ -280,7 +303,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                             HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                             ms /= reps;
                         }
-                        if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us\n", n.name.c_str(), conv_u8i_kernel_name(ac), 1e3 * ms);
+                        if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us\n", n.name.c_str(), iname(ac, c), 1e3 * ms);
                         if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; pick = c; }
                     }
                     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -291,8 +314,9 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 st.wr.push_back(access_of(y));
                 if (pool) st.wr.push_back(access_of(g->tensors[pool->out[0]]));
                 st.deps = true;
-                st.kernel = std::string(conv_u8i_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
-                st.fn = [a](hipStream_t s) { return launch_conv_u8i(a, s); };
+                st.kernel = std::string(iname(a, pick)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+                const int picked = pick;
+                st.fn = [a, picked, ilaunch](hipStream_t s) { return ilaunch(a, picked, s); };
                 g->steps.push_back(st);
                 return 0;
             }

@@ -285,6 +285,8 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int i_dbg;                 // anatomy runs only (TAMD_U8I_ABLATE): 1 no stores, 2 no requantisation, 4 no input loads -- wrong bytes by design
     int i_tw;                  // 0: linear pixel tiles; 8 | 16: 2-D tiles of this width (maps too wide for a linear tile's bounding box)
     int i_alpha, i_beta;       // in_zp - 128, w_zp - 128
+    float i_m;                 // requantisation multiplier fl(fl(in_scale * w_scale) / out_scale) (u8_epilogue.h: u8i_requant)
+    int i_qlo, i_qhi;          // clamp window of the result: [0, 255] narrowed by the conv's own activation
 };
 
 struct U8DirectArgs {          // grouped / depthwise: conv_kernel_ref_uint8.c order (conv_u8_direct), also FC
@@ -370,8 +372,15 @@ hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s);
 int conv_u8i_num_cfgs();
 int conv_u8i_bm(int cfg);
 bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW);          // fills i_cfg / i_npad / i_nchunks / pk_k*; false: not applicable
-size_t conv_u8i_packed_bytes(const U8ConvArgs& a);
-void conv_u8i_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec);    // w: [cout][K] as in the model
+size_t conv_u8i_packed_bytes(const U8ConvArgs& a, int bm);                          // bm: channel rows of a block tile (conv_u8i_bm / conv_u8i_pw_bm)
+void conv_u8i_pack(const U8ConvArgs& a, int bm, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec);    // w: [cout][K] as in the model
+// pointwise layers (1x1, stride 1, no padding): register-only transposes, no LDS, dword stores
+int conv_u8i_pw_num_cfgs();
+int conv_u8i_pw_bm(int cfg);
+int conv_u8i_pw_bn(int cfg);
+bool conv_u8i_pw_prepare(U8ConvArgs& a, int cfg, int KH, int KW);
+const char* conv_u8i_pw_kernel_name(const U8ConvArgs& a);
+hipError_t launch_conv_u8i_pw(const U8ConvArgs& a, hipStream_t s);
 const char* conv_u8i_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8i(const U8ConvArgs& a, hipStream_t s);
 // first layers of the integer path (3x3, <= 4 input channels): the whole K in one v_mfma_i32_16x16x64_i8

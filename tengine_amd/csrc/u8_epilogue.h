@@ -50,6 +50,46 @@ __device__ __forceinline__ uint8_t quant_round_sat_u8_w(float s, float out_scale
     return sat_u8(r + zp);
 }
 
+// Four values at once (one channel's four pixels / four channels of a pixel): four independent chains the scheduler can interleave, ONE
+// wave-level test for the group, and a hand-over that simply evaluates the reference expression for all four (it is the definition;
+// the fast form equals it wherever the test does not fire).  A group of 256 values takes it with probability ~6 %.
+__device__ __forceinline__ void quant_round_sat_u8_w4(const float (&s)[4], float out_scale, float inv, int zp, int (&q)[4])
+{
+    bool rare = (unsigned)zp > 255u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float y = __fmaf_rn(s[k], inv, copysignf(0.5f + 0x1p-13f, s[k]));
+        const float ay = fabsf(y);
+        q[k] = (int)fminf(fmaxf(y, -65536.f), 65536.f);
+        rare = rare || (__builtin_amdgcn_fractf(ay) < 0x1p-12f && ay < 300.5f);
+    }
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = (int)fminf(fmaxf(roundf(__fdiv_rn(s[k], out_scale)), -65536.f), 65536.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = min(max(q[k] + zp, 0), 255);
+}
+
+// ---- the INTEGER path's requantisation (u8i_kernels.hip) ------------------------------------------------------------------------
+// t = the exact int32 value of sum (x - zx)(w - zw) + bias.  The reference computes, on its fp32 sum s ~ t * (in_s * w_s):
+// activation clamp, round(fl(s / out_s)) + zp, clamp [0, 255] (conv_kernel_x86.c:1746-1790).  The integer path is not tied to
+// that expression's bits (its bar is one quantisation step), so it spends ONE multiply-add per value:
+//   y = fma((float)t, M, copysign(0.5, t)),  M = fl(fl(in_s * w_s) / out_s)   (planner, binary32)
+//   q = clamp(trunc(y) + zp, lo, hi)          round half away from zero, like the reference's round()
+// and the conv's own activation becomes the clamp window (requantisation is monotone): relu -> lo = zp; relu6 -> also
+// hi = round(fl(6 / out_s)) + zp.  Against the reference expression on the same real value the result can differ only where
+// the value sits within ~1e-6 relative of a rounding boundary: never by more than one step.  tests/helpers.py u8_conv_int_model
+// evaluates the same operations (the fma exactly, in binary64) -- the device is byte-exact against it.
+struct U8IRq { float m; int zp, lo, hi; };
+__device__ __forceinline__ int u8i_requant(int t, const U8IRq r)
+{
+    const float tf = (float)t;
+    float y = __fmaf_rn(tf, r.m, copysignf(0.5f, tf));
+    y = fminf(fmaxf(y, -512.f), 512.f);                  // beyond the byte range either way; keeps the conversion + zp inside int
+    return min(max((int)y + r.zp, r.lo), r.hi);
+}
+
 // round(f / out_scale + zp), clamp -- relu_kernel_ref_uint8.c:83-89, upsample_ref.c:118-125 (zero point INSIDE the round)
 __device__ __forceinline__ uint8_t quant_round_in_exact(float f, U8Q q)
 {

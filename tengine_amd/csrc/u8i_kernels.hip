@@ -6,9 +6,12 @@
 // uint8 form: results within ONE quantisation step of the reference, mismatch histogram reported.  This file is that form:
 //
 //   sum_k (x_k - zx)(w_k - zw)        exactly, in int32, on v_mfma_i32_32x32x32_i8 (32x the fp32 MFMA rate)
-//   f = (float)(sum + bias) * (in_scale * w_scale)                       one rounding instead of K of them
-//   then the reference's own tail: activation clamp, (int)(round(f / out_scale) + zp), clamp [0,255]  (:1746-1790), the fused
-//   ReLU / leaky ReLU node and the fused 2x2 max-pool node exactly as the byte-exact kernels apply them (u8_epilogue.h).
+//   q = clamp(round_half_away((float)(sum + bias) * M) + zp, lo, hi),  M = fl(fl(in_scale * w_scale) / out_scale)
+//                                                                         ONE multiply-add instead of K roundings, a division and a
+//                                                                         round (u8_epilogue.h: u8i_requant); the conv's own
+//                                                                         activation (:1746-1767) is the clamp window
+//   then the fused ReLU / leaky ReLU node and the fused 2x2 max-pool node exactly as the byte-exact kernels apply them to the byte
+//   (u8_epilogue.h: fused_relu, pooled_byte -- tabulated per block, both are functions of one byte).
 //
 // Operands: x' = x - 128 and w' = w - 128 are int8 (a byte XOR 0x80).  With alpha = zx - 128, beta = zw - 128:
 //   sum_k (x'_k - alpha)(w'_k - beta) = sum x'w'  -  beta * sum_k x'_k  -  alpha * sum_k w'_k  +  Kp * alpha * beta
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
     uint8_t* lut = smem + 2 * (2 << a.i_cgs) * NPAD * 16;        // [256] fused ReLU, [256] pooled byte
     lut[t] = a.relu.on ? fused_relu((uint8_t)t, a.out_scale, a.out_zp, a.relu) : (uint8_t)t;
     if (a.pool.on) lut[256 + t] = pooled_byte(t, a.pool);
-    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
+    const U8IRq rq{a.i_m, a.out_zp, a.i_qlo, a.i_qhi};
 
     // A chunk = CG groups of 32 channels (CG = 1 | 2 | 4: small patches take more channels per barrier; 1x1 layers would otherwise
     // see a barrier per MFMA step).  Staging units: (channel quad cq of the chunk, patch pixel quad q); surplus threads repeat
@@ -212,6 +215,12 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
     v4i_q ar[D][TM];
 #pragma unroll
     for (int d = 0; d < D; d++) load_a(ar[d]);
+    // the epilogue's per-channel constants, requested now (see conv_u8i_pw_k)
+    int4 cvr[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) cvr[i][g4] = *reinterpret_cast<const int4*>(a.icv + co0 + (wm * TM + i) * 32 + 8 * g4 + 4 * hi);
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -284,24 +293,37 @@ __global__ __launch_bounds__(256) void conv_u8i_k(const U8ConvArgs a)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const int cb = co0 + (wm * TM + i) * 32 + 8 * g4 + 4 * hi;
-                const int4 cv = *reinterpret_cast<const int4*>(a.icv + cb);         // icv is padded to the cout tile
+                const int4 cv = cvr[i][g4];                                          // (icv is padded to the cout tile)
                 const int cvs[4] = {cv.x, cv.y, cv.z, cv.w};
+                int qv[4];
+                if (a.i_dbg & 2) { for (int e = 0; e < 4; e++) qv[e] = (acc[i][jn][4 * g4 + e] + cvs[e]) & 255; }   // anatomy: no requantisation arithmetic
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int co = cb + e;
-                    if (co >= a.cout) continue;                                      // uniform over a quad of lanes (hi is)
-                    float s = (float)(acc[i][jn][4 * g4 + e] - corr + cvs[e]) * a.bias_scale;
-                    if (a.act == 0) s = s < 0.f ? 0.f : s;
-                    if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                    uint8_t q;
-                    if (a.i_dbg & 2) q = (uint8_t)(acc[i][jn][4 * g4 + e] + cvs[e]);   // anatomy: no requantisation arithmetic
-                    else q = lut[quant_round_sat_u8_w(s, a.out_scale, inv_out, a.out_zp)];
-                    if ((a.i_dbg & 1) && q != 77) continue;                             // anatomy: (almost) no stores
-                    if (live && (!a.pool.on || a.pool.write_full)) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
-                    if (a.pool.on) {             // OH, OW even under a fused pool: a window's four pixels are four neighbouring lanes, live together
-                        const int m = quad_max((int)q);
-                        if (live && (l31 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = lut[256 + m];
-                    }
+                    for (int e = 0; e < 4; e++) qv[e] = u8i_requant(acc[i][jn][4 * g4 + e] - corr + cvs[e], rq);
+                }
+                // table look-ups of the group first (four LDS reads in flight, one wait), then the stores, each under ONE predicate:
+                // written value by value the compiler waits for every look-up in front of its own store
+                int qb[4], pb[4];
+                if (a.relu.on) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qb[e] = lut[qv[e]];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qb[e] = qv[e];
+                }
+                const bool full = live && (!a.pool.on || a.pool.write_full) && !(a.i_dbg & 1);
+                uint8_t* dst = a.y + (size_t)n * a.out_img + (size_t)(a.out_c0 + cb) * OHW + opix;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (full && cb + e < a.cout) dst[(size_t)e * OHW] = (uint8_t)qb[e];
+                if (a.pool.on) {                 // OH, OW even under a fused pool: a window's four pixels are four neighbouring lanes, live together
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pb[e] = lut[256 + quad_max(qb[e])];
+                    const bool pst = live && (l31 & 3) == 0 && !(a.i_dbg & 1);
+                    uint8_t* pd = a.pool.y + (size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + cb) * (OHW >> 2) + ppix;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (pst && cb + e < a.cout) pd[(size_t)e * (OHW >> 2)] = (uint8_t)pb[e];
                 }
             }
     }
@@ -335,12 +357,16 @@ __global__ __launch_bounds__(256) void conv_u8i_rgb_k(const U8ConvArgs a)
     uint8_t* lut = smem + a.i_npad * 4;                         // byte tables of the fused ReLU / pool nodes (see conv_u8i_k), behind the patch
     lut[t] = a.relu.on ? fused_relu((uint8_t)t, a.out_scale, a.out_zp, a.relu) : (uint8_t)t;
     if (a.pool.on) lut[256 + t] = pooled_byte(t, a.pool);
-    const float inv_out = __fdiv_rn(1.0f, a.out_scale);
+    const U8IRq rq{a.i_m, a.out_zp, a.i_qlo, a.i_qhi};
 
     // ---- weights of this block's output channels: RT fragments of 16 rows, lane (row l15, quarter q) ------------------------------
     v4i_q af[RT];
+    int4 cvr[RT];
 #pragma unroll
-    for (int r = 0; r < RT; r++) af[r] = *reinterpret_cast<const v4i_q*>(a.iw + (size_t)r * 1024 + lane * 16);
+    for (int r = 0; r < RT; r++) {
+        af[r] = *reinterpret_cast<const v4i_q*>(a.iw + (size_t)r * 1024 + lane * 16);
+        cvr[r] = *reinterpret_cast<const int4*>(a.icv + r * 16 + 4 * q);
+    }
 
     // ---- stage the patch: unit = 4 consecutive patch columns of one row, all channels ------------------------------------------------
     for (int u = t; u < rows * W4q; u += 256) {
@@ -355,15 +381,17 @@ __global__ __launch_bounds__(256) void conv_u8i_rgb_k(const U8ConvArgs a)
             sl |= (unsigned)((rowok && (unsigned)col < (unsigned)a.W) ? col - ixc : 4) << (8 * j);
         }
         const int goff = rowok ? iy * a.W + ixc : 0;
-        unsigned d[4], x[4];
+        // every channel slot is loaded (missing ones re-read the last real channel and are zeroed afterwards): no control flow
+        // between the loads, so all of a unit's requests are in flight together
+        unsigned d[4], x[4], v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) __builtin_memcpy(&v[c], xin + (size_t)min(c, a.C - 1) * HW + goff, 4);
+        unsigned v3 = 0u;
+        if (a.C > 3) __builtin_memcpy(&v3, xin + (size_t)3 * HW + goff, 4);          // (uniform; the 4-channel case only)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            d[c] = 0u;                                                 // the 4th (and any missing) channel slot: zero bytes
-            if (c < a.C) {
-                unsigned v;
-                __builtin_memcpy(&v, xin + (size_t)c * HW + goff, 4);
-                d[c] = __builtin_amdgcn_perm(padw, v ^ 0x80808080u, sl);
-            }
+            const unsigned vv = c < 3 ? v[c] : v3;
+            d[c] = c < a.C ? __builtin_amdgcn_perm(padw, vv ^ 0x80808080u, sl) : 0u;
         }
         transpose4x4(d, x);
         *reinterpret_cast<uint4*>(smem + (size_t)(r * Wp4 + 4 * xq) * 4) = make_uint4(x[0], x[1], x[2], x[3]);
@@ -403,21 +431,31 @@ __global__ __launch_bounds__(256) void conv_u8i_rgb_k(const U8ConvArgs a)
             v4i_q acc = {0, 0, 0, 0};
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[r], bf, acc, 0, 0, 0);
             const int cb = r * 16 + 4 * q;                               // D: col = l15 (pixel), rows 4q .. 4q+3 (channels)
-            const int4 cv = *reinterpret_cast<const int4*>(a.icv + cb);
+            const int4 cv = cvr[r];
             const int cvs[4] = {cv.x, cv.y, cv.z, cv.w};
+            int qq[4], qb[4], pb[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int co = cb + e;
-                if (co >= a.cout) continue;
-                float sv = (float)(acc[e] - corr + cvs[e]) * a.bias_scale;
-                if (a.act == 0) sv = sv < 0.f ? 0.f : sv;
-                if (a.act > 0) { sv = sv < 0.f ? 0.f : sv; sv = sv > 6.f ? 6.f : sv; }
-                const uint8_t qv = lut[quant_round_sat_u8_w(sv, a.out_scale, inv_out, a.out_zp)];
-                if (live && (!a.pool.on || a.pool.write_full)) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = qv;
-                if (a.pool.on) {
-                    const int m = quad_max((int)qv);
-                    if (live && (l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + ppix] = lut[256 + m];
-                }
+            for (int e = 0; e < 4; e++) qq[e] = u8i_requant(acc[e] - corr + cvs[e], rq);
+            if (a.relu.on) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) qb[e] = lut[qq[e]];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) qb[e] = qq[e];
+            }
+            const bool full = live && (!a.pool.on || a.pool.write_full);
+            uint8_t* dst = a.y + (size_t)n * a.out_img + (size_t)(a.out_c0 + cb) * OHW + opix;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (full && cb + e < a.cout) dst[(size_t)e * OHW] = (uint8_t)qb[e];
+            if (a.pool.on) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) pb[e] = lut[256 + quad_max(qb[e])];
+                const bool pst = live && (l15 & 3) == 0;
+                uint8_t* pd = a.pool.y + (size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + cb) * (OHW >> 2) + ppix;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (pst && cb + e < a.cout) pd[(size_t)e * (OHW >> 2)] = (uint8_t)pb[e];
             }
         }
     }
@@ -460,6 +498,181 @@ hipError_t launch_conv_u8i_rgb(const U8ConvArgs& a, hipStream_t s)
     case 2: hipLaunchKernelGGL(conv_u8i_rgb_k<2>, grid, dim3(256), lds, s, a); break;
     case 3: hipLaunchKernelGGL(conv_u8i_rgb_k<3>, grid, dim3(256), lds, s, a); break;
     default: hipLaunchKernelGGL(conv_u8i_rgb_k<4>, grid, dim3(256), lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// =================================================================================================================
+// Pointwise layers (1x1, stride 1, no padding) without LDS and without barriers.
+//
+// The matrix core wants 16 consecutive K bytes of ONE pixel per lane, NCHW has the channels H*W bytes apart -- conv_u8i_k pays
+// for that with a transposing LDS stage.  A 1x1 convolution has no taps, so the transpose can stay in registers: a lane loads
+// 16 channels x 4 CONSECUTIVE pixels as 16 dwords (lanes run along the pixel quads: every load instruction of a half-wave
+// covers 128 contiguous bytes of one channel row), four 4x4 byte transposes turn them into four 16-byte B fragments, one per
+// pixel of the quad, and FOUR MFMAs consume them -- column l31 of MFMA j is pixel 4*l31 + j of the wave's 128-pixel strip.
+// Which pixel a matrix column stands for is free, so nothing has to be moved: after the K loop a lane holds, for each of its 16
+// output channels per 32-row tile, the results of four consecutive pixels = ONE dword of the NCHW output row, and the
+// half-wave's stores are 128 contiguous bytes again.  No shared memory traffic, no barrier, loads one K step ahead; the weights
+// stream through the same fragment order (and the same 8-deep register ring) as conv_u8i_k.  Arithmetic and epilogue: identical
+// to conv_u8i_k (exact int32 sums, column sums by v_dot4, cvec, the reference's requantisation).
+// A quad that hangs over the end of an image plane reads up to 3 bytes of whatever follows (the next channel, the next tensor or
+// the allocation's slack -- graph.hip: dev_alloc) and stores byte-wise.
+// =================================================================================================================
+template <int WP, int WC, int TMC>
+__global__ __launch_bounds__(256) void conv_u8i_pw_k(const U8ConvArgs a)
+{
+    static_assert(WP * WC == 4, "four waves");
+    constexpr int BMB = WC * TMC * 32, BNB = WP * 128, D = 4;
+    __shared__ uint8_t lut[256];
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int HW = a.H * a.W;                                          // == OH * OW
+    const int tiles = (HW + BNB - 1) / BNB;
+    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles;
+    const int co0 = blockIdx.y * BMB + wc * TMC * 32;
+    lut[t] = a.relu.on ? fused_relu((uint8_t)t, a.out_scale, a.out_zp, a.relu) : (uint8_t)t;      // the fused ReLU node as a byte table
+    __syncthreads();
+    const U8IRq rq{a.i_m, a.out_zp, a.i_qlo, a.i_qhi};
+    const int pix0 = tile * BNB + wp * 128 + 4 * l31;                  // first pixel of this lane's quad
+    const int nvalid = min(max(HW - pix0, 0), 4);
+    const uint8_t* xq = a.x + (size_t)n * a.C * HW + (nvalid ? pix0 : 0);
+
+    const int ns = a.i_nchunks;                                        // K steps of 32 channels
+    const int8_t* wt = a.iw + ((size_t)blockIdx.y * ns * (BMB / 32) + wc * TMC) * 1024 + lane * 16;
+    v4i_q ar[D][TMC];
+    auto load_a = [&](v4i_q (&f)[TMC]) {
+#pragma unroll
+        for (int i = 0; i < TMC; i++) f[i] = *reinterpret_cast<const v4i_q*>(wt + i * 1024);
+        wt += (BMB / 32) * 1024;
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) load_a(ar[d]);
+    // the per-channel constants of the epilogue, requested NOW: fetched where they are used each was a round trip to the L2 in
+    // front of every group of stores (the loop cannot hide it: the stores may alias, the compiler keeps the loads behind them)
+    int4 cvr[TMC][4];
+#pragma unroll
+    for (int i = 0; i < TMC; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) cvr[i][g4] = *reinterpret_cast<const int4*>(a.icv + co0 + i * 32 + 8 * g4 + 4 * hi);
+    unsigned xv[2][16];
+    auto load_x = [&](unsigned (&v)[16], int st) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int c = min(st * 32 + hi * 16 + i, a.C - 1);         // padded channels re-read the last one: they meet w' = beta
+            if (a.i_dbg & 4) v[i] = 0x01020304u * (unsigned)(c + 1);    // anatomy: no input loads
+            else __builtin_memcpy(&v[i], xq + (size_t)c * HW, 4);
+        }
+    };
+    load_x(xv[0], 0);
+
+    v16i_q acc[TMC][4];
+#pragma unroll
+    for (int i = 0; i < TMC; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    int ssum[4] = {0, 0, 0, 0};
+    const bool need_sum = a.i_beta != 0;
+
+    for (int s0 = 0; s0 < ns; s0 += D) {
+        static_for_u8i<0, D>([&](auto Dd) {
+            constexpr int d = decltype(Dd)::value;
+            const int st = s0 + d;
+            if (st < ns) {
+                if (st + 1 < ns) load_x(xv[(d + 1) & 1], st + 1);
+                v4i_q F[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const unsigned dd[4] = {xv[d & 1][4 * g] ^ 0x80808080u, xv[d & 1][4 * g + 1] ^ 0x80808080u, xv[d & 1][4 * g + 2] ^ 0x80808080u,
+                                            xv[d & 1][4 * g + 3] ^ 0x80808080u};
+                    unsigned x[4];
+                    transpose4x4(dd, x);                               // x[p] = pixel p's channels 4g .. 4g+3
+#pragma unroll
+                    for (int p = 0; p < 4; p++) F[p][g] = (int)x[p];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < TMC; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ar[d][i], F[j], acc[i][j], 0, 0, 0);
+                if (need_sum) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) ssum[j] = __builtin_amdgcn_sdot4(F[j][g], 0x01010101, ssum[j], false);
+                }
+                load_a(ar[d]);
+            }
+        });
+    }
+
+    // ---- epilogue: lane (l31, hi) holds, per 32-row tile i and register e, channel row(e, hi) at pixels pix0 .. pix0+3 -----------------
+    int corr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) corr[j] = a.i_beta * (ssum[j] + __shfl_xor(ssum[j], 32));
+    const int OHW = HW;
+    uint8_t* yb = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + pix0;
+#pragma unroll
+    for (int i = 0; i < TMC; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int cb = co0 + i * 32 + 8 * g4 + 4 * hi;
+            const int4 cv = cvr[i][g4];
+            const int cvs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int co = cb + e;
+                int qv[4];
+                unsigned pk;
+                if (a.i_dbg & 2) { for (int j = 0; j < 4; j++) qv[j] = (acc[i][j][4 * g4 + e] + cvs[e]) & 255; }      // anatomy: no requantisation arithmetic
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) qv[j] = u8i_requant(acc[i][j][4 * g4 + e] - corr[j] + cvs[e], rq);
+                }
+                if (a.relu.on) pk = (unsigned)lut[qv[0]] | (unsigned)lut[qv[1]] << 8 | (unsigned)lut[qv[2]] << 16 | (unsigned)lut[qv[3]] << 24;
+                else pk = (unsigned)qv[0] | (unsigned)qv[1] << 8 | (unsigned)qv[2] << 16 | (unsigned)qv[3] << 24;
+                uint8_t* dst = yb + (size_t)co * OHW;
+                const bool st_ok = co < a.cout && !((a.i_dbg & 1) && pk != 0x4d4d4d4du);               // (anatomy: (almost) no stores)
+                if (st_ok && nvalid == 4) __builtin_memcpy(dst, &pk, 4);
+                if (st_ok && nvalid < 4)
+                    for (int j = 0; j < nvalid; j++) dst[j] = (uint8_t)(pk >> (8 * j));
+            }
+        }
+}
+
+static const struct { int wp, wc, tmc; const char* name; } U8IPW_CFGS[] = {
+    {4, 1, 2, "conv_u8i_pw_64x512"}, {2, 2, 2, "conv_u8i_pw_128x256"}, {4, 1, 1, "conv_u8i_pw_32x512"}, {2, 2, 1, "conv_u8i_pw_64x256"},
+    {1, 4, 2, "conv_u8i_pw_256x128"}, {1, 4, 1, "conv_u8i_pw_128x128"}};
+int conv_u8i_pw_num_cfgs() { return 6; }
+int conv_u8i_pw_bm(int cfg) { return U8IPW_CFGS[cfg].wc * U8IPW_CFGS[cfg].tmc * 32; }
+int conv_u8i_pw_bn(int cfg) { return U8IPW_CFGS[cfg].wp * 128; }
+const char* conv_u8i_pw_kernel_name(const U8ConvArgs& a) { return U8IPW_CFGS[a.i_cfg].name; }
+// 1x1 / stride 1 / no padding / no fused pool; fills i_cfg, i_nchunks and the filter shape
+bool conv_u8i_pw_prepare(U8ConvArgs& a, int cfg, int KH, int KW)
+{
+    if (cfg < 0 || cfg >= conv_u8i_pw_num_cfgs()) return false;
+    if (KH != 1 || KW != 1 || a.SH != 1 || a.SW != 1 || a.PH != 0 || a.PW != 0 || a.pool.on || a.OH != a.H || a.OW != a.W) return false;
+    if ((size_t)a.C * a.H * a.W >= (1u << 30)) return false;
+    const int bm = conv_u8i_pw_bm(cfg);
+    if (bm > 32 && a.cout <= bm / 2) return false;
+    a.pk_kh = a.pk_kw = 1; a.pk_dh = a.pk_dw = 1;
+    a.i_nchunks = (a.C + 31) / 32;
+    a.i_cfg = cfg; a.i_tw = 0; a.i_cgs = 0; a.i_npad = 0;
+    a.i_dbg = getenv("TAMD_U8I_ABLATE") ? atoi(getenv("TAMD_U8I_ABLATE")) : 0;
+    return true;
+}
+hipError_t launch_conv_u8i_pw(const U8ConvArgs& a, hipStream_t s)
+{
+    const int bm = conv_u8i_pw_bm(a.i_cfg), bn = conv_u8i_pw_bn(a.i_cfg), HW = a.H * a.W;
+    const dim3 grid(((HW + bn - 1) / bn) * a.N, (a.cout + bm - 1) / bm, 1);
+    switch (a.i_cfg) {
+    case 0: hipLaunchKernelGGL((conv_u8i_pw_k<4, 1, 2>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((conv_u8i_pw_k<2, 2, 2>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_u8i_pw_k<4, 1, 1>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((conv_u8i_pw_k<2, 2, 1>), grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((conv_u8i_pw_k<1, 4, 2>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_u8i_pw_k<1, 4, 1>), grid, dim3(256), 0, s, a); break;
     }
     return hipGetLastError();
 }
@@ -524,17 +737,17 @@ bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
 }
 
 // (w ^ 0x80) in fragment order, padded with the weight zero point (w' = beta); cvec[co] = bias - alpha * sum_k w'_k + Kp * alpha * beta
-size_t conv_u8i_packed_bytes(const U8ConvArgs& a)
+size_t conv_u8i_packed_bytes(const U8ConvArgs& a, int bm)
 {
-    const int bm = conv_u8i_bm(a.i_cfg), ntile = (a.cout + bm - 1) / bm;
+    const int ntile = (a.cout + bm - 1) / bm;
     return ((size_t)ntile * a.i_nchunks * a.pk_kh * a.pk_kw + 10) * bm * 32;         // + readable slack for the ring's last prefetches (D + 1 steps)
 }
-void conv_u8i_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec)
+void conv_u8i_pack(const U8ConvArgs& a, int bm, const uint8_t* w, int w_zp, int in_zp, const int32_t* bias, int8_t* out, int32_t* cvec)
 {
-    const int bm = conv_u8i_bm(a.i_cfg), ntile = (a.cout + bm - 1) / bm, ntaps = a.pk_kh * a.pk_kw, ns = a.i_nchunks * ntaps;
+    const int ntile = (a.cout + bm - 1) / bm, ntaps = a.pk_kh * a.pk_kw, ns = a.i_nchunks * ntaps;
     const int alpha = in_zp - 128, beta = w_zp - 128;
     const int8_t padb = (int8_t)(uint8_t)(w_zp ^ 0x80);
-    std::fill(out, out + conv_u8i_packed_bytes(a), padb);
+    std::fill(out, out + conv_u8i_packed_bytes(a, bm), padb);
     for (int co = 0; co < ntile * bm; co++) {
         long w1 = 0;
         for (int s = 0; s < ns; s++) {

@@ -425,10 +425,11 @@ def u8_conv_pool_graph(seed, n, cin, h, w, cout, k=3, p=1, slope=0.1, relu=True,
 
 # ---- the opt-in integer uint8 path (tamd_options.u8_integer; csrc/u8i_kernels.hip) ---------------------------------------------
 def u8_conv_int_model(g, x):
-    """What the integer path computes for a single group-1 uint8 Convolution graph (u8_conv_graph), operation for operation:
-    exact integer sum of (x - zx)(w - zw) + bias, ONE float32 product with fl(in_scale * w_scale), the conv's activation clamp,
-    then the reference's requantisation (int)(round(f / out_scale) + zp) -> [0, 255] (conv_kernel_x86.c:1746-1790).  Not the
-    reference's bytes (its fp32 simulation rounds K times): the bar against the reference is one quantisation step."""
+    """What the integer path computes for a single group-1 uint8 Convolution graph (u8_conv_graph), operation for operation
+    (csrc/u8_epilogue.h: u8i_requant): t = the exact integer sum of (x - zx)(w - zw) + bias; y = fma((float)t, M, copysign(0.5, t))
+    in binary32 with M = fl(fl(in_scale * w_scale) / out_scale); q = clamp(trunc(clamp(y, +-512)) + zp, lo, hi), the conv's own
+    activation being the clamp window (relu: lo = zp; relu6: also hi = round(fl(6 / out_scale)) + zp).  Not the reference's bytes
+    (its fp32 simulation rounds K times, divides and rounds): the bar against the reference is one quantisation step."""
     node = g.nodes[-1]
     assert node.op == "Convolution"
     p = node.params
@@ -451,14 +452,18 @@ def u8_conv_int_model(g, x):
     if len(node.inputs) > 2:
         acc += np.asarray(g.tensors[node.inputs[2]].data).astype(np.int64).reshape(1, cout, 1, 1)
     assert np.abs(acc).max() < 2 ** 31
-    bs = np.float32(np.float32(xt.scales[0]) * np.float32(wt.scales[0]))
-    f = acc.astype(np.float32) * bs
+    os_, zp = np.float32(yt.scales[0]), int(yt.zero_points[0])
+    m = np.float32(np.float32(np.float32(xt.scales[0]) * np.float32(wt.scales[0])) / os_)
+    tf = acc.astype(np.float32)                                          # int32 -> binary32, round to nearest even
+    # the fused multiply-add, exactly: a 24 x 24 bit product and +-0.5 fit binary64 without rounding; ONE rounding to binary32
+    y = (tf.astype(np.float64) * np.float64(m) + np.copysign(0.5, tf.astype(np.float64))).astype(np.float32)
+    y = np.clip(y, np.float32(-512), np.float32(512))
+    q = np.trunc(y).astype(np.int64) + zp
     act = p["activation"]
-    if act == 0:
-        f = np.maximum(f, np.float32(0))
+    lo, hi = 0, 255
+    if act >= 0:
+        lo = min(max(zp, 0), 255)
     if act > 0:
-        f = np.minimum(np.maximum(f, np.float32(0)), np.float32(6))
-    d = (f / np.float32(yt.scales[0])).astype(np.float64)
-    r = np.sign(d) * np.floor(np.abs(d) + 0.5)
-    q = np.clip(r, -65536, 65536).astype(np.int64) + int(yt.zero_points[0])
-    return np.clip(q, 0, 255).astype(np.uint8)
+        r6 = np.float32(6.0) / os_
+        hi = min(255, max(lo, int(np.sign(r6) * np.floor(np.abs(np.float64(r6)) + 0.5)) + zp))
+    return np.clip(q, lo, hi).astype(np.uint8)

@@ -66,6 +66,10 @@ INT_CONV = [
     (2, 48, 10, 10, 24, 5, 1, 2, -1, True, 1),       # 5x5
     (1, 64, 19, 19, 96, 3, 2, 1, 0, True, 1),        # SSD extra-layer class: 3x3 stride 2 on an odd map
     (1, 8, 8, 4, 16, 3, 1, 1, -1, True, 1),          # the narrowest map the dword staging takes (W = 4)
+    (2, 64, 1, 1, 100, 1, 1, 0, -1, True, 1),        # pointwise on a 1x1 map: one live pixel per quad, byte-wise stores
+    (3, 72, 3, 3, 40, 1, 1, 0, 0, True, 1),          # 9 pixels per image: partial quads, images back to back
+    (1, 8, 20, 20, 32, 1, 1, 0, 6, False, 1),        # 8 input channels: three quarters of the K step are padding
+    (1, 256, 19, 19, 126, 1, 1, 0, -1, True, 1),     # SSD conf head class: 361 pixels (1 mod 4), cout % 32 != 0
 ]
 
 
@@ -77,7 +81,13 @@ def test_conv_u8_integer_matches_its_model_and_the_reference_within_one_step(cas
     ref = oracle.run_graph(g, x)[0]
     seen = set()
     # every tile shape; then 2-D pixel tiles wherever they fit (wide maps get them anyway) and one 32-channel group per chunk
-    for cfg, env in [(None, None)] + [(c, None) for c in range(6)] + [(c, {"TAMD_U8I_TILES": "2"}) for c in (0, 2, 3, 5)] + [(1, {"TAMD_U8I_CG": "1"}), (4, {"TAMD_U8I_CG": "2"})]:
+    # for 1x1 layers also the six shapes of the register-only pointwise kernel (ids 6..11), and the general kernel with it switched off
+    runs = [(None, None)] + [(c, None) for c in range(6)] + [(c, {"TAMD_U8I_TILES": "2"}) for c in (0, 2, 3, 5)] + [(1, {"TAMD_U8I_CG": "2"}), (4, {"TAMD_U8I_CG": "4"})]
+    if k == 1 and s == 1 and p == 0:
+        runs += [(c, None) for c in range(6, 12)] + ([(None, {"TAMD_U8I_PW": "0"}), (0, {"TAMD_U8I_PW": "0"})] if w >= 4 else [])
+    if w < 4:
+        runs = [(None, None)] + [(c, None) for c in range(6, 12)]          # maps narrower than a dword: only the pointwise kernel takes them
+    for cfg, env in runs:
         (got,), kernels = run_int(g, x, cfg, env=env)
         got = got.reshape(model.shape)
         name = [k for k in kernels if k.startswith("conv_u8i")][0]
