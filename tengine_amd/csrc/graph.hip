@@ -666,6 +666,12 @@ struct FusedElt {            // an eltwise (+ReLU) node folded into the epilogue
     bool conv_is_first, relu;
 };
 
+// the arguments of the last first-layer convolution / pooling step planned on this thread: plan() reads them back when it turns
+// the pair into ONE launch (conv_first_pool.hip)
+static thread_local FirstArgs g_last_first;
+static thread_local bool g_last_first_valid = false;
+static thread_local PoolArgs g_last_pool;
+
 static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = nullptr)
 {
     HTensor& x = g->tensors[n.in[0]];
@@ -726,6 +732,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         a.DH = p.dilation_h; a.DW = p.dilation_w; a.kp = kp; a.kwp = kwp;
         st.kernel = "conv_first_i8";
         st.fn = [a](hipStream_t s) { return launch_conv_first(a, s); };
+        g_last_first = a; g_last_first_valid = true;
     } else if (x.nchw_raw || group != 1) {
         if (!x.nchw_raw && is_dw && KH == 3 && KW == 3 && p.dilation_h == 1 && p.dilation_w == 1 && p.stride_h == p.stride_w
             && (p.stride_h == 1 || p.stride_h == 2)) {
@@ -940,6 +947,7 @@ static int plan_pool(tamd_graph* g, HNode& n)
     a.method = n.p.pool.pool_method; a.caffe_flavor = n.p.pool.caffe_flavor;
     a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
     const PoolArgs av = a;
+    g_last_pool = a;
     Step st; st.node = n.name; st.kernel = "pool_i8";
     st.bytes = (double)x.n * x.h * x.w * x.c + (double)y.n * y.h * y.w * y.c;
     st.fn = [av](hipStream_t s) { return launch_pool(av, s); };
@@ -1406,6 +1414,37 @@ static int plan(tamd_graph* g)
         }
         case TAMD_OP_CONV: {
             int tmode = -1, prod = 0;
+            // stem: first-layer convolution whose only consumer is a MAX pool 3x3 / 2 -> one launch, the conv map stays in LDS
+            // (TAMD_FIRST_POOL=0: two launches, for A/B runs and the fused == unfused tests)
+            if (!has_fuse[ni] && g->tensors[n.in[0]].nchw_raw && count_consumers(g, n.out[0]) == 1) {
+                int pool_node = -1;
+                for (size_t nj = ni + 1; nj < g->nodes.size(); nj++)
+                    if (g->nodes[nj].op == TAMD_OP_POOL && g->nodes[nj].in[0] == n.out[0] && !fused[nj]) { pool_node = (int)nj; break; }
+                const char* fp_env = getenv("TAMD_FIRST_POOL");
+                bool is_out = false;
+                for (auto& o : g->outputs) is_out |= (o.tensor == n.out[0]);
+                if (pool_node >= 0 && !is_out && !(fp_env && atoi(fp_env) == 0)) {
+                    const size_t s0 = g->steps.size();
+                    g_last_first_valid = false;
+                    if (plan_conv(g, n, false)) return -1;
+                    if (plan_pool(g, g->nodes[pool_node])) return -1;
+                    fused[pool_node] = 1;
+                    if (g->steps.size() == s0 + 2 && g_last_first_valid && conv_first_pool_applicable(g_last_first, g_last_pool)) {
+                        const FirstPoolArgs fa = conv_first_pool_args(g_last_first, g_last_pool);
+                        Step st;
+                        st.node = g->steps[s0].node + "+" + g->steps[s0 + 1].node;
+                        st.kernel = "conv_first_pool_i8";
+                        st.macs = g->steps[s0].macs;
+                        st.bytes = g->steps[s0].bytes + g->steps[s0 + 1].bytes;      // SURVEY 8(d) accounting, per layer: the conv map still counts
+                        st.fn = [fa](hipStream_t s) { return launch_conv_first_pool(fa, s); };
+                        st.rd.push_back(access_of(g->tensors[n.in[0]])); st.wr.push_back(access_of(g->tensors[g->nodes[pool_node].out[0]])); st.deps = true;
+                        g->steps.resize(s0);
+                        g->steps.push_back(st);
+                        g->fused_away[n.out[0]] = 1;
+                    }
+                    break;
+                }
+            }
             const int tail = has_fuse[ni] ? -1 : find_pwdw_tail(g, ni, &tmode, &prod);
             if (tail >= 0 && !fused[tail]) {
                 // the pair is planned here, the tail ahead of its node order (its only input is this conv's output), then

@@ -159,6 +159,18 @@ struct PoolArgs {
     float in_scale, out_scale;
 };
 
+struct FirstPoolArgs {     // the stem in one launch: FirstArgs' convolution (7 x KW, stride 2, C = 3) + MAX pool 3x3 / 2 / pad 0 (conv_first_pool.hip)
+    const int8_t* x;       // NCHW graph input
+    const int8_t* w;       // FirstArgs::w with kwp == 8
+    const int32_t* bias; const float* wscale;
+    int8_t* y;             // NHWC pooled map
+    int N, C, H, W, OH, OW, cout;      // OH x OW: the conv map (never stored)
+    int KH, KW, PH, PW, kp;
+    int POH, POW, ldc, c_off;          // pooled map and its destination
+    float pool_in_scale, pool_out_scale;
+    RqArgs rq;
+};
+
 struct EltArgs {
     const int8_t* a; const int8_t* b; int8_t* y;
     size_t count;          // bytes (padded NHWC buffers, identical geometry)
@@ -208,6 +220,9 @@ bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_pw_rows(const ConvArgs& a, hipStream_t s);       // 1x1, shallow K, many pixels: row-major epilogue, persistent pipelined waves
 bool pw_rows_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
+bool conv_first_pool_applicable(const FirstArgs& c, const PoolArgs& p);
+FirstPoolArgs conv_first_pool_args(const FirstArgs& c, const PoolArgs& p);
+hipError_t launch_conv_first_pool(const FirstPoolArgs& a, hipStream_t s);
 int conv_first_kwp(int C, int KH, int KW, int DW);
 hipError_t launch_dwconv3x3(const DwArgs& a, hipStream_t s);
 const char* dwconv3x3_kernel_name(const DwArgs& a);   // variant <stride, fragments per row> the launcher will pick

@@ -320,6 +320,41 @@ def pwdw_graph(seed, n, cin, h, w, c, s=1, p=1, act_pw=0, act_dw=0, tail="dw", p
 
 
 
+def stem_graph(seed, n, h, w, c, kw=7, pad=3, act=0, caffe=1, pool_k=3, pool_s=2, same_scale=True, cin=3, tail_conv=False):
+    """int8 ResNet-style stem: 7 x kw / stride-2 conv on the NCHW graph input -> MAX pool (3x3 / 2 / pad 0 by default): the pair
+    conv_first_pool.hip runs as one launch.  `tail_conv`: a 1x1 conv behind the pool, so that the pooled map is an inner tensor."""
+    from tengine_amd.models import pool_out
+    rng = np.random.default_rng(seed)
+    g = Graph(name="stem_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, cin, h, w], DT_INT8, [xs], [0])
+    wq = rng.integers(-127, 128, size=(c, cin, 7, kw)).astype(np.int8)
+    ws = _scales(rng, c)
+    ins = [x, g.add_const("w1", wq, DT_INT8, ws, [0] * c), g.add_const("b1", rng.integers(-2000, 2000, size=(c,)).astype(np.int32), DT_INT32, [1.0], [0])]
+    ms = float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(cin * 7 * kw) * 73.0 / 60.0))
+    ch = (h - 7 + 2 * pad) // 2 + 1
+    cw = (w - kw + 2 * pad) // 2 + 1
+    mid = g.add_tensor("mid", [n, c, ch, cw], DT_INT8, tm2.TT_VAR, None, [ms], [0])
+    g.add_node("conv1", "Convolution", ins, [mid], kernel_h=7, kernel_w=kw, stride_h=2, stride_w=2, dilation_h=1, dilation_w=1,
+               input_channel=cin, output_channel=c, group=1, activation=act, pad_h0=pad, pad_w0=pad, pad_h1=pad, pad_w1=pad)
+    oh, _, _ = pool_out(ch, pool_k, pool_s, 0, caffe)
+    ow, _, _ = pool_out(cw, pool_k, pool_s, 0, caffe)
+    ps = ms if same_scale else float(np.float32(ms * rng.uniform(0.5, 1.2)))
+    y = g.add_tensor("pooled", [n, c, oh, ow], DT_INT8, tm2.TT_VAR, None, [ps], [0])
+    ni = g.add_node("pool1", "Pooling", [mid], [y], alg=tm2.POOL_MAX, kernel_h=pool_k, kernel_w=pool_k, stride_h=pool_s, stride_w=pool_s,
+                    **{"global": 0}, caffe_flavor=caffe, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    if tail_conv:
+        w2 = rng.integers(-127, 128, size=(32, c, 1, 1)).astype(np.int8)
+        s2 = _scales(rng, 32)
+        os_ = float(np.float32(ps * np.mean(s2) * 73.0 * np.sqrt(c) * 73.0 / 60.0))
+        z = g.add_tensor("out", [n, 32, oh, ow], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        ni = g.add_node("conv2", "Convolution", [y, g.add_const("w2", w2, DT_INT8, s2, [0] * 32)], [z], kernel_h=1, kernel_w=1, stride_h=1,
+                        stride_w=1, dilation_h=1, dilation_w=1, input_channel=c, output_channel=32, group=1, activation=0, pad_h0=0,
+                        pad_w0=0, pad_h1=0, pad_w1=0)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+
+
 def priorbox_graph(seed, dtype, img_h, img_w, feats, min_sizes, max_sizes, ratios, flip=1, clip=0, offset=0.5, step=0.0,
                    img_param=0, variance=(0.1, 0.1, 0.2, 0.2), q=(2.0 / 255, 63)):
     """data -> chain of ReLU + max-pool nodes down to each (h, w) of `feats` -> one PriorBox per feature map -> Concat(axis 2):
