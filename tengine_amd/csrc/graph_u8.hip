@@ -425,7 +425,11 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best_cfg = c; }
             }
             float pk_ms = 1e30f;
+            const char* pcfg = getenv("TAMD_U8_PATCH_CFG");
             for (int c = 0; c < conv_u8_patch_num_cfgs(); c++) {
+                // TAMD_U8_PATCH=1 pins the MFMA patch kernel (tests): the lanes configuration only competes there when it is named
+                const bool lanes_named = pk_force && pcfg && atoi(pcfg) == conv_u8_patch_num_cfgs() - 1;
+                if (pk_force && (c == conv_u8_patch_num_cfgs() - 1) != lanes_named) continue;       // (named: it alone competes where it applies)
                 U8ConvArgs ac = a;
                 const int r = patch_for(ac, c);
                 if (r < 0) return -1;
@@ -478,6 +482,14 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
+        if (!tune && !pk_force && !pk_env && pk_best < 0 && !getenv("TAMD_U8_CFG")) {
+            // layers too small to be worth timing (< 4 MMAC): lane-level chains wherever they apply -- a GEMM launch there is 8-19 us
+            // of set-up around a handful of live MFMA columns (profiles/r04_layers_mssd_uint8_b16_lanes.txt)
+            U8ConvArgs ac = a;
+            const int r = patch_for(ac, conv_u8_patch_num_cfgs() - 1);
+            if (r < 0) return -1;
+            if (r) pk_best = conv_u8_patch_num_cfgs() - 1;
+        }
         if (pk_force && pk_best < 0) {
             const char* pc = getenv("TAMD_U8_PATCH_CFG");          // tests / fuzzing: the tile configuration to try first
             const int first = pc ? atoi(pc) % conv_u8_patch_num_cfgs() : 0;

@@ -3,9 +3,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace tamd {
+
+// compile-time loop (register-ring slots and accumulator arrays must be indexed by constants)
+template <int I, int N, typename F>
+__device__ __forceinline__ void u8_static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        u8_static_for<I + 1, N>(f);
+    }
+}
 
 // (int)(round(s / out_scale) + zp), clamp [0,255] -- conv_kernel_x86.c:1783-1788, conv_kernel_ref_uint8.c:177-182,
 // fc_ref.c:196-202, eltwise_ref.c:571-578

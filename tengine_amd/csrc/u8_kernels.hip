@@ -429,6 +429,127 @@ __device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* x
     a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
 }
 
+// The MAIN pixels (j < (OH*OW)&~7) of SMALL layers the same way: a lane owns one output and walks its single chain k = 0 .. K-1 with
+// fmaf -- what the MFMA main tiles compute (conv_u8_body's header: ascending steps of 4, four fused multiply-adds in ascending k
+// inside a step) -- reading the weights of its row from the same fragment stream (the four k%4 lanes' float4 groups of a
+// super-step, in k order) and the dequantised im2col column of its pixel from LDS.  A block = (four main pixels of the BATCH --
+// the flat index v = image * N8 + j, so a 3x3 map's eight main pixels do not leave half-empty tiles behind --, 64 channels); lane
+// (row l15, r) of wave w: channel 64 * slice + 16 * w + l15 of pixel 4 * group + r.  Why: the SSD pyramid's tail layers (5x5 ..
+// 1x1 maps, 16 .. 400 pixels per batch) gave the GEMM kernels 16-pixel MFMA tiles with 1 .. 8 live columns and a K loop whose
+// every 32-k stage re-gathers and re-dequantises its operands for them: 8 .. 26 us per launch for a few MMAC
+// (profiles/r03_layers_mssd_uint8_b16.txt); a lane-level chain is K steps of ~1.6 instructions.
+template <int KHW>
+__device__ __forceinline__ void conv_u8_patch_lane_main(const U8ConvArgs& a, float* xs, int mb)
+{
+    constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 4, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, r = lane >> 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, total = a.N * N8, slices = (a.cout + 63) / 64;
+    const int slice = mb % slices, grp = mb / slices;
+    const int chw = a.H * a.W;
+    const int KP = a.K + 4;                                // column pitch: the four columns' float4 reads fall into different banks
+    // ---- the four im2col columns, dequantised, natural k order: xs[p][KP].  Thread t stages pixel t & 3, k = t / 4 + 64 i; six byte
+    // loads are in flight before the first is converted (a loop of load -> convert -> store pairs is one memory round trip each)
+    {
+        const int p = tid & 3, v = grp * 4 + p;
+        const bool pv = v < total;
+        const int n = pv ? v / N8 : 0, j = pv ? v - n * N8 : 0, oy = j / a.OW, ox = j - oy * a.OW;      // (no fused pool on this path: row-major pixels)
+        const uint8_t* xin = a.x + (size_t)n * a.C * chw;
+        const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
+        float* xcol = xs + p * KP;
+        for (int k0 = tid >> 2; k0 < a.K; k0 += 64 * 6) {
+            unsigned raw[6];
+            bool ok[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int k = k0 + 64 * u;
+                const int c = k / NTAPS, tap = k - c * NTAPS, ky = tap / KHW, kx = tap - ky * KHW;
+                const int iy = iy0 + ky * a.pk_dh, ix = ix0 + kx * a.pk_dw;
+                ok[u] = pv && k < a.K && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                raw[u] = xin[ok[u] ? (size_t)c * chw + iy * a.W + ix : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int k = k0 + 64 * u;
+                if (k < a.K) xcol[k] = ok[u] ? dequant((uint8_t)raw[u], a.in_zp, a.in_scale) : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int tile16 = slice * 4 + wave;
+    if (tile16 * 16 >= a.cout) return;
+    const int nss = a.K / (4 * SS);
+    const float* wb = reinterpret_cast<const float*>(a.wpk) + (size_t)tile16 * nss * FRAG;
+    const float* xr = xs + r * KP;
+    // fragment ring: RING super-steps of weights in registers, fetched RING - 1 ahead (a lone wave per SIMD hides nothing by
+    // occupancy: with one super-step of cover -- 36 FMAs -- every step waited ~500 cycles for its weights)
+    constexpr int RING = KHW == 3 ? 4 : 8;
+    float4 w4[RING][G4][4];
+    float wr[RING][4][REM > 0 ? REM : 1];
+    auto wload = [&](auto D, int ss) {
+        constexpr int d = decltype(D)::value;
+        const float* wo = wb + (size_t)(ss < nss ? ss : nss - 1) * FRAG;
+#pragma unroll
+        for (int v = 0; v < G4; v++)
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) w4[d][v][kq] = *reinterpret_cast<const float4*>(wo + v * 256 + (kq * 16 + l15) * 4);
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++)
+#pragma unroll
+            for (int e = 0; e < REM; e++) wr[d][kq][e] = wo[G4 * 256 + (kq * 16 + l15) * REM + e];
+    };
+    float acc = 0.f;
+    auto sstep = [&](auto D, int ss) {
+        constexpr int d = decltype(D)::value;
+        wload(std::integral_constant<int, (d + RING - 1) % RING>{}, ss + RING - 1);
+        const float* xp = xr + ss * 4 * SS;
+#pragma unroll
+        for (int v = 0; v < G4; v++) {
+            // MFMA steps s = 4v .. 4v+3 of the super-step, k = 4 s + kq inside it: lane kq's float4 holds its value for each of them
+            const float4 x0 = *reinterpret_cast<const float4*>(xp + 16 * v), x1 = *reinterpret_cast<const float4*>(xp + 16 * v + 4);
+            const float4 x2 = *reinterpret_cast<const float4*>(xp + 16 * v + 8), x3 = *reinterpret_cast<const float4*>(xp + 16 * v + 12);
+            acc = __builtin_fmaf(w4[d][v][0].x, x0.x, acc); acc = __builtin_fmaf(w4[d][v][1].x, x0.y, acc);
+            acc = __builtin_fmaf(w4[d][v][2].x, x0.z, acc); acc = __builtin_fmaf(w4[d][v][3].x, x0.w, acc);
+            acc = __builtin_fmaf(w4[d][v][0].y, x1.x, acc); acc = __builtin_fmaf(w4[d][v][1].y, x1.y, acc);
+            acc = __builtin_fmaf(w4[d][v][2].y, x1.z, acc); acc = __builtin_fmaf(w4[d][v][3].y, x1.w, acc);
+            acc = __builtin_fmaf(w4[d][v][0].z, x2.x, acc); acc = __builtin_fmaf(w4[d][v][1].z, x2.y, acc);
+            acc = __builtin_fmaf(w4[d][v][2].z, x2.z, acc); acc = __builtin_fmaf(w4[d][v][3].z, x2.w, acc);
+            acc = __builtin_fmaf(w4[d][v][0].w, x3.x, acc); acc = __builtin_fmaf(w4[d][v][1].w, x3.y, acc);
+            acc = __builtin_fmaf(w4[d][v][2].w, x3.z, acc); acc = __builtin_fmaf(w4[d][v][3].w, x3.w, acc);
+        }
+#pragma unroll
+        for (int e = 0; e < REM; e++) {
+            const float4 x = *reinterpret_cast<const float4*>(xp + 16 * G4 + 4 * e);
+            acc = __builtin_fmaf(wr[d][0][e], x.x, acc); acc = __builtin_fmaf(wr[d][1][e], x.y, acc);
+            acc = __builtin_fmaf(wr[d][2][e], x.z, acc); acc = __builtin_fmaf(wr[d][3][e], x.w, acc);
+        }
+    };
+    u8_static_for<0, RING - 1>([&](auto D) { wload(D, decltype(D)::value); });
+    for (int ss = 0; ss < nss; ss += RING)
+        u8_static_for<0, RING>([&](auto D) {
+            constexpr int d = decltype(D)::value;
+            if (ss + d < nss) sstep(D, ss + d);
+        });
+    const int co = tile16 * 16 + l15, v = grp * 4 + r;
+    if (v >= total || co >= a.cout) return;
+    const int n = v / N8, opix = v - n * N8;
+    float s = acc;
+    if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+    if (a.act == 0) s = s < 0.f ? 0.f : s;
+    if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
+    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
+}
+
+// a whole (small) layer as lane-level chains: main-pixel blocks first, then the tail pixels' (launch_conv_u8_patch, configuration 4)
+template <int KHW>
+__global__ __launch_bounds__(256) void conv_u8_lanes_k(const U8ConvArgs a, int main_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < main_blocks) conv_u8_patch_lane_main<KHW>(a, smem, blockIdx.x);
+    else conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - main_blocks);
+}
+
 #ifndef TAMD_U8P_ABLATE
 #define TAMD_U8P_ABLATE 0          // tools/exp/u8_patch_anatomy.hip: 1 no MFMA, 2 no B reads, 4 no fragment fetch, 8 no patch refresh, 16 no stores
 #endif
@@ -707,11 +828,16 @@ static const struct { int wm, wn, tm, tn; const char* n3; const char* n1; } U8P_
     {4, 1, 2, 4, "conv_u8_patch_128x64<3x3>", "conv_u8_patch_128x64<1x1>"},
     {2, 2, 2, 4, "conv_u8_patch_64x128<3x3>", "conv_u8_patch_64x128<1x1>"},
     {1, 4, 2, 1, "conv_u8_patch_32x64<3x3>", "conv_u8_patch_32x64<1x1>"}};
-int conv_u8_patch_num_cfgs() { return 4; }
-int conv_u8_patch_bm(int cfg) { return U8P_CFGS[cfg].wm * U8P_CFGS[cfg].tm * 16; }
-static int u8p_bn(int cfg) { return U8P_CFGS[cfg].wn * U8P_CFGS[cfg].tn * 16; }
+static constexpr int U8P_LANES = 4;                 // configuration 4: no MFMA tiles at all, every output a lane-level chain (conv_u8_lanes_k)
+int conv_u8_patch_num_cfgs() { return 5; }
+int conv_u8_patch_bm(int cfg) { return cfg == U8P_LANES ? 64 : U8P_CFGS[cfg].wm * U8P_CFGS[cfg].tm * 16; }
+static int u8p_bn(int cfg) { return cfg == U8P_LANES ? 4 : U8P_CFGS[cfg].wn * U8P_CFGS[cfg].tn * 16; }
 int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 4 : 0; }
-const char* conv_u8_patch_kernel_name(const U8ConvArgs& a) { return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1; }
+const char* conv_u8_patch_kernel_name(const U8ConvArgs& a)
+{
+    if (a.pk_cfg == U8P_LANES) return a.pk_kh == 3 ? "conv_u8_lanes<3x3>" : "conv_u8_lanes<1x1>";
+    return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1;
+}
 
 static size_t u8p_lds(const U8ConvArgs& a)
 {
@@ -728,7 +854,18 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
     a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
     const int ss = conv_u8_patch_ss(a);
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = u8p_bn(cfg);
-    if (off || !ss || N8 == 0 || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 16) != 0 || a.PH < 0 || a.PW < 0) return false;
+    if (off || !ss || a.K % (4 * ss) != 0 || a.C % (KH == 3 ? 4 : 16) != 0 || a.PH < 0 || a.PW < 0) return false;
+    if (cfg == U8P_LANES) {
+        // lane-level chains for the whole layer: bounded to small layers (a chain is K dependent steps; 4096 waves are 4 per SIMD),
+        // no fused pool (the pool's window-major pixel order belongs to the MFMA tiles).  TAMD_U8_LANES=0: never
+        const char* le = getenv("TAMD_U8_LANES");                // (read at every prerun: tests and A/B runs flip it inside one process)
+        const bool lanes_ok = !(le && atoi(le) == 0);
+        const long waves = ((long)a.N * N8 + 3) / 4 * ((a.cout + 15) / 16) + (long)a.N * (OHW - N8) * ((a.cout + 15) / 16);
+        if (!lanes_ok || a.pool.on || waves > 4096 || (size_t)a.K * 16 > 150 * 1024 || (size_t)a.C * a.H * a.W >= (1u << 31)) return false;
+        a.pk_wp = 0; a.pk_npad = 4; a.pk_cfg = cfg;
+        return true;
+    }
+    if (N8 == 0) return false;                                   // no main pixel: nothing for the MFMA tiles (the lanes configuration takes these)
     if ((size_t)a.C * a.H * a.W >= (1u << 31) || (size_t)a.K * 4 > 150 * 1024) return false;      // (the tail blocks keep an im2col column in LDS)
     if (KH == 1) { a.pk_wp = 0; a.pk_npad = bn; a.pk_cfg = cfg; return true; }      // the patch is the tile's own pixels
     a.pk_wp = (a.OW - 1) * a.SW + (KW - 1) * DW + 1;
@@ -771,6 +908,17 @@ void conv_u8_patch_pack(const U8ConvArgs& a, const uint8_t* w, uint8_t w_zp, flo
 hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s)
 {
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    if (a.pk_cfg == U8P_LANES) {
+        const int slices = (a.cout + 63) / 64;
+        const int main_blocks = (a.N * N8 + 3) / 4 * slices, tail_blocks = (OHW - N8) * a.N * slices;
+        const size_t lds = main_blocks ? (size_t)(a.K + 4) * 16 : (size_t)a.K * 4;
+        auto go = [&](auto kern) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(main_blocks + tail_blocks), dim3(256), lds, s, a, main_blocks);
+            return hipGetLastError();
+        };
+        return a.pk_kh == 3 ? go(conv_u8_lanes_k<3>) : go(conv_u8_lanes_k<1>);
+    }
     const int bm = conv_u8_patch_bm(a.pk_cfg), bn = u8p_bn(a.pk_cfg);
     const int main_blocks = ((N8 + bn - 1) / bn) * a.N * ((a.cout + bm - 1) / bm);
     const int tail_blocks = (OHW - N8) * a.N * ((a.cout + 63) / 64);        // conv_u8_patch_tail: (image, tail pixel, 64 channels)
