@@ -92,13 +92,14 @@ def main():
     import numpy as np
     import torch
 
-    from tengine_amd import capi, models, tm2
+    from tengine_amd import capi, models, plans, tm2
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # every graph of this process (second timed region, concurrent streams) takes the plan the first one measured: the same kernels in
     # every region, one plan-time autotune instead of one per graph (csrc/graph.hip: plan cache)
     plan_tmp = None
+    shipped_plan = None
     if "TAMD_PLAN_CACHE" not in os.environ:
         import tempfile
         plan_tmp = os.path.join(tempfile.gettempdir(), "tamd_plan_%d_%d.txt" % (os.getpid(), rank))
@@ -125,6 +126,12 @@ def main():
         if args.batch == 0:
             raise SystemExit("bench.py: --global-batch %d leaves rank %d without images" % (args.global_batch, rank))
     total_images = args.global_batch if args.global_batch else world * args.batch
+    if plan_tmp:
+        # the plan the committed evidence was taken with (tengine_amd/plans/, written by tools/make_plans.py on the GPU box): a COPY
+        # seeds this job's plan file, so the driver's run launches the kernels the layer tables name instead of re-rolling the
+        # plan-time autotune.  The library ignores the file as a whole when its header names another build or candidate list, and
+        # re-checks every cached choice before using it (csrc/graph.hip: plan cache); layers the file does not hold are timed as usual.
+        shipped_plan = plans.seed(plan_tmp, args.model, args.dtype + ("_int" if args.u8_integer else ""), args.batch)
     max_shard = tdist.shard_range(total_images, world, 0)[1]
 
     # ---- model: rank 0 synthesises the int8 tmfile, RCCL broadcast of the raw bytes ----------------
@@ -417,7 +424,7 @@ def main():
             "value_definition": "device-resident: %d step(s) of the launch list with the input batch already in HBM, outputs left in HBM" % args.steps,
             "host_to_host_images_per_s": host_to_host["images_per_s_median"] if host_to_host else None,
             "host_to_host_pipelined_images_per_s": host_to_host["pipelined_images_per_s"] if host_to_host else None,
-            "prerun_ms": prerun_ms,
+            "prerun_ms": prerun_ms, "shipped_plan": shipped_plan,
             # which N = 1 figure a scaling curve of `value` has to be read against: at N > 1 the per-step-gather region replays
             # hipGraphs (it needs the stream order), so its N = 1 counterpart is `hipgraph_replay`, not the direct-dispatch `value`
             "scaling_baseline_key": "hipgraph_replay" if (use_dist and gather_mode == "every") or (not use_dist and "hipgraph_replay" in side) else "value",

@@ -1,0 +1,24 @@
+"""Shipped launch plans: what the plan-time autotune chose for the BASELINE configurations on the box the committed evidence
+was taken on (tengine_amd/plans/<model>_<dtype>_b<batch>.txt, the library's own TAMD_PLAN_CACHE format, written by
+tools/make_plans.py).  Nothing here decides anything: a plan file only pre-answers the timing races (csrc/graph.hip: plan
+cache) -- a header that names another build or candidate list voids the whole file, every cached choice is re-checked for
+applicability before it is used, and layers the file does not hold are timed as they always were."""
+import os
+import shutil
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PLAN_DIR = os.path.join(HERE, "plans")
+
+
+def path_for(model, dtype, batch):
+    return os.path.join(PLAN_DIR, "%s_%s_b%d.txt" % (model, dtype, batch))
+
+
+def seed(dst, model, dtype, batch):
+    """Copy the shipped plan of (model, dtype, per-GPU batch) to `dst` (this job's TAMD_PLAN_CACHE file) unless that file
+    already exists.  Returns the shipped file's name, or None when there is none (the job then times everything itself)."""
+    src = path_for(model, dtype, batch)
+    if not os.path.isfile(src) or os.path.exists(dst):
+        return None
+    shutil.copyfile(src, dst)
+    return os.path.relpath(src, os.path.dirname(HERE))

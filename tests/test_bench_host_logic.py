@@ -83,3 +83,20 @@ def test_reference_thread_cap_defaults_to_the_smallest_allowance(monkeypatch):
     assert bench.ref_thread_cap(256, 128, env="40") == (40, "TAMD_BENCH_REF_THREADS")
     assert bench.ref_thread_cap(256, 128, env="200")[0] == 63
     assert bench.ref_thread_cap(8, 4, env="") == (4, "physical cores")
+
+
+def test_shipped_plan_seeds_a_copy_and_never_overwrites(tmp_path, monkeypatch):
+    """tengine_amd/plans.py: the job's plan file starts as a COPY of the shipped one; an existing file is left alone; no shipped plan -> None"""
+    from tengine_amd import plans
+    monkeypatch.setattr(plans, "PLAN_DIR", str(tmp_path / "plans"))
+    os.makedirs(plans.PLAN_DIR)
+    src = plans.path_for("mobilenet_v1", "int8", 1)
+    open(src, "w").write("#tamd-plan v2 test\nkey\tvalue\n")
+    dst = str(tmp_path / "job_plan.txt")
+    assert plans.seed(dst, "mobilenet_v1", "int8", 1) is not None
+    assert open(dst).read() == open(src).read()
+    open(dst, "a").write("mine\t1\n")
+    assert plans.seed(dst, "mobilenet_v1", "int8", 1) is None              # the job's own file wins
+    assert "mine" in open(dst).read() and "mine" not in open(src).read()
+    assert plans.seed(str(tmp_path / "other.txt"), "resnet50", "int8", 32) is None
+    assert not os.path.exists(str(tmp_path / "other.txt"))
