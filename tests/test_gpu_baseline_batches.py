@@ -53,8 +53,8 @@ def run_and_compare(name, dtype, batch, seed, device_only=False, res=None):
 
 def test_mobilenet_v1_int8_batch64():
     kernels = run_and_compare("mobilenet_v1", "int8", 64, 21)
-    # the batched depthwise layers run the two-fragment kernel on the wide early maps
-    assert any(k.startswith("dwconv3x3_i8<1,2>") or "dwpw" in k or "pwdw" in k for k in kernels), kernels
+    # the batched depthwise layers run the tall-lane forms (two / four output rows per lane)
+    assert any(k.startswith("dwconv3x3_i8<1,1,r") or "dwpw" in k or "pwdw" in k for k in kernels), kernels
 
 
 def test_resnet50_int8_batch32():
@@ -70,20 +70,28 @@ def test_mssd_uint8_300_batch16():
 
 
 WIDE_DW = [
-    # n, c, hw, stride, expected kernel
-    (16, 64, 112, 1, "dwconv3x3_i8<1,2>"),
-    (32, 64, 112, 2, "dwconv3x3_i8<2,2>"),       # 32 x 56^2 outputs x 16 quads: past the wide-kernel threshold
-    (24, 128, 57, 1, "dwconv3x3_i8<1,2>"),      # odd width: strip tail of the 6-output strips, ragged rows
-    (64, 128, 57, 2, "dwconv3x3_i8<2,2>"),      # stride 2 on an odd map: last window touches the right border
-    (1, 64, 112, 1, "dwconv3x3_i8<1,1>"),       # the batch-1 variants, by name
-    (1, 64, 112, 2, "dwconv3x3_i8<2,1>"),
+    # n, c, hw, stride, pinned form (TAMD_DW_FORM, None: the launcher's choice), expected kernel
+    (16, 64, 112, 1, None, "dwconv3x3_i8<1,1,r4>"),   # large batch, tall map: four output rows per lane
+    (32, 64, 112, 2, None, "dwconv3x3_i8<2,1,r2>"),
+    (24, 128, 57, 1, None, "dwconv3x3_i8<1,1,r4>"),   # odd width and height: strip tail, last band has one row of four
+    (64, 128, 57, 2, None, "dwconv3x3_i8<2,1,r2>"),   # stride 2 on an odd map: last window touches the right border, last band one row
+    (64, 512, 14, 1, None, "dwconv3x3_i8<1,1,r2>"),   # MobileNet-v1 conv5_x/dw at batch 64
+    (1, 64, 112, 1, None, "dwconv3x3_i8<1,1>"),       # the batch-1 forms
+    (1, 64, 112, 2, None, "dwconv3x3_i8<2,1>"),
+    (16, 64, 112, 1, "21", "dwconv3x3_i8<1,2>"),      # the two-fragment strips (alignbyte windows across two fragments), pinned
+    (32, 64, 112, 2, "22", "dwconv3x3_i8<2,2,r2>"),
+    (24, 128, 57, 1, "22", "dwconv3x3_i8<1,2,r2>"),   # odd width: strip tail of the 6-output strips, ragged rows
+    (64, 128, 57, 2, "21", "dwconv3x3_i8<2,2>"),
+    (3, 32, 9, 1, "14", "dwconv3x3_i8<1,1,r4>"),      # 9 rows in bands of four: the last band holds one
 ]
 
 
-@pytest.mark.parametrize("n,c,hw,s,kernel", WIDE_DW)
-def test_depthwise_variants_by_name(n, c, hw, s, kernel):
-    """the launcher's <stride, fragments> choice is asserted by name, so the wide variants (alignbyte windows across two
-    fragments) cannot silently go untested; batch > 1 also switches the reference to its naive-ref epilogue"""
+@pytest.mark.parametrize("n,c,hw,s,form,kernel", WIDE_DW)
+def test_depthwise_variants_by_name(n, c, hw, s, form, kernel, monkeypatch):
+    """the launcher's <stride, fragments, rows> choice is asserted by name, so no form (alignbyte windows across two fragments,
+    partial last bands) can silently go untested; batch > 1 also switches the reference to its naive-ref epilogue"""
+    if form:
+        monkeypatch.setenv("TAMD_DW_FORM", form)
     g, x = conv_graph(300 + n + c + hw + s, n, c, hw, hw, c, 3, s, 1, group=c, act=0)
     x[:] = np.random.default_rng(n + hw).integers(-127, 128, size=x.shape)
     want = oracle.run_graph(g, x)[0]
