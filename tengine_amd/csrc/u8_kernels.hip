@@ -1239,53 +1239,42 @@ __global__ __launch_bounds__(256) void conv_u8_dw3_k(const U8DirectArgs a)
         if (total > 6.f && a.act == 6) total = 6.f;
         if (total < -1.f && a.act == 1) total = -1.f;
     }
-    uint8_t q = quant_round_sat_u8(total, a.out_scale, a.out_zp);
+    uint8_t q = quant_round_sat_u8_w(total, a.out_scale, __fdiv_rn(1.0f, a.out_scale), a.out_zp);
     if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
     a.y[(size_t)n * a.out_img + (size_t)a.out_c0 * OHW + idx] = q;
 }
 
-// The same, four horizontally adjacent outputs per thread (pad 1, dilation 1, stride S): the 3 x (3S+3) input bytes
-// they share are loaded once (4.5 resp. 6.75 loads per output instead of 9) and -- what matters more on this
-// latency-bound op -- every thread keeps four outputs' worth of bytes in flight.  Each output still runs its own
-// nine-step chain in (ky, kx) order.
-template <int S>
+// The same, a TH x 4 block of outputs per thread (pad 1, dilation 1, stride S): the ((TH-1) S + 3) x (3S+3) input bytes they share
+// are loaded, dequantised and masked once -- an input value costs ~5 instructions (extract, convert, subtract, scale, select) and a
+// 1 x 4 block needs 4.5 of them per output, a 2 x 4 block 3, a 4 x 4 block 2.25 (stride 1) -- and the index arithmetic is paid once
+// per block.  Each output still runs its own nine-step chain in (ky, kx) order.
+template <int S, int TH>
 __global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
 {
-    constexpr int NC = 3 * S + 3;
-    const int QW = (a.OW + 3) >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (idx >= a.cout * a.OH * QW) return;
-    const int xq = idx % QW, r = idx / QW, oy = r % a.OH, oc = r / a.OH;
-    const int ox0 = xq * 4, iy0 = oy * S - 1, ix0 = ox0 * S - 1;
+    constexpr int NC = 3 * S + 3, NR = (TH - 1) * S + 3;
+    const int QW = (a.OW + 3) >> 2, BH = (a.OH + TH - 1) / TH, per = BH * QW;
+    // threads run over the flattened (image, channel, band, quad) index, so 10x10 and 19x19 maps still fill their wavefronts
+    const long gidx = ((long)blockIdx.x + (long)blockIdx.y * 32768) * 256 + threadIdx.x;
+    if (gidx >= (long)a.N * a.cout * per) return;
+    const int nc = (int)(gidx / per), idx = (int)(gidx - (long)nc * per);
+    const int n = nc / a.cout, oc = nc - n * a.cout;
+    const int band = idx / QW, xq = idx - band * QW;
+    const int oy0 = band * TH, ox0 = xq * 4, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const uint8_t* xc = a.x + ((size_t)n * a.C + oc) * a.H * a.W;
     const float* wk = a.wf + (size_t)oc * 9;
     // the NC input bytes of a row as unaligned DWORD loads (2 for stride 1, 3 for stride 2) instead of NC byte gathers: the op
     // is bound by the number of load instructions (a wave's byte gather occupies the address unit for 16 cycles whatever it
     // fetches), not by bytes.  The window starts at column max(ix0, 0) (never in front of the buffer) and may run past the row
-    // or the tensor (allocations carry slack); columns outside the image are masked below and enter the chain as 0.0f.
+    // or the tensor (allocations carry slack); columns / rows outside the image are masked below and enter the chain as 0.0f.
     constexpr int ND = (NC + 1 + 3) / 4;                // dwords that cover NC bytes from a start shifted by at most one
-    unsigned u[3][NC];
-    unsigned okm = 0;
     const int sh = ix0 < 0 ? 1 : 0;                     // left border: the window's first column is outside the image
+    unsigned d[NR][ND];
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-        const int iy = iy0 + ky;
-        const bool rok = (unsigned)iy < (unsigned)a.H;
-        const uint8_t* row = xc + (rok ? iy : 0) * a.W + (ix0 + sh);
-        unsigned d[ND], e[ND];
+    for (int r = 0; r < NR; r++) {
+        const int iy = iy0 + r;
+        const uint8_t* row = xc + ((unsigned)iy < (unsigned)a.H ? iy : 0) * a.W + (ix0 + sh);
 #pragma unroll
-        for (int k = 0; k < ND; k++) __builtin_memcpy(&d[k], row + 4 * k, 4);
-        // at the left border the loaded window starts one column late: shift it up by a byte so that byte c is column c again
-        // (byte 0 is then a don't-care: that column is masked)
-#pragma unroll
-        for (int k = 0; k < ND; k++) e[k] = sh ? ((d[k] << 8) | (k ? d[k - 1] >> 24 : 0u)) : d[k];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const int ix = ix0 + c;
-            const bool ok = rok & ((unsigned)ix < (unsigned)a.W);
-            u[ky][c] = (e[c >> 2] >> (8 * (c & 3))) & 0xffu;
-            okm |= ok ? 1u << (ky * NC + c) : 0u;
-        }
+        for (int k = 0; k < ND; k++) __builtin_memcpy(&d[r][k], row + 4 * k, 4);
     }
     float w[9];
 #pragma unroll
@@ -1295,29 +1284,71 @@ __global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
         bf = (float)a.bias[oc] * a.in_scale;
         bf = bf * a.w_scale;
     }
-    float xf[3][NC];
+    unsigned colok = 0;
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++)
+    for (int c = 0; c < NC; c++) colok |= ((unsigned)(ix0 + c) < (unsigned)a.W) ? 1u << c : 0u;
+    float xf[NR][NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++)
-            xf[ky][c] = (okm >> (ky * NC + c) & 1u) ? dequant((uint8_t)u[ky][c], a.in_zp, a.in_scale) : 0.f;
-    uint8_t* yo = a.y + (size_t)n * a.out_img + ((size_t)(a.out_c0 + oc) * a.OH + oy) * a.OW + ox0;
+    for (int r = 0; r < NR; r++) {
+        const bool rok = (unsigned)(iy0 + r) < (unsigned)a.H;
+        // at the left border the loaded window starts one column late: shift it up by a byte so that byte c is column c again
+        // (byte 0 is then a don't-care: that column is masked)
+        unsigned e[ND];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float total = 0.f;
+        for (int k = 0; k < ND; k++) e[k] = sh ? ((d[r][k] << 8) | (k ? d[r][k - 1] >> 24 : 0u)) : d[r][k];
 #pragma unroll
-        for (int t = 0; t < 9; t++) total = __builtin_fmaf(xf[t / 3][j * S + t % 3], w[t], total);
-        if (a.bias) total = total + bf;
-        if (a.act >= 0) {
-            if (total < 0.f && a.act != 1) total = 0.f;
-            if (total > 1.f && a.act == 1) total = 1.f;
-            if (total > 6.f && a.act == 6) total = 6.f;
-            if (total < -1.f && a.act == 1) total = -1.f;
+        for (int c = 0; c < NC; c++) {
+            const unsigned u = (e[c >> 2] >> (8 * (c & 3))) & 0xffu;
+            xf[r][c] = (rok && (colok >> c & 1u)) ? dequant((uint8_t)u, a.in_zp, a.in_scale) : 0.f;
         }
-        uint8_t q = quant_round_sat_u8(total, a.out_scale, a.out_zp);
-        if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
-        if (ox0 + j < a.OW) yo[j] = q;
     }
+    const float inv = __fdiv_rn(1.0f, a.out_scale);
+#pragma unroll
+    for (int t = 0; t < TH; t++) {
+        const int oy = oy0 + t;
+        if (TH > 1 && oy >= a.OH) break;
+        float tot[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float total = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) total = __builtin_fmaf(xf[t * S + k / 3][j * S + k % 3], w[k], total);
+            if (a.bias) total = total + bf;
+            if (a.act >= 0) {
+                if (total < 0.f && a.act != 1) total = 0.f;
+                if (total > 1.f && a.act == 1) total = 1.f;
+                if (total > 6.f && a.act == 6) total = 6.f;
+                if (total < -1.f && a.act == 1) total = -1.f;
+            }
+            tot[j] = total;
+        }
+        // one reciprocal per thread and ONE wave-level test for the four values' rare hand-over to the reference expression
+        int q4[4];
+        quant_round_sat_u8_w4(tot, a.out_scale, inv, a.out_zp, q4);
+        if (a.relu.on) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) q4[j] = fused_relu((uint8_t)q4[j], a.out_scale, a.out_zp, a.relu);
+        }
+        uint8_t* yo = a.y + (size_t)n * a.out_img + ((size_t)(a.out_c0 + oc) * a.OH + oy) * a.OW + ox0;
+        if (ox0 + 3 < a.OW) {                            // the four bytes as one (unaligned) dword store
+            const unsigned pk = (unsigned)q4[0] | ((unsigned)q4[1] << 8) | ((unsigned)q4[2] << 16) | ((unsigned)q4[3] << 24);
+            __builtin_memcpy(yo, &pk, 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ox0 + j < a.OW) yo[j] = (uint8_t)q4[j];
+        }
+    }
+}
+
+// output rows per thread of the depthwise block kernel: taller blocks once the launch has blocks to spare (measured,
+// profiles/r04_u8_dw_forms.txt).  TAMD_U8_DW_TH=1|2|4 pins it (experiments; read per launch)
+static int u8_dw_th(const U8DirectArgs& a)
+{
+    if (const char* e = getenv("TAMD_U8_DW_TH")) { const int v = atoi(e); if (v == 1 || v == 2 || (v == 4 && a.SH == 1)) return v; }
+    if ((long)a.N * a.cout * a.OH < 65536) return 1;                    // small launches keep the most threads
+    if (a.SH == 1) return a.OH >= 64 ? 4 : a.OH >= 32 ? 2 : 1;           // 16 x 32 @ 150^2: 28.1 -> 20.7 us; 16 x 128 @ 75^2: 28.2 -> 20.8; 16 x 256 @ 38^2: 16.3 -> 13.5
+    return a.OH >= 32 ? 2 : 1;                                            // 16 x 128 @ 75^2 stride 2: 10.7 -> 9.5 us; 19^2 outputs and below: one row
 }
 
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s)
@@ -1325,9 +1356,17 @@ hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s)
     if (a.group == a.C && a.cout == a.C && a.KH == 3 && a.KW == 3) {
         const bool quad = a.PH == 1 && a.PW == 1 && a.DH == 1 && a.DW == 1 && a.SH == a.SW && (a.SH == 1 || a.SH == 2) && a.OW >= 4;
         if (quad) {
-            dim3 grid((a.cout * a.OH * ((a.OW + 3) / 4) + 255) / 256, a.N);
-            if (a.SH == 1) hipLaunchKernelGGL(conv_u8_dw3x4_k<1>, grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(conv_u8_dw3x4_k<2>, grid, dim3(256), 0, s, a);
+            const int th = u8_dw_th(a);
+            const long blocks = ((long)a.N * a.cout * ((a.OH + th - 1) / th) * ((a.OW + 3) / 4) + 255) / 256;
+            dim3 grid((unsigned)(blocks < 32768 ? blocks : 32768), (unsigned)((blocks + 32767) / 32768));
+            if (a.SH == 1) {
+                if (th == 4) hipLaunchKernelGGL((conv_u8_dw3x4_k<1, 4>), grid, dim3(256), 0, s, a);
+                else if (th == 2) hipLaunchKernelGGL((conv_u8_dw3x4_k<1, 2>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((conv_u8_dw3x4_k<1, 1>), grid, dim3(256), 0, s, a);
+            } else {
+                if (th == 2) hipLaunchKernelGGL((conv_u8_dw3x4_k<2, 2>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((conv_u8_dw3x4_k<2, 1>), grid, dim3(256), 0, s, a);
+            }
             return hipGetLastError();
         }
         dim3 grid((a.cout * a.OH * a.OW + 255) / 256, a.N);

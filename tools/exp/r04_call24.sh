@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r04_call24
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_parity_uint8.py tests/test_gpu_u8_patch.py tests/test_gpu_u8_int.py tests/test_gpu_u8_lanes.py tests/test_gpu_baseline_batches.py tests/test_gpu_edge_cases.py tests/test_gpu_glue_int8.py -q -m gpu --tb=short -p no:cacheprovider > $O/pytest.txt 2>&1
+grep -E "passed|failed|error" $O/pytest.txt | tail -3
+grep -E "^FAILED|^ERROR|differ|^E  " $O/pytest.txt | head -30
