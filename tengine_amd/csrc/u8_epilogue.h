@@ -134,6 +134,14 @@ __device__ __forceinline__ uint8_t fused_relu(uint8_t q, float scale, int zp, co
     return quant_round_in(f, r.out);
 }
 
+// The fused ReLU node and the fused pool node are functions of ONE byte (fused_relu of the conv's own byte, pooled_byte of the window
+// maximum): tabulated once per block -- tail[t] = fused_relu(t) (identity without the node), tail[256 + t] = pooled_byte(t) -- and
+// looked up per output: the same bytes as evaluating them per output (they ARE those evaluations), without two more IEEE
+// divisions per value in every epilogue.  The integer path has done this since it exists (u8i_kernels.hip); round 4 brought the
+// byte-exact kernels over together with the wave-level hand-over test of quant_round_sat_u8_w.  Callers put a barrier between
+// this and the first look-up.
+__device__ __forceinline__ void u8_tail_tables(uint8_t* tail, int tid, int nthreads, const U8Relu& relu, float out_scale, int out_zp, const U8PoolFuse& pool);
+
 // Output pixel j of a conv launch -> (oy, ox).  Row-major normally; with a fused 2x2 max-pool (U8PoolFuse) window-major, so
 // that lanes 4w..4w+3 of a pixel column group hold the window w = (py, px): j = 4 * (py * OW/2 + px) + 2 * dy + dx.
 // The reference's main / tail split of a pixel (j < (OH*OW)&~7) is a property of its ROW-MAJOR index; the planner only
@@ -162,6 +170,15 @@ __device__ __forceinline__ uint8_t pooled_byte(int m, const U8PoolFuse& p)
     const float f = ((float)(m - p.in.zp)) * p.in.scale;
     const int od = quant_round_div(f, p.out.scale, p.out.zp);
     return (uint8_t)(od > 255 ? 255 : od);
+}
+
+__device__ __forceinline__ void u8_tail_tables(uint8_t* tail, int tid, int nthreads, const U8Relu& relu, float out_scale, int out_zp, const U8PoolFuse& pool)
+{
+    if (!relu.on && !pool.on) return;
+    for (int t = tid; t < 256; t += nthreads) {
+        tail[t] = relu.on ? fused_relu((uint8_t)t, out_scale, out_zp, relu) : (uint8_t)t;
+        if (pool.on) tail[256 + t] = pooled_byte(t, pool);
+    }
 }
 
 }  // namespace tamd

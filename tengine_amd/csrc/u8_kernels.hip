@@ -50,8 +50,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int WM, int WN, int TM, int TN, int KC, bool TAIL>
 __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restrict__ ws, float* __restrict__ xs,
-                                             const unsigned* __restrict__ lut, int n, int jbase, int jlimit, int co0)
+                                             const unsigned* __restrict__ lut, int n, int jbase, int jlimit, int co0, const uint8_t* tail)
 {
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LD = KC + 4, NT = WM * WN * 64, D = 3;
     constexpr int NPOS = KC / 4;                         // slots per class (k%4) in a row == quads (float4) per row
     constexpr int QPC = NPOS / 4;                        // quads per class
@@ -248,12 +249,12 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                 if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+                if (a.relu.on) q = tail[q];
                 if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
                 if (a.pool.on) {                 // jlimit and co are uniform over a quad of lanes: all four pixels of the window are here
                     const int m = quad_max((int)q);
-                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = pooled_byte(m, a.pool);
+                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = tail[256 + m];
                 }
             }
     }
@@ -268,13 +269,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_u8_gemm_k(const U8ConvArgs 
     float* xs = smem + 2 * BM * LD;                 // [2][BN][LD]
     unsigned* lut = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LD);   // [Kpad]
     for (int k = threadIdx.x; k < a.Kpad; k += WM * WN * 64) lut[k] = a.klut[k];
+    __shared__ uint8_t tail[512];                   // fused ReLU / pool nodes as byte tables (u8_epilogue.h)
+    u8_tail_tables(tail, threadIdx.x, WM * WN * 64, a.relu, a.out_scale, a.out_zp, a.pool);
     __syncthreads();
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     const int tiles = (N8 + BN - 1) / BN, tpi = tiles + (OHW != N8);
     // x = (image, pixel tile): blocks that stream the same weight tile are neighbours in launch order (L2 reuse)
     const int n = blockIdx.x / tpi, tile = blockIdx.x - n * tpi, co0 = blockIdx.y * BM;
-    if (tile < tiles) conv_u8_body<WM, WN, TM, TN, KC, false>(a, ws, xs, lut, n, tile * BN, N8, co0);
-    else conv_u8_body<WM, WN, TM, TN, KC, true>(a, ws, xs, lut, n, N8, OHW, co0);
+    if (tile < tiles) conv_u8_body<WM, WN, TM, TN, KC, false>(a, ws, xs, lut, n, tile * BN, N8, co0, tail);
+    else conv_u8_body<WM, WN, TM, TN, KC, true>(a, ws, xs, lut, n, N8, OHW, co0, tail);
 }
 
 // configurations: block tile (channels x pixels) and K stage depth.  conv_u8_gemm_pick is the geometry heuristic (the
@@ -361,8 +364,9 @@ hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s)
 // (conv_u8_body: rows inside an 8-/4-row block ((0+(s0+s1))+(s2+s3)), the last cout%4 rows ((s0+s1)+s2)+s3).  K%4 == 0 here
 // (the patch kernel takes whole super-steps only), so there is no scalar remainder.  A block = (image, tail pixel, 64 channels).
 template <int KHW>
-__device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* xs, int tb)
+__device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* xs, int tb, const uint8_t* tail)
 {
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
     constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 4, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64, RING = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, r = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, T = OHW - N8, slices = (a.cout + 63) / 64;
@@ -424,8 +428,8 @@ __device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* x
     if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
     if (a.act == 0) s = s < 0.f ? 0.f : s;
     if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+    if (a.relu.on) q = tail[q];
     a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
 }
 
@@ -439,8 +443,9 @@ __device__ __forceinline__ void conv_u8_patch_tail(const U8ConvArgs& a, float* x
 // every 32-k stage re-gathers and re-dequantises its operands for them: 8 .. 26 us per launch for a few MMAC
 // (profiles/r03_layers_mssd_uint8_b16.txt); a lane-level chain is K steps of ~1.6 instructions.
 template <int KHW>
-__device__ __forceinline__ void conv_u8_patch_lane_main(const U8ConvArgs& a, float* xs, int mb)
+__device__ __forceinline__ void conv_u8_patch_lane_main(const U8ConvArgs& a, float* xs, int mb, const uint8_t* tail)
 {
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
     constexpr int NTAPS = KHW * KHW, SS = KHW == 3 ? 9 : 4, G4 = SS / 4, REM = SS - 4 * G4, FRAG = SS * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, r = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, total = a.N * N8, slices = (a.cout + 63) / 64;
@@ -536,8 +541,8 @@ __device__ __forceinline__ void conv_u8_patch_lane_main(const U8ConvArgs& a, flo
     if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
     if (a.act == 0) s = s < 0.f ? 0.f : s;
     if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-    uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-    if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+    uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+    if (a.relu.on) q = tail[q];
     a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
 }
 
@@ -546,8 +551,10 @@ template <int KHW>
 __global__ __launch_bounds__(256) void conv_u8_lanes_k(const U8ConvArgs a, int main_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < main_blocks) conv_u8_patch_lane_main<KHW>(a, smem, blockIdx.x);
-    else conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - main_blocks);
+    __shared__ uint8_t tail[512];                   // fused ReLU node as a byte table (both callees put a barrier behind their staging)
+    u8_tail_tables(tail, threadIdx.x, 256, a.relu, a.out_scale, a.out_zp, a.pool);
+    if ((int)blockIdx.x < main_blocks) conv_u8_patch_lane_main<KHW>(a, smem, blockIdx.x, tail);
+    else conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - main_blocks, tail);
 }
 
 #ifndef TAMD_U8P_ABLATE
@@ -570,13 +577,16 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     constexpr int CPT = CC / PG;                         // channels per thread
     constexpr int G4 = SS / 4, REM = SS - 4 * G4;        // float4 groups / single floats of a lane's fragment per super-step
     extern __shared__ __attribute__((aligned(16))) float smem[];          // patch [2][CC][NP]
+    __shared__ uint8_t tail[512];                   // fused ReLU / pool nodes as byte tables (u8_epilogue.h); the chunk loop's barriers
+    u8_tail_tables(tail, threadIdx.x, 256, a.relu, a.out_scale, a.out_zp, a.pool);      // (>= 1) stand between this and the epilogue
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM, l15 = lane & 15, kq = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     const int tiles = (N8 + BN - 1) / BN, PT = tiles * a.N, CT = (a.cout + BM - 1) / BM;
     if ((int)blockIdx.x >= PT * CT) {                    // the blocks behind the main grid: tail pixels
-        conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - PT * CT);
+        conv_u8_patch_tail<KHW>(a, smem, blockIdx.x - PT * CT, tail);
         return;
     }
     int pt, ct;
@@ -811,12 +821,12 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
                 if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+                if (a.relu.on) q = tail[q];
                 if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
                 if (a.pool.on) {
                     const int m = quad_max((int)q);
-                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = pooled_byte(m, a.pool);
+                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = tail[256 + m];
                 }
             }
     }
@@ -957,10 +967,14 @@ template <int TM, int KS>
 __global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];          // used by the tail blocks only
+    __shared__ uint8_t tail[512];                   // fused ReLU node as a byte table (u8_epilogue.h)
+    u8_tail_tables(tail, threadIdx.x, 256, a.relu, a.out_scale, a.out_zp, a.pool);
     if ((int)blockIdx.x >= main_blocks) {
-        conv_u8_patch_tail<1>(a, smem, blockIdx.x - main_blocks);
+        conv_u8_patch_tail<1>(a, smem, blockIdx.x - main_blocks, tail);
         return;
     }
+    if (a.relu.on) __syncthreads();                 // the only barrier of a main block: the table before the first look-up (uniform)
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, PTI = (N8 + 15) / 16, CT = (a.cout + 16 * TM - 1) / (16 * TM);
     const int nwaves = main_blocks * 4, gw = blockIdx.x * 4 + wave;
@@ -1017,8 +1031,8 @@ __global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main
                 if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
                 if (a.act == 0) s = s < 0.f ? 0.f : s;
                 if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-                if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+                if (a.relu.on) q = tail[q];
                 a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = q;
             }
     };
@@ -1076,7 +1090,10 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
     // are not ordered against the byte stores of the channel loop (which the compiler must assume may alias them)
     extern __shared__ float wl[];
     for (int i = threadIdx.x; i < a.cout * LD; i += 256) wl[i] = a.wf[i];
+    __shared__ uint8_t tail[512];                   // fused ReLU / pool nodes as byte tables (u8_epilogue.h)
+    u8_tail_tables(tail, threadIdx.x, 256, a.relu, a.out_scale, a.out_zp, a.pool);
     __syncthreads();
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
     const int OHW = a.OH * a.OW;
     const int pj = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     if (pj >= OHW) return;           // OHW % 4 == 0 with a fused pool: a quad of lanes leaves together
@@ -1097,7 +1114,7 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
     float xf[K];
 #pragma unroll
     for (int k = 0; k < K; k++) xf[k] = (okm >> k & 1ull) ? dequant((uint8_t)u[k], a.in_zp, a.in_scale) : 0.f;   // im2col zero
-    const bool tail = pj >= (OHW & ~7);
+    const bool tail_px = pj >= (OHW & ~7);
     uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + oy * a.OW + ox;
     uint8_t* yp = a.pool.on ? a.pool.y + (size_t)n * a.pool.out_img + (size_t)a.pool.out_c0 * (OHW >> 2) + (pj >> 2) : nullptr;
     for (int co = 0; co < a.cout; co++) {
@@ -1108,7 +1125,7 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
             w[k] = f.x; w[k + 1] = f.y; w[k + 2] = f.z; w[k + 3] = f.w;
         }
         float s = 0.f;
-        if (!tail) {
+        if (!tail_px) {
 #pragma unroll
             for (int k = 0; k < K; k++) s = __builtin_fmaf(xf[k], w[k], s);
         } else {
@@ -1128,12 +1145,12 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
         if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
         if (a.act == 0) s = s < 0.f ? 0.f : s;
         if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-        uint8_t q = quant_round_sat_u8(s, a.out_scale, a.out_zp);
-        if (a.relu.on) q = fused_relu(q, a.out_scale, a.out_zp, a.relu);
+        uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+        if (a.relu.on) q = tail[q];
         if (!a.pool.on || a.pool.write_full) yo[(size_t)co * OHW] = q;
         if (a.pool.on) {
             const int m = quad_max((int)q);
-            if ((threadIdx.x & 3) == 0) yp[(size_t)co * (OHW >> 2)] = pooled_byte(m, a.pool);
+            if ((threadIdx.x & 3) == 0) yp[(size_t)co * (OHW >> 2)] = tail[256 + m];
         }
     }
 }
