@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import u8_conv_graph
+from helpers import u8_conv_graph, u8_conv_pool_graph
 from oracle import oracle
 from tengine_amd import capi, models, tm2
 
@@ -66,6 +66,20 @@ def test_lane_chains_equal_oracle_and_gemm_member(case):
         assert bad == 0, "%d / %d bytes differ from the oracle (max |d| %d)" % (bad, wv.size, np.abs(a.astype(int) - wv.astype(int)).max())
         assert np.array_equal(a, b.reshape(wv.shape))
         assert len(np.unique(wv)) > 3
+
+
+@pytest.mark.parametrize("dims,kw", [((4, 32, 5, 5, 48, 3, 1), dict(slope=0.1)), ((3, 64, 6, 4, 20, 1, 0), dict(slope=0.0)), ((2, 16, 2, 2, 16, 3, 1), dict(slope=0.1, pool_k=2, pool_s=1))],
+                         ids=["3x3 leaky 5x5", "1x1 relu 6x4", "3x3 leaky 2x2 (all tail pixels)"])
+def test_lane_chains_with_a_fused_relu_node(dims, kw):
+    """conv -> (leaky) ReLU node folded into the conv launch (the byte table of u8_epilogue.h) -> a pool that does NOT fuse
+    (3x3 / stride 1), so the conv runs on the lanes kernel with relu.on"""
+    kw = dict(dict(pool_k=3, pool_s=1), **kw)
+    g, x = u8_conv_pool_graph(77 + dims[1] + dims[2], *dims, **kw)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, {"TAMD_U8_PATCH": "1", "TAMD_U8_PATCH_CFG": "4"})
+    assert any(kn.startswith("conv_u8_lanes") and "+relu" in kn for kn in kernels), kernels
+    for wv, a in zip(want, got):
+        assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
 
 
 def test_default_plan_of_the_ssd_tail_uses_lane_chains():
