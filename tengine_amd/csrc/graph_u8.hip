@@ -475,7 +475,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         st.deps = true;
         if (use_rgb) {
             if (rgb_ready()) return -1;
-            st.kernel = std::string("conv_u8_rgb3x3") + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+            st.kernel = std::string(conv_u8_rgb3x3_kernel_name(rgb)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
             st.fn = [rgb](hipStream_t s) { return launch_conv_u8_rgb3x3(rgb, s); };
             g->steps.push_back(st);
             return 0;

@@ -406,6 +406,7 @@ void conv_u8i_rgb_pack(const U8ConvArgs& a, const uint8_t* w, int w_zp, int in_z
 hipError_t launch_conv_u8i_rgb(const U8ConvArgs& a, hipStream_t s);
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group);
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s);
+const char* conv_u8_rgb3x3_kernel_name(const U8ConvArgs& a);      // "conv_u8_rgb3x3_mfma" (main pixels on the matrix cores) | "conv_u8_rgb3x3"
 const char* conv_u8_gemm_kernel_name(const U8ConvArgs& a);
 hipError_t launch_conv_u8_direct(const U8DirectArgs& a, hipStream_t s);
 

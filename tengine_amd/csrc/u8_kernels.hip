@@ -1155,13 +1155,231 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
     }
 }
 
+// The same layers with the MAIN pixels (j < (OH*OW)&~7) on the matrix cores (round 4).  The per-pixel kernel above is bound by its
+// VALU work -- 9 C fused multiply-adds per output, 16 .. 64 outputs per pixel: YOLOv3-tiny conv0 at batch 8 was 62 us of arithmetic --
+// while the single chain of a main pixel is exactly what v_mfma_f32_16x16x4f32 accumulates (conv_u8_body's header): K = 9 C is
+// (9 C + 3) / 4 MFMA steps for 16 channels x 16 pixels at once.  A wave keeps the dequantised weight rows of all its channel tiles
+// in registers (A: lane (row l15, kq) holds k = 4 s + kq), walks 16-pixel tiles of one image (window-major under a fused pool, as
+// everywhere), gathers the B operand straight from the NCHW input -- lane (pixel l15, kq) needs the (9 C + 3) / 4 taps k = 4 s + kq of
+// its pixel: byte loads at offsets tabulated once per lane, out-of-image taps as 0.0f -- and issues the steps in ascending k.  The
+// padded k (27 -> 28) carries a zero weight and a zero tap: fma(0, 0, s) == s.  Tail pixels: one extra block per image runs the
+// per-pixel code (their four k%4 chains are lane-level arithmetic anyway).
+template <int C>
+__device__ __forceinline__ void conv_u8_rgb3x3_pixel(const U8ConvArgs& a, const float* wl, const uint8_t* tail, float rq_inv, int n, int pj)
+{
+    constexpr int K = 9 * C, K4 = K & ~3, LD = (K + 3) & ~3;
+    const int OHW = a.OH * a.OW;
+    int oy, ox;
+    conv_pixel(a, pj, &oy, &ox);
+    const int iy0 = oy * a.SH - a.PH, ix0 = ox * a.SW - a.PW;
+    const uint8_t* xin = a.x + (size_t)n * C * a.H * a.W;
+    float xf[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        const unsigned u = xin[ok ? (c * a.H + iy) * a.W + ix : 0];
+        xf[k] = ok ? dequant((uint8_t)u, a.in_zp, a.in_scale) : 0.f;
+    }
+    uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + oy * a.OW + ox;
+    for (int co = 0; co < a.cout; co++) {
+        const float* w = wl + co * LD;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s;
+#pragma unroll
+        for (int k = 0; k < K4; k += 4) {
+            s0 = __builtin_fmaf(w[k], xf[k], s0);
+            s1 = __builtin_fmaf(w[k + 1], xf[k + 1], s1);
+            s2 = __builtin_fmaf(w[k + 2], xf[k + 2], s2);
+            s3 = __builtin_fmaf(w[k + 3], xf[k + 3], s3);
+        }
+        if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
+        else s = ((s0 + s1) + s2) + s3;
+#pragma unroll
+        for (int k = K4; k < K; k++) s = __builtin_fmaf(w[k], xf[k], s);
+        if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+        if (a.act == 0) s = s < 0.f ? 0.f : s;
+        if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+        uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
+        if (a.relu.on) q = tail[q];
+        yo[(size_t)co * OHW] = q;                     // (a layer with tail pixels has no fused pool: OH*OW % 8 != 0)
+    }
+}
+
+template <int C, int TM>
+__global__ __launch_bounds__(256) void conv_u8_rgb3x3_mfma_k(const U8ConvArgs a, int main_x)
+{
+    constexpr int K = 9 * C, KS = (K + 3) / 4, LD = (K + 3) & ~3;
+    extern __shared__ float wl[];                   // tail blocks only: the weight rows
+    __shared__ uint8_t tail[512];                   // fused ReLU / pool nodes as byte tables (u8_epilogue.h)
+    const int tid = threadIdx.x, n = blockIdx.y;
+    u8_tail_tables(tail, tid, 256, a.relu, a.out_scale, a.out_zp, a.pool);
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    if ((int)blockIdx.x >= main_x) {                // the tail pixels of image n
+        for (int i = tid; i < a.cout * LD; i += 256) wl[i] = a.wf[i];
+        __syncthreads();
+        if (N8 + tid < OHW) conv_u8_rgb3x3_pixel<C>(a, wl, tail, rq_inv, n, N8 + tid);
+        return;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    // A: this lane's weights of every step, rows past cout repeat the last one (never stored)
+    float af[TM][KS];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int row = min(i * 16 + l15, a.cout - 1);
+#pragma unroll
+        for (int s = 0; s < KS; s++) af[i][s] = a.wf[(size_t)row * LD + 4 * s + kq];          // (k >= K: the zero padding of the rows)
+    }
+    float bf4[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bf4[i][e] = a.bias ? (float)a.bias[min(i * 16 + 4 * kq + e, a.cout - 1)] * a.bias_scale : 0.f;
+    // B: the taps k = 4 s + kq of a pixel: plane offset + in-window offset, and the (dy, dx) the border test needs
+    int toff[KS], tdy[KS], tdx[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const int k = 4 * s + kq, c = k / 9, r = k - 9 * c, dy = r / 3, dx = r - 3 * dy;
+        toff[s] = c * a.H * a.W + dy * a.W + dx;
+        tdy[s] = k < K ? dy : (1 << 20);            // the padded k: a row no image has
+        tdx[s] = dx;
+    }
+    const uint8_t* xin = a.x + (size_t)n * C * a.H * a.W;
+    // (N8 % 16 == 8: the last tile has eight live pixels)
+    // the taps of a tile are requested one tile AHEAD (two register sets): without that every tile paid a whole memory round trip
+    // between its address arithmetic and its first MFMA (the first version of this kernel lost to the per-pixel one: 83 vs 62 us)
+    struct TileIn { unsigned raw[KS]; unsigned okm; int oy, ox, pj; };
+    auto fetch = [&](int t, TileIn& ti) {
+        ti.pj = t * 16 + l15;
+        const bool live = ti.pj < N8;
+        conv_pixel(a, live ? ti.pj : N8 - 1, &ti.oy, &ti.ox);
+        const int iy0 = ti.oy * a.SH - a.PH, ix0 = ti.ox * a.SW - a.PW, base = iy0 * a.W + ix0;
+        ti.okm = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const bool ok = ((unsigned)(iy0 + tdy[s]) < (unsigned)a.H) & ((unsigned)(ix0 + tdx[s]) < (unsigned)a.W);
+            ti.raw[s] = xin[ok ? base + toff[s] : 0];
+            ti.okm |= ok ? 1u << s : 0u;
+        }
+    };
+    auto compute = [&](const TileIn& ti) {
+        const bool live = ti.pj < N8;
+        v4f acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const float bv = (ti.okm >> s & 1u) ? dequant((uint8_t)ti.raw[s], a.in_zp, a.in_scale) : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bv, acc[i], 0, 0, 0);
+        }
+        // D[row = 4 kq + e][col = l15]: this lane holds channels i * 16 + 4 kq + e of its pixel.  The epilogue runs in PHASES over all
+        // 4 TM values -- requantise, table look-ups, window maxima, table look-ups, stores -- so that the LDS round trips of the
+        // byte tables overlap (value by value they were two dependent LDS latencies per output)
+        const int opix = ti.oy * a.OW + ti.ox;
+        int qv[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            float sv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sv[e] = acc[i][e];
+                if (a.bias) sv[e] = sv[e] + bf4[i][e];
+                if (a.act == 0) sv[e] = sv[e] < 0.f ? 0.f : sv[e];
+                if (a.act > 0) { sv[e] = sv[e] < 0.f ? 0.f : sv[e]; sv[e] = sv[e] > 6.f ? 6.f : sv[e]; }
+            }
+            quant_round_sat_u8_w4(sv, a.out_scale, rq_inv, a.out_zp, qv[i]);
+        }
+        if (a.relu.on) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) qv[i][e] = tail[qv[i][e]];
+        }
+        if (!a.pool.on || a.pool.write_full) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int co = i * 16 + 4 * kq + e;
+                    if (live && co < a.cout) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = (uint8_t)qv[i][e];
+                }
+        }
+        if (a.pool.on) {                             // N8 == OHW under a fused pool (OHW % 8 == 0): every lane of a quad is live
+            int pb[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) pb[i][e] = tail[256 + quad_max(qv[i][e])];
+            if ((l15 & 3) == 0 && live) {
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int co = i * 16 + 4 * kq + e;
+                        if (co < a.cout) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (ti.pj >> 2)] = (uint8_t)pb[i][e];
+                    }
+            }
+        }
+    };
+    const int stride = main_x * 4;
+    int t = blockIdx.x * 4 + wave;
+    if (t * 16 >= N8) return;
+    TileIn ta, tb;
+    fetch(t, ta);
+    for (; t * 16 < N8; t += 2 * stride) {
+        const bool more = (t + stride) * 16 < N8;
+        if (more) fetch(t + stride, tb);
+        compute(ta);
+        if (!more) break;
+        if ((t + 2 * stride) * 16 < N8) fetch(t + 2 * stride, ta);
+        compute(tb);
+    }
+}
+
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group)
 {
     return group == 1 && kh == 3 && kw == 3 && dh == 1 && dw == 1 && (cin == 1 || cin == 3 || cin == 4);
 }
 
+// the MFMA form of a first layer: cout <= 64 (four channel tiles of weights per lane), at least one 16-pixel tile of main pixels.
+// OFF by default -- TAMD_U8_RGB_MFMA=1 enables it (tests, A/B runs; read per launch): measured inside one box it does not beat the
+// per-pixel kernel (YOLOv3-tiny b8 conv0 64.7 vs 62.2 us isolated, the step +12 us; mssd b16 conv0 41 vs 35 us,
+// profiles/r04_experiment_u8_first_layer_mfma.txt): both forms issue the same number of byte gathers and byte stores per pixel, and
+// with 16 .. 32 outputs per pixel the requantisation, not the 27 multiply-adds, is most of the arithmetic.
+static bool u8_rgb_mfma(const U8ConvArgs& a)
+{
+    const char* e = getenv("TAMD_U8_RGB_MFMA");
+    return e && atoi(e) == 1 && a.cout <= 64 && ((a.OH * a.OW) & ~7) >= 16 && (a.C == 3 || a.C == 4);
+}
+const char* conv_u8_rgb3x3_kernel_name(const U8ConvArgs& a) { return u8_rgb_mfma(a) ? "conv_u8_rgb3x3_mfma" : "conv_u8_rgb3x3"; }
+
+template <int C>
+static hipError_t launch_rgb_mfma(const U8ConvArgs& a, hipStream_t s)
+{
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7;
+    const int tiles = (N8 + 15) / 16, tail_x = OHW != N8 ? 1 : 0;
+    // eight tiles per wave where the layer has them (the kernel requests a tile's taps while it multiplies the previous one),
+    // fewer when that would leave CUs without a block
+    int per_wave = 8;
+    while (per_wave > 1 && (long)((tiles + 4 * per_wave - 1) / (4 * per_wave)) * a.N < 1024) per_wave >>= 1;
+    const int main_x = std::min((tiles + 4 * per_wave - 1) / (4 * per_wave), 2048);
+    const dim3 grid(main_x + tail_x, a.N);
+    const size_t lds = tail_x ? (size_t)a.cout * ((9 * C + 3) & ~3) * 4 : 0;
+    switch ((a.cout + 15) / 16) {
+    case 1: hipLaunchKernelGGL((conv_u8_rgb3x3_mfma_k<C, 1>), grid, dim3(256), lds, s, a, main_x); break;
+    case 2: hipLaunchKernelGGL((conv_u8_rgb3x3_mfma_k<C, 2>), grid, dim3(256), lds, s, a, main_x); break;
+    case 3: hipLaunchKernelGGL((conv_u8_rgb3x3_mfma_k<C, 3>), grid, dim3(256), lds, s, a, main_x); break;
+    default: hipLaunchKernelGGL((conv_u8_rgb3x3_mfma_k<C, 4>), grid, dim3(256), lds, s, a, main_x); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s)
 {
+    if (u8_rgb_mfma(a)) return a.C == 3 ? launch_rgb_mfma<3>(a, s) : launch_rgb_mfma<4>(a, s);
     dim3 grid((a.OH * a.OW + 255) / 256, a.N);
     switch (a.C) {
     case 1: hipLaunchKernelGGL(conv_u8_rgb3x3_k<1>, grid, dim3(256), (size_t)a.cout * 12 * 4, s, a); break;
