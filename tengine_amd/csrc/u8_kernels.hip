@@ -1117,40 +1117,62 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_k(const U8ConvArgs a)
     const bool tail_px = pj >= (OHW & ~7);
     uint8_t* yo = a.y + (size_t)n * a.out_img + (size_t)a.out_c0 * OHW + oy * a.OW + ox;
     uint8_t* yp = a.pool.on ? a.pool.y + (size_t)n * a.pool.out_img + (size_t)a.pool.out_c0 * (OHW >> 2) + (pj >> 2) : nullptr;
-    for (int co = 0; co < a.cout; co++) {
-        float w[LD];
+    // four output channels per iteration, the epilogue in phases: requantise (one wave-level hand-over test for the four), the ReLU
+    // table, the window maxima, the pool table, the stores -- value by value every output waited for two dependent LDS look-ups
+    for (int co0 = 0; co0 < a.cout; co0 += 4) {
+        float sv[4];
 #pragma unroll
-        for (int k = 0; k < LD; k += 4) {
-            const float4 f = *reinterpret_cast<const float4*>(wl + co * LD + k);
-            w[k] = f.x; w[k + 1] = f.y; w[k + 2] = f.z; w[k + 3] = f.w;
-        }
-        float s = 0.f;
-        if (!tail_px) {
+        for (int u = 0; u < 4; u++) {
+            const int co = min(co0 + u, a.cout - 1);          // (a ragged last group repeats the last row: never stored)
+            float w[LD];
 #pragma unroll
-            for (int k = 0; k < K; k++) s = __builtin_fmaf(xf[k], w[k], s);
-        } else {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int k = 0; k < K4; k += 4) {
-                s0 = __builtin_fmaf(w[k], xf[k], s0);
-                s1 = __builtin_fmaf(w[k + 1], xf[k + 1], s1);
-                s2 = __builtin_fmaf(w[k + 2], xf[k + 2], s2);
-                s3 = __builtin_fmaf(w[k + 3], xf[k + 3], s3);
+            for (int k = 0; k < LD; k += 4) {
+                const float4 f = *reinterpret_cast<const float4*>(wl + co * LD + k);
+                w[k] = f.x; w[k + 1] = f.y; w[k + 2] = f.z; w[k + 3] = f.w;
             }
-            if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
-            else s = ((s0 + s1) + s2) + s3;
+            float s = 0.f;
+            if (!tail_px) {
 #pragma unroll
-            for (int k = K4; k < K; k++) s = __builtin_fmaf(w[k], xf[k], s);
+                for (int k = 0; k < K; k++) s = __builtin_fmaf(xf[k], w[k], s);
+            } else {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < K4; k += 4) {
+                    s0 = __builtin_fmaf(w[k], xf[k], s0);
+                    s1 = __builtin_fmaf(w[k + 1], xf[k + 1], s1);
+                    s2 = __builtin_fmaf(w[k + 2], xf[k + 2], s2);
+                    s3 = __builtin_fmaf(w[k + 3], xf[k + 3], s3);
+                }
+                if (co < a.m_blocked) s = (0.f + (s0 + s1)) + (s2 + s3);
+                else s = ((s0 + s1) + s2) + s3;
+#pragma unroll
+                for (int k = K4; k < K; k++) s = __builtin_fmaf(w[k], xf[k], s);
+            }
+            if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
+            if (a.act == 0) s = s < 0.f ? 0.f : s;
+            if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
+            sv[u] = s;
         }
-        if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
-        if (a.act == 0) s = s < 0.f ? 0.f : s;
-        if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-        uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
-        if (a.relu.on) q = tail[q];
-        if (!a.pool.on || a.pool.write_full) yo[(size_t)co * OHW] = q;
+        int q4[4];
+        quant_round_sat_u8_w4(sv, a.out_scale, rq_inv, a.out_zp, q4);
+        if (a.relu.on) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) q4[u] = tail[q4[u]];
+        }
+        if (!a.pool.on || a.pool.write_full) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (co0 + u < a.cout) yo[(size_t)(co0 + u) * OHW] = (uint8_t)q4[u];
+        }
         if (a.pool.on) {
-            const int m = quad_max((int)q);
-            if ((threadIdx.x & 3) == 0) yp[(size_t)co * (OHW >> 2)] = tail[256 + m];
+            int pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pb[u] = tail[256 + quad_max(q4[u])];
+            if ((threadIdx.x & 3) == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (co0 + u < a.cout) yp[(size_t)(co0 + u) * (OHW >> 2)] = (uint8_t)pb[u];
+            }
         }
     }
 }
