@@ -172,6 +172,47 @@ __device__ __forceinline__ uint8_t pooled_byte(int m, const U8PoolFuse& p)
     return (uint8_t)(od > 255 ? 255 : od);
 }
 
+// The epilogue of FOUR accumulator values of one lane -- output channels co .. co+3 of one pixel (the rows of a 16x16 MFMA tile a lane
+// holds) -- in phases: bias / activation, requantisation with ONE wave-level hand-over test, the fused ReLU table, the stores, the
+// window maxima (the four pixels of a 2x2 window sit in four neighbouring lanes), the pool table, the pooled stores.  Value by value
+// every output waited for two dependent LDS look-ups and carried its own ballot.  s[] = the finished fp32 sums (chain order is the
+// caller's business); opix / pj: the pixel's offset in its output plane / its index in the launch's pixel enumeration.
+__device__ __forceinline__ void u8_finish4(const U8ConvArgs& a, const float (&s)[4], int co, int n, int OHW, int opix, int pj, bool quad_lead,
+                                           float rq_inv, const uint8_t* tail)
+{
+    float sv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        sv[e] = s[e];
+        // the compiled reference hoists (float)bias * bias_scale out of its pixel loop and ADDS the rounded product
+        // (conv_kernel_x86.c:1733-1743: vmulss, then vaddps -- not an fma)
+        if (a.bias) sv[e] = sv[e] + (float)a.bias[min(co + e, a.cout - 1)] * a.bias_scale;
+        if (a.act == 0) sv[e] = sv[e] < 0.f ? 0.f : sv[e];
+        if (a.act > 0) { sv[e] = sv[e] < 0.f ? 0.f : sv[e]; sv[e] = sv[e] > 6.f ? 6.f : sv[e]; }
+    }
+    int q[4];
+    quant_round_sat_u8_w4(sv, a.out_scale, rq_inv, a.out_zp, q);
+    if (a.relu.on) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) q[e] = tail[q[e]];
+    }
+    if (!a.pool.on || a.pool.write_full) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (co + e < a.cout) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co + e) * OHW + opix] = (uint8_t)q[e];
+    }
+    if (a.pool.on) {                                 // the launch's pixel limit and co are uniform over a quad of lanes: all four pixels of the window are here
+        int pb[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) pb[e] = tail[256 + quad_max(q[e])];
+        if (quad_lead) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (co + e < a.cout) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co + e) * (OHW >> 2) + (pj >> 2)] = (uint8_t)pb[e];
+        }
+    }
+}
+
 __device__ __forceinline__ void u8_tail_tables(uint8_t* tail, int tid, int nthreads, const U8Relu& relu, float out_scale, int out_zp, const U8PoolFuse& pool)
 {
     if (!relu.on && !pool.on) return;

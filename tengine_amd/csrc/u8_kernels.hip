@@ -221,11 +221,13 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
         conv_pixel(a, pj, &oy, &ox);
         const int opix = oy * a.OW + ox;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++) {
+            const int cb = co0 + (wm * TM + i) * 16 + 4 * kq;
+            if (cb >= a.cout) continue;
+            float s4[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int co = co0 + (wm * TM + i) * 16 + 4 * kq + e;
-                if (co >= a.cout) continue;
+                const int co = min(cb + e, a.cout - 1);          // (rows past cout repeat the last one: never stored)
                 float s;
                 if constexpr (TAIL) {
                     const float s0 = acc[0][i][j][e], s1 = acc[1][i][j][e], s2 = acc[2][i][j][e], s3 = acc[3][i][j][e];
@@ -244,19 +246,10 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                     }
                 } else
                     s = acc[0][i][j][e];
-                // the compiled reference hoists (float)bias * bias_scale out of its pixel loop and ADDS the rounded product
-                // (conv_kernel_x86.c:1733-1743: vmulss, then vaddps -- not an fma)
-                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
-                if (a.act == 0) s = s < 0.f ? 0.f : s;
-                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
-                if (a.relu.on) q = tail[q];
-                if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
-                if (a.pool.on) {                 // jlimit and co are uniform over a quad of lanes: all four pixels of the window are here
-                    const int m = quad_max((int)q);
-                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = tail[256 + m];
-                }
+                s4[e] = s;
             }
+            u8_finish4(a, s4, cb, n, OHW, opix, pj, (l15 & 3) == 0, rq_inv, tail);
+        }
     }
 }
 
@@ -812,23 +805,12 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
         conv_pixel(a, pj, &oy, &ox);
         const int opix = oy * a.OW + ox;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int co = co0 + (wm * TM + i) * 16 + 4 * kq + e;
-                if (co >= a.cout) continue;
-                float s = acc[i][j][e];
-                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
-                if (a.act == 0) s = s < 0.f ? 0.f : s;
-                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
-                if (a.relu.on) q = tail[q];
-                if (!a.pool.on || a.pool.write_full) a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + opix] = q;
-                if (a.pool.on) {
-                    const int m = quad_max((int)q);
-                    if ((l15 & 3) == 0) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co) * (OHW >> 2) + (pj >> 2)] = tail[256 + m];
-                }
-            }
+        for (int i = 0; i < TM; i++) {
+            const int co = co0 + (wm * TM + i) * 16 + 4 * kq;
+            if (co >= a.cout) continue;
+            const float s4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            u8_finish4(a, s4, co, n, OHW, opix, pj, (l15 & 3) == 0, rq_inv, tail);
+        }
     }
 }
 
@@ -1022,19 +1004,12 @@ __global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main
         tile_ptr(t, &n, &pj);
         if (pj >= N8) return;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int co = co0 + i * 16 + 4 * kq + e;
-                if (co >= a.cout) continue;
-                float s = acc[i][e];
-                if (a.bias) s = s + (float)a.bias[co] * a.bias_scale;
-                if (a.act == 0) s = s < 0.f ? 0.f : s;
-                if (a.act > 0) { s = s < 0.f ? 0.f : s; s = s > 6.f ? 6.f : s; }
-                uint8_t q = quant_round_sat_u8_w(s, a.out_scale, rq_inv, a.out_zp);
-                if (a.relu.on) q = tail[q];
-                a.y[(size_t)n * a.out_img + (size_t)(a.out_c0 + co) * OHW + pj] = q;
-            }
+        for (int i = 0; i < TM; i++) {
+            const int co = co0 + i * 16 + 4 * kq;
+            if (co >= a.cout) continue;
+            const float s4[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            u8_finish4(a, s4, co, n, OHW, pj, pj, false, rq_inv, tail);      // (no fused pool on this kernel: row-major pixels, opix == pj)
+        }
     };
     int t = gw / CT;                                     // this wave's first pixel tile; the next ones follow at a stride of lanes_of_ct
     if (t >= total) return;
