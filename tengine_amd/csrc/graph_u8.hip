@@ -426,10 +426,18 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             }
             float pk_ms = 1e30f;
             const char* pcfg = getenv("TAMD_U8_PATCH_CFG");
+            int named = -1;
+            if (pk_force && pcfg) {
+                U8ConvArgs ac = a;
+                const int c = atoi(pcfg) % conv_u8_patch_num_cfgs();
+                if (conv_u8_patch_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) named = c;
+            }
             for (int c = 0; c < conv_u8_patch_num_cfgs(); c++) {
                 // TAMD_U8_PATCH=1 pins the MFMA patch kernel (tests): the lanes configuration only competes there when it is named
-                const bool lanes_named = pk_force && pcfg && atoi(pcfg) == conv_u8_patch_num_cfgs() - 1;
-                if (pk_force && (c == conv_u8_patch_num_cfgs() - 1) != lanes_named) continue;       // (named: it alone competes where it applies)
+                // TAMD_U8_PATCH=1 + TAMD_U8_PATCH_CFG=<c>: that configuration alone competes where it applies (tests pin forms with it);
+                // without a name the lanes configuration stays out of the forced race (it pins the MFMA patch kernel)
+                if (pk_force && named >= 0 && c != named) continue;
+                if (pk_force && named < 0 && c == conv_u8_patch_lanes_cfg()) continue;
                 U8ConvArgs ac = a;
                 const int r = patch_for(ac, c);
                 if (r < 0) return -1;
@@ -486,9 +494,9 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             // layers too small to be worth timing (< 4 MMAC): lane-level chains wherever they apply -- a GEMM launch there is 8-19 us
             // of set-up around a handful of live MFMA columns (profiles/r04_layers_mssd_uint8_b16_lanes.txt)
             U8ConvArgs ac = a;
-            const int r = patch_for(ac, conv_u8_patch_num_cfgs() - 1);
+            const int r = patch_for(ac, conv_u8_patch_lanes_cfg());
             if (r < 0) return -1;
-            if (r) pk_best = conv_u8_patch_num_cfgs() - 1;
+            if (r) pk_best = conv_u8_patch_lanes_cfg();
         }
         if (pk_force && pk_best < 0) {
             const char* pc = getenv("TAMD_U8_PATCH_CFG");          // tests / fuzzing: the tile configuration to try first

@@ -292,6 +292,8 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     int pk_cfg;                // -1: not used; else tile configuration of launch_conv_u8_patch
     int pk_npad, pk_wp;        // floats per channel plane of the patch (3x3: 256 | 512, 1x1: the pixel tile) / patch row pitch (input columns incl. halo)
     int pk_kh, pk_kw, pk_dh, pk_dw;    // filter shape / dilation (the GEMM kernel gets them through klut)
+    int pk_tw;                 // 0: a pixel tile is a run of consecutive pixels (rows of the whole map width in the patch); > 0 (round 4): 2-D pixel
+                               // tiles of 8 rows x pk_tw columns (= the configuration's pixel-tile size / 8), the patch is the tile + its halo
     // conv_u8i (u8i_kernels.hip): the opt-in INTEGER path -- exact int32 sums on the int8 MFMA, results within one step of the reference
     const int8_t* iw;          // (w ^ 0x80) in MFMA A-fragment order [cout tile][step = (32-channel chunk, tap)][32-row fragment][lane][16 B]
     const int32_t* icv;        // per output channel: bias - alpha * sum_k w'_k + Kp * alpha * beta, padded to the cout tile
@@ -372,6 +374,7 @@ size_t conv_u8_gemm_lds(const U8ConvArgs& a);      // dynamic LDS bytes of the c
 hipError_t launch_conv_u8_gemm(const U8ConvArgs& a, hipStream_t s);
 // main pixels from an LDS-resident fp32 patch (3x3 and 1x1, group 1); tail pixels, if any, on the VALU by extra blocks of the same launch
 int conv_u8_patch_num_cfgs();
+int conv_u8_patch_lanes_cfg();                                      // the configuration index of the lane-level chain kernel (conv_u8_lanes)
 int conv_u8_patch_bm(int cfg);
 int conv_u8_patch_ss(const U8ConvArgs& a);                         // MFMA steps per super-step (9: 3x3, 4: 1x1); 0: shape not supported
 bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW);     // fills pk_*; false: not applicable

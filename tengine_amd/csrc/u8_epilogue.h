@@ -148,6 +148,20 @@ __device__ __forceinline__ void u8_tail_tables(uint8_t* tail, int tid, int nthre
 // fuses when OH*OW % 8 == 0, where every pixel is a main pixel whatever the order.
 __device__ __forceinline__ void conv_pixel(const U8ConvArgs& a, int j, int* oy, int* ox)
 {
+    if (a.pk_tw > 0) {
+        // 2-D tiles (conv_u8_patch, wide maps): tile t = j / (8 * pk_tw) in row-major tile order, inside it row-major -- or, under a
+        // fused pool, window-major over the tile's (4 x pk_tw / 2) windows, so the four pixels of a window still sit in four
+        // neighbouring lanes.  Only used where OH % 8 == 0 and OW % pk_tw == 0 (every tile is whole)
+        const int tw = a.pk_tw, bn = 8 * tw, t = j / bn, l = j - t * bn, tx_n = a.OW / tw, ty = t / tx_n, tx = t - ty * tx_n;
+        if (a.pool.on) {
+            const int hw = tw >> 1, w = l >> 2, wy = w / hw, wx = w - wy * hw;
+            *oy = ty * 8 + 2 * wy + ((l >> 1) & 1); *ox = tx * tw + 2 * wx + (l & 1);
+        } else {
+            const int r = l / tw;
+            *oy = ty * 8 + r; *ox = tx * tw + (l - r * tw);
+        }
+        return;
+    }
     if (a.pool.on) {
         const int half = a.OW >> 1, w = j >> 2, py = w / half, px = w - py * half;
         *oy = 2 * py + ((j >> 1) & 1); *ox = 2 * px + (j & 1);
@@ -176,8 +190,8 @@ __device__ __forceinline__ uint8_t pooled_byte(int m, const U8PoolFuse& p)
 // holds) -- in phases: bias / activation, requantisation with ONE wave-level hand-over test, the fused ReLU table, the stores, the
 // window maxima (the four pixels of a 2x2 window sit in four neighbouring lanes), the pool table, the pooled stores.  Value by value
 // every output waited for two dependent LDS look-ups and carried its own ballot.  s[] = the finished fp32 sums (chain order is the
-// caller's business); opix / pj: the pixel's offset in its output plane / its index in the launch's pixel enumeration.
-__device__ __forceinline__ void u8_finish4(const U8ConvArgs& a, const float (&s)[4], int co, int n, int OHW, int opix, int pj, bool quad_lead,
+// caller's business); opix / ppool: the pixel's offset in its output plane / its window's offset in the pooled plane.
+__device__ __forceinline__ void u8_finish4(const U8ConvArgs& a, const float (&s)[4], int co, int n, int OHW, int opix, int ppool, bool quad_lead,
                                            float rq_inv, const uint8_t* tail)
 {
     float sv[4];
@@ -208,7 +222,7 @@ __device__ __forceinline__ void u8_finish4(const U8ConvArgs& a, const float (&s)
         if (quad_lead) {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (co + e < a.cout) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co + e) * (OHW >> 2) + (pj >> 2)] = (uint8_t)pb[e];
+                if (co + e < a.cout) a.pool.y[(size_t)n * a.pool.out_img + (size_t)(a.pool.out_c0 + co + e) * (OHW >> 2) + ppool] = (uint8_t)pb[e];
         }
     }
 }

@@ -248,7 +248,7 @@ __device__ __forceinline__ void conv_u8_body(const U8ConvArgs& a, float* __restr
                     s = acc[0][i][j][e];
                 s4[e] = s;
             }
-            u8_finish4(a, s4, cb, n, OHW, opix, pj, (l15 & 3) == 0, rq_inv, tail);
+            u8_finish4(a, s4, cb, n, OHW, opix, (oy >> 1) * (a.OW >> 1) + (ox >> 1), (l15 & 3) == 0, rq_inv, tail);
         }
     }
 }
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     else { pt = blockIdx.x % PT; ct = blockIdx.x / PT; }
     const int n = pt / tiles, tile = pt - n * tiles, co0 = ct * BM;
     const int jbase = tile * BN, jlimit = N8;
-    const int Wp = a.pk_wp;
+    const int Wp = a.pk_wp;                              // patch row pitch: the map's width + halo, or (2-D tiles) the tile's
     const int DH = a.pk_dh, DW = a.pk_dw;
 
     // ---- patch geometry of this pixel tile ---------------------------------------------------------------------------------
@@ -596,6 +596,8 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     conv_pixel(a, (jbase + BN < jlimit ? jbase + BN : jlimit) - 1, &oy_b, &ox_b);
     const uint8_t* xin = a.x + (size_t)n * a.C * a.H * a.W;
     const int chw = a.H * a.W;
+    // first input column the patch holds / first output column of the tile: the whole row (1-D runs of pixels) or the tile's own (2-D)
+    const int oxt = a.pk_tw > 0 ? ox_a : 0, px0 = oxt * a.SW - a.PW;
     const int pg = PG > 1 ? tid / NP : 0, ppix = PG > 1 ? tid % NP : tid;
     int soff[NPS];                                       // this thread's patch pixels: offset inside a channel plane, -1: a zero
 #pragma unroll
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
         if (KHW == 3) {
             const int NPX = ((oy_b - oy_a) * a.SH + (KHW - 1) * DH + 1) * Wp;
             const int prow = pp / Wp, pcol = pp - prow * Wp;
-            const int iy = oy_a * a.SH - a.PH + prow, ix = pcol - a.PW;
+            const int iy = oy_a * a.SH - a.PH + prow, ix = pcol + px0;
             soff[q] = (pp < NPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? iy * a.W + ix : -1;
         } else {
             const int pj = jbase + pp;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
             pj = pj < jlimit ? pj : jlimit - 1;
             int oy, ox;
             conv_pixel(a, pj, &oy, &ox);
-            pp0 = ((oy - oy_a) * a.SH) * Wp + ox * a.SW;
+            pp0 = ((oy - oy_a) * a.SH) * Wp + (ox - oxt) * a.SW;
         }
 #pragma unroll
         for (int s = 0; s < SS; s++) {
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
             const int co = co0 + (wm * TM + i) * 16 + 4 * kq;
             if (co >= a.cout) continue;
             const float s4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            u8_finish4(a, s4, co, n, OHW, opix, pj, (l15 & 3) == 0, rq_inv, tail);
+            u8_finish4(a, s4, co, n, OHW, opix, (oy >> 1) * (a.OW >> 1) + (ox >> 1), (l15 & 3) == 0, rq_inv, tail);
         }
     }
 }
@@ -821,13 +823,23 @@ static const struct { int wm, wn, tm, tn; const char* n3; const char* n1; } U8P_
     {2, 2, 2, 4, "conv_u8_patch_64x128<3x3>", "conv_u8_patch_64x128<1x1>"},
     {1, 4, 2, 1, "conv_u8_patch_32x64<3x3>", "conv_u8_patch_32x64<1x1>"}};
 static constexpr int U8P_LANES = 4;                 // configuration 4: no MFMA tiles at all, every output a lane-level chain (conv_u8_lanes_k)
-int conv_u8_patch_num_cfgs() { return 5; }
-int conv_u8_patch_bm(int cfg) { return cfg == U8P_LANES ? 64 : U8P_CFGS[cfg].wm * U8P_CFGS[cfg].tm * 16; }
-static int u8p_bn(int cfg) { return cfg == U8P_LANES ? 4 : U8P_CFGS[cfg].wn * U8P_CFGS[cfg].tn * 16; }
+// configurations 5 .. 8 (round 4): tile shapes 0 .. 3 with 2-D pixel tiles (8 rows x BN/8 columns) -- wide maps, where a run of 64
+// consecutive pixels drags 3-6 whole input rows per channel chunk into LDS (YOLOv3-tiny conv1 / conv2: 208- and 104-wide).
+// OPT-IN (TAMD_U8_PATCH_2D=1): byte-exact (tests/test_gpu_u8_patch.py::test_patch_conv_2d_tiles), but measured it only wins conv2
+// in isolation (61.6 vs 66.1 us) and not inside the pass (851.3 vs 856.6 us per step), and loses conv1 (cout 32, one chunk of K: a block
+// is all prologue and epilogue, 110-246 vs 83 us) -- profiles/r04_experiment_u8_patch_2d_tiles.txt
+static constexpr int U8P_2D = 5;
+int conv_u8_patch_num_cfgs() { return 9; }
+int conv_u8_patch_lanes_cfg() { return U8P_LANES; }
+static int u8p_base(int cfg) { return cfg >= U8P_2D ? cfg - U8P_2D : cfg; }
+int conv_u8_patch_bm(int cfg) { return cfg == U8P_LANES ? 64 : U8P_CFGS[u8p_base(cfg)].wm * U8P_CFGS[u8p_base(cfg)].tm * 16; }
+static int u8p_bn(int cfg) { return cfg == U8P_LANES ? 4 : U8P_CFGS[u8p_base(cfg)].wn * U8P_CFGS[u8p_base(cfg)].tn * 16; }
 int conv_u8_patch_ss(const U8ConvArgs& a) { return (a.pk_kh == 3 && a.pk_kw == 3) ? 9 : (a.pk_kh == 1 && a.pk_kw == 1) ? 4 : 0; }
 const char* conv_u8_patch_kernel_name(const U8ConvArgs& a)
 {
+    static const char* n2d[4] = {"conv_u8_patch_64x64<3x3,2d>", "conv_u8_patch_128x64<3x3,2d>", "conv_u8_patch_64x128<3x3,2d>", "conv_u8_patch_32x64<3x3,2d>"};
     if (a.pk_cfg == U8P_LANES) return a.pk_kh == 3 ? "conv_u8_lanes<3x3>" : "conv_u8_lanes<1x1>";
+    if (a.pk_cfg >= U8P_2D) return n2d[a.pk_cfg - U8P_2D];
     return a.pk_kh == 3 ? U8P_CFGS[a.pk_cfg].n3 : U8P_CFGS[a.pk_cfg].n1;
 }
 
@@ -843,6 +855,7 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
     const char* env = getenv("TAMD_U8_PATCH");
     const bool off = env && atoi(env) == 0;
     a.pk_cfg = -1;
+    a.pk_tw = 0;
     a.pk_kh = KH; a.pk_kw = KW; a.pk_dh = DH; a.pk_dw = DW;
     const int ss = conv_u8_patch_ss(a);
     const int OHW = a.OH * a.OW, N8 = OHW & ~7, bn = u8p_bn(cfg);
@@ -858,6 +871,22 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
         return true;
     }
     if (N8 == 0) return false;                                   // no main pixel: nothing for the MFMA tiles (the lanes configuration takes these)
+    a.pk_tw = 0;
+    if (cfg >= U8P_2D) {
+        // 2-D tiles: 3x3 only (a 1x1 patch is the tile's own pixels either way), whole tiles only, no tail pixels (the reference's
+        // main / tail split is a property of the ROW-MAJOR pixel index: with OH*OW % 8 == 0 every pixel is a main pixel in any order)
+        const char* e2 = getenv("TAMD_U8_PATCH_2D");
+        const int tw = bn / 8;
+        if (!(e2 && atoi(e2) == 1) || KH != 3 || OHW != N8 || a.OH % 8 != 0 || a.OW % tw != 0 || (a.pool.on && (tw & 1))) return false;
+        if ((size_t)a.C * a.H * a.W >= (1u << 31)) return false;
+        a.pk_wp = (tw - 1) * a.SW + (KW - 1) * DW + 1;
+        const int worst2 = (7 * a.SH + (KH - 1) * DH + 1) * a.pk_wp;
+        if (worst2 > 512) return false;
+        a.pk_tw = tw;
+        a.pk_npad = worst2 <= 256 ? 256 : 512;
+        a.pk_cfg = cfg;
+        return true;
+    }
     if ((size_t)a.C * a.H * a.W >= (1u << 31) || (size_t)a.K * 4 > 150 * 1024) return false;      // (the tail blocks keep an im2col column in LDS)
     if (KH == 1) { a.pk_wp = 0; a.pk_npad = bn; a.pk_cfg = cfg; return true; }      // the patch is the tile's own pixels
     a.pk_wp = (a.OW - 1) * a.SW + (KW - 1) * DW + 1;
@@ -925,7 +954,7 @@ hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s)
 #define U8P_GO(WM, WN, TM, TN)                                                                                                   \
     e = a.pk_kh == 1 ? go(conv_u8_patch_k<WM, WN, TM, TN, 1, 0>)                                                                  \
                      : a.pk_npad == 256 ? go(conv_u8_patch_k<WM, WN, TM, TN, 3, 256>) : go(conv_u8_patch_k<WM, WN, TM, TN, 3, 512>)
-    switch (a.pk_cfg) {
+    switch (u8p_base(a.pk_cfg)) {
     case 0: U8P_GO(2, 2, 2, 2); break;
     case 1: U8P_GO(4, 1, 2, 4); break;
     case 2: U8P_GO(2, 2, 2, 4); break;
@@ -1008,7 +1037,7 @@ __global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main
             const int co = co0 + i * 16 + 4 * kq;
             if (co >= a.cout) continue;
             const float s4[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-            u8_finish4(a, s4, co, n, OHW, pj, pj, false, rq_inv, tail);      // (no fused pool on this kernel: row-major pixels, opix == pj)
+            u8_finish4(a, s4, co, n, OHW, pj, 0, false, rq_inv, tail);       // (no fused pool on this kernel: row-major pixels, opix == pj)
         }
     };
     int t = gw / CT;                                     // this wave's first pixel tile; the next ones follow at a stride of lanes_of_ct

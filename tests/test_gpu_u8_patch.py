@@ -97,6 +97,42 @@ def test_models_with_the_patch_member_pinned(name, batch, res):
         assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
 
 
+# n, cin, h, w, cout, stride, pad, act, pool, configuration (TAMD_U8_PATCH_CFG: 5 .. 8 = the 2-D tile forms of 0 .. 3)
+TILE2D_CASES = [
+    (1, 16, 32, 48, 32, 1, 1, 0, False, 5),       # 8x8 tiles: 4 x 6 tiles, every tile touches at most two borders
+    (2, 16, 16, 208, 32, 1, 1, -1, False, 8),     # YOLO conv1 width, 32x64 configuration, batch 2
+    (1, 32, 24, 104, 64, 1, 1, 0, False, 6),      # 64x128 configuration: 8 x 16 tiles, 104 = 6.5 tiles -> NOT whole: must fall back to a 1-D form
+    (1, 32, 24, 96, 64, 1, 1, 6, False, 6),       # 8 x 16 tiles, whole
+    (1, 16, 32, 64, 24, 2, 1, 0, False, 5),       # stride 2: 16 x 32 outputs, 17 x 17 input floats per tile and channel (512-float planes)
+    (1, 16, 16, 48, 32, 1, 1, -1, True, 5),       # fused leaky ReLU + 2x2 pool: window-major inside the tile
+    (1, 16, 32, 208, 32, 1, 1, -1, True, 8),      # YOLO conv1 class under the pool
+    (1, 20, 16, 16, 70, 1, 1, 0, False, 7),       # C = 20 (five super-steps), cout 70, 128x64 configuration
+]
+
+
+@pytest.mark.parametrize("case", TILE2D_CASES, ids=[str(c) for c in TILE2D_CASES])
+def test_patch_conv_2d_tiles(case, monkeypatch):
+    """the 2-D pixel tiles of the patch kernel (configurations 5 .. 8): same bytes as the oracle and as the GEMM member"""
+    n, cin, h, w, cout, s, p, act, pool, cfg = case
+    monkeypatch.setenv("TAMD_U8_PATCH_CFG", str(cfg))     # with TAMD_U8_PATCH=1: this configuration alone where it applies
+    monkeypatch.setenv("TAMD_U8_PATCH_2D", "1")           # the 2-D forms are opt-in
+    if pool:
+        g, x = u8_conv_pool_graph(190 + cin + w, n, cin, h, w, cout, 3, p)
+    else:
+        g, x = u8_conv_graph(57 + cin + cout + w, n, cin, h, w, cout, 3, s, p, 1, act, True, 1)
+    want = oracle.run_graph(g, x)
+    got, kernels = run_with(g, x, "1")
+    whole = (h // s if s == 2 else h) % 8 == 0 and (w // s if s == 2 else w) % (16 if cfg == 6 else 8) == 0
+    assert any("conv_u8_patch" in kn for kn in kernels), kernels
+    if whole:          # (a map the pinned tile does not divide falls through to the next applicable form)
+        assert any("conv_u8_patch" in kn and "2d" in kn for kn in kernels), kernels
+    ref, _ = run_with(g, x, "0")
+    for wv, a, b in zip(want, got, ref):
+        a = a.reshape(wv.shape)
+        assert np.array_equal(a, wv), "%d / %d bytes differ from the oracle" % (np.count_nonzero(a != wv), wv.size)
+        assert np.array_equal(a, b.reshape(wv.shape))
+
+
 PW_CASES = [
     # n, cin, h, w, cout, act, bias      (1x1, stride 1, pad 0; K = cin in {32, 64})
     (2, 32, 20, 20, 64, 0, True),        # K = 32, 400 px: 25 column tiles, no tail
