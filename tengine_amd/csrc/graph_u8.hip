@@ -350,6 +350,20 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
             return 0;
         };
+        // conv_u8_c3 (shallow 3x3 layers of large maps) shares the 3x3 fragment-order weights and the tail blocks with the patch kernel
+        auto c3_ready = [&](U8ConvArgs& ac) -> int {
+            ac.pk_kh = ac.pk_kw = 3; ac.pk_dh = ac.pk_dw = 1; ac.pk_wp = 0; ac.pk_cfg = 0; ac.pk_npad = 256; ac.pk_tw = 0;
+            if (!pk_w) {
+                std::vector<float> wp(conv_u8_patch_packed_bytes(ac) / 4);
+                conv_u8_patch_pack(ac, w.data.data(), (uint8_t)qw.zp, qw.scale, wp.data());
+                if (upload(g, wp, &pk_w)) return -1;
+            }
+            ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
+            return 0;
+        };
+        const char* c3_env = getenv("TAMD_U8_C3");                     // 0: never, 1: wherever it applies (tests)
+        const bool c3_ok = conv_u8_c3_applicable(a, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w);
+        bool use_c3 = false;
         // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
         const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
         const bool rgb_ok = conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
@@ -376,10 +390,11 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                  p.stride_h, p.dilation_h, relu ? "+relu" : "", pool ? "+pool" : "");
         std::string cached;
         bool from_cache = false;
-        if (tune && !pk_force && !rgb_env && !pk_env && !pw_env && plan_cache_get(ckey, &cached) && cached.size() >= 2) {
+        if (tune && !pk_force && !rgb_env && !pk_env && !pw_env && !c3_env && plan_cache_get(ckey, &cached) && cached.size() >= 2) {
             const int c = atoi(cached.c_str() + 1);
             if (cached == "rgb" && rgb_ok) { use_rgb = true; from_cache = true; }
             else if (cached == "pw" && conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) { use_pw = true; from_cache = true; }
+            else if (cached == "c3" && c3_ok) { use_c3 = true; from_cache = true; }
             else if (cached[0] == 'g' && c >= 0 && c < conv_u8_gemm_num_cfgs()) {
                 U8ConvArgs ac = a; ac.cfg = c; ac.Kpad = rup(K, conv_u8_gemm_kc(c));
                 if (conv_u8_gemm_lds(ac) <= 150 * 1024) { a.cfg = c; from_cache = true; }      // the same filter the autotune applies
@@ -457,6 +472,14 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                     if (ms < best_ms * 0.96f) { use_pw = true; best_ms = ms; }
                 }
             }
+            if (c3_ok) {
+                U8ConvArgs ac = a;
+                if (c3_ready(ac)) return -1;
+                float ms = 1e30f;
+                if (time_of([&]() { return launch_conv_u8_c3(ac, g->stream); }, &ms)) return -1;
+                if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s: %s %.2f us (best so far %.2f us)\n", n.name.c_str(), conv_u8_c3_kernel_name(ac), 1e3 * ms, 1e3 * best_ms);
+                if (ms < best_ms * 0.96f) { use_c3 = true; use_pw = false; pk_best = -1; best_ms = ms; }
+            }
             if (rgb_ok) {
                 if (rgb_ready()) return -1;
                 float ms = 1e30f;
@@ -465,7 +488,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
             a.cfg = best_cfg;
-            plan_cache_put(ckey, use_rgb ? std::string("rgb") : use_pw ? std::string("pw") : pk_best >= 0 ? "p" + std::to_string(pk_best) : "g" + std::to_string(best_cfg));
+            plan_cache_put(ckey, use_rgb ? std::string("rgb") : use_c3 ? std::string("c3") : use_pw ? std::string("pw") : pk_best >= 0 ? "p" + std::to_string(pk_best) : "g" + std::to_string(best_cfg));
         }
         if (rgb_ok && rgb_env && atoi(rgb_env) == 1) use_rgb = true;
         if (pw_env && atoi(pw_env) == 1 && conv_u8_pw_applicable(a, p.kernel_h, p.kernel_w)) use_pw = true;
@@ -481,6 +504,14 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         st.wr.push_back(access_of(y));
         if (pool) st.wr.push_back(access_of(g->tensors[pool->out[0]]));
         st.deps = true;
+        if (c3_ok && c3_env && atoi(c3_env) == 1) use_c3 = true;
+        if (use_c3 && !use_rgb) {
+            if (c3_ready(a)) return -1;
+            st.kernel = std::string(conv_u8_c3_kernel_name(a)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");
+            st.fn = [a](hipStream_t s) { return launch_conv_u8_c3(a, s); };
+            g->steps.push_back(st);
+            return 0;
+        }
         if (use_rgb) {
             if (rgb_ready()) return -1;
             st.kernel = std::string(conv_u8_rgb3x3_kernel_name(rgb)) + (relu ? "+relu" : "") + (pool ? "+maxpool" : "");

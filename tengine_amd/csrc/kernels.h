@@ -385,6 +385,10 @@ hipError_t launch_conv_u8_patch(const U8ConvArgs& a, hipStream_t s);
 // shallow pointwise layers of large maps (K = 32 | 64): weights resident in registers, B straight from the NCHW input, one wave per tile
 bool conv_u8_pw_applicable(const U8ConvArgs& a, int KH, int KW);
 const char* conv_u8_pw_kernel_name(const U8ConvArgs& a);
+// shallow 3x3 layers of large maps (C = 16 | 32): weights resident in registers, the 3x3 gather straight from the NCHW input, one wave per tile
+bool conv_u8_c3_applicable(const U8ConvArgs& a, int KH, int KW, int DH, int DW);
+const char* conv_u8_c3_kernel_name(const U8ConvArgs& a);
+hipError_t launch_conv_u8_c3(const U8ConvArgs& a, hipStream_t s);
 hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s);
 // the integer path (u8i_kernels.hip); shares U8ConvArgs (geometry, fused ReLU / max-pool tails) with the byte-exact kernels
 int conv_u8i_num_cfgs();

@@ -1079,6 +1079,151 @@ hipError_t launch_conv_u8_pw(const U8ConvArgs& a, hipStream_t s)
 }
 
 // =================================================================================================================
+// Shallow 3x3 layers of large maps (YOLOv3-tiny conv1 / conv2: 16 -> 32 @ 208^2, 32 -> 64 @ 104^2; K = 144 | 288): K is one or two
+// patch chunks for 32 .. 64 output channels, so a conv_u8_patch block -- and a staging-GEMM block -- is all prologue and epilogue
+// there (88 / 66 us for 1.6 GMAC each; profiles/r04_experiment_u8_patch_2d_tiles.txt).  conv_u8_pw's shape with a 3x3 gather (round 4):
+// a WAVE keeps the weight fragments of its 16 * TM output channels for the WHOLE K in registers (the patch kernel's fragment stream,
+// read once: 9 floats per 16-row tile and super-step of 4 channels), walks 16-pixel tiles of the batch (window-major under a fused
+// pool, as everywhere), and gathers the B operand straight from the NCHW input: lane (pixel l15, kq) needs tap k = 4 s + kq of its
+// pixel for the nine steps of a super-step -- the (dy, dx, channel-in-group) of those nine k are the same in every super-step, so
+// nine per-lane offsets + a plane stride name them all; out-of-image taps enter as 0.0f; the bytes of super-step ss + 1 are requested
+// while ss multiplies.  Chain order: accumulator tile i receives its k in ascending steps of four (conv_u8_body's header) -- the
+// reference's single chain of a main pixel.  Tail pixels: conv_u8_patch_tail blocks behind the main grid.  No LDS operands, no barrier
+// in the loop.
+// =================================================================================================================
+template <int TM, int NSS>
+__global__ __launch_bounds__(256) void conv_u8_c3_k(const U8ConvArgs a, int main_blocks)
+{
+    constexpr int SS = 9, FRAG = SS * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // used by the tail blocks only
+    __shared__ uint8_t tail[512];                   // fused ReLU / pool nodes as byte tables (u8_epilogue.h)
+    u8_tail_tables(tail, threadIdx.x, 256, a.relu, a.out_scale, a.out_zp, a.pool);
+    if ((int)blockIdx.x >= main_blocks) {
+        conv_u8_patch_tail<3>(a, smem, blockIdx.x - main_blocks, tail);
+        return;
+    }
+    __syncthreads();                                // the only barrier of a main block: the tables before the first look-up
+    const float rq_inv = __fdiv_rn(1.0f, a.out_scale);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, PTI = (N8 + 15) / 16, CT = (a.cout + 16 * TM - 1) / (16 * TM);
+    const int nwaves = main_blocks * 4, gw = blockIdx.x * 4 + wave;
+    const int ct = gw % CT, stride = nwaves / CT;    // (main_blocks * 4 is a multiple of CT: the launcher rounds it)
+    const int co0 = ct * 16 * TM;
+    // ---- the weights of this wave: [tile16][super-step][2 float4 groups][lane] + [lane] (conv_u8_patch_pack, 3x3) ------------------
+    float4 af4[TM][NSS][2];
+    float afr[TM][NSS];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const float* wb = reinterpret_cast<const float*>(a.wpk) + (size_t)(co0 / 16 + i) * NSS * FRAG;
+#pragma unroll
+        for (int ss = 0; ss < NSS; ss++) {
+            af4[i][ss][0] = *reinterpret_cast<const float4*>(wb + ss * FRAG + lane * 4);
+            af4[i][ss][1] = *reinterpret_cast<const float4*>(wb + ss * FRAG + 256 + lane * 4);
+            afr[i][ss] = wb[ss * FRAG + 512 + lane];
+        }
+    }
+    // ---- the nine taps k = 4 s + kq of a super-step: channel-in-group, dy, dx --------------------------------------------------
+    const int chw = a.H * a.W;
+    int toff[SS], tdy[SS], tdx[SS];
+#pragma unroll
+    for (int s = 0; s < SS; s++) {
+        const int kl = 4 * s + kq, cl = kl / 9, tap = kl - 9 * cl, dy = tap / 3, dx = tap - 3 * dy;
+        toff[s] = cl * chw + dy * a.W + dx;
+        tdy[s] = dy; tdx[s] = dx;
+    }
+    const int total = a.N * PTI;
+    struct TileIn { const uint8_t* img; int base; unsigned okm; int n, oy, ox, pj; };
+    auto locate = [&](int t, TileIn& ti) __attribute__((always_inline)) {
+        const int tc = t < total ? t : total - 1;
+        ti.n = tc / PTI;
+        ti.pj = (tc - ti.n * PTI) * 16 + l15;
+        conv_pixel(a, ti.pj < N8 ? ti.pj : N8 - 1, &ti.oy, &ti.ox);
+        const int iy0 = ti.oy * a.SH - a.PH, ix0 = ti.ox * a.SW - a.PW;
+        ti.okm = 0;
+#pragma unroll
+        for (int s = 0; s < SS; s++)
+            ti.okm |= (((unsigned)(iy0 + tdy[s]) < (unsigned)a.H) & ((unsigned)(ix0 + tdx[s]) < (unsigned)a.W)) ? 1u << s : 0u;
+        ti.img = a.x + (size_t)ti.n * a.C * chw;
+        ti.base = iy0 * a.W + ix0;                       // (negative at the top-left border: only ever added to an in-image tap)
+    };
+    unsigned raw[2][SS];
+    auto bload = [&](auto D, const TileIn& ti, int ss) __attribute__((always_inline)) {
+        constexpr int d = decltype(D)::value;
+        // unconditional loads (an out-of-image tap reads the image's first byte and is replaced by 0.0f at conversion): written as
+        // `ok ? load : 0` every load sits in its own divergent branch
+        const int o = ti.base + 4 * ss * chw;
+#pragma unroll
+        for (int s = 0; s < SS; s++) raw[d][s] = ti.img[(ti.okm >> s & 1u) ? o + toff[s] : 0];
+    };
+    TileIn cur, nxt;
+    int t = gw / CT;                                     // this wave's first pixel tile; the next ones follow at `stride`
+    if (t >= total) return;
+    locate(t, cur);
+    bload(std::integral_constant<int, 0>{}, cur, 0);
+    for (; t < total; t += stride) {
+        locate(t + stride, nxt);
+        v4f acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; i++) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        u8_static_for<0, NSS>([&](auto SSI) {
+            constexpr int ss = decltype(SSI)::value, d = ss & 1;
+            // request the next super-step's bytes (or the next tile's first) before this one's are converted
+            if constexpr (ss + 1 < NSS) bload(std::integral_constant<int, d ^ 1>{}, cur, ss + 1);
+            else bload(std::integral_constant<int, d ^ 1>{}, nxt, 0);
+#pragma unroll
+            for (int s = 0; s < SS; s++) {
+                const float bv = (cur.okm >> s & 1u) ? dequant((uint8_t)raw[d][s], a.in_zp, a.in_scale) : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const float av = s == 8 ? afr[i][ss] : (s & 3) == 0 ? af4[i][ss][s >> 2].x : (s & 3) == 1 ? af4[i][ss][s >> 2].y : (s & 3) == 2 ? af4[i][ss][s >> 2].z : af4[i][ss][s >> 2].w;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        });
+        static_assert((NSS & 1) == 0, "the tile in flight lands in register set 0 again");
+        if (cur.pj < N8) {
+            const int opix = cur.oy * a.OW + cur.ox;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int co = co0 + i * 16 + 4 * kq;
+                if (co >= a.cout) continue;
+                const float s4[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                u8_finish4(a, s4, co, cur.n, OHW, opix, (cur.oy >> 1) * (a.OW >> 1) + (cur.ox >> 1), (l15 & 3) == 0, rq_inv, tail);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// 3x3, stride 1 | 2, dilation 1, group 1, C = 16 | 32 (4 | 8 super-steps, both even), at least one 16-pixel tile of main pixels.
+// TAMD_U8_C3=0: never; =1: wherever it applies (tests); default: plan-time race against the other members
+bool conv_u8_c3_applicable(const U8ConvArgs& a, int KH, int KW, int DH, int DW)
+{
+    const char* env = getenv("TAMD_U8_C3");
+    if (env && atoi(env) == 0) return false;
+    return KH == 3 && KW == 3 && DH == 1 && DW == 1 && (a.C == 16 || a.C == 32) && a.K == 9 * a.C && ((a.OH * a.OW) & ~7) >= 16
+           && (size_t)a.C * a.H * a.W < (1u << 31) && (size_t)a.K * 4 <= 150 * 1024;
+}
+
+const char* conv_u8_c3_kernel_name(const U8ConvArgs& a) { return a.C == 16 ? "conv_u8_c3<c16>" : "conv_u8_c3<c32>"; }
+
+hipError_t launch_conv_u8_c3(const U8ConvArgs& a, hipStream_t s)
+{
+    const int OHW = a.OH * a.OW, N8 = OHW & ~7, PTI = (N8 + 15) / 16;
+    const int tm = 2, CT = (a.cout + 16 * tm - 1) / (16 * tm);
+    const long items = (long)a.N * PTI * CT;             // (pixel tile, cout group) pairs; ~8 tiles per wave where the layer has them
+    long blocks = std::min<long>(std::max<long>((items + 31) / 32, std::min<long>(1024, (items + 3) / 4)), 4096);
+    while ((blocks * 4) % CT) blocks++;                  // waves a multiple of CT: a wave keeps ONE cout group for all its tiles
+    const int main_blocks = (int)blocks;
+    const int tail_blocks = (OHW - N8) * a.N * ((a.cout + 63) / 64);
+    const size_t lds = tail_blocks ? (size_t)a.K * 4 : 0;
+    const dim3 grid(main_blocks + tail_blocks, 1, 1);
+    if (a.C == 16) hipLaunchKernelGGL((conv_u8_c3_k<2, 4>), grid, dim3(256), lds, s, a, main_blocks);
+    else hipLaunchKernelGGL((conv_u8_c3_k<2, 8>), grid, dim3(256), lds, s, a, main_blocks);
+    return hipGetLastError();
+}
+
+// =================================================================================================================
 // First layers (3x3, <= 4 input channels, dilation 1: YOLOv3-tiny conv0, MobileNet / SSD conv0): K = 9*C is one
 // MFMA stage at most, so the GEMM kernel above is all set-up and epilogue there.  Here a thread owns one pixel, keeps
 // its K dequantised taps in registers and walks the output channels: weights are LDS broadcasts, each

@@ -133,6 +133,40 @@ def test_patch_conv_2d_tiles(case, monkeypatch):
         assert np.array_equal(a, b.reshape(wv.shape))
 
 
+# n, cin, h, w, cout, stride, pad, act, pool
+C3_CASES = [
+    (1, 16, 32, 48, 32, 1, 1, 0, False),          # YOLOv3-tiny conv1 class: C = 16 (four super-steps), two cout tiles
+    (2, 32, 24, 40, 64, 1, 1, 6, False),          # conv2 class: C = 32 (eight super-steps), two cout groups, relu6, batch 2
+    (3, 16, 21, 23, 24, 1, 1, -1, False),         # 483 px: 480 main + 3 tail pixels (patch-tail blocks), cout 24 (a tile and a half)
+    (1, 16, 33, 47, 70, 2, 1, 0, False),          # stride 2, 17 x 24 = 408 outputs, cout 70: three cout groups (waves % 3 == 0), ragged rows
+    (1, 32, 9, 9, 40, 1, 0, 0, False),            # no padding, 7 x 7 = 49 px: 48 main (three tiles) + 1 tail
+    (1, 16, 16, 48, 32, 1, 1, -1, True),          # fused leaky ReLU + 2x2 pool (window-major tiles, byte tables)
+    (2, 32, 32, 104, 64, 1, 1, -1, True),         # conv2 under the pool, batch 2
+]
+
+
+@pytest.mark.parametrize("case", C3_CASES, ids=[str(c) for c in C3_CASES])
+def test_shallow_3x3_wave_kernel(case, monkeypatch):
+    """conv_u8_c3 (weights resident in registers, 3x3 gather straight from the NCHW input) pinned with TAMD_U8_C3=1: the oracle's bytes
+    and the GEMM member's"""
+    n, cin, h, w, cout, s, p, act, pool = case
+    if pool:
+        g, x = u8_conv_pool_graph(230 + cin + w, n, cin, h, w, cout, 3, p)
+    else:
+        g, x = u8_conv_graph(91 + cin + cout + w, n, cin, h, w, cout, 3, s, p, 1, act, True, 1)
+    want = oracle.run_graph(g, x)
+    monkeypatch.setenv("TAMD_U8_C3", "1")
+    got, kernels = run_with(g, x, "0")
+    assert any(kn.startswith("conv_u8_c3") for kn in kernels), kernels
+    monkeypatch.setenv("TAMD_U8_C3", "0")
+    ref, kernels0 = run_with(g, x, "0")
+    assert not any(kn.startswith("conv_u8_c3") for kn in kernels0), kernels0
+    for wv, a, b in zip(want, got, ref):
+        a = a.reshape(wv.shape)
+        assert np.array_equal(a, wv), "%d / %d bytes differ from the oracle" % (np.count_nonzero(a != wv), wv.size)
+        assert np.array_equal(a, b.reshape(wv.shape))
+
+
 PW_CASES = [
     # n, cin, h, w, cout, act, bias      (1x1, stride 1, pad 0; K = cin in {32, 64})
     (2, 32, 20, 20, 64, 0, True),        # K = 32, 400 px: 25 column tiles, no tail
