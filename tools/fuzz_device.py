@@ -36,7 +36,8 @@ def main():
     while time.time() - t0 < a.seconds:
         patch = a.dtype == "uint8" and rng.random() < 0.6
         g, x = random_graph(rng, a.dtype, int(rng.choice([4, 4, 32])) if patch else 1)
-        for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS", "TAMD_U8_PATCH", "TAMD_U8_PATCH_CFG"):
+        for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS", "TAMD_U8_PATCH", "TAMD_U8_PATCH_CFG", "TAMD_U8_PATCH_2D",
+                  "TAMD_U8_C3", "TAMD_U8_DW_TH", "TAMD_U8_RGB_MFMA", "TAMD_DW_FORM"):
             os.environ.pop(k, None)
         if a.dtype == "int8":
             m = I8_MEMBERS[int(rng.integers(len(I8_MEMBERS)))]
@@ -44,12 +45,22 @@ def main():
                 os.environ["TAMD_FORCE_GEMM"] = m
             if rng.random() < 0.3:
                 os.environ["TAMD_FIRST_ROWS"] = "0"
+            if rng.random() < 0.7:                 # round 4: the depthwise launch forms (fragments per row x output rows per lane)
+                os.environ["TAMD_DW_FORM"] = str(rng.choice(["11", "12", "14", "21", "22"]))
         else:
             if rng.random() < 0.8:
                 os.environ["TAMD_U8_CFG"] = str(int(rng.integers(8)))
             if patch:                              # the patch convolution wherever it applies, a random tile configuration first
                 os.environ["TAMD_U8_PATCH"] = "1"
-                os.environ["TAMD_U8_PATCH_CFG"] = str(int(rng.integers(4)))
+                os.environ["TAMD_U8_PATCH_CFG"] = str(int(rng.integers(9)))      # round 4: 4 = lane-level chains, 5 .. 8 = 2-D pixel tiles
+                os.environ["TAMD_U8_PATCH_2D"] = "1"
+            # round 4: the wave-level shallow 3x3 kernel, the depthwise block heights, the first layer's main pixels on the matrix cores
+            if rng.random() < 0.5:
+                os.environ["TAMD_U8_C3"] = str(int(rng.integers(2)))
+            if rng.random() < 0.7:
+                os.environ["TAMD_U8_DW_TH"] = str(rng.choice(["1", "2", "4"]))
+            if rng.random() < 0.5:
+                os.environ["TAMD_U8_RGB_MFMA"] = "1" 
         want = oracle.run_graph(g, x)
         try:
             gr = capi.Graph(tm2.write_tm2(g))
@@ -68,7 +79,7 @@ def main():
             bad += d
             if d:
                 print("MISMATCH", g.name, [t.dims for t in g.tensors[:3]], g.nodes[-1].params,
-                      {k: os.environ.get(k) for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG")}, d, "of", w.size, flush=True)
+                      {k: v for k, v in os.environ.items() if k.startswith("TAMD_")}, d, "of", w.size, flush=True)
     print("%s: %d graphs, %d outputs, %d mismatches" % (a.dtype, graphs, tot, bad))
     print("kernels exercised:", dict(sorted(kernels.items())))
 
