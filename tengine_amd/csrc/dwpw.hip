@@ -1,0 +1,238 @@
+// int8 depthwise 3x3 (stride 1) -> pointwise 1x1 in ONE launch: the depthwise result is the GEMM's B operand and never leaves LDS.
+//
+// Arithmetic = dwconv.hip followed by the implicit-GEMM family, value for value: the depthwise output is formed as the int8 tensor
+// the reference stores between the two nodes (conv_dw_hcl_x86.c:42-95,97-269 / batch > 1: conv_kernel_ref_int8.c:42-177, with the
+// epilogue formula the planner selected for that node; bias, activation, requantisation, saturation), then multiplied
+// (conv_kernel_x86.c:1008-1630 sgemm_i8) and requantised with the pointwise node's own constants (:1796-1893).
+//
+// Why (round 4): MobileNet-v1 at batch 64 runs its 14x14 block unfused -- five (depthwise 8.4 us + pointwise 10.2-11.5 us) pairs, each
+// writing and re-reading a 6.4 MB tensor -- because the pointwise -> depthwise fusion (pwdw.hip) loses there to halo recomputation
+// (profiles/r04_pwdw_cfgs_b64.txt).  The other direction has no halo: a block owns 64 output pixels and ALL output channels.
+//
+//   * block = 512 threads, tile = 4 rows x 16 columns of the depthwise OUTPUT map, the rows counted through the whole batch (row index
+//     = image * OH + oy, so a 14-row map leaves no partial row tiles; columns >= OW are dead lanes);
+//   * K loop over the channels in stages of 128: (a) every thread computes one (4 adjacent pixels x 4 channels) unit of the depthwise
+//     layer -- dwconv.hip's scheme: dword loads with lanes along channels, 4x4 byte transposes, v_dot4 rows -- requantises it and
+//     writes four dwords into the stage's B buffer, granule-major [16-B channel granule][pixel] (a B fragment read is then 32
+//     consecutive 16-B units: conflict-free); (b) wave w multiplies output channels [64 w, 64 w + 64) x 64 pixels: 16
+//     v_mfma_i32_32x32x32_i8 per stage, A fragments straight from global memory in fragment order ([32-cout tile][32-k step][lane][16 B],
+//     packed by the planner), requested behind the MFMAs of the previous stage; two B buffers, one barrier per stage;
+//   * epilogue: requant4 + half-wave regroup -> one 16-byte store per lane and tile (gemm_epilogue.h's scheme on this tile's pixel map).
+#include "dw_common.h"
+#include "epilogue.h"
+#include "kernels.h"
+
+namespace tamd {
+
+typedef int v4i_dp __attribute__((ext_vector_type(4)));
+typedef int v16i_dp __attribute__((ext_vector_type(16)));
+
+// NW = waves along the output channels (cout <= 64 * NW); 512 threads always (the depthwise stage needs 512 units per 128 channels)
+template <int NW>
+__global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
+{
+    constexpr int KST = 128;                             // channels per stage
+    __shared__ __attribute__((aligned(16))) int8_t bs[2][KST / 16][64][16];      // [buffer][channel granule][pixel][16 B]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int rows_total = a.N * a.OH;
+    const int gr0 = blockIdx.x * 4;                      // first row (image * OH + oy) of the tile
+
+    // ---- this thread's depthwise unit: pixels (row ur, columns 4 ucg .. 4 ucg + 3), channels 4 cq .. 4 cq + 3 of the stage ----
+    const int cq = t & 31, pq = t >> 5, ur = pq >> 2, ucg = pq & 3;
+    const int ugr = min(gr0 + ur, rows_total - 1);       // (a dead row repeats the last live one: computed, never stored)
+    const int un = ugr / a.OH, uoy = ugr - un * a.OH;
+    const int8_t* xn = a.x + (size_t)un * a.H * a.W * a.cs_in + 4 * cq;
+    const int ixb = 4 * ucg - a.PW;
+    int pixoff[6];
+    unsigned colok = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const int ix = ixb + p;
+        const bool ok = (unsigned)ix < (unsigned)a.W;
+        pixoff[p] = (ok ? ix : 0) * a.cs_in;
+        colok |= ok ? 1u << p : 0u;
+    }
+    int rowoff[3];
+    unsigned rowok = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int iy = uoy - a.PH + r;
+        const bool ok = (unsigned)iy < (unsigned)a.H;
+        rowoff[r] = (ok ? iy : 0) * a.W * a.cs_in;
+        rowok |= ok ? 1u << r : 0u;
+    }
+    const Rq drq = a.dw_rq;
+    const int nst = (a.C + KST - 1) / KST;
+
+    // depthwise of stage `st` -> B buffer `buf`.  Channels past C (a ragged last stage) read the tensor's zero padding / repeat: their
+    // weights are zero rows of the pointwise fragments, so whatever they hold is multiplied by 0.
+    unsigned raw[3][6];
+    auto dw_load = [&](int st) {
+        const int c0 = min(st * KST + 4 * cq, a.cw - 4) - 4 * cq;      // keep the dword inside the padded channel row
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int p = 0; p < 6; p++) raw[r][p] = *reinterpret_cast<const unsigned*>(xn + rowoff[r] + pixoff[p] + c0);
+    };
+    auto dw_compute = [&](int st, int buf) {
+        const int c = min(st * KST + 4 * cq, a.cw - 4);
+        unsigned wrow[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.dw_w + ((size_t)r * a.cw + c) * 4);
+            wrow[r][0] = v.x; wrow[r][1] = v.y; wrow[r][2] = v.z; wrow[r][3] = v.w;
+        }
+        const int4 b4 = *reinterpret_cast<const int4*>(a.dw_bias + c);
+        const float4 s4 = *reinterpret_cast<const float4*>(a.dw_wscale + c);
+        int acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[j][k] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            unsigned d0[4], d1[4], f0[4], f1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) d0[q] = ((rowok >> r) & (colok >> q) & 1u) ? raw[r][q] : 0u;
+            d1[0] = ((rowok >> r) & (colok >> 4) & 1u) ? raw[r][4] : 0u;
+            d1[1] = ((rowok >> r) & (colok >> 5) & 1u) ? raw[r][5] : 0u;
+            d1[2] = 0u; d1[3] = 0u;
+            transpose4x4(d0, f0);
+            transpose4x4(d1, f1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc[0][k] = __builtin_amdgcn_sdot4((int)f0[k], (int)wrow[r][k], acc[0][k], false);
+                acc[1][k] = __builtin_amdgcn_sdot4((int)f0[k], (int)(wrow[r][k] << 8), acc[1][k], false);
+                acc[2][k] = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(f1[k], f0[k], 2), (int)wrow[r][k], acc[2][k], false);
+                acc[3][k] = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(f1[k], f0[k], 3), (int)wrow[r][k], acc[3][k], false);
+            }
+        }
+        const int cl = 4 * cq;                           // channel inside the stage
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned pk = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, c, drq);
+            *reinterpret_cast<unsigned*>(&bs[buf][cl >> 4][ur * 16 + 4 * ucg + j][cl & 15]) = pk;
+        }
+    };
+
+    // ---- pointwise: wave w -> output channels [64 w, 64 w + 64): two 32-row tiles, A fragments one stage ahead in registers ----
+    const int nk32 = nst * (KST / 32);
+    const int8_t* wf = a.pw_wfrag + ((size_t)(wave * 2) * nk32 * 64 + lane) * 16;       // tile 2w, step 0, this lane
+    v4i_dp af[2][KST / 32];                              // [cout tile][k step]: ONE stage of fragments
+    auto a_load = [&](int st) {
+        if (wave >= NW) return;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ks = 0; ks < KST / 32; ks++)
+                af[i][ks] = *reinterpret_cast<const v4i_dp*>(wf + ((size_t)i * nk32 + (size_t)(st < nst ? st : nst - 1) * (KST / 32) + ks) * 1024);
+    };
+    v16i_dp acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    auto mma = [&](int buf) {
+        if (wave >= NW) return;
+#pragma unroll
+        for (int ks = 0; ks < KST / 32; ks++) {
+            v4i_dp bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) bf[j] = *reinterpret_cast<const v4i_dp*>(&bs[buf][ks * 2 + hi][j * 32 + l31][0]);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i][ks], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- the stages: stage s multiplies, then the fragments of stage s + 1 are requested into the same registers (behind the MFMAs that
+    // read them) and the depthwise layer of stage s + 1 is computed into the other B buffer -- its ~150 VALU instructions hide the
+    // fragment fetch and run beside the matrix pipe; one barrier per stage
+    a_load(0);
+    dw_load(0);
+    dw_compute(0, 0);
+    if (nst > 1) dw_load(1);
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        mma(st & 1);
+        if (st + 1 < nst) {
+            a_load(st + 1);
+            dw_compute(st + 1, (st + 1) & 1);
+            if (st + 2 < nst) dw_load(st + 2);
+        }
+        __syncthreads();
+    }
+    if (wave >= NW) return;
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cout) ----
+    const Rq prq = a.pw_rq;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = j * 32 + l31, pr = p >> 4, pc = p & 15;
+        const int gr = gr0 + pr;
+        const bool live = gr < rows_total && pc < a.OW;
+        int8_t* yp = a.y + ((size_t)gr * a.OW + pc) * a.ldc + a.c_off;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int cb = (wave * 2 + i) * 32;
+            unsigned pk[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int c = cb + 8 * g4 + 4 * hi;
+                const int4 b4 = *reinterpret_cast<const int4*>(a.pw_bias + c);
+                const float4 s4 = *reinterpret_cast<const float4*>(a.pw_wscale + c);
+                pk[g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y, acc[i][j][4 * g4 + 2] + b4.z, acc[i][j][4 * g4 + 3] + b4.w, s4, c, prq);
+            }
+            half_wave_regroup(pk);
+            const int c16 = cb + hi * 16;
+            if (live && c16 < a.c_limit) *reinterpret_cast<uint4*>(yp + c16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+}
+
+// depthwise 3x3 stride 1 (any padding the map allows) feeding a pointwise 1x1 stride-1 convolution with no padding; output channels
+// in whole 64-channel wave slices up to 512, destination on 16-channel granularity (16-byte stores); OW <= 16 (one tile row spans the map)
+bool dwpw_applicable(const DwArgs& d, const ConvArgs& p)
+{
+    if (d.S != 1 || d.OW > 16 || d.C % 4 != 0 || d.cw < 4) return false;
+    if (p.KH != 1 || p.KW != 1 || p.SH != 1 || p.SW != 1 || p.PH != 0 || p.PW != 0 || p.elt.res) return false;
+    if (p.cout % 64 != 0 || p.cout > 512 || p.cin != d.C) return false;
+    if (((p.c_limit | p.c_off | p.ldc) & 15) != 0 || p.c_limit < p.cout) return false;
+    return p.N == d.N && p.H == d.OH && p.W == d.OW;
+}
+
+// A-fragment order of the pointwise weights: [32-cout tile][32-k step][lane = half * 32 + row][16 B]; `w` = [cout][cin] int8 (OIHW, 1x1);
+// k steps padded to whole 128-channel stages with zeros
+size_t dwpw_packed_bytes(int cout, int cin) { return (size_t)((cout + 31) / 32) * ((cin + 127) / 128 * 4) * 1024; }
+void dwpw_pack(const int8_t* w, int cout, int cin, int8_t* out)
+{
+    const int nk32 = (cin + 127) / 128 * 4;
+    for (size_t i = 0; i < dwpw_packed_bytes(cout, cin); i++) out[i] = 0;
+    for (int co = 0; co < cout; co++)
+        for (int k = 0; k < cin; k++) {
+            const int tile = co >> 5, row = co & 31, ks = k >> 5, half = (k >> 4) & 1;
+            out[(((size_t)tile * nk32 + ks) * 64 + half * 32 + row) * 16 + (k & 15)] = w[(size_t)co * cin + k];
+        }
+}
+
+hipError_t launch_dwpw(const DwPwArgs& a, hipStream_t s)
+{
+    const int blocks = (a.N * a.OH + 3) / 4;
+    switch (a.cout / 64) {
+    case 1: hipLaunchKernelGGL(dwpw_i8_kernel<1>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(dwpw_i8_kernel<2>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(dwpw_i8_kernel<3>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(dwpw_i8_kernel<4>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(dwpw_i8_kernel<5>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 6: hipLaunchKernelGGL(dwpw_i8_kernel<6>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 7: hipLaunchKernelGGL(dwpw_i8_kernel<7>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(dwpw_i8_kernel<8>, dim3(blocks), dim3(512), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tamd

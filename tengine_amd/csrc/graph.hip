@@ -671,6 +671,11 @@ struct FusedElt {            // an eltwise (+ReLU) node folded into the epilogue
 static thread_local FirstArgs g_last_first;
 static thread_local bool g_last_first_valid = false;
 static thread_local PoolArgs g_last_pool;
+// ... of the last depthwise 3x3 / implicit-GEMM convolution planned on this thread (dwpw.hip: depthwise -> pointwise in one launch)
+static thread_local DwArgs g_last_dw;
+static thread_local bool g_last_dw_valid = false;
+static thread_local ConvArgs g_last_gemm;
+static thread_local bool g_last_gemm_valid = false;
 
 static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = nullptr)
 {
@@ -754,6 +759,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
             a.ldc = y.cs; a.c_off = y.c_off; a.S = p.stride_h; a.PH = p.pad_h0; a.PW = p.pad_w0;
             st.kernel = dwconv3x3_kernel_name(a);
             st.fn = [a](hipStream_t s) { return launch_dwconv3x3(a, s); };
+            g_last_dw = a; g_last_dw_valid = true;
         } else {
             // ---- generic direct (first layer from NCHW, grouped, non-3x3 depthwise) ----
             std::vector<int8_t> wv(wd, wd + w.elems());
@@ -799,6 +805,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         a.mg_ow = ((1ull << 40) + (unsigned)y.w - 1) / (unsigned)y.w;
         a.M = y.n * y.h * y.w;
         a.cfg = -1;
+        g_last_gemm = a; g_last_gemm_valid = !fz;
         if (fz) {      // conv -> eltwise (-> relu) in one launch: the conv's own int8 rounding is kept, see epilogue.h
             HTensor& r = g->tensors[fz->res_tensor];
             HTensor& o = g->tensors[fz->out_tensor];
@@ -1182,6 +1189,59 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     return 0;
 }
 
+// ---- depthwise 3x3 (stride 1) + the pointwise conv that consumes it in one launch: dwpw.hip ------------------------------------
+// Called with the pair planned as two steps at s0, s0 + 1 (the depthwise step, then whichever GEMM-family member the pointwise race
+// chose).  Large batches only: at batch 1 the pointwise conv pairs with the depthwise BEHIND it instead (pwdw.hip), which this
+// fusion would take away.  TAMD_FUSE_DWPW=0 never, =2 always (tests); default: the faster of the two by plan-time timing.
+static int plan_dwpw(tamd_graph* g, HNode& dw, HNode& pw, size_t s0)
+{
+    const char* env = getenv("TAMD_FUSE_DWPW");
+    const int fmode = env ? atoi(env) : 1;
+    if (!fmode || !g_last_dw_valid || !g_last_gemm_valid || !dwpw_applicable(g_last_dw, g_last_gemm)) return 0;
+    const DwArgs& d = g_last_dw;
+    const ConvArgs& c = g_last_gemm;
+    if (fmode != 2 && (long)d.N * d.OH * d.OW < 4096) return 0;
+    const HTensor& w = g->tensors[pw.in[1]];
+    std::vector<int8_t> wp(dwpw_packed_bytes(c.cout, c.cin));
+    dwpw_pack((const int8_t*)w.data.data(), c.cout, c.cin, wp.data());
+    int8_t* dwf = nullptr;
+    if (upload(g, wp, &dwf)) return -1;
+    DwPwArgs a{};
+    a.x = d.x; a.dw_w = d.w; a.dw_bias = d.bias; a.dw_wscale = d.wscale; a.dw_rq = d.rq;
+    a.pw_wfrag = dwf; a.pw_bias = c.bias; a.pw_wscale = c.wscale; a.pw_rq = c.rq;
+    a.y = c.y;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.cs_in = d.cs_in; a.cw = d.cw; a.OH = d.OH; a.OW = d.OW; a.PH = d.PH; a.PW = d.PW;
+    a.cout = c.cout; a.ldc = c.ldc; a.c_off = c.c_off; a.c_limit = c.c_limit;
+    Step& sa = g->steps[s0];
+    Step& sb = g->steps[s0 + 1];
+    bool fuse = fmode == 2;
+    if (fmode != 2) {
+        char ckey[256];
+        snprintf(ckey, sizeof(ckey), "dwpw|%s|n%d %dx%d c%d>%d", sa.node.c_str(), d.N, d.OH, d.OW, d.C, c.cout);
+        std::string cached;
+        if (autotune_enabled() && plan_cache_get(ckey, &cached)) fuse = cached == "1";
+        else if (autotune_enabled()) {
+            float tf, ta, tb;
+            if (time_fn(g, [a](hipStream_t s) { return launch_dwpw(a, s); }, &tf) || time_fn(g, sa.fn, &ta) || time_fn(g, sb.fn, &tb)) return -1;
+            fuse = tf < 0.97f * (ta + tb);
+            if (getenv("TAMD_DEBUG")) fprintf(stderr, "[tamd] %s + %s: dwpw %.2f us vs %.2f + %.2f us -> %s\n", sa.node.c_str(), sb.node.c_str(), 1e3 * tf, 1e3 * ta, 1e3 * tb, fuse ? "fused" : "two launches");
+            plan_cache_put(ckey, fuse ? "1" : "0");
+        }
+    }
+    if (!fuse) return 0;
+    Step st;
+    st.node = sa.node + "+" + sb.node;
+    st.kernel = "dwpw_i8";
+    st.macs = sa.macs + sb.macs;
+    st.bytes = sa.bytes + sb.bytes;      // SURVEY 8(d) accounting, per layer: the intermediate tensor still counts as algorithmic bytes
+    st.fn = [a](hipStream_t s) { return launch_dwpw(a, s); };
+    st.rd.push_back(access_of(g->tensors[dw.in[0]])); st.wr.push_back(access_of(g->tensors[pw.out[0]])); st.deps = true;
+    g->steps.resize(s0);
+    g->steps.push_back(st);
+    g->fused_away[dw.out[0]] = 1;
+    return 1;
+}
+
 static int plan(tamd_graph* g)
 {
     // ---- 1. geometry + device buffers for every non-const tensor -------------------------------
@@ -1414,6 +1474,40 @@ static int plan(tamd_graph* g)
         }
         case TAMD_OP_CONV: {
             int tmode = -1, prod = 0;
+            // depthwise 3x3 whose only consumer is a pointwise conv (large batches): one launch, the depthwise map stays in LDS (dwpw.hip).
+            // `try_dwpw(dwi)`: the depthwise node dwi has just been planned as the LAST step (g_last_dw describes it); plans its
+            // pointwise consumer behind it and lets plan_dwpw turn the two steps into one.  1: fused (the consumer is marked), 0: the
+            // depthwise step stands alone and the consumer goes through the ordinary path later, -1: error
+            auto try_dwpw = [&](size_t dwi) -> int {
+                HNode& d = g->nodes[dwi];
+                const HTensor& dy = g->tensors[d.out[0]];
+                const char* dp_env = getenv("TAMD_FUSE_DWPW");
+                if ((dp_env && atoi(dp_env) == 0) || !g_last_dw_valid || d.p.conv.stride_h != 1 || count_consumers(g, d.out[0]) != 1 || dy.is_view) return 0;
+                if ((long)dy.n * dy.h * dy.w < 4096 && !(dp_env && atoi(dp_env) == 2)) return 0;
+                for (auto& o : g->outputs) if (o.tensor == d.out[0]) return 0;
+                int pw_node = -1;
+                for (size_t nj = dwi + 1; nj < g->nodes.size(); nj++)
+                    if (g->nodes[nj].op == TAMD_OP_CONV && g->nodes[nj].in.size() >= 2 && g->nodes[nj].in[0] == d.out[0] && !fused[nj] && !has_fuse[nj]
+                        && g->nodes[nj].p.conv.group == 1 && g->nodes[nj].p.conv.kernel_h == 1 && g->nodes[nj].p.conv.kernel_w == 1) { pw_node = (int)nj; break; }
+                if (pw_node < 0) return 0;
+                const size_t sdw = g->steps.size() - 1;
+                g_last_gemm_valid = false;
+                if (plan_conv(g, g->nodes[pw_node], false)) return -1;
+                int r = 0;
+                if (g->steps.size() == sdw + 2) r = plan_dwpw(g, d, g->nodes[pw_node], sdw);
+                if (r < 0) return -1;
+                if (r == 1) { fused[pw_node] = 1; return 1; }
+                g->steps.resize(sdw + 1);                      // not fused: forget the trial plan of the consumer
+                return 0;
+            };
+            if (!has_fuse[ni] && n.p.conv.group > 1 && n.p.conv.group == g->tensors[n.in[0]].c && n.p.conv.kernel_h == 3 && n.p.conv.stride_h == 1
+                && !g->tensors[n.in[0]].nchw_raw) {
+                const size_t s0 = g->steps.size();
+                g_last_dw_valid = false;
+                if (plan_conv(g, n, false)) return -1;
+                if (g->steps.size() == s0 + 1 && try_dwpw(ni) < 0) return -1;
+                break;
+            }
             // stem: first-layer convolution whose only consumer is a MAX pool 3x3 / 2 -> one launch, the conv map stays in LDS
             // (TAMD_FIRST_POOL=0: two launches, for A/B runs and the fused == unfused tests)
             if (!has_fuse[ni] && g->tensors[n.in[0]].nchw_raw && count_consumers(g, n.out[0]) == 1) {
@@ -1450,10 +1544,14 @@ static int plan(tamd_graph* g)
                 // the pair is planned here, the tail ahead of its node order (its only input is this conv's output), then
                 // possibly replaced by ONE fused launch
                 const size_t s0 = g->steps.size();
+                g_last_dw_valid = false;
                 if (plan_conv(g, n, false)) return -1;
                 if (tmode == 0 ? plan_pool(g, g->nodes[tail]) : plan_conv(g, g->nodes[tail], false)) return -1;
                 fused[tail] = 1;
+                g_last_dw_valid = g_last_dw_valid && tmode == 1;
                 if (g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, prod, s0)) return -1;
+                // the pair stayed two launches: the depthwise tail may still go together with ITS consumer (dwpw.hip)
+                if (tmode == 1 && g->steps.size() == s0 + 2 && try_dwpw((size_t)tail) < 0) return -1;
                 break;
             }
             if (plan_conv(g, n, false, has_fuse[ni] ? &fuse_at[ni] : nullptr)) return -1;

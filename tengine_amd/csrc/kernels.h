@@ -81,6 +81,17 @@ struct DwArgs {
     RqArgs rq;             // requantisation constants, see epilogue.h (wscale[] holds M[c])
 };
 
+struct DwPwArgs {          // depthwise 3x3 (stride 1) -> pointwise 1x1 in one launch (dwpw.hip): the depthwise result only exists in LDS
+    const int8_t* x;       // NHWC input of the depthwise conv (channel offset applied)
+    const int8_t* dw_w;    // DwArgs::w
+    const int32_t* dw_bias; const float* dw_wscale; RqArgs dw_rq;
+    const int8_t* pw_wfrag;        // pointwise weights in A-fragment order (dwpw_pack)
+    const int32_t* pw_bias; const float* pw_wscale; RqArgs pw_rq;
+    int8_t* y;             // NHWC output of the pointwise conv
+    int N, H, W, C, cs_in, cw, OH, OW, PH, PW;     // depthwise geometry (C channels in and out, cw = roundup(C, 16))
+    int cout, ldc, c_off, c_limit;                 // pointwise output
+};
+
 struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.hip)
     const int8_t* x;       // NHWC input of the pointwise conv (channel offset applied)
     const int8_t* wf;      // pointwise weights in MFMA fragment order: [16-channel slice][64-deep K step][64 lanes][16 B]
@@ -220,6 +231,10 @@ bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_pw_rows(const ConvArgs& a, hipStream_t s);       // 1x1, shallow K, many pixels: row-major epilogue, persistent pipelined waves
 bool pw_rows_applicable(const ConvArgs& a);
 hipError_t launch_conv_first(const FirstArgs& a, hipStream_t s);
+bool dwpw_applicable(const DwArgs& d, const ConvArgs& p);
+size_t dwpw_packed_bytes(int cout, int cin);
+void dwpw_pack(const int8_t* w, int cout, int cin, int8_t* out);        // w: [cout][cin] (OIHW, 1x1)
+hipError_t launch_dwpw(const DwPwArgs& a, hipStream_t s);
 bool conv_first_pool_applicable(const FirstArgs& c, const PoolArgs& p);
 FirstPoolArgs conv_first_pool_args(const FirstArgs& c, const PoolArgs& p);
 hipError_t launch_conv_first_pool(const FirstPoolArgs& a, hipStream_t s);

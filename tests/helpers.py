@@ -355,6 +355,35 @@ def stem_graph(seed, n, h, w, c, kw=7, pad=3, act=0, caffe=1, pool_k=3, pool_s=2
     return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
 
 
+def dwpw_graph(seed, n, c, h, w, cout, p=1, act_dw=0, act_pw=0, bias=True):
+    """int8: depthwise 3x3 stride 1 (pad p) -> pointwise 1x1 (c -> cout): the pair dwpw.hip runs as one launch"""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="dwpw_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, c, h, w], DT_INT8, [xs], [0])
+    dq = rng.integers(-127, 128, size=(c, 1, 3, 3)).astype(np.int8)
+    dsc = _scales(rng, c)
+    dins = [x, g.add_const("w_dw", dq, DT_INT8, dsc, [0] * c)]
+    if bias:
+        dins.append(g.add_const("b_dw", rng.integers(-2000, 2000, size=(c,)).astype(np.int32), DT_INT32, [1.0], [0]))
+    oh, ow = h - 3 + 2 * p + 1, w - 3 + 2 * p + 1
+    ms = float(np.float32(xs * np.mean(dsc) * 73.0 * 3.0 * 73.0 / 60.0))
+    mid = g.add_tensor("mid", [n, c, oh, ow], DT_INT8, tm2.TT_VAR, None, [ms], [0])
+    g.add_node("dw", "Convolution", dins, [mid], kernel_h=3, kernel_w=3, stride_h=1, stride_w=1, dilation_h=1, dilation_w=1,
+               input_channel=c, output_channel=c, group=c, activation=act_dw, pad_h0=p, pad_w0=p, pad_h1=p, pad_w1=p)
+    wq = rng.integers(-127, 128, size=(cout, c, 1, 1)).astype(np.int8)
+    ws = _scales(rng, cout)
+    pins = [mid, g.add_const("w_pw", wq, DT_INT8, ws, [0] * cout)]
+    if bias:
+        pins.append(g.add_const("b_pw", rng.integers(-2000, 2000, size=(cout,)).astype(np.int32), DT_INT32, [1.0], [0]))
+    os_ = float(np.float32(ms * np.mean(ws) * 73.0 * np.sqrt(c) * 73.0 / 60.0))
+    y = g.add_tensor("out", [n, cout, oh, ow], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+    ni = g.add_node("pw", "Convolution", pins, [y], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1, dilation_w=1,
+                    input_channel=c, output_channel=cout, group=1, activation=act_pw, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)
+
+
 def priorbox_graph(seed, dtype, img_h, img_w, feats, min_sizes, max_sizes, ratios, flip=1, clip=0, offset=0.5, step=0.0,
                    img_param=0, variance=(0.1, 0.1, 0.2, 0.2), q=(2.0 / 255, 63)):
     """data -> chain of ReLU + max-pool nodes down to each (h, w) of `feats` -> one PriorBox per feature map -> Concat(axis 2):
