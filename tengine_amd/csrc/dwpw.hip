@@ -18,6 +18,8 @@
 //     v_mfma_i32_32x32x32_i8 per stage, A fragments straight from global memory in fragment order ([32-cout tile][32-k step][lane][16 B],
 //     packed by the planner), requested behind the MFMAs of the previous stage; two B buffers, one barrier per stage;
 //   * epilogue: requant4 + half-wave regroup -> one 16-byte store per lane and tile (gemm_epilogue.h's scheme on this tile's pixel map).
+#include <type_traits>
+
 #include "dw_common.h"
 #include "epilogue.h"
 #include "kernels.h"
@@ -66,15 +68,17 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
 
     // depthwise of stage `st` -> B buffer `buf`.  Channels past C (a ragged last stage) read the tensor's zero padding / repeat: their
     // weights are zero rows of the pointwise fragments, so whatever they hold is multiplied by 0.
-    unsigned raw[3][6];
-    auto dw_load = [&](int st) {
+    unsigned raw[2][3][6];                               // two sets: the taps of stage s + 2 are requested before stage s + 1 is computed
+    auto dw_load = [&](auto D, int st) {
+        constexpr int d = decltype(D)::value;
         const int c0 = min(st * KST + 4 * cq, a.cw - 4) - 4 * cq;      // keep the dword inside the padded channel row
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int p = 0; p < 6; p++) raw[r][p] = *reinterpret_cast<const unsigned*>(xn + rowoff[r] + pixoff[p] + c0);
+            for (int p = 0; p < 6; p++) raw[d][r][p] = *reinterpret_cast<const unsigned*>(xn + rowoff[r] + pixoff[p] + c0);
     };
-    auto dw_compute = [&](int st, int buf) {
+    auto dw_compute = [&](auto D, int st, int buf) {
+        constexpr int d = decltype(D)::value;
         const int c = min(st * KST + 4 * cq, a.cw - 4);
         unsigned wrow[3][4];
 #pragma unroll
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
         for (int r = 0; r < 3; r++) {
             unsigned d0[4], d1[4], f0[4], f1[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) d0[q] = ((rowok >> r) & (colok >> q) & 1u) ? raw[r][q] : 0u;
-            d1[0] = ((rowok >> r) & (colok >> 4) & 1u) ? raw[r][4] : 0u;
-            d1[1] = ((rowok >> r) & (colok >> 5) & 1u) ? raw[r][5] : 0u;
+            for (int q = 0; q < 4; q++) d0[q] = ((rowok >> r) & (colok >> q) & 1u) ? raw[d][r][q] : 0u;
+            d1[0] = ((rowok >> r) & (colok >> 4) & 1u) ? raw[d][r][4] : 0u;
+            d1[1] = ((rowok >> r) & (colok >> 5) & 1u) ? raw[d][r][5] : 0u;
             d1[2] = 0u; d1[3] = 0u;
             transpose4x4(d0, f0);
             transpose4x4(d1, f1);
@@ -151,17 +155,28 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
     // ---- the stages: stage s multiplies, then the fragments of stage s + 1 are requested into the same registers (behind the MFMAs that
     // read them) and the depthwise layer of stage s + 1 is computed into the other B buffer -- its ~150 VALU instructions hide the
     // fragment fetch and run beside the matrix pipe; one barrier per stage
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     a_load(0);
-    dw_load(0);
-    dw_compute(0, 0);
-    if (nst > 1) dw_load(1);
+    dw_load(I0{}, 0);
+    if (nst > 1) dw_load(I1{}, 1);
+    dw_compute(I0{}, 0, 0);
+    if (nst > 2) dw_load(I0{}, 2);
     __syncthreads();
-    for (int st = 0; st < nst; st++) {
-        mma(st & 1);
+    for (int st = 0; st < nst; st += 2) {
+        mma(0);
         if (st + 1 < nst) {
             a_load(st + 1);
-            dw_compute(st + 1, (st + 1) & 1);
-            if (st + 2 < nst) dw_load(st + 2);
+            dw_compute(I1{}, st + 1, 1);
+            if (st + 3 < nst) dw_load(I1{}, st + 3);
+        }
+        __syncthreads();
+        if (st + 1 >= nst) break;
+        mma(1);
+        if (st + 2 < nst) {
+            a_load(st + 2);
+            dw_compute(I0{}, st + 2, 0);
+            if (st + 4 < nst) dw_load(I0{}, st + 4);
         }
         __syncthreads();
     }
