@@ -1490,6 +1490,11 @@ static int plan(tamd_graph* g)
                     if (g->nodes[nj].op == TAMD_OP_CONV && g->nodes[nj].in.size() >= 2 && g->nodes[nj].in[0] == d.out[0] && !fused[nj] && !has_fuse[nj]
                         && g->nodes[nj].p.conv.group == 1 && g->nodes[nj].p.conv.kernel_h == 1 && g->nodes[nj].p.conv.kernel_w == 1) { pw_node = (int)nj; break; }
                 if (pw_node < 0) return 0;
+                {   // what dwpw_applicable will ask of the shapes, before the consumer is planned (and its weights uploaded) for nothing
+                    const HTensor& py = g->tensors[g->nodes[pw_node].out[0]];
+                    const tamd_conv_param& q = g->nodes[pw_node].p.conv;
+                    if (py.c % 64 != 0 || py.c > 512 || dy.w > 16 || q.stride_h != 1 || q.stride_w != 1 || q.pad_h0 || q.pad_w0 || q.pad_h1 || q.pad_w1) return 0;
+                }
                 const size_t sdw = g->steps.size() - 1;
                 g_last_gemm_valid = false;
                 if (plan_conv(g, g->nodes[pw_node], false)) return -1;
