@@ -136,7 +136,8 @@ def main():
 
     # ---- model: rank 0 synthesises the int8 tmfile, RCCL broadcast of the raw bytes ----------------
     if rank == 0:
-        g = models.build(args.model, args.dtype, args.batch, device_only=(args.model != "mobilenet_v1"))
+        # the benchmark graph as tm_benchmark runs it, classifier Softmax included (ResNet-50 int8: softmax_i8 since round 4)
+        g = models.build(args.model, args.dtype, args.batch)
         tm_bytes = tm2.write_tm2(g)
     if use_dist:
         # RCCL over xGMI, once, outside the timed loop (tengine_amd/dist.py; gloo-tested on CPU)
@@ -670,7 +671,7 @@ def dry_run(args, rank, world):
         counts = [tdist.shard_range(total, world, r)[1] for r in range(world)]
         tm_bytes = None
         if rank == 0:
-            tm_bytes = tm2.write_tm2(models.build(args.model, args.dtype, 1, device_only=(args.model != "mobilenet_v1")))
+            tm_bytes = tm2.write_tm2(models.build(args.model, args.dtype, 1))
         tm_bytes = tdist.broadcast_tmfile(tm_bytes, dist, "cpu")
         g = tm2.read_tm2(tm_bytes)
         outs = [g.tensors[g.nodes[ni].outputs[0]] for ni in g.output_nodes]

@@ -250,6 +250,16 @@ def softmax_uint8(x, axis, in_q, out_q):
     return y
 
 
+def softmax_int8(x, axis, in_scale, out_scale):
+    x = np.ascontiguousarray(x, np.int8)
+    axis = axis % x.ndim
+    outer = int(np.prod(x.shape[:axis])) if axis else 1
+    inner = int(np.prod(x.shape[axis + 1:])) if axis + 1 < x.ndim else 1
+    y = np.empty_like(x)
+    lib().orc_softmax_int8(_p(x), _p(y), outer, x.shape[axis], inner, C.c_float(in_scale), C.c_float(out_scale))
+    return y
+
+
 def priorbox(feat_dims, data_dims, p, dtype, out_q=None):
     """PriorBox node (priorbox_ref.c:53-213): [1, 2, out_dim, 1] in the output tensor's dtype."""
     fa = lambda v: np.ascontiguousarray(v, np.float32)
@@ -357,6 +367,8 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
             y = a.reshape(g.tensors[o0].dims)
         elif op == "Softmax" and dt == DT_UINT8:
             y = softmax_uint8(a, p.get("axis", 1), qp(i0), qp(o0))
+        elif op == "Softmax" and dt == DT_INT8:
+            y = softmax_int8(a, p.get("axis", 1), sc(i0), sc(o0))
         elif op == "Flatten":       # flatten/flatten_ref.c:53-77: element copy; shape [n, prod(rest)] (flatten.c:34-61)
             y = a.reshape(a.shape[0], -1)
         elif op == "Concat" and dt == DT_UINT8:

@@ -247,6 +247,43 @@ ORC_API int orc_eltwise_int8(const int8_t* a, const int8_t* b, int8_t* y, size_t
     return 0;
 }
 
+/* int8 softmax -- softmax/softmax_kernel_ref_int8.c:41-117 with softmax_kernel_ref.h:35-85: f = (float)q * in_scale
+ * (:86-89); per (outer, inner) position: max over the axis (softmax_kernel_ref.h:35-50), out = (float)exp((double)(f - max))
+ * -- C `exp`, i.e. the DOUBLE routine, rounded to float on the store (:67) --, sum accumulated in fp32 in axis order
+ * (:68), out / sum (:72-79); y = round(out / out_scale) clamp +-127 (:101-111).  Zero points are not read.      */
+ORC_API int orc_softmax_int8(const int8_t* x, int8_t* y, int out_size, int on_size, int in_size, float in_scale,
+                             float out_scale)
+{
+    float* f = (float*)malloc(sizeof(float) * (size_t)on_size * in_size);
+    float* o = (float*)malloc(sizeof(float) * (size_t)on_size * in_size);
+    float* mx = (float*)malloc(sizeof(float) * (size_t)in_size);
+    float* sm = (float*)malloc(sizeof(float) * (size_t)in_size);
+    for (int i = 0; i < out_size; i++)
+    {
+        const int8_t* xi = x + (size_t)i * on_size * in_size;
+        int8_t* yi = y + (size_t)i * on_size * in_size;
+        for (int j = 0; j < on_size * in_size; j++) f[j] = (float)xi[j] * in_scale;
+        for (int l = 0; l < in_size; l++) mx[l] = f[l];
+        for (int j = 0; j < on_size; j++)
+            for (int l = 0; l < in_size; l++)
+                if (mx[l] < f[j * in_size + l]) mx[l] = f[j * in_size + l];
+        for (int l = 0; l < in_size; l++) sm[l] = 0.f;
+        for (int j = 0; j < on_size; j++)
+            for (int l = 0; l < in_size; l++)
+            {
+                o[j * in_size + l] = (float)exp((double)(f[j * in_size + l] - mx[l]));
+                sm[l] = sm[l] + o[j * in_size + l];
+            }
+        for (int j = 0; j < on_size * in_size; j++)
+        {
+            float v = o[j] / sm[j % in_size];
+            yi[j] = sat_i8((int)round((double)(v / out_scale)));
+        }
+    }
+    free(f); free(o); free(mx); free(sm);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * fp32 (tolerance 1e-4, order-free): conv = im2col+sgemm+bias+relu/relu6 (conv_kernel_x86.c:1632-1701),
  * fc (fc_ref.c:52-83), pooling (pooling_kernel_ref_fp32.c).  Accumulated in double here so the oracle is

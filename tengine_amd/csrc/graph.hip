@@ -1316,7 +1316,8 @@ static int plan(tamd_graph* g)
             bool is_out = false, dword_producer = false;
             for (auto& o : g->outputs) is_out |= (o.tensor == (int)i);
             for (auto& n : g->nodes)
-                if (!n.out.empty() && n.out[0] == (int)i) dword_producer = (n.op == TAMD_OP_CONV || n.op == TAMD_OP_FC || n.op == TAMD_OP_POOL);
+                if (!n.out.empty() && n.out[0] == (int)i)
+                    dword_producer = (n.op == TAMD_OP_CONV || n.op == TAMD_OP_FC || n.op == TAMD_OP_POOL || n.op == TAMD_OP_SOFTMAX);   // (softmax: byte stores, any stride)
             if (is_out && dword_producer) t.cs = t.c;
         }
         own.push_back(i);
@@ -1568,6 +1569,25 @@ static int plan(tamd_graph* g)
         case TAMD_OP_POOL:
             if (plan_pool(g, n)) return -1;
             break;
+        case TAMD_OP_SOFTMAX: {            // ResNet-50's prob; softmax_kernel_ref_int8.c over the channel axis
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            int ax = n.p.softmax.axis < 0 ? n.p.softmax.axis + (int)x.dims.size() : n.p.softmax.axis;
+            if (ax != 1 || (x.dims.size() != 2 && x.dims.size() != 4) || x.c < 1 || x.c > kSoftmaxI8MaxC) {
+                set_error("softmax %s is not supported on the device: int8 softmax runs over the channel axis of a 2-D / 4-D tensor of at most %d channels",
+                          n.name.c_str(), kSoftmaxI8MaxC);
+                return -1;
+            }
+            if (x.scales.empty() || y.scales.empty()) { set_error("softmax %s: missing quant params", n.name.c_str()); return -1; }
+            SoftmaxI8Args a{};
+            a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr + y.c_off;
+            a.positions = (long)x.n * x.h * x.w; a.C = x.c; a.cs_in = x.cs; a.cs_out = y.cs;
+            a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
+            Step st; st.node = n.name; st.kernel = "softmax_i8"; st.bytes = 2.0 * a.positions * x.c;
+            st.fn = [a](hipStream_t s) { return launch_softmax_i8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
         case TAMD_OP_RELU: {
             HTensor& x = g->tensors[n.in[0]];
             HTensor& y = g->tensors[n.out[0]];
@@ -1903,7 +1923,8 @@ int tamd_op_supported(int op, int dtype)
     if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
     if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
     if (op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
-    if (op == TAMD_OP_SOFTMAX || op == TAMD_OP_RESHAPE || op == TAMD_OP_PRIORBOX) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
+    if (op == TAMD_OP_SOFTMAX) return 1;                           // int8: over the channel axis only (tamd_node_supported)
+    if (op == TAMD_OP_RESHAPE || op == TAMD_OP_PRIORBOX) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
     if (op == TAMD_OP_PERMUTE) return dtype == TAMD_DT_UINT8;      // SSD heads (Permute -> Flatten -> Concat), uint8 graphs
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
@@ -1963,6 +1984,14 @@ int tamd_node_supported(const tamd_node_desc* n, const tamd_tensor_desc* in, int
         if (ax < 0) ax += out[0].dim_num;
         if (dt == TAMD_DT_INT8) return ax == 1 && out[0].dim_num >= 2;       // NHWC device tensors: channel concat
         return ax >= 0 && ax < out[0].dim_num;                               // dense NCHW: any axis
+    }
+    case TAMD_OP_SOFTMAX: {
+        if (dt != TAMD_DT_INT8) return 1;
+        // int8 tensors are NHWC on the device: the channel axis of a 2-D / 4-D tensor is the contiguous one (softmax_i8_kernel)
+        if (n_in < 1 || (in[0].dim_num != 2 && in[0].dim_num != 4) || in[0].ttype == TAMD_TT_CONST) return 0;
+        int ax = n->param ? ((const tamd_softmax_param*)n->param)->axis : 1;
+        if (ax < 0) ax += in[0].dim_num;
+        return ax == 1 && in[0].dims[1] >= 1 && in[0].dims[1] <= kSoftmaxI8MaxC;
     }
     case TAMD_OP_PRIORBOX: {
         if (!n->param || n_in < 2 || in[0].dim_num != 4 || in[1].dim_num != 4 || out[0].dim_num < 1 || out[0].dims[0] != 1) return 0;

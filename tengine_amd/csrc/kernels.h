@@ -195,6 +195,14 @@ struct ReluArgs {
     const int8_t* x; int8_t* y; size_t count; float slope, in_scale, out_scale;
 };
 
+struct SoftmaxI8Args {     // softmax over the channels of an NHWC int8 tensor (a view's channel slice included)
+    const int8_t* x; int8_t* y;
+    long positions;        // N * H * W
+    int C, cs_in, cs_out;
+    float in_scale, out_scale;
+};
+constexpr int kSoftmaxI8MaxC = 16384;      // one wave keeps the axis' exponentials in LDS (64 KB)
+
 struct CatCopyArgs {       // one concat input that cannot be written in place: (re-scaling) copy into its channel slice
     const int8_t* x; int8_t* y;
     long pixels;
@@ -253,6 +261,7 @@ int pwdw_steps(int nsteps);
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);
 hipError_t launch_relu(const ReluArgs& a, hipStream_t s);
+hipError_t launch_softmax_i8(const SoftmaxI8Args& a, hipStream_t s);
 hipError_t launch_concat_copy_i8(const CatCopyArgs& a, hipStream_t s);
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // 16-byte aligned buffers
 hipError_t launch_nchw_to_nhwc(const LayoutArgs& a, hipStream_t s);

@@ -251,6 +251,49 @@ hipError_t launch_relu(const ReluArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- softmax over the channel axis: softmax/softmax_kernel_ref_int8.c:41-117 over softmax_kernel_ref.h:35-85 ------------------
+// f = (float)q * in_scale; per position: max over the axis; o = (float)exp((double)(f - max)) -- the reference calls C `exp` on a
+// float argument, i.e. the DOUBLE routine, and rounds to float on the store (:67); the sum is accumulated in fp32 IN AXIS ORDER
+// (:68) -- a dependent chain, so one lane adds the exponentials out of LDS; o / sum; y = round(o / out_scale), clamp +-127.
+// exp runs in fp64 here too (ocml, <= 1 ulp): see softmax_u8_kernel (u8_kernels.hip) for what that can and cannot change.
+// One wave per position (ResNet-50's prob: 1000 channels; NHWC keeps the axis contiguous), NW positions per block; the waves of
+// a block never meet, so there is no block-level barrier and a wave past the last position just leaves.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void softmax_i8_kernel(SoftmaxI8Args a)
+{
+    extern __shared__ float softmax_e[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * NW + wave;
+    if (p >= a.positions) return;
+    float* e = softmax_e + (size_t)wave * a.C;
+    const int8_t* x = a.x + (size_t)p * a.cs_in;
+    int8_t* y = a.y + (size_t)p * a.cs_out;
+    float mx = -__builtin_inff();
+    for (int j = lane; j < a.C; j += 64) mx = fmaxf(mx, __fmul_rn((float)x[j], a.in_scale));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    for (int j = lane; j < a.C; j += 64) e[j] = (float)exp((double)__fsub_rn(__fmul_rn((float)x[j], a.in_scale), mx));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float sum = 0.f;
+    if (lane == 0)
+        for (int j = 0; j < a.C; j++) sum = __fadd_rn(sum, e[j]);
+    sum = __shfl(sum, 0, 64);
+    for (int j = lane; j < a.C; j += 64) y[j] = (int8_t)round_sat(__fdiv_rn(__fdiv_rn(e[j], sum), a.out_scale));
+}
+
+hipError_t launch_softmax_i8(const SoftmaxI8Args& a, hipStream_t s)
+{
+    if (a.C < 1 || a.C > kSoftmaxI8MaxC) return hipErrorInvalidValue;
+    if (a.C <= 2048) {
+        hipLaunchKernelGGL(softmax_i8_kernel<4>, dim3((unsigned)((a.positions + 3) / 4)), dim3(256), (size_t)4 * a.C * sizeof(float), s, a);
+    } else {
+        hipLaunchKernelGGL(softmax_i8_kernel<1>, dim3((unsigned)a.positions), dim3(64), (size_t)a.C * sizeof(float), s, a);
+    }
+    return hipGetLastError();
+}
+
 // ---- layout at the subgraph edges (the IR is NCHW: source/operator/prototype/convolution.c:60-70) ----
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)

@@ -659,7 +659,9 @@ def strip_tail(g: Graph, ops=("Softmax",)) -> Graph:
 
 
 def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
-    """`device_only`: strip the tail ops the HIP device leaves to the CPU subgraph (Softmax)."""
+    """`device_only`: without the classifier's trailing Softmax -- the graph output is the logits' tensor, which parity tests of
+    the convolution stack want (a softmaxed output is mostly zeros).  The name is historical: until round 4 the int8 Softmax was
+    the one tail op the HIP device left to the CPU subgraph; it runs on the device now (csrc/misc_kernels.hip softmax_i8)."""
     gf = BUILDERS[name](batch=1, **kw)
     if dtype == "fp32":
         g = set_batch(gf, batch)

@@ -104,6 +104,19 @@ def eltwise_relu_graph(seed, n, c, h, w, with_relu=True, etype=tm2.ELT_SUM):
 from tengine_amd.tm2 import DT_UINT8  # noqa: E402
 
 
+def i8_unary_graph(seed, op, dims, out_scale=None, **params):
+    """one int8 node (Softmax, ..) on a seeded input; out_scale None: a scale that spreads a softmax's (0, 1] over the int8 range"""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="i8_%s_case" % op)
+    xs = float(np.float32(rng.uniform(0.01, 0.06)))
+    x = g.add_input("data", list(dims), DT_INT8, [xs], [0])
+    os_ = float(np.float32(out_scale if out_scale is not None else rng.uniform(0.5, 1.5) / 127.0))
+    y = g.add_tensor("out", list(dims), DT_INT8, tm2.TT_VAR, None, [os_], [0])
+    ni = g.add_node(op.lower(), op, [x], [y], **params)
+    g.output_nodes = [ni]
+    return g, rng.integers(-127, 128, size=dims).astype(np.int8)
+
+
 def _u8q(rng, lo=0.01, hi=0.05):
     # zero points near mid-range keep the accumulators centred (a random zp pair saturates every output);
     # extreme zero points are exercised through the explicit in_zp / w_zp / out_zp arguments

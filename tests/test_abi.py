@@ -135,7 +135,12 @@ def test_node_supported_query():
     assert ask(7, [a, a], [t(I8, VAR, [2, 8, 4, 4])], cat0) == 0               # batch axis
     elt = (C.c_int * 5)(9, 0, 0, 0, 0)                                          # an eltwise type the device does not run
     assert ask(6, [a, a], [a], elt) == 0
-    assert ask(12, [a], [a]) == 0                                               # softmax int8 stays on the CPU
+    assert ask(12, [a], [a]) == 1                                               # softmax int8: over the channel axis (NHWC on the device)
+    assert ask(12, [a], [a], (C.c_int * 1)(2)) == 0                             # .. any other axis stays on the CPU
+    assert ask(12, [a], [a], (C.c_int * 1)(-3)) == 1
+    assert ask(12, [t(I8, VAR, [2, 1000])], [t(I8, VAR, [2, 1000])], (C.c_int * 1)(-1)) == 1
+    assert ask(12, [t(I8, VAR, [2, 5, 1000])], [t(I8, VAR, [2, 5, 1000])], (C.c_int * 1)(1)) == 0     # 3-D: no NHWC geometry
+    assert ask(12, [t(I8, VAR, [1, 20000])], [t(I8, VAR, [1, 20000])]) == 0     # the axis must fit a wave's LDS slice
     assert ask(12, [t(F32, VAR, [1, 8], 0)], [t(F32, VAR, [1, 8], 0)]) == 1
     # uint8 / fp32 device tensors are dense NCHW: concat on any axis; int8 (NHWC blocks): channels only
     cat2 = (C.c_int * 1)(2)

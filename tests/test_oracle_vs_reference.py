@@ -4,8 +4,8 @@ covering every kernel-selection branch of the reference and on w
 import numpy as np
 import pytest
 
-from helpers import (PRIORBOX_CASES, axis_concat_graph, conv_graph, eltwise_relu_graph, fc_graph, i8_concat_graph, pool_graph,
-                     priorbox_graph)
+from helpers import (PRIORBOX_CASES, axis_concat_graph, conv_graph, eltwise_relu_graph, fc_graph, i8_concat_graph, i8_unary_graph,
+                     pool_graph, priorbox_graph)
 from oracle import oracle
 from tengine_amd import models, tm2
 
@@ -110,6 +110,33 @@ def test_resnet50_int8_whole_model(ref):
     got = oracle.run_graph(g, x)[0]
     assert np.array_equal(want.reshape(got.shape), got)
     assert np.abs(got.astype(int)).max() > 40
+
+
+SOFTMAX_I8_CASES = [([2, 21, 5, 7], 1, None), ([3, 40, 21], 2, None), ([4, 1000], 1, 2e-4), ([2, 1000, 1, 1], 1, 1e-4),
+                    ([2, 6, 9], 1, None), ([1, 7, 3, 5], 3, None), ([5, 64], -1, 0.02)]
+
+
+@pytest.mark.parametrize("dims,axis,out_scale", SOFTMAX_I8_CASES, ids=[str(c) for c in SOFTMAX_I8_CASES])
+def test_softmax_int8_oracle_equals_reference(ref, dims, axis, out_scale):
+    """softmax_kernel_ref_int8.c: dequantise, C `exp` on a double rounded to float, sequential fp32 sum over the
+    axis, requantise with clamp +-127 -- any axis, any rank"""
+    for seed in (51, 52):
+        g, x = i8_unary_graph(seed, "Softmax", dims, out_scale=out_scale, axis=axis)
+        want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 1)[0]
+        got = oracle.run_graph(g, x)[0]
+        assert np.array_equal(np.asarray(want).reshape(got.shape), got)
+        assert len(np.unique(got)) >= 3
+
+
+def test_resnet50_int8_whole_model_with_its_softmax(ref):
+    """the benchmark graph as the reference runs it (.. fc, 1 softmax): oracle == real reference"""
+    g = models.build("resnet50", "int8", 1)
+    assert g.nodes[-1].op == "Softmax"
+    x = models.synth_input(g, 6)
+    want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 8)[0]
+    got = oracle.run_graph(g, x)[0]
+    assert np.array_equal(want.reshape(got.shape), got)
+    assert got.max() > 0
 
 
 @pytest.mark.parametrize("dtype", [tm2.DT_UINT8, tm2.DT_FP32], ids=["uint8", "fp32"])

@@ -100,13 +100,26 @@ def test_split_keeps_whole_ssd_on_the_device(ref):
     assert ops.count("PriorBox") == 6 and ops.count("Concat") == 3 and "Softmax" in ops and ops.count("Convolution") == 47, pl
 
 
+def test_split_keeps_whole_resnet50_int8_on_the_device(ref):
+    """round 4: the benchmark graph of BASELINE configs[2] ends in an int8 Softmax; with softmax_i8 on the
+    device it is ONE "HIP" subgraph -- no CPU tail, so run_graph(g, 0) pipelines it like MobileNet"""
+    _load_plugin(ref)
+    g = models.build("resnet50", "int8", 1)
+    assert g.nodes[-1].op == "Softmax"
+    pl = _split_only(ref, g, models.synth_input(g, 5), ref.MODE_INT8)
+    real = [(dev, ops) for dev, _, r, ops in pl if r]
+    assert len(real) == 1 and real[0][0] == "HIP", pl
+    assert real[0][1].count("Convolution") == 53 and real[0][1][-1] == "Softmax", pl
+
+
 def test_split_cuts_around_an_unsupported_node_instead_of_surrendering(ref):
-    """conv -> int8 Softmax (not on the device) -> conv: the two convolutions stay on "HIP", only the softmax goes to the CPU"""
+    """conv -> int8 Softmax over the ROWS of the map (not on the device: int8 tensors are NHWC there, only the channel axis is
+    contiguous) -> conv: the two convolutions stay on "HIP", only the softmax goes to the CPU"""
     _load_plugin(ref)
     g, x = conv_graph(5, 1, 32, 6, 6, 16, 1, act=-1)
     y = g.nodes[-1].outputs[0]
     o = g.add_tensor("prob", list(g.tensors[y].dims), tm2.DT_INT8, tm2.TT_VAR, None, [1.0 / 127.0], [0])
-    g.add_node("softmax", "Softmax", [y], [o], axis=1)
+    g.add_node("softmax", "Softmax", [y], [o], axis=2)
     rng = np.random.default_rng(1)
     w2 = g.add_const("w2", rng.integers(-127, 128, size=(8, 16, 1, 1)).astype(np.int8), tm2.DT_INT8, [0.01] * 8, [0] * 8)
     o2 = g.add_tensor("out2", [1, 8, 6, 6], tm2.DT_INT8, tm2.TT_VAR, None, [0.02], [0])
@@ -119,13 +132,16 @@ def test_split_cuts_around_an_unsupported_node_instead_of_surrendering(ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["conv3x3", "resblock_tail", "mobilenet_v1"])
+@pytest.mark.parametrize("case", ["conv3x3", "resblock_tail", "resnet50_prob", "mobilenet_v1"])
 def test_hip_device_equals_reference_cpu_device(ref, case):
     _load_plugin(ref)
     if case == "conv3x3":
         g, x = conv_graph(31, 2, 64, 20, 20, 96, 3, 1, 1)
     elif case == "resblock_tail":
         g, x = eltwise_relu_graph(9, 2, 64, 14, 14, True)
+    elif case == "resnet50_prob":          # the whole benchmark graph, its int8 Softmax included, all on "HIP"
+        g = models.build("resnet50", "int8", 1)
+        x = models.synth_input(g, 8)
     else:
         g = models.build("mobilenet_v1", "int8", 1)
         x = models.synth_input(g, 7)
@@ -145,12 +161,13 @@ def test_hip_device_equals_reference_cpu_device(ref, case):
 
 @pytest.mark.gpu
 def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
-    """int8 graph with a Softmax tail: the splitter gives conv->HIP, softmax->CPU (SURVEY §7 'subgraph ping-pong')."""
+    """int8 graph with a Softmax tail over the rows of the map (axis 2: not a device op): the splitter gives conv->HIP,
+    softmax->CPU (SURVEY §7 'subgraph ping-pong')."""
     _load_plugin(ref)
     g, x = conv_graph(5, 1, 32, 6, 6, 10, 1, act=-1)
     y = g.nodes[-1].outputs[0]
     o = g.add_tensor("prob", list(g.tensors[y].dims), tm2.DT_INT8, tm2.TT_VAR, None, [1.0 / 127.0], [0])
-    ni = g.add_node("softmax", "Softmax", [y], [o], axis=1)
+    ni = g.add_node("softmax", "Softmax", [y], [o], axis=2)
     g.output_nodes = [ni]
     b = tm2.write_tm2(g)
     want = ref.run_model(b, x, ref.MODE_INT8, 1)[0]
@@ -293,7 +310,7 @@ def test_async_run_graph_through_the_plugins_scheduler(ref, model):
 @pytest.mark.gpu
 def test_async_runs_of_a_mixed_graph_pipeline_its_hip_piece_and_finish_the_cpu_tail_at_wait(ref):
     """a graph that is one leading "HIP" subgraph + CPU pieces behind it (an SSD model's DetectionOutput; here an
-    int8 Softmax) used to run blocking under run_graph(g, 0).  Now the HIP piece is submitted asynchronously (two in flight) and
+    int8 Softmax over a spatial axis) used to run blocking under run_graph(g, 0).  Now the HIP piece is submitted asynchronously (two in flight) and
     hip_wait_graph delivers the oldest run's device outputs, then runs the CPU tail on them -- reference bytes, submission order."""
     L = _load_plugin(ref)
     P = C.CDLL(PLUGIN)
@@ -302,7 +319,7 @@ def test_async_runs_of_a_mixed_graph_pipeline_its_hip_piece_and_finish_the_cpu_t
     g, x1 = conv_graph(5, 1, 32, 6, 6, 10, 1, act=-1)
     y = g.nodes[-1].outputs[0]
     o = g.add_tensor("prob", list(g.tensors[y].dims), tm2.DT_INT8, tm2.TT_VAR, None, [1.0 / 127.0], [0])
-    ni = g.add_node("softmax", "Softmax", [y], [o], axis=1)
+    ni = g.add_node("softmax", "Softmax", [y], [o], axis=2)          # over the rows of the map: a CPU-device node
     g.output_nodes = [ni]
     b = tm2.write_tm2(g)
     x2 = np.random.default_rng(3).integers(-127, 128, size=x1.shape).astype(np.int8)
