@@ -59,7 +59,7 @@ enum {
     TAMD_OP_RELU6 = 10,
     TAMD_OP_FLATTEN = 11,
     TAMD_OP_SOFTMAX = 12, /* param: tamd_softmax_param (NULL: axis 1); fp32 / uint8 graphs: any axis; int8 graphs (NHWC on the
-                           * device): the channel axis of a 2-D / 4-D tensor, <= 16384 channels (softmax_kernel_ref_int8.c)   */
+                           * device): the channel axis of a 2-D / 4-D tensor, <= 16000 channels (softmax_kernel_ref_int8.c)   */
     TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 graphs, order (0,2,3,1) -- the SSD head permute */
     TAMD_OP_RESHAPE = 14, /* param: tamd_reshape_param; uint8 / fp32 graphs (dense NCHW on the device: a view)        */
     TAMD_OP_PRIORBOX = 15,/* param: tamd_priorbox_param; uint8 / fp32 graphs, batch 1.  Depends on shapes only: evaluated ONCE

@@ -201,7 +201,7 @@ struct SoftmaxI8Args {     // softmax over the channels of an NHWC int8 tensor (
     int C, cs_in, cs_out;
     float in_scale, out_scale;
 };
-constexpr int kSoftmaxI8MaxC = 16384;      // one wave keeps the axis' exponentials in LDS (64 KB)
+constexpr int kSoftmaxI8MaxC = 16000;      // the axis' exponentials live in LDS as floats (<= 64 KB with the chain's padding)
 
 struct CatCopyArgs {       // one concat input that cannot be written in place: (re-scaling) copy into its channel slice
     const int8_t* x; int8_t* y;

@@ -254,42 +254,85 @@ hipError_t launch_relu(const ReluArgs& a, hipStream_t s)
 // ---- softmax over the channel axis: softmax/softmax_kernel_ref_int8.c:41-117 over softmax_kernel_ref.h:35-85 ------------------
 // f = (float)q * in_scale; per position: max over the axis; o = (float)exp((double)(f - max)) -- the reference calls C `exp` on a
 // float argument, i.e. the DOUBLE routine, and rounds to float on the store (:67); the sum is accumulated in fp32 IN AXIS ORDER
-// (:68) -- a dependent chain, so one lane adds the exponentials out of LDS; o / sum; y = round(o / out_scale), clamp +-127.
+// (:68) -- a dependent chain, so ONE lane adds the exponentials out of LDS (16-byte reads, 16 values ahead of the chain; the row
+// is zero-padded to a multiple of 32, and x + 0.0f == x); o / sum; y = round(o / out_scale), clamp +-127.
 // exp runs in fp64 here too (ocml, <= 1 ulp): see softmax_u8_kernel (u8_kernels.hip) for what that can and cannot change.
-// One wave per position (ResNet-50's prob: 1000 channels; NHWC keeps the axis contiguous), NW positions per block; the waves of
-// a block never meet, so there is no block-level barrier and a wave past the last position just leaves.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void softmax_i8_kernel(SoftmaxI8Args a)
+// A TEAM of TW waves works on one position (NHWC keeps the axis contiguous); TPB teams per block.  Two forms: <1, 4> for short
+// axes on many positions (class scores over a map: the waves of a block never meet, a wave past the last position just leaves)
+// and <4, 1> for long axes on few positions (ResNet-50's prob, 1000 channels x batch: the fp64 exponentials and the two
+// divisions per output spread over 256 threads; 17.4 -> see profiles/r04_softmax_i8_resnet50_b32*.txt).
+template <int TW, int TPB>
+__global__ __launch_bounds__(64 * TW * TPB) void softmax_i8_kernel(SoftmaxI8Args a)
 {
-    extern __shared__ float softmax_e[];
+    static_assert(TW == 1 || TPB == 1, "a multi-wave team owns its block (block-level barriers)");
+    extern __shared__ __attribute__((aligned(16))) float softmax_e[];
+    constexpr int T = 64 * TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long p = (long)blockIdx.x * NW + wave;
-    if (p >= a.positions) return;
-    float* e = softmax_e + (size_t)wave * a.C;
+    const int tid = TW == 1 ? lane : (int)threadIdx.x, team = TW == 1 ? wave : 0;
+    const long p = (long)blockIdx.x * TPB + team;
+    if (p >= a.positions) return;                      // whole teams
+    const int pitch = (a.C + 31) & ~31;                // + 16 floats the chain's read-ahead touches and never adds
+    float* e = softmax_e + (size_t)team * (pitch + 16);
+    float* red = softmax_e + (size_t)TPB * (pitch + 16);          // TW > 1: the waves' maxima [TW], then the sum [TW]
+    auto team_sync = [&]() {
+        if constexpr (TW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     const int8_t* x = a.x + (size_t)p * a.cs_in;
     int8_t* y = a.y + (size_t)p * a.cs_out;
     float mx = -__builtin_inff();
-    for (int j = lane; j < a.C; j += 64) mx = fmaxf(mx, __fmul_rn((float)x[j], a.in_scale));
+    for (int j = tid; j < a.C; j += T) mx = fmaxf(mx, __fmul_rn((float)x[j], a.in_scale));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-    for (int j = lane; j < a.C; j += 64) e[j] = (float)exp((double)__fsub_rn(__fmul_rn((float)x[j], a.in_scale), mx));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (TW > 1) {
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < TW; w++) mx = fmaxf(mx, red[w]);
+    }
+    for (int j = tid; j < pitch; j += T)
+        e[j] = j < a.C ? (float)exp((double)__fsub_rn(__fmul_rn((float)x[j], a.in_scale), mx)) : 0.f;
+    team_sync();
     float sum = 0.f;
-    if (lane == 0)
-        for (int j = 0; j < a.C; j++) sum = __fadd_rn(sum, e[j]);
-    sum = __shfl(sum, 0, 64);
-    for (int j = lane; j < a.C; j += 64) y[j] = (int8_t)round_sat(__fdiv_rn(__fdiv_rn(e[j], sum), a.out_scale));
+    if (tid == 0) {
+        const float4* q = reinterpret_cast<const float4*>(e);
+        float4 b0[4], b1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) b0[k] = q[k];
+        for (int j = 0; j < pitch; j += 32) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) b1[k] = q[(j >> 2) + 4 + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sum = __fadd_rn(sum, b0[k].x); sum = __fadd_rn(sum, b0[k].y); sum = __fadd_rn(sum, b0[k].z); sum = __fadd_rn(sum, b0[k].w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) b0[k] = q[(j >> 2) + 8 + k];            // the last round reads the 16 spare floats
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sum = __fadd_rn(sum, b1[k].x); sum = __fadd_rn(sum, b1[k].y); sum = __fadd_rn(sum, b1[k].z); sum = __fadd_rn(sum, b1[k].w);
+            }
+        }
+        if constexpr (TW > 1) red[TW] = sum;
+    }
+    if constexpr (TW == 1) sum = __shfl(sum, 0, 64);
+    else { __syncthreads(); sum = red[TW]; }
+    for (int j = tid; j < a.C; j += T) y[j] = (int8_t)round_sat(__fdiv_rn(__fdiv_rn(e[j], sum), a.out_scale));
 }
 
 hipError_t launch_softmax_i8(const SoftmaxI8Args& a, hipStream_t s)
 {
     if (a.C < 1 || a.C > kSoftmaxI8MaxC) return hipErrorInvalidValue;
-    if (a.C <= 2048) {
-        hipLaunchKernelGGL(softmax_i8_kernel<4>, dim3((unsigned)((a.positions + 3) / 4)), dim3(256), (size_t)4 * a.C * sizeof(float), s, a);
+    const size_t row = (size_t)(((a.C + 31) & ~31) + 16) * sizeof(float);
+    if (a.C <= 256) {
+        hipLaunchKernelGGL((softmax_i8_kernel<1, 4>), dim3((unsigned)((a.positions + 3) / 4)), dim3(256), 4 * row, s, a);
     } else {
-        hipLaunchKernelGGL(softmax_i8_kernel<1>, dim3((unsigned)a.positions), dim3(64), (size_t)a.C * sizeof(float), s, a);
+        hipLaunchKernelGGL((softmax_i8_kernel<4, 1>), dim3((unsigned)a.positions), dim3(256), row + 8 * sizeof(float), s, a);
     }
     return hipGetLastError();
 }
