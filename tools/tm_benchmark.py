@@ -44,7 +44,7 @@ def main():
             raise SystemExit("no synthetic model for -s %d (have %s)" % (a.model, sorted(MODELS)))
         name, key, dtype = MODELS[a.model]
         dtype = a.precision or dtype
-        g = models.build(key, dtype, a.batch, device_only=True)
+        g = models.build(key, dtype, a.batch)           # the benchmark graph whole, classifier Softmax included (on the device for all three dtypes)
         b = tm2.write_tm2(g)
     dt = {"fp32": tm2.DT_FP32, "int8": tm2.DT_INT8, "uint8": tm2.DT_UINT8}[dtype]
     gr = capi.Graph(b, batch=a.batch, direct_dispatch=True)      # the plugin's default: the blocking run as one AQL pass
