@@ -10,6 +10,8 @@
 // operands, no barrier in the loop.  The epilogue re-distributes the packed results between the two
 // half-waves with v_permlane32_swap so that every lane stores 16 contiguous output channels (one
 // dwordx4 instead of four dword stores into 4 different 64-B segments).
+#include <stdlib.h>
+
 #include "epilogue.h"
 #include "kernels.h"
 
@@ -105,7 +107,11 @@ static hipError_t launch_pw(const ConvArgs& a, hipStream_t s)
     const int tiles_m = (a.M + 31) / 32;
     const int groups = (a.cout + NT * 32 - 1) / (NT * 32);
     int bx = (tiles_m + 3) / 4;
-    const int cap = 2048 / groups > 0 ? 2048 / groups : 1;
+    // blocks of a launch (the waves stride over the pixel tiles beyond it).  TAMD_PW_STREAM_BLOCKS: experiments only -- a copy kernel
+    // with this layer's read : write mix ran 15.3 us from 512 blocks against 20.9 us from 2048 (profiles/r02_write_bw_access_shapes.txt)
+    const char* be = getenv("TAMD_PW_STREAM_BLOCKS");
+    const int total = be && atoi(be) > 0 ? atoi(be) : 2048;
+    const int cap = total / groups > 0 ? total / groups : 1;
     if (bx > cap) bx = cap;
     if (a.elt.res) hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, true>), dim3(bx, groups), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, false>), dim3(bx, groups), dim3(256), 0, s, a);
