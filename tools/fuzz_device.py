@@ -35,7 +35,7 @@ def main():
     t0, graphs, tot, bad, kernels = time.time(), 0, 0, 0, {}
     while time.time() - t0 < a.seconds:
         patch = a.dtype == "uint8" and rng.random() < 0.6
-        g, x = random_graph(rng, a.dtype, int(rng.choice([4, 4, 32])) if patch else 1)
+        g, x = random_graph(rng, a.dtype, int(rng.choice([4, 4, 32])) if patch else 1, device=True)
         for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS", "TAMD_U8_PATCH", "TAMD_U8_PATCH_CFG", "TAMD_U8_PATCH_2D",
                   "TAMD_U8_C3", "TAMD_U8_DW_TH", "TAMD_U8_RGB_MFMA", "TAMD_DW_FORM"):
             os.environ.pop(k, None)

@@ -2,7 +2,7 @@
 
 The hand-picked parity cases pin the semantics; this pins the *rare events*: one fp32 rounding that differs (an fma
 where the reference's compiler emitted mul+add, say) flips one output byte in 1e5..1e6, far below what a few test
-layers can see.  Random single-op graphs (conv incl. depthwise, pooling, fc, relu, eltwise, concat routes, SSD head
+layers can see.  Random single-op graphs (conv incl. depthwise, pooling, fc, relu, eltwise, int8 softmax, concat routes, SSD head
 plumbing) are run through the real reference CPU backend and through oracle/tg_oracle.c; every byte must agree.
 
     python tools/fuzz_oracle.py --dtype uint8 --seconds 150 --seed 1
@@ -26,7 +26,8 @@ from oracle import oracle, ref_capi  # noqa: E402
 from tengine_amd import tm2  # noqa: E402
 
 
-def random_graph(rng, dtype, cin_mult=1):
+def random_graph(rng, dtype, cin_mult=1, device=False):
+    """`device`: only what the HIP backend runs (fuzz_device): an int8 Softmax over the channel axis of a 2-D / 4-D tensor"""
     u8 = dtype == "uint8"
     seed = int(rng.integers(1 << 30))
     kind = int(rng.integers(0, 10))
@@ -54,6 +55,12 @@ def random_graph(rng, dtype, cin_mult=1):
         f = H.u8_fc_graph if u8 else H.fc_graph
         hid = (int(rng.integers(8, 600)),) if rng.random() < 0.7 else (int(rng.integers(2, 40)), int(rng.integers(1, 5)), int(rng.integers(1, 5)))
         return f(seed, int(rng.integers(1, 5)), hid, int(rng.integers(2, 300)))
+    if not u8 and kind == 9:          # softmax_kernel_ref_int8.c: any rank and axis in the reference
+        rank = int(rng.choice([2, 4])) if device else int(rng.integers(2, 5))
+        dims = [int(rng.integers(1, 5))] + [int(rng.integers(1, 9)) for _ in range(rank - 1)]
+        axis = 1 if device else int(rng.integers(0, rank))
+        dims[axis] = int(rng.choice([int(rng.integers(2, 40)), int(rng.integers(40, 1200))]))
+        return H.i8_unary_graph(seed, "Softmax", dims, out_scale=float(rng.choice([1.0 / 127.0, 0.5 / dims[axis], 2e-4])), axis=axis)
     if not u8:
         et = int(rng.choice([tm2.ELT_SUM, tm2.ELT_SUB, tm2.ELT_MAX, tm2.ELT_PROD]))
         return H.eltwise_relu_graph(seed, 2, 32, 14, 14, bool(rng.integers(0, 2)), et)
