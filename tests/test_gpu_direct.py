@@ -25,7 +25,7 @@ def _resident(gr, x, launches):
 @pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 1), ("mobilenet_v1", "int8", 8), ("resnet50", "int8", 2),
                                               ("yolov3_tiny", "uint8", 1), ("mssd", "uint8", 2), ("squeezenet_v1.1", "fp32", 1)])
 def test_direct_dispatch_same_bytes_as_graph_replay(name, dtype, batch):
-    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))      # the Softmax tails stay on the CPU device
+    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))      # logits-only graphs (a softmaxed output is mostly zeros)
     x = models.synth_input(g, 77, NP[dtype])
     b = tm2.write_tm2(g)
     ref = capi.Graph(b)

@@ -102,8 +102,8 @@ def test_mobilenet_v1_int8_whole_model(ref):
 
 
 def test_resnet50_int8_whole_model(ref):
-    """53 conv (1x1, 1x1 s2, 3x3, 7x7 s2) + 16 eltwise + 16 relu + max/avg pool + fc (+ softmax left to the
-    reference): oracle == real reference on the device-side part of the graph."""
+    """53 conv (1x1, 1x1 s2, 3x3, 7x7 s2) + 16 eltwise + 16 relu + max/avg pool + fc: oracle == real reference on the logits
+    (the graph with its Softmax: test_resnet50_int8_whole_model_with_its_softmax)."""
     g = models.build("resnet50", "int8", 1, device_only=True)
     x = models.synth_input(g, 5)
     want = ref.run_model(tm2.write_tm2(g), x, ref.MODE_INT8, 8)[0]
