@@ -112,6 +112,26 @@ def test_split_keeps_whole_resnet50_int8_on_the_device(ref):
     assert real[0][1].count("Convolution") == 53 and real[0][1][-1] == "Softmax", pl
 
 
+BASELINE_GRAPHS = [("squeezenet_v1.1", "fp32", {}), ("mobilenet_v1", "int8", {}), ("resnet50", "int8", {}), ("yolov3_tiny", "uint8", {}),
+                   ("mssd", "uint8", {})]
+
+
+@pytest.mark.parametrize("name,dtype,kw", BASELINE_GRAPHS, ids=[b[0] for b in BASELINE_GRAPHS])
+def test_split_gives_every_baseline_graph_to_the_device_whole(ref, name, dtype, kw):
+    """the five BASELINE config graphs as tengine_amd.models builds them (SURVEY appendix C census): after hip_split_graph every
+    compute node sits in ONE subgraph of device "HIP" -- no CPU piece, hence no hand-over inside a run (checked without a GPU: the
+    split happens before the device is touched)"""
+    _load_plugin(ref)
+    g = models.build(name, dtype, 1, **kw)
+    dt = {"fp32": tm2.DT_FP32, "int8": tm2.DT_INT8, "uint8": tm2.DT_UINT8}[dtype]
+    mode = {"fp32": ref.MODE_FP32, "int8": ref.MODE_INT8, "uint8": ref.MODE_UINT8}[dtype]
+    pl = _split_only(ref, g, models.synth_input(g, 5, dt), mode)
+    real = [(dev, ops) for dev, _, r, ops in pl if r]
+    assert len(real) == 1 and real[0][0] == "HIP", pl
+    want = sorted(n.op for n in g.nodes if n.op not in ("InputOp", "Const"))
+    assert sorted(o for o in real[0][1] if o not in ("InputOp", "Const")) == want, (real[0][1], want)
+
+
 def test_split_cuts_around_an_unsupported_node_instead_of_surrendering(ref):
     """conv -> int8 Softmax over the ROWS of the map (not on the device: int8 tensors are NHWC there, only the channel axis is
     contiguous) -> conv: the two convolutions stay on "HIP", only the softmax goes to the CPU"""
