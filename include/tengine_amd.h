@@ -224,7 +224,9 @@ TAMD_API int tamd_graph_direct_packets(const tamd_graph* g);
  * use the code-object-v5 default layout, vouched for by the prerun self-check) */
 TAMD_API int tamd_graph_direct_meta_packets(const tamd_graph* g);
 TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
-/* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather) */
+/* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather).  Valid after any pass: a
+ * direct-dispatch tamd_graph_run / tamd_graph_wait leaves its outputs in the pinned host buffers only (zero-copy lists) and this
+ * call refreshes the device copy from there first; it fails while asynchronous runs are in flight. */
 TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);
 TAMD_API void* tamd_graph_stream(tamd_graph* g);          /* hipStream_t                           */
 /* wall time tamd_graph_prerun took (planning incl. the plan-time autotune, capture, direct-dispatch programs), milliseconds */

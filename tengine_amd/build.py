@@ -21,13 +21,13 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
+SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 # int8 GEMM kernels: MFMA accumulators in architectural VGPRs.  hipcc's heuristic keeps them in AccVGPRs and every value
 # of the requantising epilogue then costs a v_accvgpr_read on top of its ~8 VALU instructions; the VGPR form also lowers
 # the total register count of these kernels (pw_stream<2,4>: 112 -> 90, conv_igemm2 128x128: 232 -> 175)
-VGPR_FORM = {"pw_stream.hip", "pw_rows.hip", "conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_first.hip", "conv_first_pool.hip", "dwpw.hip", "gemm_direct.hip", "u8i_kernels.hip"}
+VGPR_FORM = {"pw_stream.hip", "pw_rows.hip", "conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "conv_first.hip", "conv_first_pool.hip", "dwpw.hip", "gemm_direct.hip", "u8i_kernels.hip"}
 
 
 def _newer(target, deps):

@@ -22,46 +22,9 @@
 //     counted waits are exact.
 //   * XCD-aware tile map: an XCD (blocks b, b+8, ..) owns a CONTIGUOUS range of pixel tiles -> its L2 holds one eighth of
 //     the input plus the weights; neighbouring tiles share their halo rows in that L2.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "epilogue.h"
-#include "gemm_epilogue.h"
-#include "kernels.h"
+#include "conv_pgemm_common.h"
 
 namespace tamd {
-
-typedef int v4i_p __attribute__((ext_vector_type(4)));
-typedef int v16i_p __attribute__((ext_vector_type(16)));
-
-#define PG_GLDS16(gptr, lptr)                                                                          \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// s_waitcnt immediate (gfx9 encoding): vmcnt = n, lgkmcnt = 0, expcnt untouched
-#define PG_WAITCNT(n) ((((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14)))
-
-// floor(v / d) by multiply-high: mg = ceil(2^40 / d), exact for v < 2^24, d < 2^16 (the launcher checks both)
-__device__ __forceinline__ int pg_div(int v, unsigned long long mg) { return (int)(((unsigned long long)(unsigned)v * mg) >> 40); }
-
-template <int N> struct pg_int { static constexpr int value = N; };
-
-// tools/exp/pgemm_anatomy.hip only: per-block device-clock stamps (wave 0) and ablation switches
-#ifdef TAMD_IGEMM_STAMPS
-#define PG_STAMP(i) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[((size_t)pg_rep * gridDim.x + blockIdx.x) * 8 + (i)] = ((i) == 0 || (i) == 6) ? (long long)wall_clock64() : (long long)clock64(); } while (0)
-// the whole tile computation pg_reps times in ONE launch (dbg_flags >> 8 extra passes): the second pass runs the same code with a
-// warm instruction cache -- how much of a block's time is instruction fetch?
-#define PG_REPS ((a.dbg_flags >> 8) + 1)
-#else
-#define PG_STAMP(i) do { } while (0)
-#define PG_REPS 1
-#endif
-#ifdef TAMD_PG_ABLATE            // run-time ablation switches (each costs a scalar branch where it is tested: only for A/B runs)
-#define PG_ON(bit) (!(a.dbg_flags & (bit)))
-#else
-#define PG_ON(bit) true
-#endif
 
 template <int BM, int BN, bool PATCH, int LA, int NPC>
 __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
@@ -305,15 +268,6 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
         a.dbg_stamps[(size_t)blockIdx.x * 8 + 7] = ((long long)xcc << 32) | hwid;
     }
 #endif
-}
-
-// loads a wave has issued in the D-2 stages before pair-local stage u (each stage: NA weight pieces, + NPC patch pieces in the
-// first four taps of a chunk): what may stay in flight when the weights of stage u+1 must have landed
-constexpr int pg_inflight(int u, int d, int nt, int na, int npc)
-{
-    int w = 0;
-    for (int q = 1; q <= d - 2; q++) w += na + ((((u - q + 2 * nt) % (2 * nt)) % nt) < 4 ? npc : 0);
-    return w;
 }
 
 // ---- k x k with a COMPILE-TIME filter shape: the K loop unrolled over the taps of a 64-channel chunk ---------------------------
@@ -587,11 +541,12 @@ int conv_pgemm_stages(const ConvArgs& a) { return pg_kind(a) == PG_ROWS ? (a.ckp
 
 // variants: bit 0: BN 128 (else 64); bit 1: BM 64 (else 128); bit 2: KS 2 (512-thread blocks, intra-block split-K; 3x3 only)
 static constexpr int PG_LA = 4;            // ring depth of the generic kernels (the unrolled-taps kernel has 3 slots)
-int conv_pgemm_num_variants() { return 8; }        // (bit 3, the 3-slot ring, stays reachable through TAMD_PGEMM_RS3=1: measured slower everywhere)
+// variants with bit 4 (16 .. 31, 48 .. 63): the wave-grid form of conv_pgemm_w.hip (3x3 only; the same tile bits and packed weights)
+int conv_pgemm_num_variants() { return 64; }       // (8 .. 15 are not used: the 3-slot ring they once named measured slower everywhere, profiles/r03_members_3x3_b32.txt)
 int conv_pgemm_bn(int variant) { return (variant & 1) ? 128 : 64; }
 static int pg_bm(int variant) { return (variant & 2) ? 64 : 128; }
 static int pg_ks(int variant) { return (variant & 4) ? 2 : 1; }
-static int pg_rs(int variant) { return (variant & 8) ? 3 : 6; }       // ring slots of the 3x3 kernel: 3 (copies 2 stages ahead, small LDS: more blocks per CU) or 6 (5 ahead)
+static int pg_rs(int) { return 6; }       // ring slots of the 3x3 kernel (copies 5 stages ahead)
 
 static int pg_npad(const ConvArgs& a, int variant)
 {
@@ -613,12 +568,13 @@ static size_t pg_lds(const ConvArgs& a, int variant, int npad)
 bool conv_pgemm_applicable(const ConvArgs& a, int variant)
 {
     static const int mode = pg_env("TAMD_PGEMM", 1);
+    if (variant & 16) return mode && conv_pgemm_w_applicable(a, variant);
     if (!mode || a.zeros == nullptr || a.M >= (1 << 24) || a.OH * a.OW >= 65536) return false;
     const int bn = conv_pgemm_bn(variant), bm = pg_bm(variant), ks = pg_ks(variant), kind = pg_kind(a);
     if (bn == 128 && a.cout <= 64) return false;
     if (bm == 128 && a.M <= 64) return false;
     if (ks == 2 && (kind != PG_TAPS3 || bm != 128 || (a.ckp / 64) % 2 != 0)) return false;
-    if ((variant & 8) && (kind != PG_TAPS3 || ks == 2)) return false;
+    if (variant & 8) return false;
     if (kind == PG_ROWS) return a.ckp >= 32;
     const int Hp = (a.OH - 1) * a.SH + (a.KH - 1) * a.DH + 1, Wp = (a.OW - 1) * a.SW + (a.KW - 1) * a.DW + 1;
     if (a.ckp % 64 != 0 || a.cs_in < a.ckp) return false;
@@ -633,6 +589,7 @@ bool conv_pgemm_applicable(const ConvArgs& a, int variant)
 // fills the patch geometry fields of `a` for `variant` (the planner then attaches the packed weights: conv_pgemm_pack)
 void conv_pgemm_prepare(ConvArgs& a, int variant)
 {
+    if (variant & 16) { conv_pgemm_w_prepare(a, variant); return; }
     a.pg_ns = conv_pgemm_stages(a);
     a.pg_variant = variant;
     if (pg_kind(a) == PG_ROWS) { a.pg_hp = a.pg_wp = 1; a.pg_npad = 0; a.mg_hp = a.mg_wp = 0; return; }
@@ -677,8 +634,7 @@ const char* conv_pgemm_kernel_name(const ConvArgs& a)
                                       {"conv_pgemm_i8<128x64,3x3>", "conv_pgemm_i8<128x128,3x3>", "conv_pgemm_i8<64x64,3x3>", "conv_pgemm_i8<64x128,3x3>"},
                                       {"conv_pgemm_i8<128x64,patch>", "conv_pgemm_i8<128x128,patch>", "conv_pgemm_i8<64x64,patch>", "conv_pgemm_i8<64x128,patch>"},
                                       {"conv_pgemm_i8<128x64,3x3,ks2>", "conv_pgemm_i8<128x128,3x3,ks2>", "?", "?"}};
-    static const char* shallow[4] = {"conv_pgemm_i8<128x64,3x3,rs3>", "conv_pgemm_i8<128x128,3x3,rs3>", "conv_pgemm_i8<64x64,3x3,rs3>", "conv_pgemm_i8<64x128,3x3,rs3>"};
-    if (a.pg_variant & 8) return shallow[a.pg_variant & 3];
+    if (a.pg_variant & 16) return conv_pgemm_w_kernel_name(a);
     return names[(a.pg_variant & 4) ? 3 : pg_kind(a)][a.pg_variant & 3];
 }
 
@@ -705,10 +661,6 @@ static hipError_t pg_launch_mn(const ConvArgs& a, hipStream_t s)
                 return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 2, 2>, a, BM, BN, 512, s);
             }
         }
-        if (a.pg_variant & 8) {
-            if (a.pg_npad <= 256) return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 1, 3, 2>, a, BM, BN, 256, s);
-            return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 2, 3, 2>, a, BM, BN, 256, s);
-        }
         if (a.pg_npad <= 256) return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 1>, a, BM, BN, 256, s);
         return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 2>, a, BM, BN, 256, s);
     default:
@@ -719,6 +671,7 @@ static hipError_t pg_launch_mn(const ConvArgs& a, hipStream_t s)
 
 hipError_t launch_conv_pgemm(const ConvArgs& a, hipStream_t s)
 {
+    if (a.pg_variant & 16) return launch_conv_pgemm_w(a, s);
     switch (a.pg_variant & 3) {
     case 0: return pg_launch_mn<128, 64>(a, s);
     case 1: return pg_launch_mn<128, 128>(a, s);

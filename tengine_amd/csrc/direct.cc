@@ -392,8 +392,12 @@ int direct_submit(DirectProgram* p, bool close_burst, unsigned long long* burst)
         d->completion_signal.handle = 0;
         uint16_t h = i == 0 ? (dq->open ? p->h_wrap : p->h_open) : p->hdr[i];
         if (close_burst && i + 1 == n) {
+            // the closing packet carries the completion signal, so it must retire LAST: barrier bit forced (a packet recorded
+            // "beside" its predecessor -- independent heads with TAMD_DIRECT_OVERLAP=1 -- has none and could complete, and
+            // decrement the signal, while earlier packets of the pass still run) and system-scope release
             d->completion_signal = dq->done;
-            h = (uint16_t)((h & ~(3u << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+            h = (uint16_t)((h & ~(3u << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE)
+                           | (1u << HSA_PACKET_HEADER_BARRIER));
         }
         __atomic_store_n(&d->header, h, __ATOMIC_RELEASE);
     }

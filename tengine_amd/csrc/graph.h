@@ -177,6 +177,9 @@ struct tamd_graph {
     bool stream_dirty = true;                  // something may be pending on `stream` (uploads, eager launches): drain it before a direct burst
     bool stream_exposed = false;               // tamd_graph_stream() handed the stream out: the caller may queue work this library cannot see
     bool io_zero_copy = false;                 // the host-to-host lists store graph outputs straight into the pinned host buffers
+    bool io_zero_copy2 = false;                //   .. the list of I/O slot 1 does
+    int out_fresh_in = 0;                      // 0: the outputs' device staging buffers hold the last pass; 1 / 2: only pinned slot 0 / 1 does
+                                               // (a zero-copy host-to-host run): stage_from_pinned() before anything reads the device copy
     // TAMD_H2H_TRACE=1: where a blocking tamd_graph_run spends its time on the host (ns): copy in, stream drain, submit, wait, copy out
     long long h2h_ns[5] = {0, 0, 0, 0, 0};
     long long h2h_runs = 0;

@@ -842,6 +842,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         // lean-loop kernels (conv_pgemm.hip): fragment-ordered weights, k x k activations as an LDS-resident patch
         {
             int8_t* packed[2] = {nullptr, nullptr};       // per cout-tile width (64 / 128), packed on first use
+            int* geom[2] = {nullptr, nullptr};            // conv_pgemm_w.hip: the per-tile geometry table, per pixel-tile height (128 / 64)
             for (int v = 0; v < conv_pgemm_num_variants(); v++) {
                 if (!conv_pgemm_applicable(a, v)) continue;
                 if ((v & 2) && a.M >= 65536) continue;    // 64-pixel tiles: only where 128-pixel tiles leave CUs idle
@@ -854,6 +855,15 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
                     if (upload(g, wf, &packed[slot])) return -1;
                 }
                 ap.wfrag = packed[slot];
+                if (v & 16) {
+                    const int gs = (v & 2) ? 1 : 0;
+                    if (!geom[gs]) {
+                        std::vector<int> tab;
+                        conv_pgemm_w_table(ap, tab);
+                        if (upload(g, tab, &geom[gs])) return -1;
+                    }
+                    ap.pg_tab = geom[gs];
+                }
                 cands.push_back({conv_pgemm_kernel_name(ap), [ap](hipStream_t s) { return launch_conv_pgemm(ap, s); }});
             }
         }
@@ -2212,6 +2222,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
                     }
                 }
                 if (slot == 0) g->io_zero_copy = zc_ok;
+                else g->io_zero_copy2 = zc_ok;
                 if (!pio) fprintf(stderr, "tengine_amd: direct dispatch not used for host-to-host runs (slot %d): %s\n", slot, why);
                 (slot ? g->direct_io2 : g->direct_io) = pio;
             }
@@ -2314,10 +2325,26 @@ int tamd_graph_upload_inputs(tamd_graph* g)
     return 0;
 }
 
+// A zero-copy host-to-host run leaves its outputs in the pinned host buffers ONLY (the launch that would have written the device
+// staging buffer was re-pointed): whoever reads the device copy next -- tamd_graph_output_device (the RCCL gather),
+// tamd_graph_read_tensor of a 1x1-map output -- gets it refreshed from the pinned slot first.
+static int stage_from_pinned(tamd_graph* g)
+{
+    if (!g->out_fresh_in) return 0;
+    if (!g->inflight.empty()) { set_error("the outputs of the last host-to-host run live in a pinned buffer that a run in flight may overwrite: tamd_graph_wait first"); return -1; }
+    if (direct_drain(g)) return -1;
+    for (auto& io : g->outputs)
+        HIPCHK(hipMemcpyAsync(io.stage, g->out_fresh_in == 2 ? io.pinned2 : io.pinned, io.bytes, hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->out_fresh_in = 0;
+    return 0;
+}
+
 int tamd_graph_launch(tamd_graph* g)
 {
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    g->out_fresh_in = 0;                       // the pass writes the staging buffers itself
     if (g->direct) {
         // the pass reads what the stream wrote (uploaded inputs): drain it before the first packet of a burst
         if (!g->direct_busy) { HIPCHK(hipStreamSynchronize(g->stream)); g->stream_dirty = false; }
@@ -2356,6 +2383,11 @@ int tamd_graph_download_outputs(tamd_graph* g)
     if (bind_device(g)) return -1;
     if (!g->inflight.empty()) { set_error("tamd_graph_download_outputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
+    if (g->out_fresh_in) {                     // the last pass was a zero-copy host-to-host run: its pinned slot IS the newest copy
+        for (auto& io : g->outputs)
+            if (io.host_out) memcpy(io.host_out, g->out_fresh_in == 2 ? io.pinned2 : io.pinned, io.bytes);
+        return 0;
+    }
     for (auto& io : g->outputs) HIPCHK(hipMemcpyAsync(io.pinned, io.stage, io.bytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     for (auto& io : g->outputs)
@@ -2398,6 +2430,7 @@ int tamd_graph_run(tamd_graph* g)
         HIPCHK(hipStreamSynchronize(g->stream));
     }
     if (trace) t[4] = now_ns();
+    g->out_fresh_in = (g->direct_io && g->io_zero_copy) ? 1 : 0;
     for (auto& io : g->outputs)
         if (io.host_out) memcpy(io.host_out, io.pinned, io.bytes);
     if (trace) {
@@ -2472,6 +2505,7 @@ int tamd_graph_wait(tamd_graph* g)
         HIPCHK(hipEventSynchronize(f.done));
     for (size_t i = 0; i < g->outputs.size(); i++)
         if (f.host_out[i]) memcpy(f.host_out[i], f.slot ? g->outputs[i].pinned2 : g->outputs[i].pinned, g->outputs[i].bytes);
+    g->out_fresh_in = (f.direct && (f.slot ? g->io_zero_copy2 : g->io_zero_copy)) ? 1 + f.slot : 0;
     g->inflight.erase(g->inflight.begin());
     return 0;
 }
@@ -2481,6 +2515,7 @@ int tamd_graph_inflight(const tamd_graph* g) { return g ? (int)g->inflight.size(
 int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 {
     if (idx < 0 || idx >= (int)g->outputs.size() || !g->prepared) return -1;
+    if (g->out_fresh_in && (bind_device(g) || stage_from_pinned(g))) return -1;
     *dptr = g->outputs[idx].stage;
     *bytes = g->outputs[idx].bytes;
     return 0;
@@ -2585,6 +2620,9 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
     }
     size_t need = t.elems() * esize(t.dtype);
     if (bytes != need) { set_error("read_tensor: %zu bytes given, %zu needed", bytes, need); return -1; }
+    if (g->out_fresh_in)                       // an output whose staging buffer is the tensor itself (1x1 map): see stage_from_pinned
+        for (auto& io : g->outputs)
+            if (io.tensor == idx && io.stage == t.dptr && stage_from_pinned(g)) return -1;
     if (direct_drain(g)) return -1;
     HIPCHK(hipStreamSynchronize(g->stream));
     if (t.nchw_raw && t.is_view) {      // NCHW channel slice of a concat buffer (uint8 / fp32 planners): one row per image

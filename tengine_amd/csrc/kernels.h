@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace tamd {
 
 struct EltFuse {              // eltwise (+ReLU) node applied in the conv epilogue (epilogue.h: fuse_elt4)
@@ -63,6 +65,12 @@ struct ConvArgs {
     int pg_npad;           // patch pixels of the worst pixel tile, rounded up to 64 (k x k convolutions)
     int pg_hp, pg_wp;      // rows per image / columns of the virtual padded input the patch is cut from
     unsigned long long mg_hp, mg_wp;     // ceil(2^40 / pg_hp), ceil(2^40 / pg_wp)
+    // conv_pgemm_w.hip only (conv_pgemm_w_prepare / conv_pgemm_w_table)
+    const int* pg_tab;     // per pixel tile: [pg_npad] NHWC pixel index of each patch unit (-1: zeros), [BM] patch origin | edge bits << 16 of each output pixel
+    int pg_ts;             // dwords per tile of pg_tab
+    int pg_tiles_m, pg_tiles_n;
+    int pg_zarea;          // bytes of the zero area behind each patch buffer (edge taps)
+    unsigned mg_tn;        // ceil(2^32 / pg_tiles_n) (pg_tiles_n > 1)
 #ifdef TAMD_IGEMM_STAMPS
     long long* dbg_stamps; // tools/exp/igemm_anatomy.hip only: s_memtime at the stage boundaries of wave 0 of block 0
     int dbg_flags;         // .. ablation: 1 no MFMA, 2 no LDS traffic, 4 no global loads
@@ -234,6 +242,12 @@ size_t conv_pgemm_packed_bytes(const ConvArgs& a, int bn);
 void conv_pgemm_pack(const ConvArgs& a, const int8_t* w, int cout_pad, int bn, int8_t* out);   // w: [cout_pad][kpad] family layout
 const char* conv_pgemm_kernel_name(const ConvArgs& a);
 hipError_t launch_conv_pgemm(const ConvArgs& a, hipStream_t s);
+// wave-grid form for 3x3 (conv_pgemm_w.hip): variants 16 .. 31 of the family above; the same packed weights, plus a geometry table
+bool conv_pgemm_w_applicable(const ConvArgs& a, int variant);
+void conv_pgemm_w_prepare(ConvArgs& a, int variant);               // fills pg_* except pg_tab
+void conv_pgemm_w_table(const ConvArgs& a, std::vector<int>& out); // after prepare: the table the planner uploads (pg_tab)
+const char* conv_pgemm_w_kernel_name(const ConvArgs& a);
+hipError_t launch_conv_pgemm_w(const ConvArgs& a, hipStream_t s);
 hipError_t launch_pw_stream(const ConvArgs& a, hipStream_t s);     // 1x1, shallow K, many pixels
 bool pw_stream_applicable(const ConvArgs& a);
 hipError_t launch_pw_rows(const ConvArgs& a, hipStream_t s);       // 1x1, shallow K, many pixels: row-major epilogue, persistent pipelined waves

@@ -27,7 +27,7 @@ LAYOUT_NCHW = 0
 # tm2 operator type codes (tm2_format.h:157-264)
 OPTYPE = {
     "Concat": 3, "Const": 4, "Convolution": 5, "Dropout": 8, "Eltwise": 9, "Flatten": 10,
-    "FullyConnected": 11, "InputOp": 12, "Permute": 15, "Pooling": 16, "PriorBox": 18, "ReLU": 20, "ReLU6": 21,
+    "DetectionOutput": 7, "FullyConnected": 11, "InputOp": 12, "Permute": 15, "Pooling": 16, "PriorBox": 18, "ReLU": 20, "ReLU6": 21,
     "Reshape": 23, "Softmax": 28, "Upsample": 51,
 }
 OPNAME = {v: k for k, v in OPTYPE.items()}
@@ -125,6 +125,8 @@ def _pack_param(op: str, p: Dict) -> Optional[bytes]:
     if op == "Permute":          # TM2_PermuteParam {flag, order0..3}
         o = p["order"]
         return struct.pack("<5i", p.get("flag", 0), o[0], o[1], o[2], o[3])
+    if op == "DetectionOutput":  # TM2_DetectionOutputParam tm2_format.h:455-463
+        return struct.pack("<3i2f", p["num_classes"], p["keep_top_k"], p["nms_top_k"], p["confidence_threshold"], p["nms_threshold"])
     if op in ("Const", "InputOp", "Dropout", "ReLU6"):
         return None
     raise NotImplementedError("tm2 writer: op %s" % op)
@@ -165,6 +167,8 @@ def _unpack_param(op: str, b: bytes, off: int) -> Dict:
         return {"min_size": vf(v[0]), "max_size": vf(v[1]), "variance": vf(v[2]), "aspect_ratio": vf(v[3]), "flip": v[4],
                 "clip": v[5], "img_size": v[6], "img_h": v[7], "img_w": v[8], "step_w": v[9], "step_h": v[10],
                 "offset": v[11], "num_priors": v[12], "out_dim": v[13]}
+    if op == "DetectionOutput":
+        return dict(zip(["num_classes", "keep_top_k", "nms_top_k", "confidence_threshold", "nms_threshold"], struct.unpack_from("<3i2f", b, off)))
     if op == "Reshape":
         is_mx, rev, voff, is_onnx = struct.unpack_from("<iiIi", b, off)
         n = struct.unpack_from("<I", b, voff)[0] if voff else 0

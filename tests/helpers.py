@@ -75,21 +75,21 @@ def pool_graph(seed, n, c, h, w, alg, k, s, p=0, glob=0, caffe=0, same_scale=Fal
     return g, rng.integers(-127, 128, size=(n, c, h, w)).astype(np.int8)
 
 
-def eltwise_relu_graph(seed, n, c, h, w, with_relu=True, etype=tm2.ELT_SUM):
-    """two 1x1 convs -> eltwise -> [relu]; mirrors a ResNet block tail."""
+def eltwise_relu_graph(seed, n, c, h, w, with_relu=True, etype=tm2.ELT_SUM, k=1):
+    """two k x k convs (same-size output) -> eltwise -> [relu]; mirrors a ResNet block tail (k = 3: a basic block's)."""
     rng = np.random.default_rng(seed)
-    g, xin = conv_graph(seed, n, c, h, w, c, 1, act=-1)
+    g, xin = conv_graph(seed, n, c, h, w, c, k, 1, k // 2, act=-1)
     g.output_nodes = []
     x = g.nodes[g.input_nodes[0]].outputs[0]
     a = g.nodes[-1].outputs[0]
-    wq = rng.integers(-127, 128, size=(c, c, 1, 1)).astype(np.int8)
+    wq = rng.integers(-127, 128, size=(c, c, k, k)).astype(np.int8)
     ws = _scales(rng, c)
     wt = g.add_const("w2", wq, DT_INT8, ws, [0] * c)
     sb = float(np.float32(g.tensors[a].scales[0] * 1.37))
     b = g.add_tensor("out2", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [sb], [0])
-    g.add_node("conv2", "Convolution", [x, wt], [b], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1,
-               dilation_w=1, input_channel=c, output_channel=c, group=1, activation=-1, pad_h0=0, pad_w0=0,
-               pad_h1=0, pad_w1=0)
+    g.add_node("conv2", "Convolution", [x, wt], [b], kernel_h=k, kernel_w=k, stride_h=1, stride_w=1, dilation_h=1,
+               dilation_w=1, input_channel=c, output_channel=c, group=1, activation=-1, pad_h0=k // 2, pad_w0=k // 2,
+               pad_h1=k // 2, pad_w1=k // 2)
     so = float(np.float32(g.tensors[a].scales[0] * 1.9))
     e = g.add_tensor("sum", [n, c, h, w], DT_INT8, tm2.TT_VAR, None, [so], [0])
     ni = g.add_node("elt", "Eltwise", [a, b], [e], type=etype, caffe_flavor=1)

@@ -169,3 +169,39 @@ def test_back_to_back_passes_overlap_at_the_seam_and_keep_the_bytes(name, dtype,
         for u, v in zip(a, c):
             assert np.array_equal(u, v)
     assert any(not np.array_equal(u, v) for u, v in zip(res["1"][0], res["1"][1]))
+
+
+@pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 1), ("yolov3_tiny", "uint8", 1)])
+def test_device_copy_of_the_outputs_after_a_zero_copy_run(name, dtype, batch):
+    """tamd_graph_run on the direct path stores the outputs straight into the pinned host buffers (no download launch): the
+    device-side copy -- tamd_graph_output_device (the RCCL gather reads it), tamd_graph_download_outputs -- must still be THIS
+    run's bytes, not the previous pass's (it used to be stale)."""
+    import ctypes as C
+    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
+    b = tm2.write_tm2(g)
+    gr = capi.Graph(b, direct_dispatch=True)
+    x1, x2 = models.synth_input(g, 31, NP[dtype]), models.synth_input(g, 32, NP[dtype])
+    first = _resident(gr, x1, 1)                  # the staging buffers now hold x1's outputs
+    gr.set_input(x2)
+    got = [o.copy() for o in gr.run()]            # host-to-host, zero-copy outputs
+    assert any(not np.array_equal(a, c) for a, c in zip(first, got))
+    again = gr.download()                         # no pass in between: must be x2's outputs
+    for a, c in zip(got, again):
+        assert np.array_equal(a, c)
+    hip = C.CDLL("libamdhip64.so")
+    for i, want in enumerate(got):
+        p, n = gr.output_device(i)
+        assert n == want.nbytes
+        host = np.empty_like(want)
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(p), C.c_size_t(n), 2) == 0      # hipMemcpyDeviceToHost
+        assert np.array_equal(host, want), "output %d: the device copy is not the last run's" % i
+    # the asynchronous pair: the newest run decides
+    gr.set_input(x1)
+    gr.run_async()
+    gr.set_input(x2)
+    gr.run_async()
+    gr.wait()
+    gr.wait()
+    for a, c in zip(got, gr.download()):
+        assert np.array_equal(a, c)
+    gr.close()

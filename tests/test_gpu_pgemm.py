@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = ["conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
 KS2 = ["conv_pgemm_i8<128x64,3x3,ks2", "conv_pgemm_i8<128x128,3x3,ks2"]       # 512-thread blocks, intra-block split-K (3x3, cin % 128 == 0)
+# conv_pgemm_w.hip (round 5): eight-wave blocks with table-driven set-up (4 x 2 / 2 x 4 wave grids; ks2w: two K groups adding their
+# partial sums into one LDS tile, row-major epilogue).  The trailing comma / "w" keeps the prefix from matching the older kernels.
+WGRID = ["conv_pgemm_i8<128x64,3x3,w8>", "conv_pgemm_i8<128x128,3x3,w8>", "conv_pgemm_i8<64x128,3x3,w8>",
+         "conv_pgemm_i8<128x64,3x3,ks2w>", "conv_pgemm_i8<64x64,3x3,ks2w>",
+         # four waves with the table-driven set-up (w4t), and the forms with ONE barrier per filter row (b3: a 9-slot ring, the waves drift)
+         "conv_pgemm_i8<128x64,3x3,w4t>", "conv_pgemm_i8<64x64,3x3,w4t>", "conv_pgemm_i8<128x64,3x3,w4b3>", "conv_pgemm_i8<64x64,3x3,w4b3>",
+         "conv_pgemm_i8<128x128,3x3,w8b3>", "conv_pgemm_i8<64x64,3x3,ks2wb3>"]
 
 # n, cin, h, w, cout, k, s, p, group, act, bias, dil
 PATCH_CASES = [
@@ -59,7 +66,7 @@ def _run(member, case, seed):
     return want, got, name
 
 
-@pytest.mark.parametrize("member", VARIANTS + KS2)
+@pytest.mark.parametrize("member", VARIANTS + KS2 + WGRID)
 @pytest.mark.parametrize("ci", range(len(PATCH_CASES)))
 def test_patch_kernel_is_exact(member, ci):
     want, got, name = _run(member, PATCH_CASES[ci], 900 + ci)
@@ -92,6 +99,39 @@ def test_variants_really_run():
         assert KS2[0] in name, (KS2[0], name)
     # (128 x 128 tiles with two wave groups need 2 x (48 KB ring + two patch buffers): offered only where the patch is small --
     #  single-image 14 x 14 tiles -- and covered by the parametrised exactness test where it applies)
+    for member in WGRID:
+        # 14 x 14 x 128 -> 130 (two chunks, ragged cout), 7 x 7 x 512 (eight chunks, tiles over three images)
+        for case in (PATCH_CASES[1], PATCH_CASES[10]):
+            _, _, name = _run(member, case, 1)
+            assert member in name, (member, name)
+    for member in [m for m in WGRID if "<64x" in m]:       # stride 2 on 17 x 17 with 256 couts: the patch of a 128-pixel tile is > 512 units, 64-pixel tiles take it
+        _, _, name = _run(member, PATCH_CASES[11], 1)
+        assert member in name, (member, name)
+    for member in [m for m in WGRID if "x64," in m]:       # the 64-cout tiles also take the narrow layers: dilation 2, pad > halo, 25-pixel images, wide rows
+        for case in (PATCH_CASES[4], PATCH_CASES[7], PATCH_CASES[9], PATCH_CASES[8]):
+            if "ks2w" in member and (case[1] // 64) % 2:
+                continue
+            _, _, name = _run(member, case, 1)
+            assert member in name, (member, name)
+
+
+@pytest.mark.parametrize("member", WGRID)
+@pytest.mark.parametrize("relu,etype", [(True, tm2.ELT_SUM), (False, tm2.ELT_SUM), (True, tm2.ELT_MAX)])
+def test_wave_grid_kernels_fused_residual_tail(member, relu, etype):
+    """3 x 3 convolution + eltwise (+ ReLU) in the wave-grid kernels' epilogues: from registers (w8) and from the LDS partial-sum tile (ks2w)"""
+    g, x = eltwise_relu_graph(78, 5, 128, 14, 14, relu, etype, k=3)
+    want = oracle.run_graph(g, x)[0]
+    os.environ["TAMD_FORCE_GEMM"] = member
+    try:
+        gr = capi.Graph(tm2.write_tm2(g))
+    finally:
+        del os.environ["TAMD_FORCE_GEMM"]
+    gr.set_input(x)
+    got = gr.run()[0].reshape(want.shape)
+    names = [k["kernel"] for k in gr.profile(1)]
+    gr.close()
+    assert np.array_equal(got, want), names
+    assert any("+eltwise" in k and member in k for k in names), names
 
 
 @pytest.mark.parametrize("member", ["conv_pgemm_i8<128x64", "conv_pgemm_i8<64x64"])

@@ -2,9 +2,13 @@
 // variant and ablation: launch time (events, 20 back to back), and from the stamps wave 0 of EVERY block leaves -- shader clock
 // for the phases of a block (setup, first loads landing, K loop, epilogue), the 100 MHz wall clock for when blocks start and end
 // relative to the launch's first block (dispatch ramp, tail) -- the question being where the ~12 us of a 1.5 us (MFMA) layer go.
+// Round 5: the wave-grid kernels of conv_pgemm_w.hip (variants 16 ..) ride in the same loop with their geometry table; flag 64 | n << 16
+// delays the second dispatch round of every XCD by n x 1024 cycles (the phase-skew experiment); argv[2] = "3x3" runs the four 3x3
+// shapes of ResNet-50 only.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm --amdgpu-mfma-vgpr-form -DTAMD_IGEMM_STAMPS -I../../tengine_amd/csrc
 //        -o pgemm_anatomy.bin pgemm_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
 #include "../../tengine_amd/csrc/conv_pgemm.hip"
+#include "../../tengine_amd/csrc/conv_pgemm_w.hip"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,13 +60,22 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             CK(hipMemcpy(packed[slot], wf.data(), wf.size(), hipMemcpyHostToDevice));
         }
         ap.wfrag = packed[slot];
+        int* dtab = nullptr;
+        if (v & 16) {
+            std::vector<int> tab;
+            conv_pgemm_w_table(ap, tab);
+            CK(hipMalloc(&dtab, tab.size() * 4));
+            CK(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            ap.pg_tab = dtab;
+        }
         const int bm = (v & 2) ? 64 : 128;
         const int tiles = ((ap.M + bm - 1) / bm) * ((CO + bn - 1) / bn);
         const int grid = (((ap.M + bm - 1) / bm + 7) / 8) * 8 * ((CO + bn - 1) / bn);
 #ifdef TAMD_PG_ABLATE
         for (int flags : {0, 2, 2 | 8, 2 | 16, 2 | 4, 2 | 32, 2 | 1, 63}) {
 #else
-        for (int flags : {0, 256}) {        // 256: the tile computation twice in one launch (second pass: warm instruction cache)
+        // TAMD_ANATOMY_SKEW=1: the phase-skew experiment (profiles/r05_pgemm_anatomy_skew.txt)
+        for (int flags : std::vector<int>((v & 16) && !(v & 8) && getenv("TAMD_ANATOMY_SKEW") ? std::vector<int>{0, 64 | (2 << 16), 64 | (4 << 16)} : std::vector<int>{0})) {
 #endif
             ap.dbg_flags = flags; ap.dbg_stamps = nullptr;
             for (int i = 0; i < 3; i++) CK(launch_conv_pgemm(ap, st));
@@ -77,7 +90,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             CK(hipMemsetAsync(ds, 0, (size_t)max_blocks * 64, st));
             CK(launch_conv_pgemm(ap, st));
             CK(hipStreamSynchronize(st));
-            const int reps = (flags >> 8) + 1;
+            const int reps = ((flags >> 8) & 0xff) + 1;
             std::vector<long long> hall((size_t)grid * 8 * reps);
             CK(hipMemcpy(hall.data(), ds, hall.size() * 8, hipMemcpyDeviceToHost));
             for (int rep = 0; rep < reps; rep++) {
@@ -103,6 +116,7 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
+        if (dtab) hipFree(dtab);
     }
     hipFree(x); hipFree(y); hipFree(z); hipFree(bias); hipFree(sc); hipFree(ds);
     for (auto p : packed) if (p) hipFree(p);
@@ -110,9 +124,16 @@ static void run_shape(int N, int HW, int C, int CO, int K, int S, hipStream_t st
 
 int main(int argc, char** argv)
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);          // a faulting kernel must not take the lines before it along
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const int B = argc > 1 ? atoi(argv[1]) : 32;
     run_shape(B, 28, 128, 128, 3, 1, st);
+    if (argc > 2 && std::string(argv[2]) == "3x3") {
+        run_shape(B, 14, 256, 256, 3, 1, st);
+        run_shape(B, 7, 512, 512, 3, 1, st);
+        run_shape(B, 56, 64, 64, 3, 1, st);
+        return 0;
+    }
     if (argc > 2) return 0;
     run_shape(B, 14, 256, 256, 3, 1, st);
     run_shape(B, 56, 64, 64, 3, 1, st);
