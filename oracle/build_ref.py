@@ -15,6 +15,9 @@ Outputs go ONLY to oracle/_ref/ (git-ignored, shipped to the GPU box as a prebui
                                    source/CMakeLists.txt:324-327) so a device plugin can be loaded
                                    with load_tengine_plugin() (source/api/plugin.c:88-159)
   oracle/_ref/gen/                 generated registries + defines.h
+  oracle/_ref/models/              the structure-only model files tm_benchmark runs (benchmark/models/*_benchmark.tmfile,
+                                   10 - 80 KB each, no weights): test data for tests/test_reference_benchmark_files.py, which
+                                   must also run on the GPU box where /root/reference does not exist
 No reference source is copied into this repository.
 """
 import concurrent.futures as cf
@@ -121,7 +124,20 @@ def build(ref="/root/reference", jobs=None, verbose=False):
         subprocess.check_call(["gcc", "-shared", "-fopenmp", "-o", lib, "@" + rsp, "-ldl", "-lm", "-lpthread"])
     if verbose:
         print("reference lib: %s (%d objects)" % (lib, len(objs)))
+    copy_benchmark_models(ref)
     return lib
+
+
+def copy_benchmark_models(ref="/root/reference"):
+    """tm_benchmark's model files (benchmark/tm_benchmark.cc:250-289) -> oracle/_ref/models/ (git-ignored, travels with the prebuilt library)"""
+    import shutil
+    dst = os.path.join(OUT, "models")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(glob.glob(os.path.join(ref, "benchmark", "models", "*_benchmark.tmfile"))):
+        t = os.path.join(dst, os.path.basename(f))
+        if not os.path.exists(t) or os.path.getmtime(t) < os.path.getmtime(f):
+            shutil.copyfile(f, t)
+    return dst
 
 
 def build_tm_benchmark(ref="/root/reference", verbose=False):

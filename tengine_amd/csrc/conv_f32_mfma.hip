@@ -22,6 +22,7 @@
 //     hit four different bank quarters (conflict-free ds_read_b32);
 //   * out-of-image taps and padded k rows copy from a zero page instead of being predicated.
 #include <hip/hip_runtime.h>
+#include "env.h"
 
 #include <cstdlib>
 
@@ -257,7 +258,7 @@ static int region_dw(int wd) { return (32 / (64 / wd)) * (wd == 16 ? 64 : 80); }
 
 int conv_f32_mfma_pick(const F32ConvArgs& a)
 {
-    static const char* e = getenv("TAMD_F32_CFG");
+    static const char* e = exp_env("TAMD_F32_CFG");
     if (e && *e) return atoi(e) % 5;
     const int OHW = a.OH * a.OW, N8 = a.tail_split ? (OHW & ~7) : OHW;
     auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW != N8 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };

@@ -18,6 +18,7 @@
 //     given consecutive cout-tiles of the same pixel-tile, so the activation tile is fetched from
 //     HBM once per XCD and re-read from that XCD's L2.
 #include <stdlib.h>
+#include "env.h"
 
 #include <type_traits>
 
@@ -351,7 +352,7 @@ static hipError_t launch_ring_d(const ConvArgs& a, hipStream_t s, bool is1x1)
     const int tiles_n = (a.cout + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const size_t lds = 2 * (size_t)(BM + BN) * 64;
-    static const bool no_fast = getenv("TAMD_IGEMM_FAST") && atoi(getenv("TAMD_IGEMM_FAST")) == 0;      // tests: the generic loader
+    static const bool no_fast = exp_env("TAMD_IGEMM_FAST") && atoi(exp_env("TAMD_IGEMM_FAST")) == 0;      // tests: the generic loader
     if constexpr (BM % 64 == 0 && BN % 64 == 0) {
         if (fast_loader_ok(a) && !no_fast) {
             if (is1x1) hipLaunchKernelGGL((conv_igemm_fast_i8_kernel<BM, BN, WM, WN, true, D>), dim3(grid), dim3(256), lds, s, a);
@@ -413,7 +414,7 @@ static constexpr int NCFG = 16;
 static int pick_cfg(const ConvArgs& a)
 {
     static int forced = -2;
-    if (forced == -2) { const char* e = getenv("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
+    if (forced == -2) { const char* e = exp_env("TAMD_IGEMM_CFG"); forced = e ? atoi(e) : -1; }
     if (forced >= 0 && forced < NCFG) return forced;
     if (a.cfg >= 0 && a.cfg < NCFG) return a.cfg;            // plan-time autotune result
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.cout + bn - 1) / bn); };

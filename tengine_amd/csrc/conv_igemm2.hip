@@ -16,6 +16,7 @@
 
 #include "epilogue.h"
 #include "gemm_epilogue.h"
+#include "env.h"
 #include "kernels.h"
 
 namespace tamd {
@@ -188,9 +189,9 @@ static hipError_t launch2(const ConvArgs& a, hipStream_t s, bool is1x1)
     return hipGetLastError();
 }
 
-static int env_int(const char* name, int dflt)
+static int env_int(const char* name, int dflt)        // experiment builds only (csrc/env.h): the product always takes the default
 {
-    const char* e = getenv(name);
+    const char* e = exp_env(name);
     return e ? atoi(e) : dflt;
 }
 

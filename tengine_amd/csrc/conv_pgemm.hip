@@ -270,242 +270,6 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
 #endif
 }
 
-// ---- k x k with a COMPILE-TIME filter shape: the K loop unrolled over the taps of a 64-channel chunk ---------------------------
-// The generic kernel above still spends ~540 cycles per stage on its skeleton (profiles/r03_pgemm_anatomy_v1.txt: the same loop
-// with MFMAs, weight copies and epilogue all switched off): one wave issues an instruction every 4-5 cycles, and the scalar tap
-// walk, the ring-slot arithmetic and the padding loads are ~100 of them.  Here a chunk's KH*KW stages are straight-line code:
-//   * ring of LA = 3 slots and KH*KW % 3 == 0  ->  slot = tap % 3 is an immediate, so are all fragment offsets of the weights;
-//   * tap offsets are KH*KW scalars computed once; the only vector arithmetic of a stage is 4 adds (B fragment addresses);
-//   * the next chunk's patch granules are issued in stages 0..3 -- no padding loads, the counted waits are compile-time
-//     constants per tap position;
-//   * KS = 2: a 512-thread block whose second wave group takes the odd 64-channel chunks with its own ring and patch buffers
-//     (intra-block split-K).  Two waves per SIMD overlap one wave's instruction issue with the other's MFMAs -- with one
-//     block per CU there is nothing else to overlap with -- and the epilogue is split between the two groups after a
-//     partial-sum exchange through LDS (each keeps 32 of the wave tile's 64 pixel columns).
-template <int BM, int BN, int KH, int KW, int KS, int NPC, int RS_ = 6, int D_ = 5>
-__global__ __launch_bounds__(256 * KS) void conv_pgemm_taps_i8_kernel(ConvArgs a)
-{
-    // ring of RS slots, copies issued D stages ahead.  Two chunks (2 * NT stages) are one straight-line body, so slot = stage % RS
-    // is an immediate (2 * NT % RS == 0).  D: the first copies of a launch take ~1100 cycles to land (r03 anatomy: `land`), a stage
-    // is 250-300 cycles when it runs at the MFMA rate -- with D = 2 (round 3's first version) every stage waited for its weights.
-    constexpr int NT = KH * KW, RS = RS_, D = D_, LA = RS;
-    static_assert((2 * NT) % RS == 0 && D < RS && D >= 2 && NT - (D - 2) > 4, "ring slots static; patch granules land before their chunk");
-    static_assert(KS == 1 || BM == 128, "the split epilogue halves a 64-pixel wave tile");
-    constexpr int TM = BM / 64, TN = BN / 64, NA = BN / 64;
-    constexpr int STG = BN * 64;                         // bytes of a weight stage
-
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-
-    for (int pg_rep = 0; pg_rep < PG_REPS; pg_rep++) {
-    if (pg_rep) __syncthreads();
-    PG_STAMP(0);
-    PG_STAMP(1);
-    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = KS > 1 ? wave >> 2 : 0, w4 = wave & 3, wm = w4 & 1, wn = w4 >> 1;
-    const int tiles_n = (a.cout + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const int per_xcd = (tiles_m + 7) >> 3;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int lm = local / tiles_n, tile_n = local - lm * tiles_n;
-    const int tile_m = xcd * per_xcd + lm;
-    if (tile_m >= tiles_m) return;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int npad = a.pg_npad;                          // multiple of 64, <= NPC * 256
-    const int GRP = LA * STG + 2 * npad * 64;            // LDS bytes of a wave group: [ring][patch buffer 0][patch buffer 1]
-    int8_t* const lds = smem + grp * GRP;
-    const int nchunks = a.ckp >> 6, nck = nchunks / KS;  // 64-channel chunks; this group takes grp, grp + KS, ..
-
-    // ---- weights first: the copies of stages 0..D-1 fly while the patch addresses are worked out -----------------------------
-    const int8_t* wc = a.wfrag + ((size_t)tile_n * a.pg_ns + (size_t)grp * NT) * STG + lane * 16;      // stage 0 of chunk `grp`
-    // pair-local stage v (v / NT: chunk of the pair and beyond, v % NT: tap) -> bytes from wc; the group's chunks are KS apart
-    auto stage_off = [](int v) { return ((v / NT) * KS * NT + v % NT) * STG; };
-    auto issue_a = [&](int off, int slot) {              // off: bytes from wc (compile-time per call site)
-#pragma unroll
-        for (int i = 0; i < NA; i++) PG_GLDS16(wc + off + (i * 4 + w4) * 1024, lds + slot * STG + (i * 4 + w4) * 1024);
-    };
-#pragma unroll
-    for (int p = 0; p < D; p++) issue_a(stage_off(p), p);
-    // .. and the epilogue's per-channel vectors (bias, multipliers: 8 bytes per cout, touched once per layer -- fetched from global
-    // memory at the START of the epilogue they were a cold round trip of ~1000 cycles in every block): one LDS-DMA piece by wave 0,
-    // lanes 0-31 the bias granules, lanes 32-63 the multipliers'
-    const int EOFF = KS * GRP + 64;
-    if (wave == 0) {
-        const int gq = (lane & 31) % (BN / 4);
-        const int8_t* src = lane < 32 ? (const int8_t*)(a.bias + n0) + gq * 16 : (const int8_t*)(a.wscale + n0) + gq * 16;
-        PG_GLDS16(src, smem + EOFF);
-    }
-
-    // ---- the patch (see the generic kernel for the virtual padded input) ------------------------------------------------------
-    const int ohw = a.OH * a.OW, Hp = a.pg_hp, Wp = a.pg_wp;
-    const int ml = (m0 + BM - 1) < a.M ? (m0 + BM - 1) : a.M - 1;
-    const int na = pg_div(m0, a.mg_ohw), oya = pg_div(m0 - na * ohw, a.mg_ow);
-    const int nb = pg_div(ml, a.mg_ohw), oyb = pg_div(ml - nb * ohw, a.mg_ow);
-    const int R0 = na * Hp + oya * a.SH;
-    const int NP = (nb * Hp + oyb * a.SH + (KH - 1) * a.DH - R0 + 1) * Wp;
-    const int8_t* psrc[NPC];
-    int pstep[NPC];
-    // 64-pixel pieces of the patch, NPC per wave; where the piece count is not a multiple of 4 the surplus waves copy the LAST
-    // piece once more (same bytes to the same place) -- every wave issues the same number of loads, the counted waits stay static
-    const int pieces = npad >> 6;
-    int pq[NPC];
-#pragma unroll
-    for (int j = 0; j < NPC; j++) {
-        pq[j] = (j * 4 + w4) < pieces ? (j * 4 + w4) : pieces - 1;
-        const int pp = pq[j] * 64 + lane;
-        const int vrow = pg_div(pp, a.mg_wp), ix = pp - vrow * Wp;        // Wp == W here: patch columns are the input's own
-        const int VR = R0 + vrow, n = pg_div(VR, a.mg_hp);
-        const int iy = VR - n * Hp - a.PH;
-        const bool ok = pp < NP && (unsigned)iy < (unsigned)a.H && n < a.N;
-        psrc[j] = ok ? a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.cs_in : a.zeros;
-        pstep[j] = ok ? 16 : 0;
-    }
-    auto issue_patch = [&](int c, int g, int buf) {      // granule g of chunk c -> patch buffer buf
-#pragma unroll
-        for (int j = 0; j < NPC; j++)
-            PG_GLDS16(psrc[j] + (c * 4 + g) * pstep[j], lds + LA * STG + buf * (npad * 64) + (g * npad + pq[j] * 64) * 16);
-    };
-#pragma unroll
-    for (int g = 0; g < 4; g++) issue_patch(grp, g, 0);
-
-    int toff[NT];                                        // tap -> byte offset inside a patch granule plane (scalars)
-#pragma unroll
-    for (int tp = 0; tp < NT; tp++) toff[tp] = ((tp / KW) * a.DH * Wp + (tp % KW) * a.DW) * 16;
-    const int afr = grp * GRP + (wn * TN * 2) * 1024 + lane * 16;
-    // The patch has NO halo columns (row pitch = W): consecutive output pixels are consecutive 16-byte units even across a row
-    // wrap, so the 16 lanes of a ds_read_b128 group always hit 16 different bank quads (with halo columns every wrap shifted the
-    // rest of the wave by two units: 30 % of the LDS cycles were bank conflicts, profiles/r03_pmc_pgemm_v2_*).  Taps that fall off
-    // the left / right edge are per-lane instead: such a lane reads a zero unit (one select on the address, no data masking).
-    int bfr[TM][2];
-    bool edge[TM][KW];                                   // lane's pixel x tap column kx is outside the image
-#pragma unroll
-    for (int j = 0; j < TM; j++) {
-        int m = m0 + (wm * TM + j) * 32 + l31;
-        m = m < a.M ? m : a.M - 1;
-        const int n = pg_div(m, a.mg_ohw), rem = m - n * ohw, oy = pg_div(rem, a.mg_ow), ox = rem - oy * a.OW;
-        const int ix0 = ox * a.SW - a.PW;
-        const int pp0 = (n * Hp + oy * a.SH - R0) * Wp + ix0;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) bfr[j][kk] = grp * GRP + LA * STG + ((kk * 2 + hi) * npad + pp0) * 16;
-#pragma unroll
-        for (int kx = 0; kx < KW; kx++) edge[j][kx] = (unsigned)(ix0 + kx * a.DW) >= (unsigned)a.W;
-    }
-    const int ZOFF = KS * GRP;                           // 16 zero bytes behind the groups' buffers
-    if (t < 4) reinterpret_cast<int*>(smem + ZOFF)[t] = 0;
-
-    v16i_p acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
-
-    // fragment registers: fr[set][r], r < 2*TN: weights (cout tile r/2, k half r%2); then activations (pixel tile, k half)
-    constexpr int NR = 2 * TN + 2 * TM, NM = 2 * TN * TM;
-    v4i_p fr[2][NR];
-    auto read_one = [&](auto P, auto R, auto SLOT, auto KX, int boff) {
-        constexpr int p = decltype(P)::value, r = decltype(R)::value, slot = decltype(SLOT)::value, kx = decltype(KX)::value;
-        if constexpr (r < 2 * TN) fr[p][r] = *reinterpret_cast<const v4i_p*>(smem + afr + slot * STG + r * 1024);
-        else {
-            constexpr int j = (r - 2 * TN) / 2, kk = (r - 2 * TN) % 2;
-            fr[p][r] = *reinterpret_cast<const v4i_p*>(smem + (edge[j][kx] ? ZOFF : bfr[j][kk] + boff));
-        }
-    };
-    auto mfma_one = [&](auto P, auto Mi) {
-        constexpr int p = decltype(P)::value, m = decltype(Mi)::value;
-        constexpr int kk = m / (TN * TM), i = (m / TM) % TN, j = m % TM;
-        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[p][i * 2 + kk], fr[p][2 * TN + j * 2 + kk], acc[i][j], 0, 0, 0);
-    };
-#define PG_SB() __builtin_amdgcn_sched_barrier(0)
-
-    PG_STAMP(2);
-    __builtin_amdgcn_s_waitcnt(PG_WAITCNT(0));           // every copy has landed, the zero unit is written
-    __builtin_amdgcn_s_barrier();
-    static_for<0, NR>([&](auto R) { read_one(pg_int<0>{}, R, pg_int<0>{}, pg_int<0>{}, toff[0]); });
-    PG_STAMP(3);
-
-    // Two 64-channel chunks = 2 * NT stages, straight-line.  The first chunk of a pair multiplies patch buffer 0, the second
-    // buffer 1.  A stage, in issue order (pinned with scheduling barriers: left alone, hipcc sinks the fragment reads of stage
-    // s+1 behind the MFMAs of stage s and then waits for them twice per stage):
-    //   wait for the copies of stage s+1, barrier | MFMA 0 | issue the copies of stage s+D (and a patch granule) | MFMA 1 |
-    //   fragment reads of stage s+1 into the OTHER register set, spread behind MFMAs 1.. | remaining MFMAs
-    // so the matrix pipe starts right behind the barrier and every LDS read has at least two MFMAs (64+ cycles) to land.
-    auto half = [&](auto H, int ci) {
-        constexpr int h = decltype(H)::value;
-        // patch granules issued during this half: for the NEXT chunk of the group (clamped: the last one re-fetches itself)
-        const int cnext = ci + h + 1 < nck ? ci + h + 1 : nck - 1;
-        static_for<0, NT>([&](auto T) {
-            constexpr int tp = decltype(T)::value, u = h * NT + tp, p = u & 1;
-            // copies issued by the previous D-2 stages may stay in flight; everything older -- stage u+1's weights included -- has landed
-            constexpr int W = pg_inflight(u, D, NT, NA, NPC);
-            if (PG_ON(32)) __builtin_amdgcn_s_waitcnt(PG_WAITCNT(W));
-            if (PG_ON(8)) __builtin_amdgcn_s_barrier();
-            PG_SB();
-            if (PG_ON(1)) mfma_one(pg_int<p>{}, pg_int<0>{});
-            PG_SB();
-            if constexpr (tp < 4) { if (PG_ON(4)) issue_patch(grp + cnext * KS, tp, h ^ 1); }
-            if (PG_ON(4)) issue_a(stage_off(u + D), (u + D) % RS);
-            PG_SB();
-            constexpr int un = (u + 1) % (2 * NT), tn = un % NT;                           // the stage whose fragments are read now
-            const int boff = (un / NT) * (npad * 64) + toff[tn];
-            constexpr int slots = NM > 4 ? NM / 2 : (NM > 1 ? NM - 1 : 1);        // MFMAs 1 .. slots get fragment reads in front of them
-            constexpr int per = (NR + slots - 1) / slots;
-            static_for<1, NM>([&](auto Mi) {
-                constexpr int m = decltype(Mi)::value;
-                static_for<0, per>([&](auto Q) {
-                    constexpr int r = (m - 1) * per + decltype(Q)::value;
-                    if constexpr (m <= slots && r < NR) { if (PG_ON(16)) read_one(pg_int<p ^ 1>{}, pg_int<r>{}, pg_int<(u + 1) % RS>{}, pg_int<tn % KW>{}, boff); }
-                });
-                PG_SB();
-                if (PG_ON(1)) mfma_one(pg_int<p>{}, Mi);
-                PG_SB();
-            });
-            if constexpr (NM == 1) static_for<0, NR>([&](auto R) { read_one(pg_int<p ^ 1>{}, R, pg_int<(u + 1) % RS>{}, pg_int<tn % KW>{}, boff); });
-        });
-    };
-    for (int ci = 0; ci < nck; ci += 2) {
-        half(pg_int<0>{}, ci);
-        if (ci + 1 < nck) half(pg_int<1>{}, ci);
-        wc += (size_t)2 * KS * NT * STG;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's trailing copies must not outlive the workgroup
-    PG_STAMP(4);
-
-    if constexpr (KS == 1) {
-        if (PG_ON(2)) igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});
-    } else {
-        // partial sums of the two groups: group 0 keeps pixel columns [0,32) of each wave tile, group 1 keeps [32,64); the other
-        // half goes to the partner wave (wave ^ 4) through LDS -- then each runs the epilogue on its half
-        if (grp == 1) {
-#pragma unroll
-            for (int i = 0; i < TN; i++) { const v16i_p tmp = acc[i][0]; acc[i][0] = acc[i][1]; acc[i][1] = tmp; }
-        }
-        __builtin_amdgcn_s_barrier();                     // every wave is past its last fragment read (and its copies have landed)
-#pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const v4i_p v = {acc[i][1][4 * q], acc[i][1][4 * q + 1], acc[i][1][4 * q + 2], acc[i][1][4 * q + 3]};
-                *reinterpret_cast<v4i_p*>(smem + ((wave * TN + i) * 4 + q) * 1024 + lane * 16) = v;
-            }
-        __builtin_amdgcn_s_waitcnt(PG_WAITCNT(0));
-        __builtin_amdgcn_s_barrier();
-        v16i_p fin[TN][1];
-#pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const v4i_p v = *reinterpret_cast<const v4i_p*>(smem + (((wave ^ 4) * TN + i) * 4 + q) * 1024 + lane * 16);
-#pragma unroll
-                for (int k = 0; k < 4; k++) fin[i][0][4 * q + k] = acc[i][0][4 * q + k] + v[k];
-            }
-        if (PG_ON(2)) igemm_epilogue_src<1, TN>(a, fin, m0 + (wm + grp) * 32, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});
-    }
-    PG_STAMP(5);
-    PG_STAMP(6);
-    }
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static int pg_env(const char* name, int dflt)
 {
@@ -513,15 +277,14 @@ static int pg_env(const char* name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-enum { PG_ROWS = 0, PG_TAPS3 = 1, PG_PATCH = 2 };      // 1x1 | 3x3 (unrolled taps kernel) | any other k x k (generic patch kernel)
+enum { PG_ROWS = 0, PG_PATCH = 2 };      // 1x1 | any other k x k (generic patch kernel; 3x3 has its own kernels in conv_pgemm_w.hip)
 static int pg_kind(const ConvArgs& a)
 {
-    if (a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0) return PG_ROWS;
-    return (a.KH == 3 && a.KW == 3) ? PG_TAPS3 : PG_PATCH;
+    return (a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0) ? PG_ROWS : PG_PATCH;
 }
 
 // patch pixels the worst pixel tile of `bm` outputs needs (rows it touches, halo included, times the padded row length)
-static int pg_pitch(const ConvArgs& a) { return pg_kind(a) == PG_TAPS3 ? a.W : (a.OW - 1) * a.SW + (a.KW - 1) * a.DW + 1; }
+static int pg_pitch(const ConvArgs& a) { return (a.OW - 1) * a.SW + (a.KW - 1) * a.DW + 1; }
 
 static int pg_patch_pixels(const ConvArgs& a, int bm)
 {
@@ -539,14 +302,14 @@ static int pg_patch_pixels(const ConvArgs& a, int bm)
 
 int conv_pgemm_stages(const ConvArgs& a) { return pg_kind(a) == PG_ROWS ? (a.ckp + 63) / 64 : (a.ckp / 64) * a.KH * a.KW; }
 
-// variants: bit 0: BN 128 (else 64); bit 1: BM 64 (else 128); bit 2: KS 2 (512-thread blocks, intra-block split-K; 3x3 only)
-static constexpr int PG_LA = 4;            // ring depth of the generic kernels (the unrolled-taps kernel has 3 slots)
-// variants with bit 4 (16 .. 31, 48 .. 63): the wave-grid form of conv_pgemm_w.hip (3x3 only; the same tile bits and packed weights)
-int conv_pgemm_num_variants() { return 64; }       // (8 .. 15 are not used: the 3-slot ring they once named measured slower everywhere, profiles/r03_members_3x3_b32.txt)
+// variants 0 .. 3 (this file): bit 0: BN 128 (else 64); bit 1: BM 64 (else 128).  Variants with bit 4 (16 .. 31, 48 .. 63): the 3x3
+// kernels of conv_pgemm_w.hip (same tile bits and packed weights; its own bits 2, 3, 5).  Everything else is unused: the round-3
+// unrolled-taps kernel (3x3, its split-K and 3-slot-ring forms) that lived here lost to conv_pgemm_w.hip on every ResNet-50
+// shape (profiles/r05_pgemm_anatomy_v2_b3.txt) and was removed in round 5.
+static constexpr int PG_LA = 4;            // ring depth
+int conv_pgemm_num_variants() { return 64; }
 int conv_pgemm_bn(int variant) { return (variant & 1) ? 128 : 64; }
 static int pg_bm(int variant) { return (variant & 2) ? 64 : 128; }
-static int pg_ks(int variant) { return (variant & 4) ? 2 : 1; }
-static int pg_rs(int) { return 6; }       // ring slots of the 3x3 kernel (copies 5 stages ahead)
 
 static int pg_npad(const ConvArgs& a, int variant)
 {
@@ -560,7 +323,6 @@ static size_t pg_lds(const ConvArgs& a, int variant, int npad)
     const int bn = conv_pgemm_bn(variant), bm = pg_bm(variant);
     switch (pg_kind(a)) {
     case PG_ROWS: return (size_t)PG_LA * (bn + bm) * 64 + 1024;
-    case PG_TAPS3: return (size_t)pg_ks(variant) * (pg_rs(variant) * (size_t)bn * 64 + 2 * (size_t)npad * 64) + 64 + 1024;     // + zero unit, + bias / multipliers of the cout tile
     default: return (size_t)PG_LA * bn * 64 + 2 * (size_t)npad * 64 + 4096 + 1024;
     }
 }
@@ -569,13 +331,13 @@ bool conv_pgemm_applicable(const ConvArgs& a, int variant)
 {
     static const int mode = pg_env("TAMD_PGEMM", 1);
     if (variant & 16) return mode && conv_pgemm_w_applicable(a, variant);
-    if (!mode || a.zeros == nullptr || a.M >= (1 << 24) || a.OH * a.OW >= 65536) return false;
-    const int bn = conv_pgemm_bn(variant), bm = pg_bm(variant), ks = pg_ks(variant), kind = pg_kind(a);
+    if (variant >= 4 || !mode || a.zeros == nullptr || a.M >= (1 << 24) || a.OH * a.OW >= 65536) return false;
+    const int bn = conv_pgemm_bn(variant), bm = pg_bm(variant), kind = pg_kind(a);
     if (bn == 128 && a.cout <= 64) return false;
     if (bm == 128 && a.M <= 64) return false;
-    if (ks == 2 && (kind != PG_TAPS3 || bm != 128 || (a.ckp / 64) % 2 != 0)) return false;
-    if (variant & 8) return false;
     if (kind == PG_ROWS) return a.ckp >= 32;
+    // a 3x3 layer the dedicated kernels take (same pixel tile, four waves, table-driven set-up) is not offered the generic one as well
+    if (a.KH == 3 && a.KW == 3 && conv_pgemm_w_applicable(a, 16 | 8 | (variant & 2))) return false;
     const int Hp = (a.OH - 1) * a.SH + (a.KH - 1) * a.DH + 1, Wp = (a.OW - 1) * a.SW + (a.KW - 1) * a.DW + 1;
     if (a.ckp % 64 != 0 || a.cs_in < a.ckp) return false;
     if (a.KH * a.KW < PG_LA + 4 || a.KH * a.KW > 64) return false;        // a chunk's patch loads (4 stages) land LA-1 stages later, inside the chunk
@@ -630,12 +392,10 @@ size_t conv_pgemm_packed_bytes(const ConvArgs& a, int bn)
 
 const char* conv_pgemm_kernel_name(const ConvArgs& a)
 {
-    static const char* names[4][4] = {{"conv_pgemm_i8<128x64,rows>", "conv_pgemm_i8<128x128,rows>", "conv_pgemm_i8<64x64,rows>", "conv_pgemm_i8<64x128,rows>"},
-                                      {"conv_pgemm_i8<128x64,3x3>", "conv_pgemm_i8<128x128,3x3>", "conv_pgemm_i8<64x64,3x3>", "conv_pgemm_i8<64x128,3x3>"},
-                                      {"conv_pgemm_i8<128x64,patch>", "conv_pgemm_i8<128x128,patch>", "conv_pgemm_i8<64x64,patch>", "conv_pgemm_i8<64x128,patch>"},
-                                      {"conv_pgemm_i8<128x64,3x3,ks2>", "conv_pgemm_i8<128x128,3x3,ks2>", "?", "?"}};
+    static const char* names[2][4] = {{"conv_pgemm_i8<128x64,rows>", "conv_pgemm_i8<128x128,rows>", "conv_pgemm_i8<64x64,rows>", "conv_pgemm_i8<64x128,rows>"},
+                                      {"conv_pgemm_i8<128x64,patch>", "conv_pgemm_i8<128x128,patch>", "conv_pgemm_i8<64x64,patch>", "conv_pgemm_i8<64x128,patch>"}};
     if (a.pg_variant & 16) return conv_pgemm_w_kernel_name(a);
-    return names[(a.pg_variant & 4) ? 3 : pg_kind(a)][a.pg_variant & 3];
+    return names[pg_kind(a) == PG_ROWS ? 0 : 1][a.pg_variant & 3];
 }
 
 template <typename K>
@@ -654,15 +414,6 @@ static hipError_t pg_launch_mn(const ConvArgs& a, hipStream_t s)
 {
     switch (pg_kind(a)) {
     case PG_ROWS: return pg_go(conv_pgemm_i8_kernel<BM, BN, false, PG_LA, 0>, a, BM, BN, 256, s);
-    case PG_TAPS3:
-        if constexpr (BM == 128) {
-            if (a.pg_variant & 4) {
-                if (a.pg_npad <= 256) return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 2, 1>, a, BM, BN, 512, s);
-                return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 2, 2>, a, BM, BN, 512, s);
-            }
-        }
-        if (a.pg_npad <= 256) return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 1>, a, BM, BN, 256, s);
-        return pg_go(conv_pgemm_taps_i8_kernel<BM, BN, 3, 3, 1, 2>, a, BM, BN, 256, s);
     default:
         if (a.pg_npad <= 256) return pg_go(conv_pgemm_i8_kernel<BM, BN, true, PG_LA, 1>, a, BM, BN, 256, s);
         return pg_go(conv_pgemm_i8_kernel<BM, BN, true, PG_LA, 2>, a, BM, BN, 256, s);

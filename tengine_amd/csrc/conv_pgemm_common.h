@@ -46,13 +46,4 @@ template <int N> struct pg_int { static constexpr int value = N; };
 #define PG_ON(bit) true
 #endif
 
-// loads a wave has issued in the D-2 stages before pair-local stage u (each stage: NA weight pieces, + NPC patch pieces in the
-// first four taps of a chunk): what may stay in flight when the weights of stage u+1 must have landed
-constexpr int pg_inflight(int u, int d, int nt, int na, int npc)
-{
-    int w = 0;
-    for (int q = 1; q <= d - 2; q++) w += na + ((((u - q + 2 * nt) % (2 * nt)) % nt) < 4 ? npc : 0);
-    return w;
-}
-
 }  // namespace tamd

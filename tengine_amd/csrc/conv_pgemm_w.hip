@@ -1,8 +1,11 @@
-// int8 3x3 implicit-GEMM convolution, wave-grid form of conv_pgemm.hip's unrolled-taps kernel ("w": WM x WN waves per K group).
+// int8 3x3 implicit-GEMM convolution ("w": WM x WN waves per K group): the successor of round 3's unrolled-taps kernel.
 //
 // Same arithmetic, operand roles, weight fragment packing and fused epilogue as conv_pgemm.hip (reference chain
-// conv_kernel_x86.c:187-242 im2col, :963-1007 pack, :1008-1630 sgemm_i8, :1796-1893 epilogue); the K loop is the same counted-wait
-// LDS-DMA ring (6 slots, copies 5 stages ahead, two 64-channel chunks unrolled).  What changes is a block's FIXED cost -- on
+// conv_kernel_x86.c:187-242 im2col, :963-1007 pack, :1008-1630 sgemm_i8, :1796-1893 epilogue).  The K loop: the block keeps the
+// input PATCH of its pixel tile resident in LDS (granule-major, no halo columns: conv_pgemm.hip), weights arrive through a
+// counted-wait LDS-DMA ring, two 64-channel chunks = 18 stages are straight-line code so that ring slot, tap offset, register set
+// and every s_waitcnt immediate are compile-time; a stage's issue order is pinned with sched_barrier (wait + barrier, MFMA 0, the
+// copies of a later stage, the fragment reads of the NEXT stage spread behind the remaining MFMAs).  What round 5 changed is a block's FIXED cost -- on
 // ResNet-50's 3x3 layers at batch 32 a CU sees 0.8 - 1.5 tiles per launch and 48 % of a block's life was set-up, landing and
 // epilogue (profiles/r03_pgemm_anatomy_v4_taps_ring6.txt):
 //   * SET-UP FROM A TABLE.  The planner writes, per pixel tile, the NHWC pixel index of every patch unit (or -1: a zero row /
@@ -398,6 +401,11 @@ bool conv_pgemm_w_applicable(const ConvArgs& a, int v)
     if (!pw_w4(v) && ks == 1 && bm == 64 && bn == 64) return false;              // 64 x 64 has four 32 x 32 wave tiles: KS 2 or the 2 x 2 form
     if (pw_w4(v) && bn == 128) return false;                                    // the 2 x 2 form is instantiated for 64-cout tiles only
     if (pw_b3(v) && !(pw_w4(v) || (ks == 2 && bm == 64) || (bn == 128 && bm == 128))) return false;      // one barrier per filter row: the forms instantiated below
+#ifndef TAMD_EXPERIMENTS
+    // forms that lost on every ResNet-50 shape (profiles/r05_pgemm_anatomy_*.txt) are only built for tools/exp/pgemm_anatomy.hip:
+    // the two K groups (ks2w), eight waves over 64 couts with copy roles (128x64 w8) and the 2 x 4 wave grid (64x128 w8)
+    if (ks == 2 || (!pw_w4(v) && !(bn == 128 && bm == 128))) return false;
+#endif
     if ((long)a.N * a.H * a.W >= (1L << 31) || a.M >= (1 << 24)) return false;
     const long tiles_m = (a.M + bm - 1) / bm, tiles_n = (a.cout + bn - 1) / bn;
     if (((tiles_m + 7) / 8 + 1) * tiles_n >= (1L << 31) / tiles_n) return false;     // local / tiles_n by multiply-high
@@ -475,6 +483,7 @@ hipError_t launch_conv_pgemm_w(const ConvArgs& a, hipStream_t s)
 {
     const int v = a.pg_variant, npad = a.pg_npad;
     const bool b3 = pw_b3(v), wide = npad > 256;        // wide: two patch pieces per copying wave of a four-wave copy crew
+#ifdef TAMD_EXPERIMENTS
     if (pw_ks(v) == 2) {
         if (v & 2) {
             if (b3) return wide ? pw_go(PW_K(64, 64, 2, 2, 2, 2, 3), a, 512, s) : pw_go(PW_K(64, 64, 2, 2, 2, 1, 3), a, 512, s);
@@ -482,6 +491,9 @@ hipError_t launch_conv_pgemm_w(const ConvArgs& a, hipStream_t s)
         }
         return wide ? pw_go(PW_K(128, 64, 2, 2, 2, 2, 1), a, 512, s) : pw_go(PW_K(128, 64, 2, 2, 2, 1, 1), a, 512, s);
     }
+    if (!pw_w4(v) && (v & 3) == 0) return wide ? pw_go(PW_K(128, 64, 4, 2, 1, 2, 1), a, 512, s) : pw_go(PW_K(128, 64, 4, 2, 1, 1, 1), a, 512, s);
+    if (!pw_w4(v) && (v & 3) == 3) return pw_go(PW_K(64, 128, 2, 4, 1, 1, 1), a, 512, s);
+#endif
     if (pw_w4(v)) {
         if (v & 2) {
             if (b3) return wide ? pw_go(PW_K(64, 64, 2, 2, 1, 2, 3), a, 256, s) : pw_go(PW_K(64, 64, 2, 2, 1, 1, 3), a, 256, s);
@@ -490,11 +502,8 @@ hipError_t launch_conv_pgemm_w(const ConvArgs& a, hipStream_t s)
         if (b3) return wide ? pw_go(PW_K(128, 64, 2, 2, 1, 2, 3), a, 256, s) : pw_go(PW_K(128, 64, 2, 2, 1, 1, 3), a, 256, s);
         return wide ? pw_go(PW_K(128, 64, 2, 2, 1, 2, 1), a, 256, s) : pw_go(PW_K(128, 64, 2, 2, 1, 1, 1), a, 256, s);
     }
-    switch (v & 3) {
-    case 0: return wide ? pw_go(PW_K(128, 64, 4, 2, 1, 2, 1), a, 512, s) : pw_go(PW_K(128, 64, 4, 2, 1, 1, 1), a, 512, s);
-    case 1: return b3 ? pw_go(PW_K(128, 128, 4, 2, 1, 1, 3), a, 512, s) : pw_go(PW_K(128, 128, 4, 2, 1, 1, 1), a, 512, s);
-    default: return pw_go(PW_K(64, 128, 2, 4, 1, 1, 1), a, 512, s);
-    }
+    if ((v & 3) == 1) return b3 ? pw_go(PW_K(128, 128, 4, 2, 1, 1, 3), a, 512, s) : pw_go(PW_K(128, 128, 4, 2, 1, 1, 1), a, 512, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace tamd

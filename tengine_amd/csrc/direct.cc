@@ -25,6 +25,7 @@
 // queue; graph.hip drains the stream before the first packet of a burst is written).  Kernels with a scratch frame pass their
 // private segment size in the packet; the runtime backs the queue's scratch on demand as it does for HIP's queues.
 #include <hip/hip_runtime.h>
+#include "env.h"
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
@@ -231,7 +232,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         const KernelSym& k = it->second;
         // scratch (the out-of-line hand-over paths of a few epilogues reserve a call frame): the packet carries the size and the
         // runtime backs the queue's scratch on demand, as it does for HIP's own queues; TAMD_DIRECT_SCRATCH=0 refuses instead
-        static const bool allow_scratch = !(getenv("TAMD_DIRECT_SCRATCH") && atoi(getenv("TAMD_DIRECT_SCRATCH")) == 0);
+        static const bool allow_scratch = !(exp_env("TAMD_DIRECT_SCRATCH") && atoi(exp_env("TAMD_DIRECT_SCRATCH")) == 0);
         if (k.priv != 0 && !allow_scratch) { *why = "a kernel of the list uses scratch memory"; delete p; return nullptr; }
         if (r.args.size() > k.kernarg) { *why = "recorded arguments exceed the kernel's argument segment"; delete p; return nullptr; }
         // hidden arguments: at the offsets the kernel's own metadata lists (codeobj_meta.h).  Only where the code object is no
@@ -240,7 +241,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         // (graph.hip direct_selfcheck) is what then vouches for them.  TAMD_DIRECT_META=0 forces the defaults (tests).
         HiddenLayout hl;
         {
-            static const bool use_meta = !(getenv("TAMD_DIRECT_META") && atoi(getenv("TAMD_DIRECT_META")) == 0);
+            static const bool use_meta = !(exp_env("TAMD_DIRECT_META") && atoi(exp_env("TAMD_DIRECT_META")) == 0);
             auto lt = ctx->layouts.find(key);
             if (use_meta && lt != ctx->layouts.end()) {
                 hl = lt->second;
@@ -279,7 +280,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         pk.kernel_object = k.object;
         p->pkts.push_back(pk);
         // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores): flagged by their launcher
-        static const bool allow_none = !(getenv("TAMD_DIRECT_COHERENT") && atoi(getenv("TAMD_DIRECT_COHERENT")) == 0);
+        const bool allow_none = tamd_pin_int("direct_coherent", 1) != 0;      // (read at every prerun: a test flips it inside one process)
         coherent.push_back(allow_none && r.coherent);
     }
     if (hipMalloc(&p->kernargs, blob.size()) != hipSuccess || hipMemcpy(p->kernargs, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -305,7 +306,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         if (hsa_signal_create(DirectQueue::kStart, 0, nullptr, &p->dq->done) != HSA_STATUS_SUCCESS) { *why = "hsa_signal_create"; p->dq->refs = 1; direct_destroy(p); return nullptr; }
         // experiment (tools/exp): run the whole list on a subset of the CUs -- "first32" = mask bits 0..31,
         // "stride8" = every 8th bit (tools/exp/cumask_probe.hip tells which of the two is one XCD on this stack)
-        if (const char* cm = getenv("TAMD_DIRECT_CU_MASK")) {
+        if (const char* cm = exp_env("TAMD_DIRECT_CU_MASK")) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (!strcmp(cm, "first32")) mask[0] = 0xffffffffu;
             else if (!strcmp(cm, "stride8")) for (int i = 0; i < 8; i++) mask[i] = 0x01010101u;
@@ -336,7 +337,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         // already dropped every stale line; nothing it reads has been written since (or it would not be independent)
         const bool beside = i > 0 && recs[i].beside;
         n_beside += beside;
-        static const bool exp_nofence = getenv("TAMD_EXP_NOFENCE") != nullptr;        // timing experiment: bytes not trustworthy (graph.hip)
+        static const bool exp_nofence = exp_env("TAMD_EXP_NOFENCE") != nullptr;        // timing experiment: bytes not trustworthy (graph.hip)
         if (!coherent[i] && exp_nofence) p->hdr.push_back(header(K, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, !beside));
         else if (!coherent[i]) p->hdr.push_back(header(K, beside ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, !beside));
         else p->hdr.push_back(header(K, (i > 0 && !coherent[i - 1]) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE));

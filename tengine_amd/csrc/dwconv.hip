@@ -14,6 +14,7 @@
 // ~2 VALU per output-row instead of 3 sign-extends + 3 multiply-adds.  No padded copy is made:
 // out-of-image pixels are loaded as 0 (== the reference's explicit zero pad).
 #include "dw_common.h"
+#include "env.h"
 #include "epilogue.h"
 #include "kernels.h"
 
@@ -144,7 +145,7 @@ static void dw_form(const DwArgs& a, int* nf, int* th)
     *nf = 1;
     *th = rows >= 256 ? 2 : 1;
     if (a.S == 1 && a.OH >= 28 && rows >= 1024) *th = 4;
-    if (const char* e = getenv("TAMD_DW_FORM")) {
+    if (const char* e = tamd_pin("dw_form")) {
         const int v = atoi(e);
         if (v / 10 >= 1 && v / 10 <= 2 && (v % 10 == 1 || v % 10 == 2 || (v % 10 == 4 && v / 10 == 1))) { *nf = v / 10; *th = v % 10; }
     }

@@ -9,6 +9,7 @@
 // and the K dimension is split over the block's waves (partials reduced through LDS once).
 // One memory round trip + a handful of MFMAs + the fused requantising epilogue.
 #include <stdlib.h>
+#include "env.h"
 
 #include "epilogue.h"
 #include "kernels.h"
@@ -96,7 +97,7 @@ static int direct_max_m()
 {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("TAMD_DIRECT_MAX_M");
+        const char* e = exp_env("TAMD_DIRECT_MAX_M");
         v = e ? atoi(e) : 1024;
     }
     return v;

@@ -7,6 +7,7 @@
 //            the node list into a launch list and capture it into ONE hipGraph;
 //   run    : H2D inputs -> hipGraphLaunch -> D2H outputs on a private stream, pinned bounce buffers.
 #include "graph.h"
+#include "env.h"
 
 #include <stdarg.h>
 #include <stddef.h>
@@ -317,7 +318,7 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero)
     // slack: the pointwise kernels read whole 64-byte K steps, up to 8 of them past a pixel row's last channel (those
     // bytes meet zero weights, but must be readable behind the last pixel of a buffer too)
     const size_t slack = 1024;
-    const char* ae = getenv("TAMD_ARENA");                       // 0: one hipMalloc per buffer (round 1-3 behaviour; A/B runs)
+    const char* ae = tamd_pin("arena");                       // 0: one hipMalloc per buffer (round 1-3 behaviour; A/B runs)
     if (ae && atoi(ae) == 0) {
         HIPCHK(hipMalloc(p, bytes + slack));
         g->dev_allocs.push_back(*p);
@@ -436,7 +437,7 @@ static RqArgs host_rq(const RqFold& r, int cpad, std::vector<float>* mf, std::ve
 // timing experiments only (tools/exp/xcd_local.sh): TAMD_EXP_PLAIN_KERNELS=1 plans the ordinary (non-coherent) kernel
 // instances under direct dispatch; TAMD_EXP_NOFENCE=1 strips the fences of ordinary launches AND skips the self-check -- the bytes
 // of such a graph are NOT trustworthy (stale L1 lines), only its clock is looked at
-static bool exp_plain_kernels() { const char* e = getenv("TAMD_EXP_PLAIN_KERNELS"); return e && atoi(e) == 1; }
+static bool exp_plain_kernels() { const char* e = exp_env("TAMD_EXP_PLAIN_KERNELS"); return e && atoi(e) == 1; }
 
 // uploads both per-channel vectors; *wscale = the fast-path multipliers, rq->m2 = the chain's factors
 static int upload_rq(tamd_graph* g, const RqFold& r, int cpad, const float** wscale, RqArgs* rq)
@@ -467,7 +468,7 @@ void* l2_flush_buffer()
 bool autotune_cold(tamd_graph* g)
 {
     if (g->autotune_cold < 0) {
-        const char* e = getenv("TAMD_AUTOTUNE_COLD");              // 0: always warm, 1: always cold
+        const char* e = exp_env("TAMD_AUTOTUNE_COLD");              // 0: always warm, 1: always cold
         size_t bytes = 0;
         for (const HTensor& t : g->tensors)
             bytes += (t.ttype == TAMD_TT_VAR || t.ttype == TAMD_TT_INPUT) && t.n > 0 ? (size_t)t.n * t.h * t.w * (t.cs > 0 ? t.cs : t.c) : t.elems() * (t.dtype == TAMD_DT_FP32 ? 4 : 1);
@@ -716,7 +717,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
     if (x.nchw_raw && group == 1 && cin <= 4 && cin * KH * KW <= 224 && cout <= 128
         && p.dilation_h * (KH - 1) < 256 && p.dilation_w * (KW - 1) < 256) {
         // ---- first layer from the NCHW graph input on MFMA ----
-        const char* rows_env = getenv("TAMD_FIRST_ROWS");                   // 0: always the generic gather kernel (tests; read at every prerun)
+        const char* rows_env = tamd_pin("first_rows");                   // 0: always the generic gather kernel (tests; read at every prerun)
         const int kwp = (rows_env && atoi(rows_env) == 0) ? 0 : conv_first_kwp(cin, KH, KW, p.dilation_w);
         const int kreal = cin * KH * KW, kp = kwp ? rup(cin * KH * kwp, 32) : rup(kreal, 32), cpad = rup(cout, 32);
         std::vector<int8_t> wp((size_t)cpad * kp, 0);
@@ -819,7 +820,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
                 auto ordinary = [](double v) { return std::isfinite(v) && v >= 1e-30 && v <= 1e30; };
                 const bool ok = fz->type == 2 && a.elt.relu != 1 && ordinary(sc) && ordinary(sr) && ordinary(so) && (sc + sr) / so <= 2.0;
                 a.elt.thr = 0.f;
-                if (ok && !(getenv("TAMD_ELT_FOLD") && atoi(getenv("TAMD_ELT_FOLD")) == 0)) {
+                if (ok && !(tamd_pin("elt_fold") && atoi(tamd_pin("elt_fold")) == 0)) {
                     const float e = 0x1p-13f;
                     a.elt.mc = (float)(sc / so); a.elt.mr = (float)(sr / so);
                     a.elt.k0 = (float)(128.5 + (double)e - 128.0 * ((double)a.elt.mc + (double)a.elt.mr));
@@ -869,7 +870,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         }
         // small maps (batch-1 tails, 1x1-map FC): the lean 16-channel-slice kernel of pwdw.hip without a tail
         const bool is1x1 = KH == 1 && KW == 1 && p.stride_h == 1 && p.stride_w == 1 && !p.pad_h0 && !p.pad_h1 && !p.pad_w0 && !p.pad_w1;
-        if (!fz && is1x1 && a.M <= 4096 && !(getenv("TAMD_PW_SMALL") && atoi(getenv("TAMD_PW_SMALL")) == 0)) {
+        if (!fz && is1x1 && a.M <= 4096 && !(exp_env("TAMD_PW_SMALL") && atoi(exp_env("TAMD_PW_SMALL")) == 0)) {
             PwDwArgs v{};
             const int slices = (cout + 15) / 16, cws = slices * 16;
             const int steps = pwdw_steps((ckp + 63) / 64), nsteps = rup((ckp + 63) / 64, steps);
@@ -1136,7 +1137,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         std::sort(cfgs.begin(), cfgs.end(), [](const Cfg& l, const Cfg& r) { return l.cost < r.cost; });
         if (cfgs.size() > 8) cfgs.resize(8);
     }
-    if (const char* pin = getenv("TAMD_PWDW_CFG")) {
+    if (const char* pin = tamd_pin("pwdw_cfg")) {
         int th = 0, tw = 0, threads = 0;
         if (sscanf(pin, "%d,%d,%d", &th, &tw, &threads) == 3 && tmode == 1) {
             th = std::min(th, a.OH); tw = std::min(tw, a.OW);
@@ -1530,7 +1531,7 @@ static int plan(tamd_graph* g)
                 int pool_node = -1;
                 for (size_t nj = ni + 1; nj < g->nodes.size(); nj++)
                     if (g->nodes[nj].op == TAMD_OP_POOL && g->nodes[nj].in[0] == n.out[0] && !fused[nj]) { pool_node = (int)nj; break; }
-                const char* fp_env = getenv("TAMD_FIRST_POOL");
+                const char* fp_env = tamd_pin("first_pool");
                 bool is_out = false;
                 for (auto& o : g->outputs) is_out |= (o.tensor == n.out[0]);
                 if (pool_node >= 0 && !is_out && !(fp_env && atoi(fp_env) == 0)) {
@@ -1673,14 +1674,14 @@ static int run_steps(tamd_graph* g, hipStream_t s, int io_slot = -1)
     // marked to run beside them; everything else keeps the barrier bit.  OFF unless TAMD_DIRECT_OVERLAP=1: measured on
     // MobileNet-SSD b16 (21 of 59 packets lose the bit) it buys 0.5-4 % -- the packet processor does not spread such short
     // dispatches the way a second queue would -- and an unordered launch is one more thing that has to be right
-    const char* ov_env = getenv("TAMD_DIRECT_OVERLAP");
+    const char* ov_env = exp_env("TAMD_DIRECT_OVERLAP");
     const bool overlap = g_launch_rec && ov_env && atoi(ov_env) == 1;
     // ... and the same idea across passes queued back to back (TAMD_DIRECT_WRAP=1; off by default for the same reason: measured
     // 51.4 vs 51.5 us per MobileNet pass -- this packet processor does not start a barrier-free dispatch early).  When the first launch of
     // a pass touches nothing the LAST launch of the previous pass touches (MobileNet: conv1+dw reads the input and writes its own
     // tensor, fc7 reads pool6 and writes the logits; everything in between completed before fc7 started), it needs no barrier
     // bit: pass k+1 starts while pass k's last kernel drains.  Only the list without upload / download launches is marked.
-    const char* wr_env = getenv("TAMD_DIRECT_WRAP");
+    const char* wr_env = exp_env("TAMD_DIRECT_WRAP");
     const bool wrap = g_launch_rec && io_slot < 0 && wr_env && atoi(wr_env) == 1;
     const size_t rec0 = g_launch_rec ? g_launch_rec->size() : 0;
     const Step *first_step = nullptr, *last_step = nullptr;
@@ -1834,7 +1835,7 @@ static bool zero_copy_outputs(tamd_graph* g, std::vector<LaunchRec>& recs, int s
 // recs = [one upload launch per input][the rest]; every later argument that holds an input's staging address is re-pointed.
 static bool zero_copy_inputs(tamd_graph* g, std::vector<LaunchRec>& recs, int slot)
 {
-    const char* e = getenv("TAMD_IO_ZERO_COPY_IN");
+    const char* e = exp_env("TAMD_IO_ZERO_COPY_IN");
     const size_t nin = g->inputs.size();
     if (!(e && atoi(e) == 1) || nin == 0 || recs.size() <= nin) return false;
     std::vector<LaunchRec> trial(recs.begin() + nin, recs.end());
@@ -2164,11 +2165,11 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
         hipError_t e = hipStreamEndCapture(g->stream, &g->hgraph);
         if (rc) return -1;
         HIPCHK(e);
-        const char* ne = getenv("TAMD_GRAPH_EXECS");
+        const char* ne = exp_env("TAMD_GRAPH_EXECS");
         g->nexec = ne ? std::max(1, std::min(4, atoi(ne))) : 3;
         for (int i = 0; i < g->nexec; i++) HIPCHK(hipGraphInstantiate(&g->hexecs[i], g->hgraph, nullptr, nullptr, 0));
         g->hexec = g->hexecs[0];
-        const char* ioenv = getenv("TAMD_IO_GRAPH");
+        const char* ioenv = exp_env("TAMD_IO_GRAPH");
         for (int slot = 0; slot < 2 && !(ioenv && atoi(ioenv) == 0); slot++) {      // the host-to-host variants (upload / download as launches)
             HIPCHK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
             rc = run_steps(g, g->stream, slot);
@@ -2192,7 +2193,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
             // the packets carry hand-built argument segments (hidden arguments at the code-object-v5 offsets) and hand-picked
             // fence scopes: ONE direct pass must reproduce the eager pass byte for byte on a non-trivial input, or the graph
             // keeps its hipGraph (a different ROCm, a renamed kernel, a stale line would otherwise be silently wrong outputs)
-            if (g->direct && !getenv("TAMD_EXP_NOFENCE") && direct_selfcheck(g)) {
+            if (g->direct && !exp_env("TAMD_EXP_NOFENCE") && direct_selfcheck(g)) {
                 fprintf(stderr, "tengine_amd: direct dispatch DISABLED for this graph: %s (hipGraph replay instead)\n", g_err);
                 direct_destroy(g->direct);
                 g->direct = nullptr;
@@ -2306,7 +2307,7 @@ static void direct_abandon(tamd_graph* g, const char* why)
 static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool close_on_last_packet()
 {
-    const char* e = getenv("TAMD_DIRECT_CLOSE_ON_LAST");          // 0: a separate barrier packet closes the burst (round 2-3 behaviour)
+    const char* e = tamd_pin("direct_close_on_last");          // 0: a separate barrier packet closes the burst (round 2-3 behaviour)
     return !(e && atoi(e) == 0);
 }
 

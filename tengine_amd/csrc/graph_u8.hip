@@ -8,6 +8,7 @@
 //   conv (grouped)  weights -> fp32 as conv_kernel_ref_uint8.c:82-86, OIHW kept
 //   fc              weights -> fp32 as fc_ref.c:150-160, transposed to [hidden][nout_pad]
 #include <hip/hip_runtime.h>
+#include "env.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -57,7 +58,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
     Step st; st.node = n.name;
     st.macs = (double)y.n * y.h * y.w * cout * K;
     st.bytes = (double)x.n * x.c * x.h * x.w + (double)y.n * cout * y.h * y.w + 1.0 * cout * K;
-    static const char* dma_env = getenv("TAMD_U8_DMA");
+    static const char* dma_env = exp_env("TAMD_U8_DMA");
     bool use_dma = dma_env && atoi(dma_env) != 0;            // measured no faster than the register-staged kernel
     // the register-staged kernel keeps the whole k -> tap table in LDS: beyond ~28k taps it does not fit next to the
     // operand tiles (160 KB per CU) and the DMA kernel (table read with scalar loads) takes over
@@ -182,8 +183,8 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         // is shared with the byte-exact kernels.  Layers the kernel does not take (maps narrower than 4 columns, patches beyond
         // 512 pixels) fall through to the byte-exact family, whose bytes are inside the bar by definition.
         // (first layers -- 3 or 4 input channels against the kernel's 32-channel K step -- stay on conv_u8_rgb3x3 / the staging GEMM)
-        const char* imc = getenv("TAMD_U8_INT_MIN_C");
-        if (g->opt.u8_integer && x.c <= 4 && !(getenv("TAMD_U8I_RGB") && atoi(getenv("TAMD_U8I_RGB")) == 0)) {
+        const char* imc = exp_env("TAMD_U8_INT_MIN_C");
+        if (g->opt.u8_integer && x.c <= 4 && !(exp_env("TAMD_U8I_RGB") && atoi(exp_env("TAMD_U8I_RGB")) == 0)) {
             a.i_alpha = qx.zp - 128; a.i_beta = qw.zp - 128;
             if (conv_u8i_rgb_applicable(a, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w)) {
                 conv_u8i_rgb_prepare(a);
@@ -211,7 +212,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             auto iprepare = [&](U8ConvArgs& ac, int c) -> bool {
                 return c < NG ? conv_u8i_prepare(ac, c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w) : conv_u8i_pw_prepare(ac, c - NG, p.kernel_h, p.kernel_w);
             };
-            const char* pwe = getenv("TAMD_U8I_PW");                   // 0: never the pointwise kernel (tests), 1: only it where it applies
+            const char* pwe = tamd_pin("u8i_pw");                   // 0: never the pointwise kernel (tests), 1: only it where it applies
             std::vector<int> cands;
             for (int c = 0; c < NG + NP; c++) {
                 if (c >= NG && pwe && atoi(pwe) == 0) continue;
@@ -223,7 +224,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 for (int c : cands) if (c >= NG) only.push_back(c);
                 if (!only.empty()) cands.swap(only);
             }
-            const char* ic = getenv("TAMD_U8I_CFG");                 // tests / fuzzing: pin one tile shape where it applies
+            const char* ic = tamd_pin("u8i_cfg");                 // tests / fuzzing: pin one tile shape where it applies
             if (ic && *ic) {
                 const int want = atoi(ic) % (NG + NP);
                 if (std::find(cands.begin(), cands.end(), want) != cands.end()) cands.assign(1, want);
@@ -325,7 +326,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         // output does not depend on the tiling); TAMD_AUTOTUNE=0 keeps the heuristic choice
         // the patch kernel (3x3 / 1x1 with whole super-steps of channels): one more candidate of the same bytes.
         // TAMD_U8_PATCH=0 never (conv_u8_patch_prepare), =1 whenever it applies (tests), otherwise it has to win the timing
-        const char* pk_env = getenv("TAMD_U8_PATCH");
+        const char* pk_env = tamd_pin("u8_patch");
         const bool pk_force = pk_env && atoi(pk_env) == 1;
         int pk_best = -1;
         float* pk_w = nullptr;                     // dequantised weights in fragment order: one copy serves every tile configuration
@@ -361,11 +362,11 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             ac.wpk = reinterpret_cast<const uint8_t*>(pk_w);
             return 0;
         };
-        const char* c3_env = getenv("TAMD_U8_C3");                     // 0: never, 1: wherever it applies (tests)
+        const char* c3_env = tamd_pin("u8_c3");                     // 0: never, 1: wherever it applies (tests)
         const bool c3_ok = conv_u8_c3_applicable(a, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w);
         bool use_c3 = false;
         // first layers (3x3 on <= 4 channels): the per-pixel VALU kernel competes with the MFMA family (same bytes)
-        const char* rgb_env = getenv("TAMD_U8_RGB3X3");                  // 0: never, 1: always (tests)
+        const char* rgb_env = tamd_pin("u8_rgb3x3");                  // 0: never, 1: always (tests)
         const bool rgb_ok = conv_u8_rgb3x3_applicable(x.c, p.kernel_h, p.kernel_w, p.dilation_h, p.dilation_w, p.group) && cout <= 128
                             && !(rgb_env && atoi(rgb_env) == 0);
         U8ConvArgs rgb = a;
@@ -381,9 +382,9 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             return 0;
         };
         bool use_rgb = false, use_pw = false;           // conv_u8_rgb3x3 / conv_u8_pw (shallow pointwise layers of large maps)
-        const char* pw_env = getenv("TAMD_U8_PW");                     // 0: never, 1: wherever it applies (tests)
+        const char* pw_env = tamd_pin("u8_pw");                     // 0: never, 1: wherever it applies (tests)
         static const char* at_env = getenv("TAMD_AUTOTUNE");
-        const bool tune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !getenv("TAMD_U8_CFG");
+        const bool tune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !tamd_pin("u8_cfg");
         // what the autotune decided last time (TAMD_PLAN_CACHE): "g<cfg>" GEMM family, "p<cfg>" patch kernel, "rgb"
         char ckey[256];
         snprintf(ckey, sizeof(ckey), "u8conv|%s|%dx%dx%dx%d>%d k%dx%d s%d d%d%s%s", n.name.c_str(), x.n, x.c, x.h, x.w, cout, p.kernel_h, p.kernel_w,
@@ -440,7 +441,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                 if (best_ms > 1e29f || ms < best_ms * 0.96f) { best_ms = ms; best_cfg = c; }
             }
             float pk_ms = 1e30f;
-            const char* pcfg = getenv("TAMD_U8_PATCH_CFG");
+            const char* pcfg = tamd_pin("u8_patch_cfg");
             int named = -1;
             if (pk_force && pcfg) {
                 U8ConvArgs ac = a;
@@ -521,7 +522,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         }
         a.Kpad = rup(K, conv_u8_gemm_kc(a.cfg));      // stages of the chosen depth only (the tap table stays padded to 64)
         if ((a.wq = pack_for(a.cfg)) == nullptr) return -1;
-        if (!tune && !pk_force && !pk_env && pk_best < 0 && !getenv("TAMD_U8_CFG")) {
+        if (!tune && !pk_force && !pk_env && pk_best < 0 && !tamd_pin("u8_cfg")) {
             // layers too small to be worth timing (< 4 MMAC): lane-level chains wherever they apply -- a GEMM launch there is 8-19 us
             // of set-up around a handful of live MFMA columns (profiles/r04_layers_mssd_uint8_b16_lanes.txt)
             U8ConvArgs ac = a;
@@ -530,7 +531,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
             if (r) pk_best = conv_u8_patch_lanes_cfg();
         }
         if (pk_force && pk_best < 0) {
-            const char* pc = getenv("TAMD_U8_PATCH_CFG");          // tests / fuzzing: the tile configuration to try first
+            const char* pc = tamd_pin("u8_patch_cfg");          // tests / fuzzing: the tile configuration to try first
             const int first = pc ? atoi(pc) % conv_u8_patch_num_cfgs() : 0;
             for (int k = 0; k < conv_u8_patch_num_cfgs() && pk_best < 0; k++) {
                 const int c = (first + k) % conv_u8_patch_num_cfgs();

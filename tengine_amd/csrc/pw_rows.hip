@@ -15,6 +15,7 @@
 //     tile's activations (and residual rows) before it multiplies and requantises the current one, so every resident wave
 //     keeps a tile in flight; the grid is sized to the device (blocks per CU from the occupancy query), not to the layer.
 #include "epilogue.h"
+#include "env.h"
 #include "kernels.h"
 
 namespace tamd {
@@ -128,7 +129,7 @@ static hipError_t launch_rows(const ConvArgs& a, hipStream_t s)
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_rows_i8_kernel<S, ELT>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         (void)hipGetLastError();
-        const char* e = getenv("TAMD_PW_ROWS_BPC");             // experiments: blocks per CU
+        const char* e = exp_env("TAMD_PW_ROWS_BPC");             // experiments: blocks per CU
         if (e && atoi(e) > 0) per_cu = atoi(e);
         resident = cus * per_cu;
     }

@@ -11,6 +11,7 @@
 // half-waves with v_permlane32_swap so that every lane stores 16 contiguous output channels (one
 // dwordx4 instead of four dword stores into 4 different 64-B segments).
 #include <stdlib.h>
+#include "env.h"
 
 #include "epilogue.h"
 #include "kernels.h"
@@ -109,7 +110,7 @@ static hipError_t launch_pw(const ConvArgs& a, hipStream_t s)
     int bx = (tiles_m + 3) / 4;
     // blocks of a launch (the waves stride over the pixel tiles beyond it).  TAMD_PW_STREAM_BLOCKS: experiments only -- a copy kernel
     // with this layer's read : write mix ran 15.3 us from 512 blocks against 20.9 us from 2048 (profiles/r02_write_bw_access_shapes.txt)
-    const char* be = getenv("TAMD_PW_STREAM_BLOCKS");
+    const char* be = exp_env("TAMD_PW_STREAM_BLOCKS");
     const int total = be && atoi(be) > 0 ? atoi(be) : 2048;
     const int cap = total / groups > 0 ? total / groups : 1;
     if (bx > cap) bx = cap;

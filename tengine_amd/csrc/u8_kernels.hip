@@ -13,6 +13,7 @@
 // MFMA instructions happen to accumulate in exactly that sequential fused order (see below).
 // Activations stay in the reference's dense NCHW order (lanes along pixels read consecutive bytes).
 #include <hip/hip_runtime.h>
+#include "env.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -284,7 +285,7 @@ static const struct { int bm, bn, kc; const char* name; } U8_CFGS[] = {
 int conv_u8_gemm_num_cfgs() { return 8; }
 int conv_u8_gemm_pick(const U8ConvArgs& a)
 {
-    const char* e = getenv("TAMD_U8_CFG");                 // tests / fuzzing: pin one tile shape (read at every prerun)
+    const char* e = tamd_pin("u8_cfg");                 // tests / fuzzing: pin one tile shape (read at every prerun)
     if (e && *e) return atoi(e) % 8;
     const int OHW = a.OH * a.OW, N8 = OHW & ~7;
     auto blocks = [&](int bm, int bn) { return (long)((N8 + bn - 1) / bn + (OHW & 7 ? 1 : 0)) * ((a.cout + bm - 1) / bm) * a.N; };
@@ -825,11 +826,15 @@ static const struct { int wm, wn, tm, tn; const char* n3; const char* n1; } U8P_
 static constexpr int U8P_LANES = 4;                 // configuration 4: no MFMA tiles at all, every output a lane-level chain (conv_u8_lanes_k)
 // configurations 5 .. 8 (round 4): tile shapes 0 .. 3 with 2-D pixel tiles (8 rows x BN/8 columns) -- wide maps, where a run of 64
 // consecutive pixels drags 3-6 whole input rows per channel chunk into LDS (YOLOv3-tiny conv1 / conv2: 208- and 104-wide).
-// OPT-IN (TAMD_U8_PATCH_2D=1): byte-exact (tests/test_gpu_u8_patch.py::test_patch_conv_2d_tiles), but measured it only wins conv2
+// EXPERIMENT BUILDS ONLY (-DTAMD_EXPERIMENTS, then TAMD_U8_PATCH_2D=1): byte-exact in round 4's suite, but measured it only wins conv2
 // in isolation (61.6 vs 66.1 us) and not inside the pass (851.3 vs 856.6 us per step), and loses conv1 (cout 32, one chunk of K: a block
-// is all prologue and epilogue, 110-246 vs 83 us) -- profiles/r04_experiment_u8_patch_2d_tiles.txt
+// is all prologue and epilogue, 110-246 vs 83 us) -- profiles/r04_experiment_u8_patch_2d_tiles.txt.  The product offers 0 .. 4.
 static constexpr int U8P_2D = 5;
+#ifdef TAMD_EXPERIMENTS
 int conv_u8_patch_num_cfgs() { return 9; }
+#else
+int conv_u8_patch_num_cfgs() { return 5; }
+#endif
 int conv_u8_patch_lanes_cfg() { return U8P_LANES; }
 static int u8p_base(int cfg) { return cfg >= U8P_2D ? cfg - U8P_2D : cfg; }
 int conv_u8_patch_bm(int cfg) { return cfg == U8P_LANES ? 64 : U8P_CFGS[u8p_base(cfg)].wm * U8P_CFGS[u8p_base(cfg)].tm * 16; }
@@ -852,7 +857,7 @@ static size_t u8p_lds(const U8ConvArgs& a)
 // fills the patch fields of `a` for tile configuration cfg; false: this convolution does not go through the patch kernel
 bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
 {
-    const char* env = getenv("TAMD_U8_PATCH");
+    const char* env = tamd_pin("u8_patch");
     const bool off = env && atoi(env) == 0;
     a.pk_cfg = -1;
     a.pk_tw = 0;
@@ -863,7 +868,7 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
     if (cfg == U8P_LANES) {
         // lane-level chains for the whole layer: bounded to small layers (a chain is K dependent steps; 4096 waves are 4 per SIMD),
         // no fused pool (the pool's window-major pixel order belongs to the MFMA tiles).  TAMD_U8_LANES=0: never
-        const char* le = getenv("TAMD_U8_LANES");                // (read at every prerun: tests and A/B runs flip it inside one process)
+        const char* le = tamd_pin("u8_lanes");                // (read at every prerun: tests and A/B runs flip it inside one process)
         const bool lanes_ok = !(le && atoi(le) == 0);
         const long waves = ((long)a.N * N8 + 3) / 4 * ((a.cout + 15) / 16) + (long)a.N * (OHW - N8) * ((a.cout + 15) / 16);
         if (!lanes_ok || a.pool.on || waves > 4096 || (size_t)a.K * 16 > 150 * 1024 || (size_t)a.C * a.H * a.W >= (1u << 31)) return false;
@@ -873,9 +878,12 @@ bool conv_u8_patch_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int D
     if (N8 == 0) return false;                                   // no main pixel: nothing for the MFMA tiles (the lanes configuration takes these)
     a.pk_tw = 0;
     if (cfg >= U8P_2D) {
+#ifndef TAMD_EXPERIMENTS
+        return false;
+#endif
         // 2-D tiles: 3x3 only (a 1x1 patch is the tile's own pixels either way), whole tiles only, no tail pixels (the reference's
         // main / tail split is a property of the ROW-MAJOR pixel index: with OH*OW % 8 == 0 every pixel is a main pixel in any order)
-        const char* e2 = getenv("TAMD_U8_PATCH_2D");
+        const char* e2 = exp_env("TAMD_U8_PATCH_2D");
         const int tw = bn / 8;
         if (!(e2 && atoi(e2) == 1) || KH != 3 || OHW != N8 || a.OH % 8 != 0 || a.OW % tw != 0 || (a.pool.on && (tw & 1))) return false;
         if ((size_t)a.C * a.H * a.W >= (1u << 31)) return false;
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(256) void conv_u8_pw_k(const U8ConvArgs a, int main
 // 1x1 fragment order) must be prepared (conv_u8_patch_prepare with any configuration)
 bool conv_u8_pw_applicable(const U8ConvArgs& a, int KH, int KW)
 {
-    const char* env = getenv("TAMD_U8_PW");
+    const char* env = tamd_pin("u8_pw");
     if (env && atoi(env) == 0) return false;
     return KH == 1 && KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0 && a.H == a.OH && a.W == a.OW && !a.pool.on
            && (a.K == 32 || a.K == 64) && (a.OH * a.OW & ~7) >= 16 && (size_t)a.C * a.H * a.W < (1u << 31);
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(256) void conv_u8_c3_k(const U8ConvArgs a, int main
 // TAMD_U8_C3=0: never; =1: wherever it applies (tests); default: plan-time race against the other members
 bool conv_u8_c3_applicable(const U8ConvArgs& a, int KH, int KW, int DH, int DW)
 {
-    const char* env = getenv("TAMD_U8_C3");
+    const char* env = tamd_pin("u8_c3");
     if (env && atoi(env) == 0) return false;
     return KH == 3 && KW == 3 && DH == 1 && DW == 1 && (a.C == 16 || a.C == 32) && a.K == 9 * a.C && ((a.OH * a.OW) & ~7) >= 16
            && (size_t)a.C * a.H * a.W < (1u << 31) && (size_t)a.K * 4 <= 150 * 1024;
@@ -1377,6 +1385,7 @@ __device__ __forceinline__ void conv_u8_rgb3x3_pixel(const U8ConvArgs& a, const 
     }
 }
 
+#ifdef TAMD_EXPERIMENTS      // the first layer on the matrix cores: lost to the per-pixel kernel (profiles/r04_experiment_u8_first_layer_mfma.txt)
 template <int C, int TM>
 __global__ __launch_bounds__(256) void conv_u8_rgb3x3_mfma_k(const U8ConvArgs a, int main_x)
 {
@@ -1510,6 +1519,8 @@ __global__ __launch_bounds__(256) void conv_u8_rgb3x3_mfma_k(const U8ConvArgs a,
     }
 }
 
+#endif
+
 bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int group)
 {
     return group == 1 && kh == 3 && kw == 3 && dh == 1 && dw == 1 && (cin == 1 || cin == 3 || cin == 4);
@@ -1520,13 +1531,18 @@ bool conv_u8_rgb3x3_applicable(int cin, int kh, int kw, int dh, int dw, int grou
 // per-pixel kernel (YOLOv3-tiny b8 conv0 64.7 vs 62.2 us isolated, the step +12 us; mssd b16 conv0 41 vs 35 us,
 // profiles/r04_experiment_u8_first_layer_mfma.txt): both forms issue the same number of byte gathers and byte stores per pixel, and
 // with 16 .. 32 outputs per pixel the requantisation, not the 27 multiply-adds, is most of the arithmetic.
+#ifdef TAMD_EXPERIMENTS
 static bool u8_rgb_mfma(const U8ConvArgs& a)
 {
-    const char* e = getenv("TAMD_U8_RGB_MFMA");
+    const char* e = exp_env("TAMD_U8_RGB_MFMA");
     return e && atoi(e) == 1 && a.cout <= 64 && ((a.OH * a.OW) & ~7) >= 16 && (a.C == 3 || a.C == 4);
 }
+#else
+static bool u8_rgb_mfma(const U8ConvArgs&) { return false; }
+#endif
 const char* conv_u8_rgb3x3_kernel_name(const U8ConvArgs& a) { return u8_rgb_mfma(a) ? "conv_u8_rgb3x3_mfma" : "conv_u8_rgb3x3"; }
 
+#ifdef TAMD_EXPERIMENTS
 template <int C>
 static hipError_t launch_rgb_mfma(const U8ConvArgs& a, hipStream_t s)
 {
@@ -1547,10 +1563,13 @@ static hipError_t launch_rgb_mfma(const U8ConvArgs& a, hipStream_t s)
     }
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_conv_u8_rgb3x3(const U8ConvArgs& a, hipStream_t s)
 {
+#ifdef TAMD_EXPERIMENTS
     if (u8_rgb_mfma(a)) return a.C == 3 ? launch_rgb_mfma<3>(a, s) : launch_rgb_mfma<4>(a, s);
+#endif
     dim3 grid((a.OH * a.OW + 255) / 256, a.N);
     switch (a.C) {
     case 1: hipLaunchKernelGGL(conv_u8_rgb3x3_k<1>, grid, dim3(256), (size_t)a.cout * 12 * 4, s, a); break;
@@ -1751,7 +1770,7 @@ __global__ __launch_bounds__(256) void conv_u8_dw3x4_k(const U8DirectArgs a)
 // profiles/r04_u8_dw_forms.txt).  TAMD_U8_DW_TH=1|2|4 pins it (experiments; read per launch)
 static int u8_dw_th(const U8DirectArgs& a)
 {
-    if (const char* e = getenv("TAMD_U8_DW_TH")) { const int v = atoi(e); if (v == 1 || v == 2 || (v == 4 && a.SH == 1)) return v; }
+    if (const char* e = tamd_pin("u8_dw_th")) { const int v = atoi(e); if (v == 1 || v == 2 || (v == 4 && a.SH == 1)) return v; }
     if ((long)a.N * a.cout * a.OH < 65536) return 1;                    // small launches keep the most threads
     if (a.SH == 1) return a.OH >= 64 ? 4 : a.OH >= 32 ? 2 : 1;           // 16 x 32 @ 150^2: 28.1 -> 20.7 us; 16 x 128 @ 75^2: 28.2 -> 20.8; 16 x 256 @ 38^2: 16.3 -> 13.5
     return a.OH >= 32 ? 2 : 1;                                            // 16 x 128 @ 75^2 stride 2: 10.7 -> 9.5 us; 19^2 outputs and below: one row

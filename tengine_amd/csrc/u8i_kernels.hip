@@ -33,6 +33,7 @@
 //      fetched from global straight into a 3-deep register ring (shared by every pixel tile through the L2s).
 //   D: lanes run along pixels = along NCHW rows; 16 output channels per lane and 32x32 tile.
 #include <hip/hip_runtime.h>
+#include "env.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -659,7 +660,7 @@ bool conv_u8i_pw_prepare(U8ConvArgs& a, int cfg, int KH, int KW)
     a.pk_kh = a.pk_kw = 1; a.pk_dh = a.pk_dw = 1;
     a.i_nchunks = (a.C + 31) / 32;
     a.i_cfg = cfg; a.i_tw = 0; a.i_cgs = 0; a.i_npad = 0;
-    a.i_dbg = getenv("TAMD_U8I_ABLATE") ? atoi(getenv("TAMD_U8I_ABLATE")) : 0;
+    a.i_dbg = exp_env("TAMD_U8I_ABLATE") ? atoi(exp_env("TAMD_U8I_ABLATE")) : 0;
     return true;
 }
 hipError_t launch_conv_u8i_pw(const U8ConvArgs& a, hipStream_t s)
@@ -715,7 +716,7 @@ bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
     // linear tiles where their worst bounding box fits (at most 4 staging units per thread = 512 patch pixels), else 2-D tiles
     int worst = u8i_patch_pixels(a, bn);
     a.i_tw = 0;
-    const char* tm = getenv("TAMD_U8I_TILES");                                       // tests: 2 = 2-D tiles wherever they fit
+    const char* tm = tamd_pin("u8i_tiles");                                       // tests: 2 = 2-D tiles wherever they fit
     if (worst > 512 || (tm && atoi(tm) == 2)) {
         const int tw = bn >= 128 ? 16 : 8, th = bn / tw;
         const int w2 = ((th - 1) * a.SH + (KH - 1) * DH + 1) * (((tw - 1) * a.SW + (KW - 1) * DW + 1 + 3) & ~3);
@@ -724,14 +725,14 @@ bool conv_u8i_prepare(U8ConvArgs& a, int cfg, int KH, int KW, int DH, int DW)
     }
     a.i_npad = worst <= 128 ? 128 : worst <= 256 ? 256 : 512;
     a.i_nchunks = (a.C + 31) / 32;                                                   // 32-channel groups
-    a.i_dbg = getenv("TAMD_U8I_ABLATE") ? atoi(getenv("TAMD_U8I_ABLATE")) : 0;       // anatomy runs (tools/exp): wrong bytes by design
+    a.i_dbg = exp_env("TAMD_U8I_ABLATE") ? atoi(exp_env("TAMD_U8I_ABLATE")) : 0;       // anatomy runs (tools/exp): wrong bytes by design
     // groups per chunk (1 | 2 | 4): as many as the staging budget (4 units per thread = 512 patch pixels x groups) and the layer hold
     // (default ONE: measured faster than 2 / 4 on both uint8 configs -- the larger staging burst stalls the MFMAs longer than the
     // saved barriers cost; TAMD_U8I_CG=2|4 asks for more where the budget allows, tests run them)
     int cg_max = 0;
     while (cg_max < 2 && (2 << cg_max) * a.i_npad <= 512 && (2 << cg_max) <= a.i_nchunks) cg_max++;
     a.i_cgs = 0;
-    if (const char* cg = getenv("TAMD_U8I_CG")) a.i_cgs = std::min(cg_max, atoi(cg) >= 4 ? 2 : atoi(cg) >= 2 ? 1 : 0);
+    if (const char* cg = tamd_pin("u8i_cg")) a.i_cgs = std::min(cg_max, atoi(cg) >= 4 ? 2 : atoi(cg) >= 2 ? 1 : 0);
     a.i_cfg = cfg;
     return true;
 }

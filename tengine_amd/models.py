@@ -177,6 +177,8 @@ def pool_out(inp, k, s, pad, caffe):
             out = 1 + _cdiv(inp - k + 2 * pad, s)
     else:
         out = 1 + _cdiv(inp - 1, s)
+    if pad >= 0 and caffe == 2:      # darknet: the file's pad is the TOTAL, split low / high (pooling.c:81-88)
+        return out, pad // 2, pad - pad // 2
     total = (out - 1) * s + k
     pad_num = max(total - inp, 0)
     p0 = pad_num // 2 if pad < 0 else pad
@@ -257,8 +259,10 @@ def squeezenet_v11_fp32(batch=1, res=227, classes=1000):
 
 
 def yolov3_tiny_fp32(batch=1, res=416, nout=255):
-    """YOLOv3-tiny (benchmark/models/yolov3_tiny_benchmark.tmfile: 13 conv, leaky ReLUs kept as
-    separate nodes, 6 maxpool, route/upsample/concat, two 1x1 heads)."""
+    """YOLOv3-tiny, node for node benchmark/models/yolov3_tiny_benchmark.tmfile (35 compute nodes): 13 conv, leaky ReLUs kept as
+    separate nodes, 6 maxpool in the darknet flavour (caffe_flavor 2, total pad 1: the last one is the stride-1 'same' pool), the
+    single-input route (Concat) in front of the second head's 1x1, upsample + route, two 1x1 heads each behind the Dropout node the
+    converter leaves for a yolo layer."""
     b = _B("yolov3_tiny", [batch, 3, res, res])
     x = b.cur
 
@@ -272,23 +276,20 @@ def yolov3_tiny_fp32(batch=1, res=416, nout=255):
         x = cbl(i, x, c, 3)
         if i == 4:
             route8 = x
-        if i < 5:
-            x = b.pool("maxpool%d" % i, x, tm2.POOL_MAX, 2, 2, 0)
-        else:
-            x = b.pool("maxpool%d" % i, x, tm2.POOL_MAX, 2, 1, -1)     # darknet 'same' stride-1 maxpool
+        x = b.pool("maxpool%d" % i, x, tm2.POOL_MAX, 2, 2 if i < 5 else 1, 1, caffe=2)     # darknet: pad = size - 1, split 0 | 1
     x = cbl(6, x, 1024, 3)
     x13 = cbl(7, x, 256, 1)
     y = cbl(8, x13, 512, 3)
-    head1 = b.conv("conv9", y, nout, 1, act=-1)
-    z = cbl(10, x13, 128, 1)
+    head1 = b.dropout("yolo1", b.conv("conv9", y, nout, 1, act=-1))
+    z = cbl(10, b.concat("route0", [x13]), 128, 1)
     z = b.upsample("upsample", z, 2)
     z = b.concat("route", [z, route8])
     z = cbl(11, z, 256, 3)
-    head2 = b.conv("conv12", z, nout, 1, act=-1)
-    return b.finish([head2, head1])
+    head2 = b.dropout("yolo2", b.conv("conv12", z, nout, 1, act=-1))
+    return b.finish([head1, head2])
 
 
-def mssd_fp32(batch=1, res=300, classes=21, tail=False, priorbox=False):
+def mssd_fp32(batch=1, res=300, classes=21, tail=False, priorbox=False, detection=False):
     """MobileNet-v1-SSD 300x300 (benchmark/models/mssd_benchmark.tmfile, the BASELINE "MobileNet-SSD" stand-in,
     SURVEY §8d): 47 convs = conv0 + 13 (dw, pw) pairs + 4 (1x1, 3x3 s2) extra pairs + 6 loc and 6 conf 1x1 heads on
     conv11 (19x19, 3 priors), conv13 (10x10), conv14_2 (5x5), conv15_2 (3x3), conv16_2 (2x2), conv17_2 (1x1) (6 priors
@@ -299,7 +300,8 @@ def mssd_fp32(batch=1, res=300, classes=21, tail=False, priorbox=False):
     row; the device graphs are built without it.  `priorbox=True` adds the six PriorBox nodes of the
     MobileNet-SSD deploy prototxt (min / max sizes 60 | 105,150 | 150,195 | 195,240 | 240,285 | 285,300, aspect ratios
     2 | 2,3, flip, no clip, variances .1 .1 .2 .2, offset 0.5) and their Concat(axis 2) -> mbox_priorbox [1, 2, 7668, 1]:
-    with both, the graph ends exactly at detection_output's three inputs."""
+    with both, the graph ends exactly at detection_output's three inputs; `detection=True` (with both) appends that node -- the
+    whole benchmark file, 84 compute nodes (the HIP device leaves DetectionOutput to the CPU device)."""
     b = _B("mssd", [batch, 3, res, res])
     data = b.cur
     x = b.conv("conv0", b.cur, 32, 3, 2, 1, act=0)
@@ -333,6 +335,12 @@ def mssd_fp32(batch=1, res=300, classes=21, tail=False, priorbox=False):
         pbs = [b.priorbox("%s_mbox_priorbox" % name, f, data, [mn], [mx] if mx else [], [2.0] if npri == 3 else [2.0, 3.0])
                for (name, f, npri), (mn, mx) in zip(feats, sizes)]
         outs.append(b.concat("mbox_priorbox", pbs, axis=2))
+    if detection:
+        assert tail and priorbox
+        y = b.g.add_tensor("detection_out/0", [batch, 100, 6, 1], DT_FP32)         # detection_output.c infer_shape: keep_top_k rows of 6
+        b.g.add_node("detection_out", "DetectionOutput", outs, [y], num_classes=classes, keep_top_k=100, nms_top_k=100,
+                     confidence_threshold=0.25, nms_threshold=0.45)
+        outs = [y]
     return b.finish(outs)
 
 
@@ -414,6 +422,8 @@ def fp32_forward(g: Graph, x: np.ndarray):
             y = torch.zeros(g.tensors[n.outputs[0]].dims)
             y[:, 0] = 0.5
             y[:, 1] = 0.1
+        elif op == "DetectionOutput":      # host-side post-processing: nothing to calibrate behind it
+            y = torch.zeros(g.tensors[n.outputs[0]].dims)
         else:
             raise NotImplementedError(op)
         vals[n.outputs[0]] = y
@@ -594,6 +604,9 @@ def quantize_uint8(gf: Graph, table=None) -> Graph:
             g.tensors.append(tm2.Tensor(t.name, list(t.dims), DT_UINT8, t.ttype, None, [float(s)], [int(z)]))
     for n in gf.nodes:
         g.nodes.append(tm2.Node(n.name, n.op, list(n.inputs), list(n.outputs), dict(n.params)))
+        if n.op == "DetectionOutput":       # its rows (label, score, box) stay fp32: detection_output_ref.c:329-349 writes them as they are
+            t = g.tensors[n.outputs[0]]
+            t.dtype, t.scales, t.zero_points = DT_FP32, None, None
     return g
 
 
@@ -669,8 +682,123 @@ def build(name, dtype="int8", batch=1, device_only=False, **kw) -> Graph:
         table = calib_table(name, gf) if not kw else None
         g = set_batch(quantize_int8(gf, table=table), batch)
     elif dtype == "uint8":
-        table = calib_table(name, gf, dtype="uint8") if (not kw or set(kw) <= {"tail", "priorbox"}) else None
+        table = calib_table(name, gf, dtype="uint8") if (not kw or set(kw) <= {"tail", "priorbox", "detection"}) else None
         g = set_batch(quantize_uint8(gf, table=table), batch)
     else:
         raise NotImplementedError(dtype)
     return strip_tail(g) if device_only else g
+
+
+# --------------------------------------------------------------------------------------
+# the reference's own benchmark files (benchmark/models/*_benchmark.tmfile: structure only, no weights)
+# --------------------------------------------------------------------------------------
+def _node_key(op, p):
+    """what makes two nodes of one operator type the same computation (the fields the reference's kernels read)"""
+    r = lambda v: round(float(v), 5)
+    if op == "Convolution":
+        return tuple(p.get(k) for k in ("kernel_h", "kernel_w", "stride_h", "stride_w", "dilation_h", "dilation_w", "group", "activation",
+                                        "pad_h0", "pad_w0", "pad_h1", "pad_w1", "output_channel"))
+    if op == "Pooling":
+        if p.get("global"):
+            return ("global", p.get("alg"))
+        return tuple(p.get(k) for k in ("alg", "kernel_h", "kernel_w", "stride_h", "stride_w", "caffe_flavor", "pad_h0", "pad_w0"))
+    if op == "ReLU":
+        return (r(p.get("negative_slope", 0.0)),)
+    if op in ("Concat", "Softmax"):
+        return (p.get("axis", 1),)
+    if op == "Flatten":
+        return (p.get("axis", 1), p.get("end_axis", 3))
+    if op == "Permute":
+        return tuple(p.get("order", ()))
+    if op == "Reshape":
+        return tuple(p.get("re_shape", ()))
+    if op == "Upsample":
+        return (r(p.get("scale", 2)),)
+    if op == "Eltwise":
+        return (p.get("type"),)
+    if op == "FullyConnected":
+        return (p.get("num_output"),)
+    if op == "PriorBox":
+        return tuple(tuple(r(v) for v in p.get(k, [])) for k in ("min_size", "max_size", "aspect_ratio", "variance")) + \
+            (p.get("flip"), p.get("clip"), r(p.get("offset", 0.5)))
+    if op == "DetectionOutput":
+        return (p.get("num_classes"), p.get("keep_top_k"), p.get("nms_top_k"), r(p.get("confidence_threshold")), r(p.get("nms_threshold")))
+    return ()
+
+
+def match_graphs(ga: Graph, gb: Graph):
+    """Pairs the compute nodes of two graphs that are the same DAG up to node order and names: a node's signature is its
+    operator, the parameters its kernel reads, the shapes of its constant inputs and -- recursively -- the signatures of the
+    producers of its variable inputs, in input order.  Returns [(node index in ga, node index in gb)] or raises ValueError
+    naming what has no partner.  (The converters emit nodes in their own topological order; tm_benchmark's files and the
+    builders above agree on the graph, not on that order.)"""
+    def sigs(g):
+        prod = {}
+        for ni, n in enumerate(g.nodes):
+            for o in n.outputs:
+                prod[o] = ni
+        memo = {}
+
+        def sig(ni):
+            if ni in memo:
+                return memo[ni]
+            n = g.nodes[ni]
+            if n.op == "InputOp":
+                s = ("InputOp",)
+            elif n.op == "Const":
+                d = list(g.tensors[n.outputs[0]].dims)
+                while len(d) > 1 and d[0] == 1:          # darknet's converter writes a bias as [1, 1, 1, C]
+                    d.pop(0)
+                s = ("Const", tuple(d))
+            else:
+                s = (n.op, _node_key(n.op, n.params), tuple(sig(prod[i]) for i in n.inputs))
+            memo[ni] = hash(s)
+            return memo[ni]
+
+        out = {}
+        for ni, n in enumerate(g.nodes):
+            if n.op not in ("Const", "InputOp"):
+                out.setdefault(sig(ni), []).append(ni)
+        return out
+
+    sa, sb = sigs(ga), sigs(gb)
+    pairs = []
+    for k, la in sa.items():
+        lb = sb.get(k, [])
+        if len(la) != len(lb):
+            raise ValueError("no partner for node(s) %s" % [(ga.nodes[i].name, ga.nodes[i].op) for i in la[len(lb):]])
+        pairs += list(zip(la, lb))
+    for k, lb in sb.items():
+        if k not in sa:
+            raise ValueError("no partner for node(s) %s" % [(gb.nodes[i].name, gb.nodes[i].op) for i in lb])
+    return sorted(pairs)
+
+
+def graft_reference_file(ref_bytes: bytes, gq: Graph) -> bytes:
+    """The reference's benchmark file with the tensors of `gq` (a built, possibly quantised, graph of the same topology) put in:
+    constants get their data, every tensor its data type, shape and quantisation parameters -- nodes, names, parameter blobs
+    and node order stay the file's own.  This is the "retag" SURVEY appendix E did in C for the files tm_benchmark ships
+    without weights."""
+    gr = tm2.read_tm2(ref_bytes)
+
+    def put(tr, tq):
+        tr.dims, tr.dtype, tr.scales, tr.zero_points = list(tq.dims), tq.dtype, tq.scales, tq.zero_points
+        if tq.ttype == tm2.TT_CONST:
+            tr.data = tq.data
+
+    for nr, nq in match_graphs(gr, gq):
+        a, b = gr.nodes[nr], gq.nodes[nq]
+        assert len(a.inputs) == len(b.inputs) and len(a.outputs) == len(b.outputs), (a.name, b.name)
+        for ti, tj in zip(a.inputs + a.outputs, b.inputs + b.outputs):
+            put(gr.tensors[ti], gq.tensors[tj])
+    return tm2.write_tm2(gr)
+
+
+# tm_benchmark's model list (benchmark/tm_benchmark.cc:250-289) -> the builder and options that reproduce the file's graph
+REFERENCE_BENCHMARKS = {
+    "squeezenet_v1.1": ("squeezenet_v1.1", "fp32", {}),
+    "mobilenet": ("mobilenet_v1", "int8", {}),
+    "resnet50": ("resnet50", "int8", {}),
+    "yolov3_tiny": ("yolov3_tiny", "uint8", {}),
+    "mssd": ("mssd", "uint8", {"tail": True, "priorbox": True, "detection": True}),
+}

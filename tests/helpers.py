@@ -544,3 +544,42 @@ def u8_conv_int_model(g, x):
         r6 = np.float32(6.0) / os_
         hi = min(255, max(lo, int(np.sign(r6) * np.floor(np.abs(np.float64(r6)) + 0.5)) + zp))
     return np.clip(q, lo, hi).astype(np.uint8)
+
+
+# ---- TAMD_PIN (tengine_amd/csrc/env.h): the one variable tests use to pin a plan-time choice or switch a live optimisation off ----
+def pin(**kv):
+    """merge key=value pairs into TAMD_PIN (value None removes the key); returns the previous string for restore_pins()"""
+    import os
+    old = os.environ.get("TAMD_PIN")
+    cur = dict(p.split("=", 1) for p in old.split(",") if p) if old else {}
+    for k, v in kv.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        os.environ["TAMD_PIN"] = ",".join("%s=%s" % kv2 for kv2 in cur.items())
+    else:
+        os.environ.pop("TAMD_PIN", None)
+    return old
+
+
+def restore_pins(old):
+    import os
+    if old is None:
+        os.environ.pop("TAMD_PIN", None)
+    else:
+        os.environ["TAMD_PIN"] = old
+
+
+class pinned:
+    """with pinned(u8_patch=1, u8_patch_cfg=4): ..."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = pin(**self.kv)
+
+    def __exit__(self, *a):
+        restore_pins(self.old)

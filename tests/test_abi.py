@@ -256,3 +256,38 @@ def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
     fields = re.findall(r"^\s+(?:const\s+)?\w+\*?\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in capi.Options._fields_], (fields, capi.Options._fields_)
     assert fields[-3:] == ["direct_dispatch", "keep_tensors", "u8_integer"] and ctypes.sizeof(capi.Options) == 40
+
+
+def test_environment_surface_is_the_documented_one():
+    """the library reads 23 named TAMD_* variables + TAMD_PIN (csrc/env.h); every name and every TAMD_PIN key is
+    listed in INTEGRATION.md section E AND set by some test or tool of this repository; experiment switches go through exp_env()
+    only, which is getenv in -DTAMD_EXPERIMENTS builds alone."""
+    import glob
+    import re
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "tengine_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "tengine_amd", "device", "*")):
+        if f.endswith((".hip", ".cc", ".h")) and not f.endswith("env.h"):
+            src += open(f).read()
+    named = set(re.findall(r'(?:getenv|pg_env)\("(TAMD_[A-Z0-9_]+)"', src))
+    pins = set(re.findall(r'tamd_pin(?:_int)?\("([a-z0-9_]+)"', src))
+    exps = set(re.findall(r'(?:exp_env|env_int)\("(TAMD_[A-Z0-9_]+)"', src))
+    assert len(named) <= 30 and "TAMD_PIN" not in named, sorted(named)      # (TAMD_PIN itself is read in env.h)
+    assert not (named & exps), named & exps
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## E. Environment"):doc.index("## F. ")]
+    users = ""
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) + [os.path.join(ROOT, "bench.py")] + \
+            glob.glob(os.path.join(ROOT, "tengine_amd", "*.py")):
+        if not f.endswith("test_abi.py"):
+            users += open(f).read()
+    for v in sorted(named):
+        assert v in sec, "%s is read by the library but not documented in INTEGRATION.md section E" % v
+        assert v in users, "%s is read by the library but no test / tool sets it" % v
+    for k in sorted(pins):
+        assert re.search(r"`%s[=`]" % k, sec), "TAMD_PIN key %s is not documented" % k
+        assert re.search(r"\b%s\b" % k, users), "TAMD_PIN key %s is not set by any test / tool" % k
+    for v in sorted(exps):
+        assert v in sec, "experiment switch %s is not listed" % v
+    # nothing else in the library looks at the environment
+    other = set(re.findall(r'getenv\("([A-Z0-9_]+)"', src)) - named
+    assert other <= {"TG_HIP_DEVICE", "TG_HIP_SCHEDULER", "TG_DEBUG_TIME", "ROCPROFILER_LIBRARY", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "LD_PRELOAD"}, other

@@ -24,7 +24,7 @@ def test_kernel_families():
     assert b.kernel_family("conv_u8_mfma_64x64k64+relu+maxpool") == "conv_u8_mfma"
     assert b.kernel_family("conv_u8_rgb3x3+relu+maxpool") == "conv_u8_rgb3x3"
     assert b.kernel_family("pwdw_i8<s1,7x14,512>") == "pwdw_i8"
-    assert b.kernel_family("conv_pgemm_i8<128x64,3x3,ks2>") == "conv_pgemm_i8"
+    assert b.kernel_family("conv_pgemm_i8<128x64,3x3,w4b3>") == "conv_pgemm_i8"
     assert b.kernel_family("conv_igemm_i8<64x64x64>") == "conv_igemm_i8"
     assert b.kernel_family("permute_concat_u8<x6>") == "permute_concat_u8"
 

@@ -97,7 +97,7 @@ def test_blocking_run_variants_agree(monkeypatch):
     for g, x in zip(cases, xs):
         tmb = tm2.write_tm2(g)
         outs = []
-        for env in ({}, {"TAMD_IO_ZERO_COPY": "0"}, {"TAMD_DIRECT_CLOSE_ON_LAST": "0"}, {"TAMD_IO_ZERO_COPY": "0", "TAMD_DIRECT_CLOSE_ON_LAST": "0"}, None):
+        for env in ({}, {"TAMD_IO_ZERO_COPY": "0"}, {"TAMD_PIN": "direct_close_on_last=0"}, {"TAMD_IO_ZERO_COPY": "0", "TAMD_PIN": "direct_close_on_last=0"}, None):
             for k, v in (env or {}).items():
                 monkeypatch.setenv(k, v)
             gr = capi.Graph(tmb, direct_dispatch=env is not None)

@@ -70,7 +70,7 @@ def test_mssd_uint8_300_batch16():
 
 
 WIDE_DW = [
-    # n, c, hw, stride, pinned form (TAMD_DW_FORM, None: the launcher's choice), expected kernel
+    # n, c, hw, stride, pinned form (TAMD_PIN dw_form, None: the launcher's choice), expected kernel
     (16, 64, 112, 1, None, "dwconv3x3_i8<1,1,r4>"),   # large batch, tall map: four output rows per lane
     (32, 64, 112, 2, None, "dwconv3x3_i8<2,1,r2>"),
     (24, 128, 57, 1, None, "dwconv3x3_i8<1,1,r4>"),   # odd width and height: strip tail, last band has one row of four
@@ -91,7 +91,7 @@ def test_depthwise_variants_by_name(n, c, hw, s, form, kernel, monkeypatch):
     """the launcher's <stride, fragments, rows> choice is asserted by name, so no form (alignbyte windows across two fragments,
     partial last bands) can silently go untested; batch > 1 also switches the reference to its naive-ref epilogue"""
     if form:
-        monkeypatch.setenv("TAMD_DW_FORM", form)
+        monkeypatch.setenv("TAMD_PIN", "dw_form=" + form)
     g, x = conv_graph(300 + n + c + hw + s, n, c, hw, hw, c, 3, s, 1, group=c, act=0)
     x[:] = np.random.default_rng(n + hw).integers(-127, 128, size=x.shape)
     want = oracle.run_graph(g, x)[0]

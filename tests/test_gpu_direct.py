@@ -112,7 +112,7 @@ def test_direct_dispatch_coherent_launches_never_serve_stale_tensors(batch):
 
 
 def test_direct_dispatch_coherent_kernels_with_fences_kept(monkeypatch):
-    monkeypatch.setenv("TAMD_DIRECT_COHERENT", "0")      # the same coherent instances behind agent-scope fences
+    monkeypatch.setenv("TAMD_PIN", "direct_coherent=0")      # the same coherent instances behind agent-scope fences
     g = models.build("mobilenet_v1", "int8", 1)
     x = models.synth_input(g, 9, DT_INT8)
     want = oracle.run_graph(g, x)
@@ -123,52 +123,9 @@ def test_direct_dispatch_coherent_kernels_with_fences_kept(monkeypatch):
         assert np.array_equal(o.reshape(w.shape), w)
 
 
-def test_direct_overlap_of_independent_launches_keeps_the_bytes(monkeypatch):
-    """TAMD_DIRECT_OVERLAP=1: launches that touch nothing their predecessors touch (the SSD head convolutions, the concat copies)
-    go out without the AQL barrier bit; the results must be the ordered pass's, run after run"""
-    import numpy as np
-    from tengine_amd import capi, models, tm2
-    g = models.build("mssd", "uint8", 2)
-    x = models.synth_input(g, 11, tm2.DT_UINT8)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("TAMD_DIRECT_OVERLAP", mode)
-        gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True)
-        gr.set_input(x)
-        first = [o.copy() for o in gr.run()]
-        for _ in range(20):
-            again = gr.run()
-            for a, b in zip(first, again):
-                assert np.array_equal(a, b)
-        outs[mode] = first
-        assert gr.direct_packets() > 0
-        gr.close()
-    for a, b in zip(outs["0"], outs["1"]):
-        assert np.array_equal(a, b)
-
-
-@pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 1), ("mobilenet_v1", "int8", 4), ("yolov3_tiny", "uint8", 1)])
-def test_back_to_back_passes_overlap_at_the_seam_and_keep_the_bytes(name, dtype, batch, monkeypatch):
-    """a burst of passes on the direct path: the first launch of pass k+1 carries no barrier bit when it touches nothing the last
-    launch of pass k touches (TAMD_DIRECT_WRAP=1; off by default, it buys nothing on this stack); hundreds of queued passes, a changed input in between, and the
-    results are those of the ordered list"""
-    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
-    b = tm2.write_tm2(g)
-    xs = [models.synth_input(g, s, NP[dtype]) for s in (31, 32)]
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("TAMD_DIRECT_WRAP", mode)
-        gr = capi.Graph(b, direct_dispatch=True)
-        assert gr.direct_packets() > 0
-        outs = []
-        for x in xs:
-            outs.append([o.copy() for o in _resident(gr, x, 300)])            # 300 passes queued behind each other, one wait
-        res[mode] = outs
-        gr.close()
-    for a, c in zip(res["0"], res["1"]):
-        for u, v in zip(a, c):
-            assert np.array_equal(u, v)
-    assert any(not np.array_equal(u, v) for u, v in zip(res["1"][0], res["1"][1]))
+# (packets without the AQL barrier bit -- independent launches inside a pass, the first launch of pass k+1 beside the end of pass k --
+#  bought 0.5 - 4 % / nothing on this stack, profiles/r03_*: the dependency analysis stays in graph.hip, the switches that enabled it
+#  exist in -DTAMD_EXPERIMENTS builds only since round 5, and so do their tests' subjects)
 
 
 @pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 1), ("yolov3_tiny", "uint8", 1)])

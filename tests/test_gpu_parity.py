@@ -240,7 +240,7 @@ FIRST_LAYER_CASES = [
 @pytest.mark.parametrize("rows", [True, False])
 @pytest.mark.parametrize("case", FIRST_LAYER_CASES, ids=[str(c) for c in FIRST_LAYER_CASES])
 def test_first_layer_from_nchw(case, rows):
-    """both first-layer kernels (row-granular unaligned loads / generic byte gather, TAMD_FIRST_ROWS=0) on shapes that
+    """both first-layer kernels (row-granular unaligned loads / generic byte gather, TAMD_PIN first_rows=0) on shapes that
     hit every border case; the graph input is read in NCHW, images are adjacent in memory."""
     n, cin, h, w, cout, k, s, p, act = case[:9]
     dil = case[9] if len(case) > 9 else 1
@@ -248,11 +248,11 @@ def test_first_layer_from_nchw(case, rows):
     x[:] = np.random.default_rng(7).integers(-127, 128, size=x.shape)       # dense non-zero borders
     want = oracle.run_graph(g, x)[0]
     if not rows:
-        os.environ["TAMD_FIRST_ROWS"] = "0"
+        os.environ["TAMD_PIN"] = "first_rows=0"
     try:
         gr = capi.Graph(tm2.write_tm2(g))
     finally:
-        os.environ.pop("TAMD_FIRST_ROWS", None)
+        os.environ.pop("TAMD_PIN", None)
     gr.set_input(x)
     got = gr.run()[0].reshape(want.shape)
     names = [q["kernel"] for q in gr.profile(1)]

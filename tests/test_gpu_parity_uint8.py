@@ -308,13 +308,11 @@ RGB_CASES = [
 
 @pytest.mark.parametrize("case", RGB_CASES, ids=[str(c) for c in RGB_CASES])
 @pytest.mark.parametrize("leaky", [False, True])
-@pytest.mark.parametrize("mfma", [True, False], ids=["mfma_main_pixels", "per_pixel"])
-def test_first_layer_u8_valu_kernel(case, leaky, mfma, monkeypatch):
-    """the first-layer kernels pinned with TAMD_U8_RGB3X3=1 -- conv_u8_rgb3x3_mfma (main pixels on the matrix cores, tail pixels by
-    an extra block per image; C = 3 | 4; opt-in, TAMD_U8_RGB_MFMA=1) and the per-pixel conv_u8_rgb3x3 (the default, and C = 1 always): main and tail
-    pixels, blocked and unblocked rows, fused leaky ReLU -- must equal the oracle (and therefore the GEMM family) byte for byte."""
+def test_first_layer_u8_valu_kernel(case, leaky):
+    """the per-pixel first-layer kernel conv_u8_rgb3x3 pinned with TAMD_PIN u8_rgb3x3=1 (C = 1 | 3 | 4): main and tail pixels, blocked and
+    unblocked rows, fused leaky ReLU -- must equal the oracle (and therefore the GEMM family) byte for byte.  (Its matrix-core form lost
+    the race, profiles/r04_experiment_u8_first_layer_mfma.txt, and is built for tools/exp only since round 5.)"""
     import os
-    monkeypatch.setenv("TAMD_U8_RGB_MFMA", "1" if mfma else "0")
     n, cin, h, w, cout, s, p, act = case
     g, x = u8_conv_graph(600 + h + cout, n, cin, h, w, cout, 3, s, p, 1, act, True, 1)
     if leaky:
@@ -324,17 +322,16 @@ def test_first_layer_u8_valu_kernel(case, leaky, mfma, monkeypatch):
         ni = g.add_node("lk", "ReLU", [c], [r], negative_slope=0.1)
         g.output_nodes = [ni]
     want = oracle.run_graph(g, x)[0]
-    os.environ["TAMD_U8_RGB3X3"] = "1"
+    os.environ["TAMD_PIN"] = "u8_rgb3x3=1"
     try:
         gr = capi.Graph(tm2.write_tm2(g))
     finally:
-        del os.environ["TAMD_U8_RGB3X3"]
+        del os.environ["TAMD_PIN"]
     gr.set_input(x)
     got = gr.run()[0].reshape(want.shape)
     names = [k["kernel"] for k in gr.profile(1)]
     gr.close()
-    assert names[0].startswith("conv_u8_rgb3x3"), names
-    assert names[0].startswith("conv_u8_rgb3x3_mfma") == (mfma and case[1] != 1), names
+    assert names[0] == "conv_u8_rgb3x3" or names[0].startswith("conv_u8_rgb3x3+"), names
     assert np.array_equal(got, want), "%d bytes differ" % np.count_nonzero(got != want)
     assert len(np.unique(want)) > 3
 

@@ -14,14 +14,12 @@ from tengine_amd import capi, tm2
 pytestmark = pytest.mark.gpu
 
 VARIANTS = ["conv_pgemm_i8<128x64", "conv_pgemm_i8<128x128", "conv_pgemm_i8<64x64", "conv_pgemm_i8<64x128"]
-KS2 = ["conv_pgemm_i8<128x64,3x3,ks2", "conv_pgemm_i8<128x128,3x3,ks2"]       # 512-thread blocks, intra-block split-K (3x3, cin % 128 == 0)
-# conv_pgemm_w.hip (round 5): eight-wave blocks with table-driven set-up (4 x 2 / 2 x 4 wave grids; ks2w: two K groups adding their
-# partial sums into one LDS tile, row-major epilogue).  The trailing comma / "w" keeps the prefix from matching the older kernels.
-WGRID = ["conv_pgemm_i8<128x64,3x3,w8>", "conv_pgemm_i8<128x128,3x3,w8>", "conv_pgemm_i8<64x128,3x3,w8>",
-         "conv_pgemm_i8<128x64,3x3,ks2w>", "conv_pgemm_i8<64x64,3x3,ks2w>",
-         # four waves with the table-driven set-up (w4t), and the forms with ONE barrier per filter row (b3: a 9-slot ring, the waves drift)
-         "conv_pgemm_i8<128x64,3x3,w4t>", "conv_pgemm_i8<64x64,3x3,w4t>", "conv_pgemm_i8<128x64,3x3,w4b3>", "conv_pgemm_i8<64x64,3x3,w4b3>",
-         "conv_pgemm_i8<128x128,3x3,w8b3>", "conv_pgemm_i8<64x64,3x3,ks2wb3>"]
+# conv_pgemm_w.hip (round 5), the 3x3 kernels: table-driven set-up on four waves (w4t) or eight (w8: 128 x 128 tiles), and the forms
+# with ONE barrier per filter row (b3: a 9-slot ring, the waves drift up to two stages apart).  The forms that lost on every
+# ResNet-50 shape -- two K groups adding into one LDS tile (ks2w), eight waves with copy roles over 64 couts, the 2 x 4 wave grid --
+# are built for tools/exp/pgemm_anatomy.hip only; their parity runs of round 5 are profiles/r05_pytest_pgemm_all_forms.txt.
+WGRID = ["conv_pgemm_i8<128x128,3x3,w8>", "conv_pgemm_i8<128x128,3x3,w8b3>",
+         "conv_pgemm_i8<128x64,3x3,w4t>", "conv_pgemm_i8<64x64,3x3,w4t>", "conv_pgemm_i8<128x64,3x3,w4b3>", "conv_pgemm_i8<64x64,3x3,w4b3>"]
 
 # n, cin, h, w, cout, k, s, p, group, act, bias, dil
 PATCH_CASES = [
@@ -54,11 +52,14 @@ def _run(member, case, seed):
     want = oracle.run_graph(g, x)[0]
     os.environ["TAMD_FORCE_GEMM"] = member
     os.environ["TAMD_AUTOTUNE"] = "0"
+    if member in VARIANTS:       # the generic patch kernel is offered a 3x3 layer only where the dedicated kernels are switched off
+        os.environ["TAMD_PGEMM_W"] = "0"
     try:
         gr = capi.Graph(tm2.write_tm2(g))
     finally:
         del os.environ["TAMD_FORCE_GEMM"]
         del os.environ["TAMD_AUTOTUNE"]
+        os.environ.pop("TAMD_PGEMM_W", None)
     gr.set_input(x)
     got = gr.run()[0].reshape(want.shape)
     name = gr.profile(1)[-1]["kernel"]
@@ -66,12 +67,12 @@ def _run(member, case, seed):
     return want, got, name
 
 
-@pytest.mark.parametrize("member", VARIANTS + KS2 + WGRID)
+@pytest.mark.parametrize("member", VARIANTS + WGRID)
 @pytest.mark.parametrize("ci", range(len(PATCH_CASES)))
 def test_patch_kernel_is_exact(member, ci):
     want, got, name = _run(member, PATCH_CASES[ci], 900 + ci)
     if member in name:       # a variant that does not apply to the shape (e.g. 128-pixel tiles on 64 pixels) falls back
-        assert "patch" in name or "3x3" in name, name
+        assert ("patch" in name) if member in VARIANTS else ("3x3" in name), name
     assert np.array_equal(got, want), (name, PATCH_CASES[ci], int((got != want).sum()))
     assert len(np.unique(want)) > 5
 
@@ -94,11 +95,6 @@ def test_variants_really_run():
     for member in (VARIANTS[0], VARIANTS[2]):       # dilated 3x3 with 40 couts: the 64-channel-wide tiles only
         _, _, name = _run(member, PATCH_CASES[4], 1)
         assert member in name, (member, name)
-    for case in (PATCH_CASES[1], PATCH_CASES[10]):      # two / eight 64-channel chunks per wave group pair
-        _, _, name = _run(KS2[0], case, 1)
-        assert KS2[0] in name, (KS2[0], name)
-    # (128 x 128 tiles with two wave groups need 2 x (48 KB ring + two patch buffers): offered only where the patch is small --
-    #  single-image 14 x 14 tiles -- and covered by the parametrised exactness test where it applies)
     for member in WGRID:
         # 14 x 14 x 128 -> 130 (two chunks, ragged cout), 7 x 7 x 512 (eight chunks, tiles over three images)
         for case in (PATCH_CASES[1], PATCH_CASES[10]):
@@ -109,8 +105,6 @@ def test_variants_really_run():
         assert member in name, (member, name)
     for member in [m for m in WGRID if "x64," in m]:       # the 64-cout tiles also take the narrow layers: dilation 2, pad > halo, 25-pixel images, wide rows
         for case in (PATCH_CASES[4], PATCH_CASES[7], PATCH_CASES[9], PATCH_CASES[8]):
-            if "ks2w" in member and (case[1] // 64) % 2:
-                continue
             _, _, name = _run(member, case, 1)
             assert member in name, (member, name)
 

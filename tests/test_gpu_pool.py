@@ -18,7 +18,7 @@ def test_shared_buffers_give_the_same_bytes(name, batch, kw, monkeypatch):
     x = models.synth_input(g, 31)
     want = oracle.run_graph(g, x)[0]
     outs = []
-    for keep, env in ((False, {}), (True, {}), (False, {"TAMD_ARENA": "0"}), (False, {"TAMD_AUTOTUNE": "0"})):
+    for keep, env in ((False, {}), (True, {}), (False, {"TAMD_PIN": "arena=0"}), (False, {"TAMD_AUTOTUNE": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for direct in (False, True):

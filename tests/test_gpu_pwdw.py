@@ -18,12 +18,12 @@ pytestmark = pytest.mark.gpu
 def run(g, x, fuse, cfg=None):
     os.environ["TAMD_FUSE_PWDW"] = str(fuse)
     if cfg:
-        os.environ["TAMD_PWDW_CFG"] = cfg
+        os.environ["TAMD_PIN"] = "pwdw_cfg=" + cfg
     try:
         gr = capi.Graph(tm2.write_tm2(g))
     finally:
         os.environ.pop("TAMD_FUSE_PWDW", None)
-        os.environ.pop("TAMD_PWDW_CFG", None)
+        os.environ.pop("TAMD_PIN", None)
     gr.set_input(x)
     out = gr.run()[0]
     names = [k["kernel"] for k in gr.profile(1)]

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 
 
 def run(g, x, fuse, **kw):
-    os.environ["TAMD_FIRST_POOL"] = str(fuse)
+    os.environ["TAMD_PIN"] = "first_pool=%d" % fuse
     try:
         gr = capi.Graph(tm2.write_tm2(g), **kw)
     finally:
-        os.environ.pop("TAMD_FIRST_POOL", None)
+        os.environ.pop("TAMD_PIN", None)
     gr.set_input(x)
     out = gr.run()[0]
     names = [k["kernel"] for k in gr.profile(1)]

@@ -22,19 +22,12 @@ pytestmark = pytest.mark.gpu
 
 
 def run_int(g, x, cfg=None, want_kernel="conv_u8i", env=None):
-    env = dict(env or {})
+    pins = dict(env or {})                # TAMD_PIN keys (csrc/env.h): u8i_cfg, u8i_tiles, u8i_cg, u8i_pw
     if cfg is not None:
-        env["TAMD_U8I_CFG"] = str(cfg)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+        pins["u8i_cfg"] = str(cfg)
+    from helpers import pinned
+    with pinned(**pins):
         gr = capi.Graph(tm2.write_tm2(g), u8_integer=True)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     gr.set_input(x)
     out = gr.run()
     kernels = [k["kernel"] for k in gr.profile(1)]
@@ -82,9 +75,9 @@ def test_conv_u8_integer_matches_its_model_and_the_reference_within_one_step(cas
     seen = set()
     # every tile shape; then 2-D pixel tiles wherever they fit (wide maps get them anyway) and one 32-channel group per chunk
     # for 1x1 layers also the six shapes of the register-only pointwise kernel (ids 6..11), and the general kernel with it switched off
-    runs = [(None, None)] + [(c, None) for c in range(6)] + [(c, {"TAMD_U8I_TILES": "2"}) for c in (0, 2, 3, 5)] + [(1, {"TAMD_U8I_CG": "2"}), (4, {"TAMD_U8I_CG": "4"})]
+    runs = [(None, None)] + [(c, None) for c in range(6)] + [(c, {"u8i_tiles": "2"}) for c in (0, 2, 3, 5)] + [(1, {"u8i_cg": "2"}), (4, {"u8i_cg": "4"})]
     if k == 1 and s == 1 and p == 0:
-        runs += [(c, None) for c in range(6, 12)] + ([(None, {"TAMD_U8I_PW": "0"}), (0, {"TAMD_U8I_PW": "0"})] if w >= 4 else [])
+        runs += [(c, None) for c in range(6, 12)] + ([(None, {"u8i_pw": "0"}), (0, {"u8i_pw": "0"})] if w >= 4 else [])
     if w < 4:
         runs = [(None, None)] + [(c, None) for c in range(6, 12)]          # maps narrower than a dword: only the pointwise kernel takes them
     for cfg, env in runs:
@@ -152,7 +145,7 @@ def test_conv_u8_integer_fused_tails(case, tiles2d):
     n, cin, h, w, cout, relu, second = case
     g, x = u8_conv_pool_graph(3 + cin, n, cin, h, w, cout, relu=relu, second_reader=second)
     want = oracle.run_graph(g, x)
-    got, kernels = run_int(g, x, env={"TAMD_U8I_TILES": "2"} if tiles2d else None)
+    got, kernels = run_int(g, x, env={"u8i_tiles": "2"} if tiles2d else None)
     if (h * w) % 8 == 0:                       # what the planner asks of a fused pool (the byte-exact kernels' tail-pixel rule)
         assert any(k.startswith("conv_u8i") and "+maxpool" in k for k in kernels), kernels
     for w_, o in zip(want, got):

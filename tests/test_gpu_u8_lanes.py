@@ -2,7 +2,7 @@
 conv_u8_patch_tail): the 5x5 .. 1x1 ends of an SSD pyramid, where a GEMM launch is all set-up around a handful of live MFMA
 columns.  Every output is one lane's fmaf chain in the reference's order -- the single chain over k for pixels j < (OH*OW)&~7,
 the four k%4 chains + combine for the tail pixels (conv_kernel_x86.c:322-960) -- so the bytes must equal the oracle's (pinned
-to the real reference by tests/test_uint8_oracle.py) and the GEMM member's.  TAMD_U8_PATCH=1 + TAMD_U8_PATCH_CFG=4 pins it."""
+to the real reference by tests/test_uint8_oracle.py) and the GEMM member's.  TAMD_PIN="u8_patch=1,u8_patch_cfg=4" pins it."""
 import os
 
 import numpy as np
@@ -15,21 +15,15 @@ from tengine_amd import capi, models, tm2
 pytestmark = pytest.mark.gpu
 
 
-def run_with(g, x, env):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+def run_with(g, x, pins):
+    """pins: TAMD_PIN keys (csrc/env.h) -- u8_patch, u8_patch_cfg, u8_lanes"""
+    from helpers import pinned
+    with pinned(**pins):
         gr = capi.Graph(tm2.write_tm2(g))
         gr.set_input(x)
         out = [o.copy() for o in gr.run()]
         kernels = [k["kernel"] for k in gr.profile(1)]
         gr.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
     return out, kernels
 
 
@@ -56,9 +50,9 @@ def test_lane_chains_equal_oracle_and_gemm_member(case):
     n, cin, h, w, cout, k, s, p, group, act, bias, dil = case
     g, x = u8_conv_graph(311 + cin + cout + h, n, cin, h, w, cout, k, s, p, group, act, bias, dil)
     want = oracle.run_graph(g, x)
-    got, kernels = run_with(g, x, {"TAMD_U8_PATCH": "1", "TAMD_U8_PATCH_CFG": "4"})
+    got, kernels = run_with(g, x, {"u8_patch": "1", "u8_patch_cfg": "4"})
     assert any("conv_u8_lanes" in kn for kn in kernels), kernels
-    ref, kernels0 = run_with(g, x, {"TAMD_U8_PATCH": "0"})
+    ref, kernels0 = run_with(g, x, {"u8_patch": "0"})
     assert not any("conv_u8_lanes" in kn or "conv_u8_patch" in kn for kn in kernels0), kernels0
     for wv, a, b in zip(want, got, ref):
         a = a.reshape(wv.shape)
@@ -76,7 +70,7 @@ def test_lane_chains_with_a_fused_relu_node(dims, kw):
     kw = dict(dict(pool_k=3, pool_s=1), **kw)
     g, x = u8_conv_pool_graph(77 + dims[1] + dims[2], *dims, **kw)
     want = oracle.run_graph(g, x)
-    got, kernels = run_with(g, x, {"TAMD_U8_PATCH": "1", "TAMD_U8_PATCH_CFG": "4"})
+    got, kernels = run_with(g, x, {"u8_patch": "1", "u8_patch_cfg": "4"})
     assert any(kn.startswith("conv_u8_lanes") and "+relu" in kn for kn in kernels), kernels
     for wv, a in zip(want, got):
         assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
@@ -91,7 +85,7 @@ def test_default_plan_of_the_ssd_tail_uses_lane_chains():
     assert sum("conv_u8_lanes" in kn for kn in kernels) >= 6, kernels
     for wv, a in zip(want, got):
         assert np.array_equal(a.reshape(wv.shape), wv), "%d bytes differ" % np.count_nonzero(a.reshape(wv.shape) != wv)
-    off, kernels0 = run_with(g, x, {"TAMD_U8_LANES": "0"})
+    off, kernels0 = run_with(g, x, {"u8_lanes": "0"})
     assert not any("conv_u8_lanes" in kn for kn in kernels0), kernels0
     for a, b in zip(got, off):
         assert np.array_equal(a, b)
@@ -99,7 +93,7 @@ def test_default_plan_of_the_ssd_tail_uses_lane_chains():
 
 def test_large_layers_do_not_take_lane_chains():
     g, x = u8_conv_graph(5, 8, 64, 38, 38, 256, 3, 1, 1)          # 8 x 1444 px x 16 cout tiles: far beyond the wave bound
-    got, kernels = run_with(g, x, {"TAMD_U8_PATCH": "1", "TAMD_U8_PATCH_CFG": "4"})
+    got, kernels = run_with(g, x, {"u8_patch": "1", "u8_patch_cfg": "4"})
     assert not any("conv_u8_lanes" in kn for kn in kernels), kernels
     want = oracle.run_graph(g, x)
     assert np.array_equal(got[0].reshape(want[0].shape), want[0])

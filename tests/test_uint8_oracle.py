@@ -86,7 +86,7 @@ def test_yolov3_tiny_uint8_layer_by_layer_against_reference():
         teacher[n.outputs[0]] = ref_capi.run_model(tm2.write_tm2(g2), x, ref_capi.MODE_UINT8, 4)[0]
     rep = []
     oracle.run_graph(g, x, teacher=teacher, report=rep)
-    assert len(rep) == 32
+    assert len(rep) == 35          # the benchmark file's 35 compute nodes (two Dropout heads and the single-input route included)
     assert all(r[2] == 0 for r in rep), [r for r in rep if r[2]]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""int8 depthwise 3x3 launch forms (TAMD_DW_FORM = <fragments per row><output rows per lane>) on MobileNet-shaped layers at
+"""int8 depthwise 3x3 launch forms (TAMD_PIN dw_form = <fragments per row><output rows per lane>) on MobileNet-shaped layers at
 large batch: us per isolated launch (HIP events).  usage: dw_forms.py [forms ...]"""
 import os
 import sys
@@ -19,12 +19,12 @@ for n, c, hw, s in SHAPES:
     b = tm2.write_tm2(g)
     cells = []
     for f in forms:
-        os.environ["TAMD_DW_FORM"] = f
+        os.environ["TAMD_PIN"] = "dw_form=" + f
         gr = capi.Graph(b)
         gr.set_input(x)
         gr.run()
         k = [q for q in gr.profile(30) if q["macs"] > 0][-1]
         cells.append("%10.2f" % (k["ms"] * 1e3))
         gr.close()
-    del os.environ["TAMD_DW_FORM"]
+    del os.environ["TAMD_PIN"]
     print("%-26s" % ("%d x %d @ %d, s%d" % (n, c, hw, s)) + "".join(cells))

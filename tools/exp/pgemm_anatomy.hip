@@ -5,7 +5,7 @@
 // Round 5: the wave-grid kernels of conv_pgemm_w.hip (variants 16 ..) ride in the same loop with their geometry table; flag 64 | n << 16
 // delays the second dispatch round of every XCD by n x 1024 cycles (the phase-skew experiment); argv[2] = "3x3" runs the four 3x3
 // shapes of ResNet-50 only.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm --amdgpu-mfma-vgpr-form -DTAMD_IGEMM_STAMPS -I../../tengine_amd/csrc
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm --amdgpu-mfma-vgpr-form -DTAMD_IGEMM_STAMPS -DTAMD_EXPERIMENTS -I../../tengine_amd/csrc
 //        -o pgemm_anatomy.bin pgemm_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
 #include "../../tengine_amd/csrc/conv_pgemm.hip"
 #include "../../tengine_amd/csrc/conv_pgemm_w.hip"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""uint8 depthwise 3x3 block heights (TAMD_U8_DW_TH = output rows per thread) on SSD-shaped layers: us per isolated launch."""
+"""uint8 depthwise 3x3 block heights (TAMD_PIN u8_dw_th = output rows per thread) on SSD-shaped layers: us per isolated launch."""
 import os
 import sys
 
@@ -18,12 +18,12 @@ for n, c, hw, s in SHAPES:
     b = tm2.write_tm2(g)
     cells = []
     for f in forms:
-        os.environ["TAMD_U8_DW_TH"] = f          # 0: the launcher's own choice
+        os.environ["TAMD_PIN"] = "u8_dw_th=" + f          # 0: the launcher's own choice
         gr = capi.Graph(b)
         gr.set_input(x)
         gr.run()
         k = [q for q in gr.profile(30) if q["macs"] > 0][-1]
         cells.append("%10.2f" % (k["ms"] * 1e3))
         gr.close()
-    del os.environ["TAMD_U8_DW_TH"]
+    del os.environ["TAMD_PIN"]
     print("%-26s" % ("%d x %d @ %d, s%d" % (n, c, hw, s)) + "".join(cells))

@@ -1,7 +1,7 @@
 """Randomised device-vs-oracle campaign (runs ON THE GPU BOX; the oracle is the checker, nothing under test uses it).
 
 Same random single-op graphs as tools/fuzz_oracle.py, run through the C ABI on the GPU with a randomly pinned member
-of the kernel family (TAMD_FORCE_GEMM / TAMD_U8_CFG / TAMD_U8_PATCH / TAMD_U8_RGB3X3 / TAMD_FIRST_ROWS) and compared byte for byte with
+of the kernel family (TAMD_FORCE_GEMM and the TAMD_PIN keys u8_cfg / u8_patch / u8_patch_cfg / u8_c3 / u8_dw_th / first_rows / dw_form) and compared byte for byte with
 oracle/tg_oracle.c (itself pinned to the real reference by fuzz_oracle.py).
 
     python tools/fuzz_device.py --dtype uint8 --seconds 50 --seed 1"""
@@ -21,7 +21,8 @@ from oracle import oracle  # noqa: E402
 from tengine_amd import capi, tm2  # noqa: E402
 
 I8_MEMBERS = ["", "", "igemm0", "igemm1", "igemm2", "igemm3", "igemm4", "igemm5", "igemm6", "igemm7", "igemm8", "igemm9",
-              "gemm_direct", "pw_stream", "conv_igemm2"]
+              "gemm_direct", "pw_stream", "conv_igemm2", "conv_pgemm_i8<128x64,3x3,w4t>", "conv_pgemm_i8<64x64,3x3,w4t>", "conv_pgemm_i8<128x64,3x3,w4b3>",
+              "conv_pgemm_i8<64x64,3x3,w4b3>", "conv_pgemm_i8<128x128,3x3,w8>", "conv_pgemm_i8<128x128,3x3,w8b3>", "conv_pgemm_i8<128x64", "conv_pgemm_i8<64x64"]
 
 
 def main():
@@ -36,31 +37,31 @@ def main():
     while time.time() - t0 < a.seconds:
         patch = a.dtype == "uint8" and rng.random() < 0.6
         g, x = random_graph(rng, a.dtype, int(rng.choice([4, 4, 32])) if patch else 1, device=True)
-        for k in ("TAMD_FORCE_GEMM", "TAMD_U8_CFG", "TAMD_U8_RGB3X3", "TAMD_FIRST_ROWS", "TAMD_U8_PATCH", "TAMD_U8_PATCH_CFG", "TAMD_U8_PATCH_2D",
-                  "TAMD_U8_C3", "TAMD_U8_DW_TH", "TAMD_U8_RGB_MFMA", "TAMD_DW_FORM"):
-            os.environ.pop(k, None)
+        os.environ.pop("TAMD_FORCE_GEMM", None)
+        pins = {}                                  # TAMD_PIN keys (tengine_amd/csrc/env.h): each names a live plan-time candidate
         if a.dtype == "int8":
             m = I8_MEMBERS[int(rng.integers(len(I8_MEMBERS)))]
             if m:
                 os.environ["TAMD_FORCE_GEMM"] = m
             if rng.random() < 0.3:
-                os.environ["TAMD_FIRST_ROWS"] = "0"
-            if rng.random() < 0.7:                 # round 4: the depthwise launch forms (fragments per row x output rows per lane)
-                os.environ["TAMD_DW_FORM"] = str(rng.choice(["11", "12", "14", "21", "22"]))
+                pins["first_rows"] = "0"
+            if rng.random() < 0.7:                 # the depthwise launch forms (fragments per row x output rows per lane)
+                pins["dw_form"] = str(rng.choice(["11", "12", "14", "21", "22"]))
         else:
             if rng.random() < 0.8:
-                os.environ["TAMD_U8_CFG"] = str(int(rng.integers(8)))
+                pins["u8_cfg"] = str(int(rng.integers(8)))
             if patch:                              # the patch convolution wherever it applies, a random tile configuration first
-                os.environ["TAMD_U8_PATCH"] = "1"
-                os.environ["TAMD_U8_PATCH_CFG"] = str(int(rng.integers(9)))      # round 4: 4 = lane-level chains, 5 .. 8 = 2-D pixel tiles
-                os.environ["TAMD_U8_PATCH_2D"] = "1"
-            # round 4: the wave-level shallow 3x3 kernel, the depthwise block heights, the first layer's main pixels on the matrix cores
+                pins["u8_patch"] = "1"
+                pins["u8_patch_cfg"] = str(int(rng.integers(5)))      # 4 = lane-level chains
+            # the wave-level shallow 3x3 kernel, the depthwise block heights
             if rng.random() < 0.5:
-                os.environ["TAMD_U8_C3"] = str(int(rng.integers(2)))
+                pins["u8_c3"] = str(int(rng.integers(2)))
             if rng.random() < 0.7:
-                os.environ["TAMD_U8_DW_TH"] = str(rng.choice(["1", "2", "4"]))
-            if rng.random() < 0.5:
-                os.environ["TAMD_U8_RGB_MFMA"] = "1" 
+                pins["u8_dw_th"] = str(rng.choice(["1", "2", "4"]))
+        if pins:
+            os.environ["TAMD_PIN"] = ",".join("%s=%s" % kv for kv in pins.items())
+        else:
+            os.environ.pop("TAMD_PIN", None)
         want = oracle.run_graph(g, x)
         try:
             gr = capi.Graph(tm2.write_tm2(g))
