@@ -1589,6 +1589,13 @@ static int plan(tamd_graph* g)
                           n.name.c_str(), kSoftmaxI8MaxC);
                 return -1;
             }
+            if (x.dims.size() == 2 && x.h * x.w != 1) {
+                // a 2-D tensor that is the flattened view of an H x W > 1 map keeps the map's NHWC geometry on the device: its "channel
+                // axis" is C, the reference normalises over all C*H*W values in NCHW order.  The plugin leaves such a node to
+                // the CPU device (hip_device.cc: node_runs_on_device); through the C ABI it is refused here
+                set_error("softmax %s is not supported on the device: its 2-D input is the flattened view of a %d x %d map", n.name.c_str(), x.h, x.w);
+                return -1;
+            }
             if (x.scales.empty() || y.scales.empty()) { set_error("softmax %s: missing quant params", n.name.c_str()); return -1; }
             SoftmaxI8Args a{};
             a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr + y.c_off;

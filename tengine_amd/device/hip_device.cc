@@ -18,6 +18,9 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -541,6 +544,19 @@ bool node_runs_on_device(struct graph* ir, struct node* n)
         if (ty != ELT_PROD && ty != ELT_SUM && ty != ELT_SUB && ty != ELT_MAX) return false;
     }
     if (n->op.type == OP_FLATTEN && ((const struct flatten_param*)n->op.param_mem)->axis != 1) return false;
+    if (n->op.type == OP_SOFTMAX && out_dt == TENGINE_DT_INT8 && n->input_num >= 1) {
+        // int8 tensors are NHWC on the device: a 2-D input that is the flattened view of an H x W > 1 map would be normalised per
+        // pixel over C, the reference normalises over all C*H*W values (softmax_kernel_ref_int8.c) -- such a node stays on the CPU
+        struct tensor* t = get_ir_graph_tensor(ir, n->input_tensors[0]);
+        if (t->dim_num == 2) {
+            while (t->producer >= 0) {
+                struct node* pn = get_ir_graph_node(ir, t->producer);
+                if ((pn->op.type != OP_FLATTEN && pn->op.type != OP_RESHAPE && pn->op.type != OP_DROPOUT) || pn->input_num < 1) break;
+                t = get_ir_graph_tensor(ir, pn->input_tensors[0]);
+            }
+            if (t->dim_num == 4 && t->dims[2] * t->dims[3] != 1) return false;
+        }
+    }
     return node_supported(ir, n);
 }
 
@@ -619,7 +635,7 @@ void resplit_around_unsupported(struct graph* ir, struct device* hip)
 // hip_wait_graph(graph, try_wait) with the body wait_graph was meant to have; INTEGRATION.md shows the one-token fix.
 // State per graph lives in attribute->scheduler_privacy, which the reference releases with sys_free when a graph is destroyed
 // without postrun (executer.c:51-53): it is allocated with sys_malloc, a plain struct.
-struct HipSchedState { int inflight; };
+struct HipSchedState { int inflight; int attached; };      // attached: this graph's prerun succeeded and counts in g_sched_live
 
 HipSchedState* sched_state(struct graph* ir_graph)
 {
@@ -627,16 +643,22 @@ HipSchedState* sched_state(struct graph* ir_graph)
         HipSchedState* st = (HipSchedState*)sys_malloc(sizeof(HipSchedState));
         if (!st) return nullptr;
         st->inflight = 0;
+        st->attached = 0;
         ir_graph->attribute->scheduler_privacy = st;
     }
     return (HipSchedState*)ir_graph->attribute->scheduler_privacy;
 }
 
-// A context schedules through hip_scheduler only while graphs that the plugin split are alive on it: the count per context is kept
-// here, and the reference's own scheduler goes back onto the context when the last such graph is post-run (or the plugin is
-// unregistered) -- a context must never be left pointing at a scheduler of a library that may be unloaded.
+// A context schedules through hip_scheduler only while graphs that the plugin split AND pre-ran are alive on it: the count per
+// context is kept here, and the reference's own scheduler goes back onto the context when the last such graph is post-run.  A graph
+// destroyed without postrun_graph (destroy_graph does not call it, c_api.c:662-671) leaves its count behind, and destroy_context has
+// no hook, so the map may hold pointers to contexts that no longer exist: they are compared, never dereferenced, outside the calls
+// that were handed the context by a live graph.  unregister_hip_device therefore does not walk the contexts; instead
+// the library pins itself in memory at registration (RTLD_NODELETE) and hip_scheduler turns into a plain forwarder to the
+// reference's scheduler -- a context that still points at it keeps working after the plugin is gone.
 std::mutex g_sched_mu;
 std::map<struct context*, int> g_sched_live;
+std::atomic<bool> g_sched_forward{false};
 
 void sched_attach(struct context* ctx)
 {
@@ -645,6 +667,7 @@ void sched_attach(struct context* ctx)
 }
 
 void sched_detach(struct context* ctx);
+extern struct scheduler hip_scheduler;
 
 // The one subgraph asynchronous runs are built around: the graph's ONLY subgraph on "HIP", fed by graph inputs alone (nothing
 // another subgraph produces).  Everything else of the graph -- the CPU pieces behind it: DetectionOutput of an SSD model, an
@@ -715,13 +738,21 @@ int hip_sched_prerun(struct scheduler* s, struct graph* g)
     (void)s;
     struct scheduler* d = find_default_scheduler();
     const int rc = d->prerun(d, g);
-    if (rc == 0) sched_attach(g->attribute->context);
+    if (g_sched_forward.load()) return rc;
+    struct context* ctx = g->attribute->context;
+    HipSchedState* st = rc == 0 ? sched_state(g) : nullptr;
+    if (st && !st->attached) { st->attached = 1; sched_attach(ctx); }
+    if (rc != 0) {          // a failed prerun attaches nothing: with no other live graph the context goes back to the reference's scheduler
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        if (g_sched_live.find(ctx) == g_sched_live.end() && ctx->scheduler == &hip_scheduler) ctx->scheduler = d;
+    }
     return rc;
 }
 
 int hip_sched_wait(struct scheduler* s, struct graph* ir_graph)
 {
     (void)s;
+    if (g_sched_forward.load()) { struct scheduler* d = find_default_scheduler(); return d->wait ? d->wait(d, ir_graph) : -1; }
     HipSchedState* st = sched_state(ir_graph);
     if (!st) return -1;
     if (st->inflight == 0) { ir_graph->status = GRAPH_STAT_READY; return 0; }
@@ -737,6 +768,7 @@ int hip_sched_wait(struct scheduler* s, struct graph* ir_graph)
 int hip_sched_run(struct scheduler* s, struct graph* ir_graph, int block)
 {
     struct scheduler* d = find_default_scheduler();
+    if (g_sched_forward.load()) return d->run(d, ir_graph, block);
     HipSchedState* st = sched_state(ir_graph);
     if (!st) return -1;
     if (block) {
@@ -755,15 +787,18 @@ int hip_sched_run(struct scheduler* s, struct graph* ir_graph, int block)
 
 int hip_sched_postrun(struct scheduler* s, struct graph* ir_graph)
 {
-    while (ir_graph->attribute->scheduler_privacy && sched_state(ir_graph)->inflight > 0)
+    const bool fwd = g_sched_forward.load();
+    while (!fwd && ir_graph->attribute->scheduler_privacy && sched_state(ir_graph)->inflight > 0)
         if (hip_sched_wait(s, ir_graph) != 0) break;
     struct scheduler* d = find_default_scheduler();
     const int rc = d->postrun(d, ir_graph);
+    bool attached = false;
     if (ir_graph->attribute->scheduler_privacy) {
+        attached = ((HipSchedState*)ir_graph->attribute->scheduler_privacy)->attached != 0;
         sys_free(ir_graph->attribute->scheduler_privacy);
         ir_graph->attribute->scheduler_privacy = nullptr;
     }
-    sched_detach(ir_graph->attribute->context);
+    if (attached && !fwd) sched_detach(ir_graph->attribute->context);      // only a graph that attached detaches (a failed prerun never did)
     return rc;
 }
 
@@ -786,11 +821,8 @@ int hip_split_graph(struct graph* ir_graph)
     if (0 != strcmp(HIP_DEV_NAME, cur_dev->name)) return -1;
     // split_graph runs inside prerun_graph, before the context's scheduler is asked to pre-run (c_api.c:468-530): from here on
     // this context schedules through the plugin's scheduler (TG_HIP_SCHEDULER=0 keeps the reference's)
-    if (!(getenv("TG_HIP_SCHEDULER") && atoi(getenv("TG_HIP_SCHEDULER")) == 0)) {
-        ir_graph->attribute->context->scheduler = &hip_scheduler;
-        std::lock_guard<std::mutex> lk(g_sched_mu);
-        g_sched_live.insert({ir_graph->attribute->context, 0});      // known from now on: unregister_hip_device restores it
-    }
+    if (!(getenv("TG_HIP_SCHEDULER") && atoi(getenv("TG_HIP_SCHEDULER")) == 0))
+        ir_graph->attribute->context->scheduler = &hip_scheduler;      // (the context is counted when this graph's prerun succeeds: hip_sched_prerun)
 
     struct vector* allowed_ops = create_vector(sizeof(int), nullptr);
     struct vector* blocked_ops = create_vector(sizeof(int), nullptr);
@@ -849,6 +881,11 @@ __attribute__((visibility("default"))) int register_hip_device(void)
         TLOG_INFO("Tengine plugin %s register failed.\n", hip_device.name);
         return -1;
     }
+    // the plugin hands contexts a pointer into this library (hip_scheduler): keep the library mapped for the life of the process, so
+    // that a context which outlives unload_tengine_plugin still points at valid (then forwarding) code -- see g_sched_live
+    Dl_info me;
+    if (dladdr((void*)&register_hip_device, &me) && me.dli_fname) (void)dlopen(me.dli_fname, RTLD_NOW | RTLD_NODELETE);
+    g_sched_forward.store(false);
     TLOG_INFO("Tengine plugin device %s is registered.\n", hip_device.name);
     return 0;
 }
@@ -891,10 +928,10 @@ __attribute__((visibility("default"))) int hip_device_placement(void* graph, cha
 
 __attribute__((visibility("default"))) int unregister_hip_device(void)
 {
-    {   // no context may keep pointing at this library's scheduler once the device is gone
+    {   // contexts are not walked (they may have been destroyed: see g_sched_live): from now on hip_scheduler only forwards to the
+        // reference's scheduler, and the library stays mapped (register_hip_device pinned it), so a context still pointing here is safe
         std::lock_guard<std::mutex> lk(g_sched_mu);
-        for (auto& e : g_sched_live)
-            if (e.first->scheduler == &hip_scheduler) e.first->scheduler = find_default_scheduler();
+        g_sched_forward.store(true);
         g_sched_live.clear();
     }
     int ret = unregister_device(&hip_device);
