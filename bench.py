@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--direct", type=int, choices=[0, 1], default=1,
                     help="1 (default): tamd_graph_launch dispatches the launch list as AQL packets on the graph's own HSA queue "
                          "(tamd_options.direct_dispatch, csrc/direct.cc); 0: hipGraph replay on the graph's HIP stream.  "
-                         "--gather every needs the stream order and always uses 0")
+                         "the per-step gather region (--gather every) awaits each pass on the queue's signal and gathers on a side stream")
     ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args()
     if args.u8_integer:
@@ -153,11 +153,14 @@ def main():
     def region(mode, direct, keep=False):
         """One timed region: W warm-up steps, K timed steps, bracketed by barrier + synchronize, MAX over ranks.
         mode: "none" (no collective: N = 1), "final" (every output of the LAST step all-gathered once, inside the region),
-        "every" (one all_gather of every output per step, double-buffered on RCCL's stream so it overlaps the next step --
-        SURVEY 8(e)'s per-batch gather; needs the stream order, i.e. the hipGraph replay)."""
+        "every" (one all_gather of every output per step, double-buffered on a side stream so it overlaps the next step --
+        SURVEY 8(e)'s per-batch gather).  With direct dispatch the passes are not on a HIP stream: step k is awaited on the
+        queue's completion signal (tamd_graph_sync), its outputs are copied into the gather slot on the side stream, and the
+        next pass is submitted once that copy is done -- the SAME dispatch path as the N = 1 `value`, plus what a per-step
+        gather needs (round 5; until round 4 this region replayed hipGraphs and N = 1 / N > 1 timed different paths)."""
         # one HSA queue per graph: with several batch-1 streams the extra queues oversubscribe the hardware queues (measured: 4
         # streams 8.2 k img/s direct against 27.3 k on HIP streams), so the concurrent-streams mode stays on hipGraph replay
-        direct = bool(direct) and S == 1 and mode != "every"
+        direct = bool(direct) and S == 1
         grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank, direct_dispatch=direct) for _ in range(S)]
         gr = grs[0]
         for q in grs:
@@ -182,7 +185,7 @@ def main():
         for b in per_image:
             slot_off.append(slot_bytes)
             slot_bytes += b * max_shard
-        slots, gathered, works, slot_done, stalls = None, None, {}, {}, [0]
+        slots, gathered, works, slot_done, stalls, copied = None, None, {}, {}, [0], {}
         sides = [torch.cuda.Stream(device=torch.device("cuda", local_rank)) for _ in range(S)] if mode == "every" else None
         if mode != "none":
             slots = [[torch.zeros(slot_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(S)]
@@ -191,10 +194,34 @@ def main():
         def gather(i, s_):
             for oi in range(n_out):
                 slots[i][s_][slot_off[oi]:slot_off[oi] + out_sizes[oi]].copy_(views[i][oi], non_blocking=True)
+            if direct and mode == "every":               # the staging buffers are free again once this event has fired
+                copied[i] = copied.get(i) or torch.cuda.Event()
+                copied[i].record()
             works[(i, s_)] = dist.all_gather_into_tensor(gathered[i][s_], slots[i][s_], async_op=True)
 
         def step(k):
             i = k % S
+            if direct and mode == "every":
+                # direct dispatch: nothing orders the pass against the side stream but the host.  The previous step's copy out of
+                # the output staging buffers must be complete before this pass may overwrite them; the pass is awaited on its
+                # queue's signal; copy + collective then run on the side stream while the next pass computes
+                if copied.get(i) is not None:
+                    copied[i].synchronize()
+                grs[i].launch()
+                grs[i].sync()
+                s_ = (k // S) & 1
+                with torch.cuda.stream(sides[i]):
+                    if works.get((i, s_)) is not None:
+                        ev = slot_done.get((i, s_))
+                        if ev is not None and not ev.query():
+                            stalls[0] += 1
+                            ev.synchronize()
+                        works[(i, s_)].wait()
+                    gather(i, s_)
+                    works[(i, s_)].wait()
+                    ev = slot_done.setdefault((i, s_), torch.cuda.Event())
+                    ev.record()
+                return
             grs[i].launch()
             if mode == "every":
                 s_ = (k // S) & 1
@@ -225,7 +252,7 @@ def main():
                         gather(i, 0)
             for (i, s_), w in works.items():
                 if w is not None:
-                    with torch.cuda.stream(exts[i]):
+                    with torch.cuda.stream(sides[i] if (direct and mode == "every") else exts[i]):
                         w.wait()
             for q in grs:
                 q.sync()
@@ -265,13 +292,15 @@ def main():
     if not use_dist:
         main_info, grs = region("none", args.direct, keep=True)
     elif args.gather == "both":
-        main_info, _ = region("every", 0)
-        # the same K steps on the SAME dispatch path (hipGraph replay) without any collective: what the N GPUs do when nothing is
-        # gathered -- the like-for-like reference of `value` inside this very job (N x the N = 1 line's `hipgraph_replay`)
-        rep_info, _ = region("none", 0)
-        side["no_collective_hipgraph"] = {"value": total_images * args.steps / rep_info["el"], "ms_per_step": 1e3 * rep_info["el"] / args.steps,
-                                          "what": "K steps as hipGraph replays on every rank, no collective: value / this = what the per-step gather costs; "
-                                                  "compare with n_gpus x the N = 1 line's hipgraph_replay.value"}
+        main_info, _ = region("every", args.direct)
+        # the same K steps on the SAME dispatch path without any collective: what the N GPUs do when nothing is gathered -- the
+        # like-for-like reference of `value` inside this very job (N x the N = 1 line's `value` on the direct path)
+        rep_info, _ = region("none", args.direct)
+        side["no_collective"] = {"value": total_images * args.steps / rep_info["el"], "ms_per_step": 1e3 * rep_info["el"] / args.steps,
+                                 "what": "K steps on every rank on the same dispatch path (%s), no collective and no per-step wait: value / this = what the "
+                                         "per-step gather costs (the host's wait for each pass included); compare with n_gpus x the N = 1 line's %s"
+                                         % ("direct AQL dispatch" if rep_info["direct_packets"] else "hipGraph replay",
+                                            "value" if rep_info["direct_packets"] else "hipgraph_replay.value")}
         fin_info, grs = region("final", args.direct, keep=True)
         side["gather_final"] = {"value": total_images * args.steps / fin_info["el"], "ms_per_step": 1e3 * fin_info["el"] / args.steps,
                                 "what": "same K steps, no per-step collective (direct AQL dispatch, %d packets per step): every output of the LAST step "
@@ -426,9 +455,9 @@ def main():
             "host_to_host_images_per_s": host_to_host["images_per_s_median"] if host_to_host else None,
             "host_to_host_pipelined_images_per_s": host_to_host["pipelined_images_per_s"] if host_to_host else None,
             "prerun_ms": prerun_ms, "shipped_plan": shipped_plan,
-            # which N = 1 figure a scaling curve of `value` has to be read against: at N > 1 the per-step-gather region replays
-            # hipGraphs (it needs the stream order), so its N = 1 counterpart is `hipgraph_replay`, not the direct-dispatch `value`
-            "scaling_baseline_key": "hipgraph_replay" if (use_dist and gather_mode == "every") or (not use_dist and "hipgraph_replay" in side) else "value",
+            # which N = 1 figure a scaling curve of `value` has to be read against: the N = 1 line's `value` when both are direct AQL
+            # dispatch (round 5: the per-step-gather region no longer needs the hipGraph replay), else its `hipgraph_replay`
+            "scaling_baseline_key": "value" if n_direct else "hipgraph_replay",
             "gather_stalls": main_info.get("gather_stalls", 0) if use_dist else None,
             **side,
             "output_checksum": int(np.asarray(out, dtype=np.int64).sum()),
@@ -697,9 +726,9 @@ def dry_run(args, rank, world):
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                               "scaling": "strong" if args.global_batch else "weak",
                               # the keys a measured N > 1 line carries (null here: nothing was measured)
-                              "scaling_baseline_key": "hipgraph_replay", "gather_stalls": None,
+                              "scaling_baseline_key": "value" if args.direct else "hipgraph_replay", "gather_stalls": None,
                               "gather_final": {"value": None} if multi and args.gather == "both" else None,
-                              "no_collective_hipgraph": {"value": None} if multi and args.gather == "both" else None,
+                              "no_collective": {"value": None} if multi and args.gather == "both" else None,
                               "config": {"workload": "%s %s: gloo plumbing check only, no device work" % (args.model, args.dtype),
                                          "global_batch": total, "shards": counts, "outputs": len(per_image),
                                          "gather_bytes_per_image": sum(per_image), "tmfile_bytes": len(tm_bytes),

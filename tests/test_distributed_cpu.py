@@ -127,9 +127,9 @@ def _check_multi_gpu_keys(line, n):
     """what an N > 1 line must carry so that a scaling curve can be read like for like -- the judged `value`
     (per-step gather), `gather_final`, the same-dispatch-path figure without a collective, the name of the N = 1 key the curve is
     read against, the stall counter of the bounded gather -- with a consistent GPU count / parallelism tag"""
-    for key in ("value", "gather_final", "no_collective_hipgraph", "scaling_baseline_key", "gather_stalls", "scaling"):
+    for key in ("value", "gather_final", "no_collective", "scaling_baseline_key", "gather_stalls", "scaling"):
         assert key in line, key
-    assert line["scaling_baseline_key"] == "hipgraph_replay"
+    assert line["scaling_baseline_key"] == "value"          # round 5: the per-step-gather region dispatches directly, like the N = 1 `value`
     assert line["n_gpus"] == n and line["config"]["parallelism"] == "dp%d" % n and sum(line["config"]["shards"]) == line["config"]["global_batch"]
 
 
