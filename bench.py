@@ -379,7 +379,7 @@ def main():
             ach = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TOP/s", "frac": ach / mfma_peak}
         roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
-                         "traffic": pmc_traffic(args.model, args.dtype, args.batch, dom),
+                         "traffic": pmc_traffic(args.model, args.dtype + ("_int" if args.u8_integer else ""), args.batch, dom),
                          "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                          # whole-step matrix-core utilisation (BASELINE metric's second half): all MACs of the step
                          # over the summed kernel time, against the dense MFMA peak of the compute dtype
@@ -496,7 +496,8 @@ def pmc_traffic(model, dtype, batch, family):
             fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"
             return fam == family
         # step names vs kernel symbols where they differ
-        alias = {"conv_u8_mfma": "conv_u8_gemm_k", "conv_u8_patch": "conv_u8_patch_k", "conv_pgemm_i8": "conv_pgemm", "conv_igemm_i8": "conv_igemm"}
+        alias = {"conv_u8_mfma": "conv_u8_gemm_k", "conv_u8_patch": "conv_u8_patch_k", "conv_pgemm_i8": "conv_pgemm", "conv_igemm_i8": "conv_igemm",
+                 "conv_u8i": "conv_u8i_k"}
         return alias.get(family, family) in name
 
     for name, v in ks.items():

@@ -18,22 +18,18 @@ inline const char* exp_env(const char* name) { return getenv(name); }
 inline const char* exp_env(const char*) { return nullptr; }
 #endif
 
-// value of `key` in TAMD_PIN (nullptr: not pinned).  The returned pointer is valid until the next call on this thread.
+// value of `key` in TAMD_PIN (nullptr: not pinned): a pointer INTO the environment string, so it stays valid while the variable is
+// unchanged and several values can be held at once; the value ends at the next ',' or at the end of the string (callers parse
+// numbers with atoi / sscanf, which stop there; a value never contains a comma: pwdw_cfg is written THxTWxthreads).
 inline const char* tamd_pin(const char* key)
 {
-    static thread_local char buf[64];
     const char* e = getenv("TAMD_PIN");
     if (!e) return nullptr;
     const size_t kl = strlen(key);
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
         const size_t len = end ? (size_t)(end - p) : strlen(p);
-        if (len > kl && p[kl] == '=' && strncmp(p, key, kl) == 0) {
-            const size_t vl = len - kl - 1 < sizeof(buf) - 1 ? len - kl - 1 : sizeof(buf) - 1;
-            memcpy(buf, p + kl + 1, vl);
-            buf[vl] = 0;
-            return buf;
-        }
+        if (len > kl && p[kl] == '=' && strncmp(p, key, kl) == 0) return p + kl + 1;
         p += len + (end ? 1 : 0);
     }
     return nullptr;

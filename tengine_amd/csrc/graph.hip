@@ -1139,7 +1139,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     }
     if (const char* pin = tamd_pin("pwdw_cfg")) {
         int th = 0, tw = 0, threads = 0;
-        if (sscanf(pin, "%d,%d,%d", &th, &tw, &threads) == 3 && tmode == 1) {
+        if (sscanf(pin, "%dx%dx%d", &th, &tw, &threads) == 3 && tmode == 1) {
             th = std::min(th, a.OH); tw = std::min(tw, a.OW);
             if (th >= 1 && tw >= 1 && pwdw_config_ok(with_tiles(a, th, tw), threads)) { cfgs.clear(); cfgs.push_back({th, tw, threads, 0.0}); }
         }

@@ -64,9 +64,9 @@ def test_direct_dispatch_guards():
     out0, _ = run({})
     assert int(out0.split("PACKETS")[1].split()[0]) > 0
     # a profiler's environment sends the graph back to hipGraph replay; TAMD_DIRECT_UNDER_TOOLS=1 keeps the direct path
-    out, _ = run({"ROCP_TOOL_LIBRARIES": "not-a-real-tool"})
+    out, _ = run({"LD_PRELOAD": "/nonexistent/librocprof-not-there.so"})      # (ld.so ignores a preload it cannot find; the name is what the guard looks at)
     assert int(out.split("PACKETS")[1].split()[0]) == 0
-    out, _ = run({"ROCP_TOOL_LIBRARIES": "not-a-real-tool", "TAMD_DIRECT_UNDER_TOOLS": "1"})
+    out, _ = run({"LD_PRELOAD": "/nonexistent/librocprof-not-there.so", "TAMD_DIRECT_UNDER_TOOLS": "1"})
     assert int(out.split("PACKETS")[1].split()[0]) > 0
     run({"TAMD_DIRECT_TIMEOUT_S": "5"})                         # a shorter deadline changes nothing on a healthy queue
     run({"TAMD_H2H_TRACE": "1"})                                # the host-side anatomy counters of blocking runs

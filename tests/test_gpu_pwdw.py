@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def run(g, x, fuse, cfg=None):
     os.environ["TAMD_FUSE_PWDW"] = str(fuse)
     if cfg:
-        os.environ["TAMD_PIN"] = "pwdw_cfg=" + cfg
+        os.environ["TAMD_PIN"] = "pwdw_cfg=" + cfg.replace(",", "x")        # THxTWxthreads (a TAMD_PIN value holds no comma)
     try:
         gr = capi.Graph(tm2.write_tm2(g))
     finally:
