@@ -665,10 +665,11 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     const float* wbase[TM];
 #pragma unroll
     for (int i = 0; i < TM; i++) wbase[i] = reinterpret_cast<const float*>(a.wpk) + (size_t)(co0 / 16 + wm * TM + i) * nss * FRAG;
-    // fragment registers, a ring of RA super-steps (the loaded tuples are used where they land).  In a real pass the weights come
-    // from HBM / the infinity cache (2-3 us), not from an L2 that the previous launch of the same layer warmed: the narrow
-    // configurations look seven super-steps (~3.5 us of MFMA) ahead, the wide ones (36 address registers) three
-    constexpr int RA = TN <= 2 ? 2 * CPC : CPC;
+    // fragment registers, a ring of RA super-steps (the loaded tuples are used where they land): three super-steps (~1.5 us of MFMA)
+    // ahead.  A ring of 2 * CPC for the narrow configurations (seven ahead, round 4) costs them 16-32 registers and is the slower
+    // one in a whole pass: YOLOv3-tiny b8 777.7 -> 729.9 us with this ring, MobileNet-SSD b16 unchanged
+    // (profiles/r05_ab_u8_patch_ra4_*.txt)
+    constexpr int RA = CPC;
     float4 af4[RA][TM][G4];
     float afr[RA][TM][REM > 0 ? REM : 1];
     auto aload = [&](auto D, int ss) {
@@ -722,12 +723,6 @@ __global__ __launch_bounds__(256) void conv_u8_patch_k(const U8ConvArgs a)
     aload(std::integral_constant<int, 0>{}, 0);
     aload(std::integral_constant<int, 1>{}, 1);
     aload(std::integral_constant<int, 2>{}, 2);
-    if constexpr (RA > CPC) {
-        aload(std::integral_constant<int, 3>{}, 3);
-        aload(std::integral_constant<int, 4 % RA>{}, 4);
-        aload(std::integral_constant<int, 5 % RA>{}, 5);
-        aload(std::integral_constant<int, 6 % RA>{}, 6);
-    }
     pload(0);
     pstore(0);
     pload(1);
