@@ -489,8 +489,8 @@ def pmc_traffic(model, dtype, batch, family):
     import re
 
     def member(name):
-        # the pwdw_i8_kernel<STEPS, MODE, CHUNKED, PROD> template serves four step families: tell them apart by MODE / PROD
-        m = re.search(r"pwdw_i8_kernel<\s*\d+,\s*(\d+),\s*\w+,\s*(\d+)>", name)
+        # the pwdw_i8_kernel<STEPS, MODE, CHUNKED, PROD[, WIN]> template serves four step families: tell them apart by MODE / PROD
+        m = re.search(r"pwdw_i8(?:_coh)?_kernel<\s*\d+,\s*(\d+),\s*\w+,\s*(\d+)(?:,\s*\d+)?>", name)
         if m:
             mode, prod = int(m.group(1)), int(m.group(2))
             fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void conv_first_pool_i8_kernel(FirstPoolArgs a
 
     // ---- convolution: two 32-pixel tiles per wave ---------------------------------------------------------------------------
     const Rq rq = a.rq;
+    const bool win = rq_win(rq);
 #pragma unroll 1
     for (int tt = 0; tt < 2; tt++) {
         const int q = (wave * 2 + tt) * 32 + l31;      // conv pixel of this lane (255 is padding: computed, never read)
@@ -136,27 +137,32 @@ __global__ __launch_bounds__(256) void conv_first_pool_i8_kernel(FirstPoolArgs a
                 bf[ks][2 * j] = (int)v.x;
                 bf[ks][2 * j + 1] = (int)v.y;
             }
-        v16i_fp acc[CT];
+        v16i_fp acc[CT];                   // starts at the bias (register e of lane (pixel, hi) = channel 8 (e >> 2) + 4 hi + (e & 3) of the tile)
 #pragma unroll
         for (int i = 0; i < CT; i++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][e] = 0;
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int4 b4 = *reinterpret_cast<const int4*>(&sbias[i * 32 + 8 * g4 + 4 * hi]);
+                acc[i][4 * g4 + 0] = b4.x; acc[i][4 * g4 + 1] = b4.y; acc[i][4 * g4 + 2] = b4.z; acc[i][4 * g4 + 3] = b4.w;
+            }
 #pragma unroll
         for (int ks = 0; ks < NK; ks++)
 #pragma unroll
             for (int i = 0; i < CT; i++) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i][ks], bf[ks], acc[i], 0, 0, 0);
         // requantise (C/D layout: col = lane & 31 -> pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> cout)
+        auto requantise = [&](auto WIN) {
 #pragma unroll
-        for (int i = 0; i < CT; i++)
+            for (int i = 0; i < CT; i++)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const int c0 = i * 32 + 8 * g4 + 4 * hi;
-                const int4 b4 = *reinterpret_cast<const int4*>(&sbias[c0]);
-                const float4 s4 = *reinterpret_cast<const float4*>(&sscale[c0]);
-                const unsigned p = requant4(acc[i][4 * g4 + 0] + b4.x, acc[i][4 * g4 + 1] + b4.y, acc[i][4 * g4 + 2] + b4.z,
-                                            acc[i][4 * g4 + 3] + b4.w, s4, c0, rq);
-                *reinterpret_cast<unsigned*>(cres + q * OPITCH + c0) = p ^ 0x80808080u;      // biased: unsigned byte order == signed order
-            }
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int c0 = i * 32 + 8 * g4 + 4 * hi;
+                    const float4 s4 = *reinterpret_cast<const float4*>(&sscale[c0]);
+                    const unsigned p = requant4<decltype(WIN)::value>(acc[i][4 * g4 + 0], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3], s4, c0, rq);
+                    *reinterpret_cast<unsigned*>(cres + q * OPITCH + c0) = p ^ 0x80808080u;      // biased: unsigned byte order == signed order
+                }
+        };
+        if (win) requantise(std::integral_constant<int, 1>{});      // the stem's ReLU: the one-binade form of epilogue.h
+        else requantise(std::integral_constant<int, 0>{});
     }
     __syncthreads();
 

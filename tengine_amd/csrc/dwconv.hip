@@ -24,8 +24,9 @@ namespace tamd {
 // Round 4: every load is unconditional (clamped address, the value masked afterwards) -- written as `ok ? load : 0` each of the 24
 // loads of the <1,2> kernel sat in its own divergent branch (37 s_cbranch_execz, 147 v_mov, 1089 instructions for six output
 // dwords); and a lane takes TH = 2 output rows where the map has them, so the rows between them are loaded and transposed once.
-template <int S, int NF, int TH>
-__global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
+// WIN: the one-binade requantisation of epilogue.h (the node's window starts at 128.25: a fused ReLU / ReLU6), checked once by the kernel
+template <int S, int NF, int TH, int WIN>
+__device__ __forceinline__ void dwconv3x3_body(const DwArgs& a)
 {
     constexpr int COLS = 4 * NF;
     constexpr int TW = (S == 1) ? (COLS - 2) : (NF == 1 ? 1 : 3);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
 #pragma unroll
         for (int j = 0; j < TW; j++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[j][c] = 0;
+            for (int c = 0; c < 4; c++) acc[j][c] = c == 0 ? b4.x : c == 1 ? b4.y : c == 2 ? b4.z : b4.w;      // the bias is where the dot chain starts
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -114,10 +115,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
         int8_t* yr = a.y + (((size_t)n * a.OH + oy) * a.OW + ox0) * a.ldc + a.c_off + c0;
 #pragma unroll
         for (int j = 0; j < TW; j++) {
-            const unsigned p = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, c0, rq);
+            const unsigned p = requant4<WIN>(acc[j][0], acc[j][1], acc[j][2], acc[j][3], s4, c0, rq);
             if (ox0 + j < a.OW) *reinterpret_cast<unsigned*>(yr + (size_t)j * a.ldc) = p;
         }
     }
+}
+
+template <int S, int NF, int TH>
+__global__ __launch_bounds__(256) void dwconv3x3_i8_kernel(DwArgs a)
+{
+    if (rq_win(a.rq)) dwconv3x3_body<S, NF, TH, 1>(a);
+    else dwconv3x3_body<S, NF, TH, 0>(a);
 }
 
 template <int S, int NF, int TH>

@@ -30,11 +30,14 @@ typedef int v4i_dp __attribute__((ext_vector_type(4)));
 typedef int v16i_dp __attribute__((ext_vector_type(16)));
 
 // NW = waves along the output channels (cout <= 64 * NW); 512 threads always (the depthwise stage needs 512 units per 128 channels)
-template <int NW>
-__global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
+constexpr int DWPW_KST = 128;                            // channels per stage
+typedef int8_t dwpw_bs_t[DWPW_KST / 16][64][16];         // one B buffer: [channel granule][pixel][16 B]
+
+// WIN: both requantisations (the depthwise node's and the pointwise node's) in the one-binade form of epilogue.h; checked once by the kernel
+template <int NW, int WIN>
+__device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
 {
-    constexpr int KST = 128;                             // channels per stage
-    __shared__ __attribute__((aligned(16))) int8_t bs[2][KST / 16][64][16];      // [buffer][channel granule][pixel][16 B]
+    constexpr int KST = DWPW_KST;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
     const int rows_total = a.N * a.OH;
     const int gr0 = blockIdx.x * 4;                      // first row (image * OH + oy) of the tile
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[j][k] = 0;
+            for (int k = 0; k < 4; k++) acc[j][k] = k == 0 ? b4.x : k == 1 ? b4.y : k == 2 ? b4.z : b4.w;      // the dot chain starts at the bias
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             unsigned d0[4], d1[4], f0[4], f1[4];
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
         const int cl = 4 * cq;                           // channel inside the stage
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned pk = requant4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w, s4, c, drq);
+            const unsigned pk = requant4<WIN>(acc[j][0], acc[j][1], acc[j][2], acc[j][3], s4, c, drq);
             *reinterpret_cast<unsigned*>(&bs[buf][cl >> 4][ur * 16 + 4 * ucg + j][cl & 15]) = pk;
         }
     };
@@ -131,13 +134,17 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
             for (int ks = 0; ks < KST / 32; ks++)
                 af[i][ks] = *reinterpret_cast<const v4i_dp*>(wf + ((size_t)i * nk32 + (size_t)(st < nst ? st : nst - 1) * (KST / 32) + ks) * 1024);
     };
+    // the accumulators start at the pointwise bias (C/D layout of the 32x32 MFMA: register e of lane (pixel, hi) is channel
+    // 8 (e >> 2) + 4 hi + (e & 3) of the tile): the epilogue requantises them as they are
     v16i_dp acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int4 b4 = wave < NW ? *reinterpret_cast<const int4*>(a.pw_bias + (wave * 2 + i) * 32 + 8 * g4 + 4 * hi) : make_int4(0, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+            for (int j = 0; j < 2; j++) { acc[i][j][4 * g4 + 0] = b4.x; acc[i][j][4 * g4 + 1] = b4.y; acc[i][j][4 * g4 + 2] = b4.z; acc[i][j][4 * g4 + 3] = b4.w; }
+        }
     auto mma = [&](int buf) {
         if (wave >= NW) return;
 #pragma unroll
@@ -197,15 +204,22 @@ __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const int c = cb + 8 * g4 + 4 * hi;
-                const int4 b4 = *reinterpret_cast<const int4*>(a.pw_bias + c);
                 const float4 s4 = *reinterpret_cast<const float4*>(a.pw_wscale + c);
-                pk[g4] = requant4(acc[i][j][4 * g4 + 0] + b4.x, acc[i][j][4 * g4 + 1] + b4.y, acc[i][j][4 * g4 + 2] + b4.z, acc[i][j][4 * g4 + 3] + b4.w, s4, c, prq);
+                pk[g4] = requant4<WIN>(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3], s4, c, prq);
             }
             half_wave_regroup(pk);
             const int c16 = cb + hi * 16;
             if (live && c16 < a.c_limit) *reinterpret_cast<uint4*>(yp + c16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
+{
+    __shared__ __attribute__((aligned(16))) dwpw_bs_t bs[2];
+    if (rq_win(a.dw_rq) && rq_win(a.pw_rq)) dwpw_body<NW, 1>(a, bs);
+    else dwpw_body<NW, 0>(a, bs);
 }
 
 // depthwise 3x3 stride 1 (any padding the map allows) feeding a pointwise 1x1 stride-1 convolution with no padding; output channels

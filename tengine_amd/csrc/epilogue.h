@@ -124,10 +124,47 @@ __device__ __attribute__((noinline)) static unsigned requant4_chain(int a0, int 
     return packed;
 }
 
-// four consecutive channels c .. c+3 -> one packed dword of int8; mf = M[c .. c+3]
+// The window of a node with a fused ReLU / ReLU6 (and of the residual tail with its ReLU) starts at 128.25: every clamped value lies in
+// [128, 256), ONE binade, so its bit pattern is 0x43000000 | q << 16 | fract * 2^16 -- the result byte is byte 2 of the pattern and
+// the hand-over test reads the low half.  Same y, same yc, same decisions as the general form (trunc(yc) - 128 == byte 2,
+// fract(yc) < thr <=> low half < thr * 2^16; tests/csrc/fold_requant_check.c asserts both identities on every value it draws); what
+// goes is the float -> int conversion, the shifts and the fract: 19 instead of 26 instructions per four values, 6.53 against
+// 5.26 T values/s with the SIMDs full (tools/exp/requant_rates.hip, profiles/r05_requant_rates.txt).  A COMPILE-TIME choice
+// (template parameter WIN; the kernels branch once, at their top or around their epilogue, on the node's constants): with both forms
+// inlined behind a run-time test at every call site the kernels grew by 10-24 registers and the step got 12 % SLOWER
+// (profiles/r05_ab_window_runtime_branch_*.txt).
+// (`thr_of_test` = the threshold the caller's integer test stands for: 2^-13 <-> 8, the residual tail's 2^-12 <-> 16)
+__host__ __device__ __forceinline__ bool rq_window_is_one_binade(float ylo, float thr, float thr_of_test) { return ylo >= 128.f && thr == thr_of_test; }
+__host__ __device__ __forceinline__ bool rq_win(const RqArgs& r) { return rq_window_is_one_binade(r.ylo, r.thr, 0x1p-13f); }
+__host__ __device__ __forceinline__ bool elt_win(const EltFuse& e) { return rq_window_is_one_binade(e.ylo, e.thr, 0x1p-12f); }
+
+__device__ __forceinline__ unsigned rq_pack_byte2(float y0, float y1, float y2, float y3)
+{
+    const unsigned b0 = __builtin_bit_cast(unsigned, y0), b1 = __builtin_bit_cast(unsigned, y1);
+    const unsigned b2 = __builtin_bit_cast(unsigned, y2), b3 = __builtin_bit_cast(unsigned, y3);
+    // v_perm_b32: selector 0-3 = bytes of the second operand, 4-7 = bytes of the first, 0x0c = 0x00
+    return __builtin_amdgcn_perm(b1, b0, 0x0c0c0602u) | __builtin_amdgcn_perm(b3, b2, 0x06020c0cu);
+}
+
+// min over the low halves of four patterns (v_min3_u16 / v_min_u16 read the low 16 bits; the upper half of the result is masked off)
+__device__ __forceinline__ unsigned rq_min_low_half(float y0, float y1, float y2, float y3)
+{
+    unsigned m;
+    asm("v_min3_u16 %0, %1, %2, %3" : "=v"(m) : "v"(y0), "v"(y1), "v"(y2));
+    asm("v_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(y3));
+    return m & 0xffffu;
+}
+
+// four consecutive channels c .. c+3 -> one packed dword of int8; mf = M[c .. c+3].  WIN 1: the caller has checked rq_win(r)
+template <int WIN = 0>
 __device__ __forceinline__ unsigned requant4(int a0, int a1, int a2, int a3, const float4& mf, int c, const Rq& r)
 {
     const float y0 = rq_biased(a0, mf.x, r), y1 = rq_biased(a1, mf.y, r), y2 = rq_biased(a2, mf.z, r), y3 = rq_biased(a3, mf.w, r);
+    if constexpr (WIN) {
+        unsigned p = rq_pack_byte2(y0, y1, y2, y3);
+        if (rq_min_low_half(y0, y1, y2, y3) < 8u) p = requant4_chain(a0, a1, a2, a3, mf, p, r.m2 + c, r.m1, r.lo, r.hi, r.out_scale, r.ylo, r.yhi, r.thr);
+        return p;
+    }
     // fract >= 0: the order of the bit patterns is the order of the values (v_min3_u32 instead of IEEE minimum + canonicalisation)
     const unsigned f0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y0)), f1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y1));
     const unsigned f2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y2)), f3 = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y3));
@@ -300,17 +337,25 @@ __device__ __attribute__((noinline)) static unsigned elt_sum4_chain(unsigned uc,
 }
 
 // pc: four int8 results of the conv, pr: the residual operand's bytes of the same channels -> the eltwise (+ReLU) result
+template <int WIN = 0>      // WIN 1: the caller has checked elt_win(e)
 __device__ __forceinline__ unsigned elt_sum4_fold(unsigned pc, unsigned pr, const EltFuse& e)
 {
     const unsigned uc = pc ^ 0x80808080u, ur = pr ^ 0x80808080u;
     float y[4];
-    unsigned fb[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float fc = (float)((uc >> (8 * k)) & 0xffu), fr = (float)((ur >> (8 * k)) & 0xffu);
         y[k] = __builtin_amdgcn_fmed3f(__fmaf_rn(fr, e.mr, __fmaf_rn(fc, e.mc, e.k0)), e.ylo, e.yhi);
-        fb[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y[k]));
     }
+    if constexpr (WIN) {          // a ReLU behind the sum: see requant4 (this tail's e is 2^-13, so the threshold is 2^-12)
+        unsigned q = rq_pack_byte2(y[0], y[1], y[2], y[3]);
+        if (rq_min_low_half(y[0], y[1], y[2], y[3]) < 16u)
+            q = elt_sum4_chain(uc, ur, q, e.mc, e.mr, e.k0, e.ylo, e.yhi, e.thr, e.s_conv, e.s_res, e.out_scale, e.relu);
+        return q;
+    }
+    unsigned fb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) fb[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_fractf(y[k]));
     unsigned q = ((unsigned)y[0] | ((unsigned)y[1] << 8) | ((unsigned)y[2] << 16) | ((unsigned)y[3] << 24)) ^ 0x80808080u;
     if (min(min(fb[0], fb[1]), min(fb[2], fb[3])) < __builtin_bit_cast(unsigned, e.thr))
         q = elt_sum4_chain(uc, ur, q, e.mc, e.mr, e.k0, e.ylo, e.yhi, e.thr, e.s_conv, e.s_res, e.out_scale, e.relu);
@@ -318,12 +363,13 @@ __device__ __forceinline__ unsigned elt_sum4_fold(unsigned pc, unsigned pr, cons
 }
 
 // p: the conv's int8 results (16 channels of one pixel), r: the residual operand's; result in p
+template <int WIN = 0>
 __device__ __forceinline__ void elt_sum16_fold(unsigned (&p)[4], const uint4& r, const EltFuse& e)
 {
-    p[0] = elt_sum4_fold(p[0], r.x, e);
-    p[1] = elt_sum4_fold(p[1], r.y, e);
-    p[2] = elt_sum4_fold(p[2], r.z, e);
-    p[3] = elt_sum4_fold(p[3], r.w, e);
+    p[0] = elt_sum4_fold<WIN>(p[0], r.x, e);
+    p[1] = elt_sum4_fold<WIN>(p[1], r.y, e);
+    p[2] = elt_sum4_fold<WIN>(p[2], r.z, e);
+    p[3] = elt_sum4_fold<WIN>(p[3], r.w, e);
 }
 
 // the general tail (any eltwise type / ReLU flavour) out of line, for epilogues whose hot path is elt_sum4_fold; scalars only

@@ -22,7 +22,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 // ELT: the eltwise (+ReLU) node that consumes this conv is applied in the epilogue (epilogue.h: fuse_elt4), as in conv_igemm
-template <int S, int NT, bool ELT>
+// WIN: the one-binade requantisation of epilogue.h -- of the conv's own window (ELT false) or of the residual tail's (ELT true; the conv in
+// front of an eltwise node keeps the general form); launch_pw checks the node's constants.  A kernel of its own and not a branch at the
+// top of one: with both bodies in one kernel <2,4> needs 106 registers instead of 90 / 92 and loses a wave per SIMD.
+template <int S, int NT, bool ELT, int WIN>
 __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) int sbias[NT * 32];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
                 asm volatile("" : "+v"(c));
                 const int4 b4 = *reinterpret_cast<const int4*>(&sbias[c]);
                 const float4 s4 = *reinterpret_cast<const float4*>(&sscale[c]);
-                p[g4] = requant4(acc[4 * g4 + 0] + b4.x, acc[4 * g4 + 1] + b4.y, acc[4 * g4 + 2] + b4.z,
+                p[g4] = requant4<ELT ? 0 : WIN>(acc[4 * g4 + 0] + b4.x, acc[4 * g4 + 1] + b4.y, acc[4 * g4 + 2] + b4.z,
                                  acc[4 * g4 + 3] + b4.w, s4, n0 + c, rq);
             }
             half_wave_regroup(p);
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
                 if (ELT) {         // residual operand: the same pixel, the 16 channels this lane now holds
                     const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + cb);
                     if (a.elt.thr > 0.f) {
-                        elt_sum16_fold(p, r, a.elt);
+                        elt_sum16_fold<WIN>(p, r, a.elt);
                     } else {
                         const uint4 o = fuse_elt16(make_uint4(p[0], p[1], p[2], p[3]), r, a.elt, inv_elt, inv_relu);
                         p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = o.w;
@@ -114,8 +117,11 @@ static hipError_t launch_pw(const ConvArgs& a, hipStream_t s)
     const int total = be && atoi(be) > 0 ? atoi(be) : 2048;
     const int cap = total / groups > 0 ? total / groups : 1;
     if (bx > cap) bx = cap;
-    if (a.elt.res) hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, true>), dim3(bx, groups), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, false>), dim3(bx, groups), dim3(256), 0, s, a);
+    if (a.elt.res) {
+        if (a.elt.thr > 0.f && elt_win(a.elt)) hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, true, 1>), dim3(bx, groups), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, true, 0>), dim3(bx, groups), dim3(256), 0, s, a);
+    } else if (rq_win(a.rq)) hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, false, 1>), dim3(bx, groups), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_stream_i8_kernel<S, NT, false, 0>), dim3(bx, groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

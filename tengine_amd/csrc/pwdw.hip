@@ -99,7 +99,9 @@ __device__ __forceinline__ void chain_signal(const ChainDep& d)
 
 __device__ __forceinline__ void chain_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int STEPS, int MODE, bool CHUNKED, int PROD, bool CHAINED>
+// WIN: both requantisations (the pointwise conv's and its depthwise consumer's) in the one-binade form of epilogue.h; the kernels
+// check the two windows once (pwdw_windows)
+template <int STEPS, int MODE, bool CHUNKED, int PROD, bool CHAINED, int WIN = 0>
 __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restrict__ inter, const int bx, const int by, const int bz,
                                            const int nthreads, const ChainDep& dep)
 {
@@ -121,7 +123,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     const int4 pb = *reinterpret_cast<const int4*>(a.bias + c_base + 4 * kb);
     const float4 ps = *reinterpret_cast<const float4*>(a.wscale + c_base + 4 * kb);
     const int8_t* wfp = a.wf + ((size_t)slice * a.nsteps * 64 + lane) * 16;      // nsteps: padded to a multiple of STEPS
-    const v4i zero4 = {0, 0, 0, 0};
+    const v4i bias_v = {pb.x, pb.y, pb.z, pb.w};         // the MFMA chain of a tile starts at the bias: no addition in the epilogue
     v4i af[STEPS];
     if (!CHUNKED) {
 #pragma unroll
@@ -215,7 +217,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         }
     };
     auto finish = [&](const v4i& acc, int slot) {
-        const unsigned p = requant4(acc[0] + pb.x, acc[1] + pb.y, acc[2] + pb.z, acc[3] + pb.w, ps, c_base + 4 * kb, rq);
+        const unsigned p = requant4<WIN>(acc[0], acc[1], acc[2], acc[3], ps, c_base + 4 * kb, rq);      // (the accumulator started at the bias)
         if (MODE == 4) {
             if (slot >= 0 && c_base + 4 * kb < a.c_limit) {
                 unsigned* dst = reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb);
@@ -257,7 +259,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
             int slot1 = -1;
             const bool second = i + nwaves < ntiles;
             if (PINGPONG && second) { slot1 = locate(i + nwaves, xp1); load_b(xp1, reinterpret_cast<v4i (&)[STEPS]>(b1), 0); }
-            v4i acc = zero4;
+            v4i acc = bias_v;
 #pragma unroll
             for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
             finish(acc, slot0);
@@ -265,14 +267,14 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
             const bool third = i + 2 * nwaves < ntiles;
             if (PINGPONG) {
                 if (third) { slot0 = locate(i + 2 * nwaves, xp0); load_b(xp0, b0, 0); }
-                acc = zero4;
+                acc = bias_v;
 #pragma unroll
                 for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], reinterpret_cast<v4i (&)[STEPS]>(b1)[u], acc, 0, 0, 0);
                 finish(acc, slot1);
             } else {
                 // one operand buffer (16 steps in registers): tiles one after the other
                 slot0 = locate(i + nwaves, xp0); load_b(xp0, b0, 0);
-                acc = zero4;
+                acc = bias_v;
 #pragma unroll
                 for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
                 finish(acc, slot0);
@@ -283,7 +285,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         const int nchunks = a.nsteps / STEPS;
         for (int i = wave; i < ntiles; i += nwaves) {
             if (i != wave) slot0 = locate(i, xp0);
-            v4i acc = zero4;
+            v4i acc = bias_v;
             for (int ch = 0; ch < nchunks; ch++) {
 #pragma unroll
                 for (int u = 0; u < STEPS; u++) af[u] = *reinterpret_cast<const v4i*>(wfp + (size_t)(ch * STEPS + u) * 1024);
@@ -317,7 +319,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
 #pragma unroll
             for (int j = 0; j < TWL; j++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[j][c] = 0;
+                for (int c = 0; c < 4; c++) acc[j][c] = c == 0 ? db.x : c == 1 ? db.y : c == 2 ? db.z : db.w;      // the dot chain starts at the bias
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 // a strip's 4th column may lie past the region row (odd tile widths): its products carry a zero tap or
@@ -334,7 +336,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
 #pragma unroll
             for (int j = 0; j < TWL; j++) {
                 const int oxl = st * TWL + j;
-                const unsigned p = requant4(acc[j][0] + db.x, acc[j][1] + db.y, acc[j][2] + db.z, acc[j][3] + db.w, ds, c0, drq);
+                const unsigned p = requant4<WIN>(acc[j][0], acc[j][1], acc[j][2], acc[j][3], ds, c0, drq);
                 if (oxl < tw && c0 < a.c_limit) {
                     unsigned* dst = reinterpret_cast<unsigned*>(yn + ((size_t)oyl * a.OW + oxl) * a.ldc);
                     if (CHAINED) chain_store(dst, p); else *dst = p;
@@ -375,12 +377,15 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     PWDW_STAMP(6);
 }
 
-template <int STEPS, int MODE, bool CHUNKED, int PROD>
+// both windows of the launch in the one-binade form?  (host: PWDW_LAUNCH picks the kernel instance)
+static bool pwdw_windows(const PwDwArgs& a, int mode) { return rq_win(a.rq) && (mode == 0 || mode == 4 || rq_win(a.d_rq)); }
+
+template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN>
 __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
     const ChainDep none = {nullptr, 0, nullptr, nullptr};
-    pwdw_block<STEPS, MODE, CHUNKED, PROD, false>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, false, WIN>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
 }
 
 // The COHERENT form of the same launch (PwDwArgs::coherent, used under direct dispatch -- direct.cc): every tensor the launch
@@ -390,12 +395,12 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 // "none" (0.84 us per boundary against 1.26 us with agent-scope fences, tools/exp/aql_chain.cpp), and the weights / bias /
 // multiplier vectors, which nobody ever writes, stay valid in the L2s from one pass to the next.  The first convolution's
 // graph input (PROD 1) is read with ordinary loads: it changes only between bursts, behind a system-scope acquire.
-template <int STEPS, int MODE, bool CHUNKED, int PROD>
+template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN>
 __global__ __launch_bounds__(512) void pwdw_i8_coh_kernel(PwDwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned inter[];
     const ChainDep none = {nullptr, 0, nullptr, nullptr};
-    pwdw_block<STEPS, MODE, CHUNKED, PROD, true>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, true, WIN>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
 }
 
 #ifdef TAMD_PWDW_CHAIN_EXPERIMENT
@@ -503,11 +508,17 @@ int pwdw_steps(int nsteps)
     return best;
 }
 
-// plain or coherent instance of one variant
+// plain or coherent instance of one variant, with the general or the one-binade requantisation (a kernel each: a branch at the top of
+// one kernel costs the batch-1 launches 0.1-0.3 us -- more scalar state, a longer preamble -- profiles/r05_ab_window_layers_mobilenet_v1_b1.txt)
+#define PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, WIN_)                                                                   \
+    do {                                                                                                                     \
+        if (a.coherent) { launch_rec_coherent(); hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_>), grid, dim3(threads), lds, s, a); } \
+        else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_>), grid, dim3(threads), lds, s, a);      \
+    } while (0)
 #define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_)                                                                          \
     do {                                                                                                                     \
-        if (a.coherent) { launch_rec_coherent(); hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a); } \
-        else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_>), grid, dim3(threads), lds, s, a);            \
+        if (pwdw_windows(a, MODE_)) PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, 1);                                        \
+        else PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, 0);                                                               \
     } while (0)
 
 template <int STEPS, bool CHUNKED>

@@ -41,12 +41,27 @@ static int ref_chain(int acc, float m1, float m2, float lo, float hi, float s)
     volatile float f = t * m2;
     return R(clampf(f, lo, hi), s);
 }
-static long flagged = 0;
+static long flagged = 0, binade_checked = 0, binade_bad = 0;
+/* epilogue.h's form for windows that start at 128.25 (a fused ReLU): every clamped value lies in [128, 256), so the kernels read the
+ * result byte and the hand-over flag off the bit pattern (byte 2 / low half below thr * 2^16) instead of converting.  Both must be
+ * the conversions' results for EVERY value -- checked here on every value the program draws (also by check_elt with thr = 2^-12). */
+static void check_one_binade(float yc, float thr)
+{
+    uint32_t b;
+    memcpy(&b, &yc, 4);
+    const int byte2 = (int)((b >> 16) & 0xffu), low_flag = (b & 0xffffu) < (uint32_t)(thr * 65536.f);
+    binade_checked++;
+    if (byte2 != (int)yc - 128 || low_flag != ((yc - floorf(yc)) < thr)) {
+        if (binade_bad < 5) printf("ONE-BINADE MISMATCH yc=%a: byte2 %d trunc-128 %d, low-half flag %d fract flag %d\n", yc, byte2, (int)yc - 128, low_flag, (yc - floorf(yc)) < thr);
+        binade_bad++;
+    }
+}
 static int fast(int acc, float M, float ylo, float yhi, int* risky)
 {
     float y = fmaf((float)acc, M, 128.5f + E);
     float yc = y < ylo ? ylo : (y > yhi ? yhi : y);     /* med3: ylo < yhi */
     *risky = (yc - floorf(yc)) < 2.f * E;
+    if (ylo >= 128.f) check_one_binade(yc, 2.f * E);
     return (int)yc - 128;
 }
 static uint64_t st = 0x243F6A8885A308D3ull;
@@ -77,6 +92,7 @@ static long check_elt(long layers, long* total_out, long* flagged_out)
                 const float t = fmaf((float)(qc + 128), mc, k0);
                 float y = fmaf((float)(qr + 128), mr, t);
                 y = y < ylo ? ylo : (y > yhi ? yhi : y);
+                if (relu) check_one_binade(y, thr);
                 total++;
                 if (y - floorf(y) < thr) { fl++; continue; }
                 if ((int)y - 128 != r) {
@@ -141,6 +157,8 @@ int main(int argc, char** argv)
         }
     }
     printf("requant: checked %ld mismatches %ld flagged %ld (%.2e)\n", total, bad, flagged, (double)flagged / (double)total);
+    printf("one-binade form: checked %ld mismatches %ld\n", binade_checked, binade_bad);
+    bad += binade_bad;
     if (bad == 0) printf("mismatches 0\n");
     return bad != 0;
 }
