@@ -143,12 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_i8_kernel(ConvArgs a)
     };
 
     v16i acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     // ceil: a stage may run past kpad -- the activation operand is zero there (k >= ktot / tap >= ntaps) and the
     // weight rows are followed by readable memory (next row, or the planner's 256-byte tail), so it adds exact zeros
@@ -288,12 +283,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_i8_kernel(ConvArgs a)
     };
 
     v16i acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     // the launcher picks D so that the stage count needs little padding; padded stages multiply zeros (B reads the zero page
     // once K is exhausted; the weight rows are followed by readable slack, graph.hip dev_alloc)

@@ -121,12 +121,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_i8_kernel(ConvArgs a)
     };
 
     v16i acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     // fragment read offsets: row r = 32*tile + l31, k-granule g = 2*kk + hi lives in slot g ^ ((r>>2)&3)
     const int sw = (l31 >> 2) & 3;

@@ -127,12 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_fast_i8_kernel(ConvArgs a)
     };
 
     v16i_t acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     const int nk = (nk_real + D - 1) / D * D;
     IG_STAMP(1);

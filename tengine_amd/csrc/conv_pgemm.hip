@@ -153,12 +153,7 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
     }
 
     v16i_p acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     v4i_p af[2][TN][2], bf[2][TM][2];
     auto read_frags = [&](auto P, int slot, int boff) {
@@ -257,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_pgemm_i8_kernel(ConvArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PG_STAMP(4);
 
-    if (PG_ON(2)) igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromLds{smem + EOFF, n0, 128});       // gemm_epilogue.h
+    if (PG_ON(2)) igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromLdsNoBias{smem + EOFF, n0, 128});       // gemm_epilogue.h
     PG_STAMP(5);
     PG_STAMP(6);
 #ifdef TAMD_IGEMM_STAMPS

@@ -30,12 +30,6 @@
 
 namespace tamd {
 
-struct EpiFromLdsNoBias {         // multipliers of the block's cout tile from LDS; the bias already sits in the accumulators
-    const int8_t* base; int n0, bn;
-    __device__ __forceinline__ int4 bias4(int) const { return make_int4(0, 0, 0, 0); }
-    __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(base + (bn + c - n0) * 4); }
-};
-
 // patch pieces a copying wave issues at tap `tp` of a chunk: BS 1: granule tp at taps 0..3; BS 3: granules 0, 1 at taps 0, 1 and
 // granules 2, 3 at tap 2 (they must have landed at the chunk's last barrier, tap 6, with D - 4 stages of copies still in flight)
 constexpr int pgw_patch_at(int tp, int bs, int npc) { return bs == 1 ? (tp < 4 ? npc : 0) : (tp < 2 ? npc : tp == 2 ? 2 * npc : 0); }

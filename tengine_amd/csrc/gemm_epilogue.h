@@ -15,11 +15,39 @@ struct EpiFromGlobal {
     __device__ __forceinline__ int4 bias4(int c) const { return *reinterpret_cast<const int4*>(b + c); }
     __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(s + c); }
 };
+// the same two sources for kernels whose accumulators START at the bias (igemm_acc_from_bias below: integer addition commutes, the
+// reference's acc + bias is the same 32-bit sum) -- the epilogue then costs one VALU instruction less per value and, from global
+// memory, fetches one vector instead of two
+struct EpiScaleFromGlobal {
+    const float* s;
+    __device__ __forceinline__ int4 bias4(int) const { return make_int4(0, 0, 0, 0); }
+    __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(s + c); }
+};
+struct EpiFromLdsNoBias {         // multipliers of the block's cout tile from LDS; the bias already sits in the accumulators
+    const int8_t* base; int n0, bn;
+    __device__ __forceinline__ int4 bias4(int) const { return make_int4(0, 0, 0, 0); }
+    __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(base + (bn + c - n0) * 4); }
+};
 struct EpiFromLds {               // [BN ints of bias][BN floats of multipliers] of the block's cout tile, at `base`
     const int8_t* base; int n0, bn;
     __device__ __forceinline__ int4 bias4(int c) const { return *reinterpret_cast<const int4*>(base + (c - n0) * 4); }
     __device__ __forceinline__ float4 scale4(int c) const { return *reinterpret_cast<const float4*>(base + (bn + c - n0) * 4); }
 };
+
+// accumulators of wave (., wn) of the block tile at cout n0 <- the bias of their channels (C/D layout of the 32x32 MFMA: register e of
+// lane (pixel, hi) holds channel 8 (e >> 2) + 4 hi + (e & 3) of its 32-channel tile); `bias` is padded to whole cout tiles
+template <int TM, int TN, typename V>
+__device__ __forceinline__ void igemm_acc_from_bias(V (&acc)[TN][TM], const int32_t* bias, int n0, int wn, int hi)
+{
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const int4 b4 = *reinterpret_cast<const int4*>(bias + n0 + (wn * TN + i) * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < TM; j++) { acc[i][j][4 * g4 + 0] = b4.x; acc[i][j][4 * g4 + 1] = b4.y; acc[i][j][4 * g4 + 2] = b4.z; acc[i][j][4 * g4 + 3] = b4.w; }
+        }
+}
 
 // FORM 0: everything (any destination granularity, any fused eltwise tail, the general requantisation).  FORM 1 / 2: the one-binade
 // requantisation of epilogue.h for the two common nodes, as SMALL instances (16-channel-granular destination only): 1 = a conv with
@@ -109,7 +137,7 @@ __device__ __forceinline__ void igemm_epilogue_src(const ConvArgs& a, v16i_t (&a
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi)
 {
-    igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiFromGlobal{a.bias, a.wscale});
+    igemm_epilogue_src<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, EpiScaleFromGlobal{a.wscale});      // (accumulators from igemm_acc_from_bias)
 }
 
 }  // namespace tamd

@@ -1103,45 +1103,60 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     }
 
     // ---- tile configurations: (TH, TW, threads) ranked by a small cost model, the best few timed on the device ---------
-    struct Cfg { int th, tw, threads; double cost; };
+    struct Cfg { int th, tw, threads; double cost; int sl; };      // sl: 16-channel slices per block (pwdw.hip)
     std::vector<Cfg> cfgs;
-    auto with_tiles = [&](PwDwArgs v, int th, int tw) {
+    auto with_tiles = [&](PwDwArgs v, int th, int tw, int sl = 1) {
         v.TH = th; v.TW = tw; v.tiles_y = (v.OH + th - 1) / th; v.tiles_x = (v.OW + tw - 1) / tw;
         v.RH = (th - 1) * v.S + 3; v.RW = (tw - 1) * v.S + 3;
+        v.sl = sl; v.slices = (slices + sl - 1) / sl;
         return v;
     };
     if (tmode == 0) {
-        cfgs.push_back({1, 1, 256, 0.0});
-        cfgs.push_back({1, 1, 512, 1.0});
+        cfgs.push_back({1, 1, 256, 0.0, 1});
+        cfgs.push_back({1, 1, 512, 1.0, 1});
     } else {
         std::vector<int> ths, tws;
         for (int v : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 28, a.OH}) if (v <= a.OH && std::find(ths.begin(), ths.end(), v) == ths.end()) ths.push_back(v);
         for (int v : {4, 6, 7, 8, 14, 16, 28, 56, a.OW}) if (v <= a.OW && std::find(tws.begin(), tws.end(), v) == tws.end()) tws.push_back(v);
         for (int th : ths)
             for (int tw : tws)
-                for (int threads : {256, 512}) {
-                    const PwDwArgs v = with_tiles(a, th, tw);
+                for (int threads : {256, 512})
+                  for (int sl : {1, 2}) {
+                    if (sl == 2 && (slices % 2 != 0 || nsteps > steps)) continue;
+                    const PwDwArgs v = with_tiles(a, th, tw, sl);
                     if (!pwdw_config_ok(v, threads)) continue;
+                    // two slices per block halve the grid: offered where two blocks per CU remain (the batched early layers it is for;
+                    // a batch-1 launch is a latency chain, its blocks must stay many and short)
+                    if (sl == 2 && (double)a.N * v.tiles_y * v.tiles_x * v.slices < 512.0) continue;
                     // instruction slots of the busiest wave (a lone wave issues one instruction per 4 cycles): pointwise tiles
                     // (address + K steps + requantisation) and depthwise tasks, on top of a fixed prologue
                     const int nw = threads / 64;
                     const double vp = (double)std::min(v.RH, a.H) * std::min(v.RW, a.W);
                     const double tiles_w = std::ceil(std::ceil(vp / 16.0) / nw);
                     const int twl = a.S == 1 ? 2 : 1;
-                    const double tasks_t = std::ceil((double)th * ((tw + twl - 1) / twl) * 4.0 / threads);
-                    const double block = 250.0 + tiles_w * (70.0 + 3.0 * nsteps) + tasks_t * (a.S == 1 ? 150.0 : 100.0) + vp * ktot / 400.0;
-                    const double blocks = (double)a.N * v.tiles_y * v.tiles_x * slices;
+                    const double tasks_t = std::ceil((double)th * ((tw + twl - 1) / twl) * 4.0 * sl / threads);
+                    // (a second slice repeats the K steps and the requantisation of a tile, not its address arithmetic, load and loop control)
+                    const double block = 250.0 + tiles_w * (45.0 + sl * (25.0 + 3.0 * nsteps)) + tasks_t * (a.S == 1 ? 150.0 : 100.0) + vp * ktot / 400.0;
+                    const double blocks = (double)a.N * v.tiles_y * v.tiles_x * v.slices;
                     const double rounds = std::ceil(blocks / (256.0 * (threads == 256 ? 2 : 1)));
-                    cfgs.push_back({th, tw, threads, rounds * block * (threads == 256 && blocks > 256 ? 1.3 : 1.0)});
+                    cfgs.push_back({th, tw, threads, rounds * block * (threads == 256 && blocks > 256 ? 1.3 : 1.0), sl});
                 }
         std::sort(cfgs.begin(), cfgs.end(), [](const Cfg& l, const Cfg& r) { return l.cost < r.cost; });
-        if (cfgs.size() > 8) cfgs.resize(8);
+        // the best few of EACH block width go to the device: the model ranks within a width, the race decides between them
+        std::vector<Cfg> keep;
+        for (int sl : {1, 2}) {
+            int n = 0;
+            for (auto& c : cfgs)
+                if (c.sl == sl && n < (sl == 1 ? 8 : 6)) { keep.push_back(c); n++; }
+        }
+        cfgs = keep;
     }
     if (const char* pin = tamd_pin("pwdw_cfg")) {
-        int th = 0, tw = 0, threads = 0;
-        if (sscanf(pin, "%dx%dx%d", &th, &tw, &threads) == 3 && tmode == 1) {
+        int th = 0, tw = 0, threads = 0, sl = 1;      // "THxTWxthreads" or "THxTWxthreadsx2" (two slices per block)
+        if (sscanf(pin, "%dx%dx%dx%d", &th, &tw, &threads, &sl) >= 3 && tmode == 1) {
             th = std::min(th, a.OH); tw = std::min(tw, a.OW);
-            if (th >= 1 && tw >= 1 && pwdw_config_ok(with_tiles(a, th, tw), threads)) { cfgs.clear(); cfgs.push_back({th, tw, threads, 0.0}); }
+            if (sl != 2 || slices % 2 != 0 || nsteps > steps) sl = 1;
+            if (th >= 1 && tw >= 1 && pwdw_config_ok(with_tiles(a, th, tw, sl), threads)) { cfgs.clear(); cfgs.push_back({th, tw, threads, 0.0, sl}); }
         }
     }
     if (cfgs.empty()) return 0;
@@ -1158,7 +1173,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     bool from_cache = false;
     if (autotune && plan_cache_get(ckey, &cached) && sscanf(cached.c_str(), "%d,%d", &cf, &cb) == 2 && cb >= 0 && cb < (int)cfgs.size()) {
         // a cached index is only as good as the file it came from: the configuration must still launch here
-        const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[cb].th, cfgs[cb].tw) : a;
+        const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[cb].th, cfgs[cb].tw, cfgs[cb].sl) : a;
         if (!cf || launch_pwdw(v, cfgs[cb].threads, g->stream) == hipSuccess) { fuse = cf != 0; best = (size_t)cb; from_cache = true; }
         else (void)hipGetLastError();
     }
@@ -1166,7 +1181,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     } else if (autotune) {
         float best_ms = 1e30f;
         for (size_t c = 0; c < cfgs.size(); c++) {
-            const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[c].th, cfgs[c].tw) : a;
+            const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[c].th, cfgs[c].tw, cfgs[c].sl) : a;
             const int threads = cfgs[c].threads;
             float ms;
             if (time_fn(g, [v, threads](hipStream_t s) { return launch_pwdw(v, threads, s); }, &ms)) return -1;
@@ -1180,12 +1195,12 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         plan_cache_put(ckey, std::to_string(fuse ? 1 : 0) + "," + std::to_string(best));
     }
     if (!fuse) return 0;
-    const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[best].th, cfgs[best].tw) : a;
+    const PwDwArgs v = tmode == 1 ? with_tiles(a, cfgs[best].th, cfgs[best].tw, cfgs[best].sl) : a;
     const int threads = cfgs[best].threads;
     Step st;
     st.node = sa.node + "+" + sb.node;
     char nm[48];
-    if (tmode == 1) snprintf(nm, sizeof(nm), "%s_i8<s%d,%dx%d,%d>", prod == 1 ? "firstdw" : "pwdw", a.S, v.TH, v.TW, threads);
+    if (tmode == 1) snprintf(nm, sizeof(nm), "%s_i8<s%d,%dx%d,%d%s>", prod == 1 ? "firstdw" : "pwdw", a.S, v.TH, v.TW, threads, v.sl == 2 ? ",c32" : "");
     else snprintf(nm, sizeof(nm), "pwpool_i8<%d>", threads);
     st.kernel = nm;
     st.macs = sa.macs + sb.macs;

@@ -126,7 +126,8 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     int S, PH, PW, OH, OW; // depthwise stride / leading pads / output map
     int8_t* y;             // NHWC output of the tail
     int ldc, c_off, c_limit;
-    int TH, TW, tiles_y, tiles_x, slices;      // depthwise output tile per block, grid
+    int TH, TW, tiles_y, tiles_x, slices;      // depthwise output tile per block, grid (slices: blocks along the channels)
+    int sl;                // 16-channel slices per block: 2 = two (depthwise tails with a register-resident K; slices = ceil(cout / 32)), else one
     int tile_major;        // 1: grid = (tile_x, tile_y * N, slice) instead of (slice, tile_x, tile_y * N): which operand an XCD's L2 shares
     int RH, RW;            // input region of a tile: (TH-1)*S+3, (TW-1)*S+3
     int pool_method;       // mode 0: 0 max, 1 avg

@@ -60,12 +60,7 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
         }
 #pragma unroll
         for (int i = 0; i < NT; i++) {
-            v16i acc;
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] = 0;
-#pragma unroll
-            for (int s = 0; s < S; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i][s], bf[s], acc, 0, 0, 0);
-            unsigned p[4];
+            v16i acc;                  // starts at the bias: the LDS read lands in the accumulator, the epilogue adds nothing
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 int c = i * 32 + 8 * g4 + 4 * hi;
@@ -73,9 +68,17 @@ __global__ __launch_bounds__(256) void pw_stream_i8_kernel(ConvArgs a)
                 // 32*NT VGPRs and drop the kernel to one wave per SIMD
                 asm volatile("" : "+v"(c));
                 const int4 b4 = *reinterpret_cast<const int4*>(&sbias[c]);
+                acc[4 * g4 + 0] = b4.x; acc[4 * g4 + 1] = b4.y; acc[4 * g4 + 2] = b4.z; acc[4 * g4 + 3] = b4.w;
+            }
+#pragma unroll
+            for (int s = 0; s < S; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i][s], bf[s], acc, 0, 0, 0);
+            unsigned p[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                int c = i * 32 + 8 * g4 + 4 * hi;
+                asm volatile("" : "+v"(c));
                 const float4 s4 = *reinterpret_cast<const float4*>(&sscale[c]);
-                p[g4] = requant4<ELT ? 0 : WIN>(acc[4 * g4 + 0] + b4.x, acc[4 * g4 + 1] + b4.y, acc[4 * g4 + 2] + b4.z,
-                                 acc[4 * g4 + 3] + b4.w, s4, n0 + c, rq);
+                p[g4] = requant4<ELT ? 0 : WIN>(acc[4 * g4 + 0], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3], s4, n0 + c, rq);
             }
             half_wave_regroup(p);
             const int cb = n0 + i * 32 + hi * 16;

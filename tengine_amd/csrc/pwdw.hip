@@ -101,11 +101,16 @@ __device__ __forceinline__ void chain_store(unsigned* p, unsigned v) { __hip_ato
 
 // WIN: both requantisations (the pointwise conv's and its depthwise consumer's) in the one-binade form of epilogue.h; the kernels
 // check the two windows once (pwdw_windows)
-template <int STEPS, int MODE, bool CHUNKED, int PROD, bool CHAINED, int WIN = 0>
+// SL: 16-channel slices per block (1 | 2).  Two slices share everything that is per pixel tile -- the tile's address arithmetic, its
+// activation load (PROD 1: the patch gather), the loop control -- which is 30 of the ~50 vector instructions a tile costs: the early
+// MobileNet pairs at batch 64 are bound by exactly those (73-86 % VALU busy, profiles/r05_pmc_sq_activity_mobilenet_v1_int8_b64.csv).
+// The intermediate tensor is slice-major in LDS ([slice][region pixel][16 channels]), so the depthwise phase only widens its channel index.
+template <int STEPS, int MODE, bool CHUNKED, int PROD, bool CHAINED, int WIN = 0, int SL = 1>
 __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restrict__ inter, const int bx, const int by, const int bz,
                                            const int nthreads, const ChainDep& dep)
 {
     constexpr int S = MODE == 2 ? 2 : 1;
+    static_assert(SL == 1 || (SL == 2 && !CHUNKED && MODE >= 1 && MODE <= 3), "two slices: register-resident K, depthwise tails");
     constexpr bool PINGPONG = !CHUNKED && STEPS <= 8 && PROD == 0;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
     PWDW_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = nthreads >> 6;
@@ -117,19 +122,26 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     const int slice = a.tile_major ? bz : bx, tx = a.tile_major ? bx : by;
     int ty = a.tile_major ? by : bz, n = 0;
     if (a.N > 1) { n = ty / a.tiles_y; ty -= n * a.tiles_y; }
-    const int c_base = slice * 16;
+    const int c_base = slice * 16 * SL;
 
     // ---- loads that depend on nothing but the block index go out first ----------------------------------------
-    const int4 pb = *reinterpret_cast<const int4*>(a.bias + c_base + 4 * kb);
-    const float4 ps = *reinterpret_cast<const float4*>(a.wscale + c_base + 4 * kb);
-    const int8_t* wfp = a.wf + ((size_t)slice * a.nsteps * 64 + lane) * 16;      // nsteps: padded to a multiple of STEPS
-    const v4i bias_v = {pb.x, pb.y, pb.z, pb.w};         // the MFMA chain of a tile starts at the bias: no addition in the epilogue
-    v4i af[STEPS];
+    v4i bias_v[SL];                                        // the MFMA chain of a tile starts at the bias: no addition in the epilogue
+    float4 ps[SL];
+#pragma unroll
+    for (int k = 0; k < SL; k++) {
+        const int4 pb = *reinterpret_cast<const int4*>(a.bias + c_base + 16 * k + 4 * kb);
+        bias_v[k] = v4i{pb.x, pb.y, pb.z, pb.w};
+        ps[k] = *reinterpret_cast<const float4*>(a.wscale + c_base + 16 * k + 4 * kb);
+    }
+    const int8_t* wfp = a.wf + ((size_t)slice * SL * a.nsteps * 64 + lane) * 16;      // nsteps: padded to a multiple of STEPS; slice k: + k * nsteps KB
+    v4i af[SL][STEPS];
     if (!CHUNKED) {
 #pragma unroll
-        for (int u = 0; u < STEPS; u++) af[u] = *reinterpret_cast<const v4i*>(wfp + u * 1024);
+        for (int k = 0; k < SL; k++)
+#pragma unroll
+            for (int u = 0; u < STEPS; u++) af[k][u] = *reinterpret_cast<const v4i*>(wfp + ((size_t)k * a.nsteps + u) * 1024);
     }
-    const int cq = t & 3;                                  // depthwise phase: this thread's channel quad of the slice
+    const int cq = t & (4 * SL - 1);                       // depthwise phase: this thread's channel quad of the block's 16 * SL channels
     const int c0 = c_base + cq * 4;
     unsigned wrow[3][4], wsh[3][4];
     int4 db = {0, 0, 0, 0};
@@ -216,15 +228,26 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
             for (int j = 0; j < 4; j++) bf[0][j] = ok[j] ? (int)((raw[j] << (8 * sft)) & cmask) : 0;
         }
     };
-    auto finish = [&](const v4i& acc, int slot) {
-        const unsigned p = requant4<WIN>(acc[0], acc[1], acc[2], acc[3], ps, c_base + 4 * kb, rq);      // (the accumulator started at the bias)
+    const int soff = (a.RH * a.RW + 4) * 4;               // dwords between the slices' copies of the region
+    auto finish = [&](const v4i& acc, int slot, int k = 0) {
+        const unsigned p = requant4<WIN>(acc[0], acc[1], acc[2], acc[3], ps[k], c_base + 16 * k + 4 * kb, rq);      // (the accumulator started at the bias)
         if (MODE == 4) {
             if (slot >= 0 && c_base + 4 * kb < a.c_limit) {
                 unsigned* dst = reinterpret_cast<unsigned*>(a.y + ((size_t)n * a.H * a.W + slot) * a.ldc + a.c_off + c_base + 4 * kb);
                 if (CHAINED) chain_store(dst, p); else *dst = p;
             }
         } else if (slot >= 0)
-            inter[slot] = p;
+            inter[(SL > 1 ? k * soff : 0) + slot] = p;
+    };
+    // one pixel tile: all K steps of every slice against the operand in `b`
+    auto tile = [&](const v4i (&b)[STEPS], int slot) {
+#pragma unroll
+        for (int k = 0; k < SL; k++) {
+            v4i acc = bias_v[k];
+#pragma unroll
+            for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[k][u], b[u], acc, 0, 0, 0);
+            finish(acc, slot, k);
+        }
     };
 
     // first tile's activations go out before the LDS is prepared (chained: after the producers' flags, and the LDS first)
@@ -236,7 +259,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     if (MODE != 0 && MODE != 4) {
         // depthwise zero padding: everything the pointwise phase does not overwrite
         const uint4 z = {0u, 0u, 0u, 0u};
-        for (int i = t; i < a.RH * a.RW + 4; i += nthreads) reinterpret_cast<uint4*>(inter)[i] = z;
+        for (int i = t; i < (a.RH * a.RW + 4) * SL; i += nthreads) reinterpret_cast<uint4*>(inter)[i] = z;
         if (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 3; r++)
@@ -259,25 +282,16 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
             int slot1 = -1;
             const bool second = i + nwaves < ntiles;
             if (PINGPONG && second) { slot1 = locate(i + nwaves, xp1); load_b(xp1, reinterpret_cast<v4i (&)[STEPS]>(b1), 0); }
-            v4i acc = bias_v;
-#pragma unroll
-            for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
-            finish(acc, slot0);
+            tile(b0, slot0);
             if (!second) break;
             const bool third = i + 2 * nwaves < ntiles;
             if (PINGPONG) {
                 if (third) { slot0 = locate(i + 2 * nwaves, xp0); load_b(xp0, b0, 0); }
-                acc = bias_v;
-#pragma unroll
-                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], reinterpret_cast<v4i (&)[STEPS]>(b1)[u], acc, 0, 0, 0);
-                finish(acc, slot1);
+                tile(reinterpret_cast<v4i (&)[STEPS]>(b1), slot1);
             } else {
                 // one operand buffer (16 steps in registers): tiles one after the other
                 slot0 = locate(i + nwaves, xp0); load_b(xp0, b0, 0);
-                acc = bias_v;
-#pragma unroll
-                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
-                finish(acc, slot0);
+                tile(b0, slot0);
                 if (third) { slot0 = locate(i + 2 * nwaves, xp0); load_b(xp0, b0, 0); }
             }
         }
@@ -285,13 +299,13 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         const int nchunks = a.nsteps / STEPS;
         for (int i = wave; i < ntiles; i += nwaves) {
             if (i != wave) slot0 = locate(i, xp0);
-            v4i acc = bias_v;
+            v4i acc = bias_v[0];
             for (int ch = 0; ch < nchunks; ch++) {
 #pragma unroll
-                for (int u = 0; u < STEPS; u++) af[u] = *reinterpret_cast<const v4i*>(wfp + (size_t)(ch * STEPS + u) * 1024);
+                for (int u = 0; u < STEPS; u++) af[0][u] = *reinterpret_cast<const v4i*>(wfp + (size_t)(ch * STEPS + u) * 1024);
                 load_b(xp0, b0, ch);
 #pragma unroll
-                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u], b0[u], acc, 0, 0, 0);
+                for (int u = 0; u < STEPS; u++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0][u], b0[u], acc, 0, 0, 0);
             }
             finish(acc, slot0);
         }
@@ -312,9 +326,10 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         const float inv_strips = __builtin_amdgcn_rcpf((float)strips);
         const Rq drq = a.d_rq;
         int8_t* yn = a.y + ((size_t)(n * a.OH + ty * a.TH) * a.OW + tx * a.TW) * a.ldc + a.c_off + c0;
-        for (int q = t >> 2; q < ntask; q += nthreads >> 2) {
+        constexpr int QSH = SL == 2 ? 3 : 2;                  // threads per task position: one per channel quad of the block
+        for (int q = t >> QSH; q < ntask; q += nthreads >> QSH) {
             const int oyl = (int)(((float)q + 0.5f) * inv_strips), st = q - oyl * strips;
-            const unsigned* row = inter + ((oyl * S) * RW + st * TWL * S) * 4 + cq;
+            const unsigned* row = inter + (SL > 1 ? (cq >> 2) * soff : 0) + ((oyl * S) * RW + st * TWL * S) * 4 + (cq & 3);
             int acc[TWL][4];
 #pragma unroll
             for (int j = 0; j < TWL; j++)
@@ -380,12 +395,12 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
 // both windows of the launch in the one-binade form?  (host: PWDW_LAUNCH picks the kernel instance)
 static bool pwdw_windows(const PwDwArgs& a, int mode) { return rq_win(a.rq) && (mode == 0 || mode == 4 || rq_win(a.d_rq)); }
 
-template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN>
+template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN, int SL>
 __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [region pixel][4 dwords = 16 channels]
+    extern __shared__ __attribute__((aligned(16))) unsigned inter[];       // [slice][region pixel][4 dwords = 16 channels]
     const ChainDep none = {nullptr, 0, nullptr, nullptr};
-    pwdw_block<STEPS, MODE, CHUNKED, PROD, false, WIN>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, false, WIN, SL>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
 }
 
 // The COHERENT form of the same launch (PwDwArgs::coherent, used under direct dispatch -- direct.cc): every tensor the launch
@@ -395,12 +410,12 @@ __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
 // "none" (0.84 us per boundary against 1.26 us with agent-scope fences, tools/exp/aql_chain.cpp), and the weights / bias /
 // multiplier vectors, which nobody ever writes, stay valid in the L2s from one pass to the next.  The first convolution's
 // graph input (PROD 1) is read with ordinary loads: it changes only between bursts, behind a system-scope acquire.
-template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN>
+template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN, int SL>
 __global__ __launch_bounds__(512) void pwdw_i8_coh_kernel(PwDwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned inter[];
     const ChainDep none = {nullptr, 0, nullptr, nullptr};
-    pwdw_block<STEPS, MODE, CHUNKED, PROD, true, WIN>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
+    pwdw_block<STEPS, MODE, CHUNKED, PROD, true, WIN, SL>(a, inter, blockIdx.x, blockIdx.y, blockIdx.z, blockDim.x, none);
 }
 
 #ifdef TAMD_PWDW_CHAIN_EXPERIMENT
@@ -482,7 +497,7 @@ size_t pwdw_lds_bytes(const PwDwArgs& a, int threads)
 {
     if (a.mode == 2) return 0;
     if (a.mode == 0) return ((size_t)a.H * a.W + 4) * 16;
-    return ((size_t)a.RH * a.RW + 8) * 16;
+    return ((size_t)a.RH * a.RW + 8) * 16 * (a.sl == 2 ? 2 : 1);
 }
 
 bool pwdw_config_ok(const PwDwArgs& a, int threads)
@@ -490,6 +505,7 @@ bool pwdw_config_ok(const PwDwArgs& a, int threads)
     if (threads != 256 && threads != 512) return false;
     if (pwdw_lds_bytes(a, threads) > 64 * 1024) return false;
     if (a.prod == 1 && (a.nsteps != 1 || a.mode != 1)) return false;
+    if (a.sl == 2 && (a.mode != 1 || a.nsteps > a.steps)) return false;      // two slices per block: depthwise tails, register-resident K
     if (a.mode == 0) return a.H * a.W <= 1024;
     if (a.mode == 2) return a.TH >= 1 && (long)a.TH * a.W < 16384;
     return a.TH >= 1 && a.TW >= 1 && a.RH * a.RW < 16384;
@@ -510,15 +526,23 @@ int pwdw_steps(int nsteps)
 
 // plain or coherent instance of one variant, with the general or the one-binade requantisation (a kernel each: a branch at the top of
 // one kernel costs the batch-1 launches 0.1-0.3 us -- more scalar state, a longer preamble -- profiles/r05_ab_window_layers_mobilenet_v1_b1.txt)
-#define PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, WIN_)                                                                   \
+#define PWDW_LAUNCH_WS(STEPS_, MODE_, CHUNKED_, PROD_, WIN_, SL_)                                                             \
     do {                                                                                                                     \
-        if (a.coherent) { launch_rec_coherent(); hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_>), grid, dim3(threads), lds, s, a); } \
-        else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_>), grid, dim3(threads), lds, s, a);      \
+        if (a.coherent) { launch_rec_coherent(); hipLaunchKernelGGL((pwdw_i8_coh_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_, SL_>), grid, dim3(threads), lds, s, a); } \
+        else hipLaunchKernelGGL((pwdw_i8_kernel<STEPS_, MODE_, CHUNKED_, PROD_, WIN_, SL_>), grid, dim3(threads), lds, s, a); \
     } while (0)
-#define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_)                                                                          \
+#define PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, SL_)                                                                   \
     do {                                                                                                                     \
-        if (pwdw_windows(a, MODE_)) PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, 1);                                        \
-        else PWDW_LAUNCH_W(STEPS_, MODE_, CHUNKED_, PROD_, 0);                                                               \
+        if (pwdw_windows(a, MODE_)) PWDW_LAUNCH_WS(STEPS_, MODE_, CHUNKED_, PROD_, 1, SL_);                                  \
+        else PWDW_LAUNCH_WS(STEPS_, MODE_, CHUNKED_, PROD_, 0, SL_);                                                         \
+    } while (0)
+#define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_) PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, 1)
+// depthwise tails: one or two 16-channel slices per block (PwDwArgs::sl; two only with a register-resident K)
+#define PWDW_LAUNCH_DW(STEPS_, MODE_, CHUNKED_, PROD_)                                                                       \
+    do {                                                                                                                     \
+        if constexpr (!(CHUNKED_)) { if (a.sl == 2) { PWDW_LAUNCH_S(STEPS_, MODE_, false, PROD_, 2); break; } }              \
+        if (a.sl == 2) return hipErrorInvalidValue;                                                                          \
+        PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, 1);                                                                    \
     } while (0)
 
 template <int STEPS, bool CHUNKED>
@@ -534,9 +558,9 @@ static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
     const dim3 sm(a.slices, a.mode == 0 ? 1 : a.tiles_x, a.mode == 0 ? a.N : a.tiles_y * a.N);
     const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
     if (a.mode == 0) PWDW_LAUNCH(STEPS, 0, CHUNKED, 0);
-    else if (a.S == 2) PWDW_LAUNCH(STEPS, 2, CHUNKED, 0);
-    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH(STEPS, 1, CHUNKED, 0);
-    else PWDW_LAUNCH(STEPS, 3, CHUNKED, 0);      // small tile: one output per lane
+    else if (a.S == 2) PWDW_LAUNCH_DW(STEPS, 2, CHUNKED, 0);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH_DW(STEPS, 1, CHUNKED, 0);
+    else PWDW_LAUNCH_DW(STEPS, 3, CHUNKED, 0);      // small tile: one output per lane
     return hipGetLastError();
 }
 
@@ -545,9 +569,9 @@ static hipError_t launch_first(const PwDwArgs& a, int threads, hipStream_t s)
     const dim3 sm(a.slices, a.tiles_x, a.tiles_y * a.N);
     const dim3 grid = a.tile_major ? dim3(sm.y, sm.z, sm.x) : sm;
     const size_t lds = pwdw_lds_bytes(a, threads);
-    if (a.S == 2) PWDW_LAUNCH(1, 2, false, 1);
-    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH(1, 1, false, 1);
-    else PWDW_LAUNCH(1, 3, false, 1);
+    if (a.S == 2) PWDW_LAUNCH_DW(1, 2, false, 1);
+    else if (a.TH * ((a.TW + 1) / 2) * 4 >= threads) PWDW_LAUNCH_DW(1, 1, false, 1);
+    else PWDW_LAUNCH_DW(1, 3, false, 1);
     return hipGetLastError();
 }
 

@@ -87,6 +87,34 @@ def test_tile_configurations(case):
     assert name == "pwdw_i8<s%d,%sx%s,%s>" % (s, th, tw, threads), name
 
 
+# two 16-channel slices per block ("TH,TW,threads,2": the slices share a tile's address arithmetic, load and loop control; the intermediate
+# tensor is slice-major in LDS).  Same cases as above where the channel count allows it, both strides, all three depthwise modes, ragged
+# tiles, batch > 1, a K tail inside a step, C % 32 == 0 with C % 16 channels unused by the destination view
+CFG2_CASES = [
+    (1, 32, 14, 14, 64, 1, 1, 0, 0, "14,14,256,2"),
+    (1, 32, 14, 14, 64, 1, 1, 0, 0, "4,6,256,2"),
+    (1, 32, 14, 14, 64, 1, 1, 0, 0, "1,4,256,2"),       # small tile: one output per lane (mode 3)
+    (1, 32, 14, 14, 64, 2, 1, 0, 0, "7,7,256,2"),
+    (1, 32, 14, 14, 64, 2, 1, 0, 0, "3,4,512,2"),
+    (2, 20, 13, 11, 32, 1, 1, 6, 0, "5,7,256,2"),       # odd map, cin % 16 != 0, relu6 on the pointwise, batch 2
+    (3, 20, 13, 11, 64, 2, 1, 0, 6, "3,3,256,2"),       # stride 2 on an odd map, batch 3 (naive-ref depthwise epilogue)
+    (1, 96, 9, 9, 96, 1, 0, 0, -1, "7,7,256,2"),        # pad 0, K = 96 (two steps), three slice pairs, no activation on the depthwise
+    (1, 48, 9, 9, 32, 1, 2, 0, 0, "4,4,256,2"),         # pad 2
+    (1, 16, 30, 30, 32, 1, 1, 0, 0, "8,28,512,2"),      # wide tile
+    (4, 64, 28, 28, 32, 1, 1, 1, 1, "14,14,256,2"),     # act code 1
+    (2, 32, 56, 56, 64, 2, 1, 0, 0, "14,28,512,2"),     # the MobileNet conv2_1/sep + conv2_2/dw shape at a batch-64 tile
+]
+
+
+@pytest.mark.parametrize("case", CFG2_CASES, ids=[str(c) for c in CFG2_CASES])
+def test_two_slices_per_block(case):
+    n, cin, h, w, c, s, p, act_pw, act_dw, cfg = case
+    g, x = pwdw_graph(900 + cin + h + c + s + p, n, cin, h, w, c, s, p, act_pw, act_dw)
+    name = check(g, x, cfg, str(case))
+    th, tw, threads, _ = cfg.split(",")
+    assert name == "pwdw_i8<s%d,%sx%s,%s,c32>" % (s, th, tw, threads), name
+
+
 @pytest.mark.parametrize("alg", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 64, 7, 7, 32), (3, 40, 5, 9, 24), (1, 256, 14, 14, 64)])
 def test_pointwise_plus_global_pool(alg, shape):
@@ -105,6 +133,9 @@ FIRST_CASES = [
     (3, 4, 18, 18, 32, (3, 1, 0), 1, "16,16,256"),       # 4 channels (12 patch rows: third k block), no padding, whole map per block
     (1, 3, 9, 5, 16, (3, 1, 1), 1, "5,6,256"),           # 5-pixel rows: right border inside the 4-byte row loads
     (1, 4, 16, 16, 16, (4, 1, 1), 2, "2,3,256"),         # 4x4 kernel, 4 channels: all 16 patch rows, KW = 4
+    (1, 3, 224, 224, 32, (3, 2, 1), 1, "7,14,512,2"),    # two slices per block: the patch gather is shared by the 32 output channels
+    (2, 3, 37, 41, 32, (3, 2, 1), 2, "3,4,256,2"),
+    (3, 4, 18, 18, 64, (3, 1, 0), 1, "16,16,256,2"),
 ]
 
 
