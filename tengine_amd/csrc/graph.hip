@@ -1121,13 +1121,13 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         for (int th : ths)
             for (int tw : tws)
                 for (int threads : {256, 512})
-                  for (int sl : {1, 2}) {
-                    if (sl == 2 && (slices % 2 != 0 || nsteps > steps)) continue;
+                  for (int sl : {1, 2, 4}) {
+                    if (sl > 1 && (slices % sl != 0 || nsteps > steps)) continue;
                     const PwDwArgs v = with_tiles(a, th, tw, sl);
                     if (!pwdw_config_ok(v, threads)) continue;
                     // two slices per block halve the grid: offered where two blocks per CU remain (the batched early layers it is for;
                     // a batch-1 launch is a latency chain, its blocks must stay many and short)
-                    if (sl == 2 && (double)a.N * v.tiles_y * v.tiles_x * v.slices < 512.0) continue;
+                    if (sl > 1 && (double)a.N * v.tiles_y * v.tiles_x * v.slices < 512.0) continue;
                     // instruction slots of the busiest wave (a lone wave issues one instruction per 4 cycles): pointwise tiles
                     // (address + K steps + requantisation) and depthwise tasks, on top of a fixed prologue
                     const int nw = threads / 64;
@@ -1144,7 +1144,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         std::sort(cfgs.begin(), cfgs.end(), [](const Cfg& l, const Cfg& r) { return l.cost < r.cost; });
         // the best few of EACH block width go to the device: the model ranks within a width, the race decides between them
         std::vector<Cfg> keep;
-        for (int sl : {1, 2}) {
+        for (int sl : {1, 2, 4}) {
             int n = 0;
             for (auto& c : cfgs)
                 if (c.sl == sl && n < (sl == 1 ? 8 : 6)) { keep.push_back(c); n++; }
@@ -1152,10 +1152,10 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
         cfgs = keep;
     }
     if (const char* pin = tamd_pin("pwdw_cfg")) {
-        int th = 0, tw = 0, threads = 0, sl = 1;      // "THxTWxthreads" or "THxTWxthreadsx2" (two slices per block)
+        int th = 0, tw = 0, threads = 0, sl = 1;      // "THxTWxthreads" or "THxTWxthreadsx2" / "..x4" (two / four slices per block)
         if (sscanf(pin, "%dx%dx%dx%d", &th, &tw, &threads, &sl) >= 3 && tmode == 1) {
             th = std::min(th, a.OH); tw = std::min(tw, a.OW);
-            if (sl != 2 || slices % 2 != 0 || nsteps > steps) sl = 1;
+            if ((sl != 2 && sl != 4) || slices % sl != 0 || nsteps > steps) sl = 1;
             if (th >= 1 && tw >= 1 && pwdw_config_ok(with_tiles(a, th, tw, sl), threads)) { cfgs.clear(); cfgs.push_back({th, tw, threads, 0.0, sl}); }
         }
     }
@@ -1200,7 +1200,7 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     Step st;
     st.node = sa.node + "+" + sb.node;
     char nm[48];
-    if (tmode == 1) snprintf(nm, sizeof(nm), "%s_i8<s%d,%dx%d,%d%s>", prod == 1 ? "firstdw" : "pwdw", a.S, v.TH, v.TW, threads, v.sl == 2 ? ",c32" : "");
+    if (tmode == 1) snprintf(nm, sizeof(nm), "%s_i8<s%d,%dx%d,%d%s>", prod == 1 ? "firstdw" : "pwdw", a.S, v.TH, v.TW, threads, v.sl == 4 ? ",c64" : v.sl == 2 ? ",c32" : "");
     else snprintf(nm, sizeof(nm), "pwpool_i8<%d>", threads);
     st.kernel = nm;
     st.macs = sa.macs + sb.macs;

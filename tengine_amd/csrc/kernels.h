@@ -118,6 +118,11 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     const unsigned* taps;  // prod 1: [16] patch row (c, ky) -> (c*in_H*in_W + ky*DH*in_W) | ky*DH << 28, zero padded; k = row*4 + kx
     int in_C, in_H, in_W;  // prod 1: the NCHW input;  H x W above is then the first conv's OUTPUT map
     int fSH, fSW, fPH, fPW;            // prod 1: stride, leading pads
+    int sl;                // 16-channel slices per block: 2 | 4 (depthwise tails with a register-resident K; slices = cout / (16 sl)), else one.
+                           // HERE, in what was a 4-byte alignment hole: the struct must not grow -- its size decides which 64-byte line of the
+                           // argument segment holds the hidden block size the kernels read late, and 8 bytes more cost every batch-1 launch
+                           // with a depthwise tail 0.15-0.2 us (a cold scalar-cache line on the critical path;
+                           // profiles/r05_ab_b1_call12_vs_now.txt: identical instructions, +3-6 % per launch)
     const int8_t* dw_w;    // as DwArgs::w
     const int32_t* dw_bias;
     const float* dw_wscale;
@@ -127,7 +132,6 @@ struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.
     int8_t* y;             // NHWC output of the tail
     int ldc, c_off, c_limit;
     int TH, TW, tiles_y, tiles_x, slices;      // depthwise output tile per block, grid (slices: blocks along the channels)
-    int sl;                // 16-channel slices per block: 2 = two (depthwise tails with a register-resident K; slices = ceil(cout / 32)), else one
     int tile_major;        // 1: grid = (tile_x, tile_y * N, slice) instead of (slice, tile_x, tile_y * N): which operand an XCD's L2 shares
     int RH, RW;            // input region of a tile: (TH-1)*S+3, (TW-1)*S+3
     int pool_method;       // mode 0: 0 max, 1 avg

@@ -101,7 +101,7 @@ __device__ __forceinline__ void chain_store(unsigned* p, unsigned v) { __hip_ato
 
 // WIN: both requantisations (the pointwise conv's and its depthwise consumer's) in the one-binade form of epilogue.h; the kernels
 // check the two windows once (pwdw_windows)
-// SL: 16-channel slices per block (1 | 2).  Two slices share everything that is per pixel tile -- the tile's address arithmetic, its
+// SL: 16-channel slices per block (1 | 2 | 4).  The slices of a block share everything that is per pixel tile -- the tile's address arithmetic, its
 // activation load (PROD 1: the patch gather), the loop control -- which is 30 of the ~50 vector instructions a tile costs: the early
 // MobileNet pairs at batch 64 are bound by exactly those (73-86 % VALU busy, profiles/r05_pmc_sq_activity_mobilenet_v1_int8_b64.csv).
 // The intermediate tensor is slice-major in LDS ([slice][region pixel][16 channels]), so the depthwise phase only widens its channel index.
@@ -110,7 +110,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
                                            const int nthreads, const ChainDep& dep)
 {
     constexpr int S = MODE == 2 ? 2 : 1;
-    static_assert(SL == 1 || (SL == 2 && !CHUNKED && MODE >= 1 && MODE <= 3), "two slices: register-resident K, depthwise tails");
+    static_assert(SL == 1 || ((SL == 2 || SL == 4) && !CHUNKED && MODE >= 1 && MODE <= 3), "several slices: register-resident K, depthwise tails");
     constexpr bool PINGPONG = !CHUNKED && STEPS <= 8 && PROD == 0;      // a second operand buffer: the next tile's loads fly under this tile's MFMAs
     PWDW_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = nthreads >> 6;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
         const float inv_strips = __builtin_amdgcn_rcpf((float)strips);
         const Rq drq = a.d_rq;
         int8_t* yn = a.y + ((size_t)(n * a.OH + ty * a.TH) * a.OW + tx * a.TW) * a.ldc + a.c_off + c0;
-        constexpr int QSH = SL == 2 ? 3 : 2;                  // threads per task position: one per channel quad of the block
+        constexpr int QSH = SL == 4 ? 4 : SL == 2 ? 3 : 2;    // threads per task position: one per channel quad of the block
         for (int q = t >> QSH; q < ntask; q += nthreads >> QSH) {
             const int oyl = (int)(((float)q + 0.5f) * inv_strips), st = q - oyl * strips;
             const unsigned* row = inter + (SL > 1 ? (cq >> 2) * soff : 0) + ((oyl * S) * RW + st * TWL * S) * 4 + (cq & 3);
@@ -393,7 +393,17 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
 }
 
 // both windows of the launch in the one-binade form?  (host: PWDW_LAUNCH picks the kernel instance)
-static bool pwdw_windows(const PwDwArgs& a, int mode) { return rq_win(a.rq) && (mode == 0 || mode == 4 || rq_win(a.d_rq)); }
+static bool pwdw_windows(const PwDwArgs& a, int mode)
+{
+#ifdef TAMD_EXP_PWDW_NOWIN          // tools/exp A/B builds only
+    return false;
+#endif
+    return rq_win(a.rq) && (mode == 0 || mode == 4 || rq_win(a.d_rq));
+}
+
+#ifndef TAMD_PWDW_STAMPS
+static_assert(sizeof(PwDwArgs) == 304, "PwDwArgs must not grow: see the note at PwDwArgs::sl (kernels.h)");
+#endif
 
 template <int STEPS, int MODE, bool CHUNKED, int PROD, int WIN, int SL>
 __global__ __launch_bounds__(512) void pwdw_i8_kernel(PwDwArgs a)
@@ -493,11 +503,16 @@ __global__ __launch_bounds__(512) void pwdw_chain_kernel(const PwChainArgs c)
 }
 #endif   // TAMD_PWDW_CHAIN_EXPERIMENT
 
+// This file is compiled twice: as itself (every launch with ONE slice per block -- all batch-1 launches -- plus the host-side helpers) and,
+// through pwdw_slices.hip (TAMD_PWDW_SLICES_TU), as a second code object that holds the two- and four-slice instances.  In one code
+// object the batch-1 kernels sit scattered among six times as many instances and the batch-1 step loses 0.4-0.9 %
+// (profiles/r05_ab_slices4_layers_mobilenet_v1_b1.txt: the same instructions, 2-6 % slower per isolated launch).
+#ifndef TAMD_PWDW_SLICES_TU
 size_t pwdw_lds_bytes(const PwDwArgs& a, int threads)
 {
     if (a.mode == 2) return 0;
     if (a.mode == 0) return ((size_t)a.H * a.W + 4) * 16;
-    return ((size_t)a.RH * a.RW + 8) * 16 * (a.sl == 2 ? 2 : 1);
+    return ((size_t)a.RH * a.RW + 8) * 16 * (a.sl > 1 ? a.sl : 1);
 }
 
 bool pwdw_config_ok(const PwDwArgs& a, int threads)
@@ -505,7 +520,9 @@ bool pwdw_config_ok(const PwDwArgs& a, int threads)
     if (threads != 256 && threads != 512) return false;
     if (pwdw_lds_bytes(a, threads) > 64 * 1024) return false;
     if (a.prod == 1 && (a.nsteps != 1 || a.mode != 1)) return false;
-    if (a.sl == 2 && (a.mode != 1 || a.nsteps > a.steps)) return false;      // two slices per block: depthwise tails, register-resident K
+    if (a.sl != 0 && a.sl != 1 && a.sl != 2 && a.sl != 4) return false;
+    if (a.sl > 1 && (a.mode != 1 || a.nsteps > a.steps)) return false;       // several slices per block: depthwise tails, register-resident K
+    if (a.sl == 4 && a.steps > 2) return false;                              // (four: K <= 128, the fragments of all slices stay in registers)
     if (a.mode == 0) return a.H * a.W <= 1024;
     if (a.mode == 2) return a.TH >= 1 && (long)a.TH * a.W < 16384;
     return a.TH >= 1 && a.TW >= 1 && a.RH * a.RW < 16384;
@@ -523,6 +540,7 @@ int pwdw_steps(int nsteps)
     for (int s : {8, 4}) { const int p = (nsteps + s - 1) / s * s; if (p < pad) { pad = p; best = s; } }
     return best;
 }
+#endif
 
 // plain or coherent instance of one variant, with the general or the one-binade requantisation (a kernel each: a branch at the top of
 // one kernel costs the batch-1 launches 0.1-0.3 us -- more scalar state, a longer preamble -- profiles/r05_ab_window_layers_mobilenet_v1_b1.txt)
@@ -536,14 +554,21 @@ int pwdw_steps(int nsteps)
         if (pwdw_windows(a, MODE_)) PWDW_LAUNCH_WS(STEPS_, MODE_, CHUNKED_, PROD_, 1, SL_);                                  \
         else PWDW_LAUNCH_WS(STEPS_, MODE_, CHUNKED_, PROD_, 0, SL_);                                                         \
     } while (0)
+#ifndef TAMD_PWDW_SLICES_TU
 #define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_) PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, 1)
-// depthwise tails: one or two 16-channel slices per block (PwDwArgs::sl; two only with a register-resident K)
+#define PWDW_LAUNCH_DW(STEPS_, MODE_, CHUNKED_, PROD_) PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, 1)
+#define LAUNCH_PWDW_NAME launch_pwdw
+#else
+// depthwise tails with two / four 16-channel slices per block (PwDwArgs::sl; register-resident K, four: K <= 128)
+#define PWDW_LAUNCH(STEPS_, MODE_, CHUNKED_, PROD_) return hipErrorInvalidValue
 #define PWDW_LAUNCH_DW(STEPS_, MODE_, CHUNKED_, PROD_)                                                                       \
     do {                                                                                                                     \
         if constexpr (!(CHUNKED_)) { if (a.sl == 2) { PWDW_LAUNCH_S(STEPS_, MODE_, false, PROD_, 2); break; } }              \
-        if (a.sl == 2) return hipErrorInvalidValue;                                                                          \
-        PWDW_LAUNCH_S(STEPS_, MODE_, CHUNKED_, PROD_, 1);                                                                    \
+        if constexpr (!(CHUNKED_) && (STEPS_) <= 2) { if (a.sl == 4) { PWDW_LAUNCH_S(STEPS_, MODE_, false, PROD_, 4); break; } } \
+        return hipErrorInvalidValue;                                                                                         \
     } while (0)
+#define LAUNCH_PWDW_NAME launch_pwdw_slices
+#endif
 
 template <int STEPS, bool CHUNKED>
 static hipError_t launch_steps(const PwDwArgs& a, int threads, hipStream_t s)
@@ -605,8 +630,15 @@ hipError_t launch_pwdw_chain(const PwChainArgs& c, int threads, size_t lds, hipS
 }
 #endif
 
-hipError_t launch_pwdw(const PwDwArgs& a, int threads, hipStream_t s)
+#ifndef TAMD_PWDW_SLICES_TU
+hipError_t launch_pwdw_slices(const PwDwArgs& a, int threads, hipStream_t s);      // pwdw_slices.hip
+#endif
+
+hipError_t LAUNCH_PWDW_NAME(const PwDwArgs& a, int threads, hipStream_t s)
 {
+#ifndef TAMD_PWDW_SLICES_TU
+    if (a.sl > 1) return launch_pwdw_slices(a, threads, s);
+#endif
     if (a.prod == 1) return launch_first(a, threads, s);
     const bool chunked = a.nsteps > a.steps;      // a.nsteps is a multiple of a.steps == pwdw_steps(real steps)
     switch (a.steps) {

@@ -87,7 +87,7 @@ def test_tile_configurations(case):
     assert name == "pwdw_i8<s%d,%sx%s,%s>" % (s, th, tw, threads), name
 
 
-# two 16-channel slices per block ("TH,TW,threads,2": the slices share a tile's address arithmetic, load and loop control; the intermediate
+# two / four 16-channel slices per block ("TH,TW,threads,2" / "..,4": the slices share a tile's address arithmetic, load and loop control; the intermediate
 # tensor is slice-major in LDS).  Same cases as above where the channel count allows it, both strides, all three depthwise modes, ragged
 # tiles, batch > 1, a K tail inside a step, C % 32 == 0 with C % 16 channels unused by the destination view
 CFG2_CASES = [
@@ -103,6 +103,14 @@ CFG2_CASES = [
     (1, 16, 30, 30, 32, 1, 1, 0, 0, "8,28,512,2"),      # wide tile
     (4, 64, 28, 28, 32, 1, 1, 1, 1, "14,14,256,2"),     # act code 1
     (2, 32, 56, 56, 64, 2, 1, 0, 0, "14,28,512,2"),     # the MobileNet conv2_1/sep + conv2_2/dw shape at a batch-64 tile
+    # four slices per block (K <= 128: the fragments of all four stay in registers)
+    (1, 32, 14, 14, 64, 1, 1, 0, 0, "14,14,256,4"),
+    (1, 32, 14, 14, 64, 1, 1, 0, 0, "1,4,256,4"),
+    (1, 32, 14, 14, 64, 2, 1, 0, 0, "3,4,512,4"),
+    (2, 20, 13, 11, 64, 1, 1, 6, 0, "5,7,256,4"),
+    (1, 96, 9, 9, 128, 1, 0, 0, -1, "7,7,256,4"),
+    (3, 128, 13, 11, 128, 2, 1, 0, 6, "3,3,256,4"),
+    (2, 32, 56, 56, 64, 2, 1, 0, 0, "7,28,512,4"),
 ]
 
 
@@ -111,8 +119,8 @@ def test_two_slices_per_block(case):
     n, cin, h, w, c, s, p, act_pw, act_dw, cfg = case
     g, x = pwdw_graph(900 + cin + h + c + s + p, n, cin, h, w, c, s, p, act_pw, act_dw)
     name = check(g, x, cfg, str(case))
-    th, tw, threads, _ = cfg.split(",")
-    assert name == "pwdw_i8<s%d,%sx%s,%s,c32>" % (s, th, tw, threads), name
+    th, tw, threads, sl = cfg.split(",")
+    assert name == "pwdw_i8<s%d,%sx%s,%s,c%d>" % (s, th, tw, threads, 16 * int(sl)), name
 
 
 @pytest.mark.parametrize("alg", [0, 1])
@@ -136,6 +144,7 @@ FIRST_CASES = [
     (1, 3, 224, 224, 32, (3, 2, 1), 1, "7,14,512,2"),    # two slices per block: the patch gather is shared by the 32 output channels
     (2, 3, 37, 41, 32, (3, 2, 1), 2, "3,4,256,2"),
     (3, 4, 18, 18, 64, (3, 1, 0), 1, "16,16,256,2"),
+    (1, 3, 64, 64, 64, (3, 2, 1), 1, "7,14,512,4"),      # four slices
 ]
 
 

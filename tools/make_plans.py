@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes tengine_amd/plans/<model>_<dtype>_b<batch>.txt for the BASELINE configurations (runs ON THE GPU BOX): one prerun per
-configuration under a fresh TAMD_PLAN_CACHE, i.e. exactly what the plan-time autotune chooses there, plus the step time the
-plan gives (direct dispatch, device-resident) so the file can be judged against the evidence tables.
+configuration under a fresh TAMD_PLAN_CACHE -- several of them, the plan with the fastest step ships -- i.e. what the plan-time
+autotune chooses there, plus the step time the plan gives (direct dispatch, device-resident) so the file can be judged against the
+evidence tables.
 
 usage: make_plans.py [out_dir]      (default tengine_amd/plans; TAMD_U8_INT plans get the dtype suffix _int)"""
 import os
@@ -15,32 +16,53 @@ CONFIGS = [("mobilenet_v1", "int8", 1, False), ("mobilenet_v1", "int8", 64, Fals
            ("yolov3_tiny", "uint8", 8, False), ("mssd", "uint8", 16, False), ("yolov3_tiny", "uint8", 8, True), ("mssd", "uint8", 16, True)]
 
 
+def plan_once(name, dtype, batch, integer, path):
+    """one prerun under a fresh plan file at `path` -> (launches, us per step)"""
+    if os.path.exists(path):
+        os.remove(path)
+    os.environ["TAMD_PLAN_CACHE"] = path
+    if integer:
+        os.environ["TAMD_U8_INT"] = "1"
+    try:
+        g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
+        gr = capi.Graph(tm2.write_tm2(g), batch=batch, direct_dispatch=True)
+        gr.set_input(models.synth_input(g, 3, tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8))
+        gr.run()
+        gr.upload()
+        gr.sync()
+        gr.time_launches(20)
+        us = min(1e3 * gr.time_launches(100) / 100 for _ in range(2))
+        n = gr.kernel_num()
+        gr.close()
+    finally:
+        os.environ.pop("TAMD_U8_INT", None)
+        os.environ.pop("TAMD_PLAN_CACHE", None)
+    return n, us
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else plans.PLAN_DIR
     os.makedirs(out, exist_ok=True)
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="make_plans_")
     for name, dtype, batch, integer in CONFIGS:
         path = os.path.join(out, "%s_%s%s_b%d.txt" % (name, dtype, "_int" if integer else "", batch))
-        if os.path.exists(path):
-            os.remove(path)
-        os.environ["TAMD_PLAN_CACHE"] = path
-        if integer:
-            os.environ["TAMD_U8_INT"] = "1"
-        try:
-            g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
-            gr = capi.Graph(tm2.write_tm2(g), batch=batch, direct_dispatch=True)
-            gr.set_input(models.synth_input(g, 3, tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8))
-            gr.run()
-            gr.upload()
-            gr.sync()
-            gr.time_launches(20)
-            us = 1e3 * gr.time_launches(100) / 100
-            n = gr.kernel_num()
-            gr.close()
-        finally:
-            os.environ.pop("TAMD_U8_INT", None)
-        lines = sum(1 for _ in open(path)) - 1 if os.path.exists(path) else 0
-        print("%-14s %-6s b%-3d %s: %d launches, %.1f us/step, %d cached choices -> %s" % (name, dtype, batch, "integer" if integer else "       ", n, us, lines,
-                                                                                          os.path.relpath(path, ROOT)))
+        # The plan-time races time isolated launches; a race between microsecond kernels (and every fuse / do-not-fuse decision
+        # behind one) can fall the wrong way for the STEP: the planner runs several times, the plan whose step is the fastest ships
+        # (round 5: one unlucky batch-1 plan left conv6/sep + pool6 unfused, 54.9 instead of 51.4 us -- profiles/r05_ab_b1_call12_vs_now_v2.txt)
+        tries = 5 if batch == 1 else 3
+        results = []
+        for t in range(tries):
+            cand = os.path.join(tmp, "try%d.txt" % t)
+            n, us = plan_once(name, dtype, batch, integer, cand)
+            results.append((us, n, cand))
+        us, n, best = min(results)
+        shutil.copyfile(best, path)
+        lines = sum(1 for _ in open(path)) - 1
+        print("%-14s %-6s b%-3d %s: %d launches, %.1f us/step (the %d plans: %s), %d cached choices -> %s" % (
+            name, dtype, batch, "integer" if integer else "       ", n, us, tries, " ".join("%.1f" % r[0] for r in results), lines, os.path.relpath(path, ROOT)))
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":
