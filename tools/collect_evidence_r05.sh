@@ -95,5 +95,24 @@ python $R/tools/trace_gaps.py $T $N 30 > $O/insitu_trace_resnet50_int8_b32.txt 2
 python $R/tools/replay_model.py resnet50 32 30 int8 >> $O/insitu_trace_resnet50_int8_b32.txt 2>&1
 unset TAMD_PLAN_CACHE
 rm -rf $O/trace_is $O/trace $O/tbl_plan.txt $O/replay.txt
+# ---- 5. round 4's final build against this round's, interleaved in THIS box (fresh processes, each build plans for itself)
+cd $R
+if [ -f $R/tools/exp/ab/libtengine_amd_r04_final.so ]; then
+  for cfg in "mobilenet_v1 1 int8 2000" "mobilenet_v1 64 int8 100" "resnet50 32 int8 100" "yolov3_tiny 8 uint8 50" "mssd 16 uint8 50"; do
+    set -- $cfg
+    timeout 900 python tools/exp/ab_lib.py $1 $2 $3 $4 3 round4=$R/tools/exp/ab/libtengine_amd_r04_final.so round5=product 2>&1 | grep -v "^Tengine" > $O/ab_round4_vs_round5_$1_$3_b$2.txt
+    cat $O/ab_round4_vs_round5_$1_$3_b$2.txt
+  done
+  for cfg in "yolov3_tiny 8" "mssd 16"; do
+    set -- $cfg
+    TAMD_U8_INT=1 timeout 900 python tools/exp/ab_lib.py $1 $2 uint8 50 3 round4=$R/tools/exp/ab/libtengine_amd_r04_final.so round5=product 2>&1 | grep -v "^Tengine" > $O/ab_round4_vs_round5_$1_uint8_int_b$2.txt
+    cat $O/ab_round4_vs_round5_$1_uint8_int_b$2.txt
+  done
+fi
+# ---- 6. VERDICT r4 item 1(e): every ResNet-50 GEMM layer forced onto conv_pgemm (rows for the 1x1 layers, fused residual tail included)
+# next to the table of the raced plan (step 4): what the race already knew
+TAMD_FORCE_GEMM="conv_pgemm_i8<" python tools/profile_layers.py resnet50 32 10 int8 2>&1 | grep -v "^Tengine" > $O/layers_resnet50_int8_b32_forced_pgemm.txt
+tail -1 $O/layers_resnet50_int8_b32_forced_pgemm.txt
+cd /tmp
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*counter_collection.csv" -delete; rm -rf $O/calib_FETCH_SIZE $O/calib_WRITE_SIZE
 ls $O | head -80
