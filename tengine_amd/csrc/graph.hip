@@ -1581,9 +1581,14 @@ static int plan(tamd_graph* g)
                 if (tmode == 0 ? plan_pool(g, g->nodes[tail]) : plan_conv(g, g->nodes[tail], false)) return -1;
                 fused[tail] = 1;
                 g_last_dw_valid = g_last_dw_valid && tmode == 1;
-                if (g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, prod, s0)) return -1;
-                // the pair stayed two launches: the depthwise tail may still go together with ITS consumer (dwpw.hip)
-                if (tmode == 1 && g->steps.size() == s0 + 2 && try_dwpw((size_t)tail) < 0) return -1;
+                // Where the depthwise tail can go together with ITS consumer (dwpw.hip: batched 14x14-class maps, stride 1), that pairing is
+                // tried FIRST.  In a chain pw, dw, pw, dw, .. either pairing covers every layer once per period, and in a pass dwpw is the
+                // cheaper period (MobileNet-v1 b64: 16.4 us against 22.9 us for the pwdw pair with two slices per block) -- but the
+                // plan-time race, which times a launch back to back with itself, saw the pwdw pair at < 18.8 us and took it
+                // (profiles/r05_layers_mobilenet_v1_int8_b64.txt, the evidence plan: the 14x14 block 120 us; with this order 95 us)
+                int took = 0;
+                if (tmode == 1 && g->steps.size() == s0 + 2) { took = try_dwpw((size_t)tail); if (took < 0) return -1; }
+                if (!took && g->steps.size() == s0 + 2 && plan_pwdw(g, n, g->nodes[tail], tmode, prod, s0)) return -1;
                 break;
             }
             if (plan_conv(g, n, false, has_fuse[ni] ? &fuse_at[ni] : nullptr)) return -1;
