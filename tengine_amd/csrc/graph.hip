@@ -1187,7 +1187,11 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
             if (time_fn(g, [v, threads](hipStream_t s) { return launch_pwdw(v, threads, s); }, &ms)) return -1;
             if (ms < best_ms) { best_ms = ms; best = c; }
         }
-        if (fmode != 2) {
+        // A small pair is a link of a latency chain (batch 1: 3.4 us per dependent launch whatever it does): one launch instead of two
+        // is right by construction there, and the race -- which times a launch back to back with ITSELF, i.e. its throughput -- gets
+        // exactly these wrong now and then (conv6/sep + pool6 left as two launches: 54.9 instead of 51.4 us per MobileNet-v1 pass,
+        // profiles/r05_ab_b1_call12_vs_now_v2.txt, r05_ab_firstdw_pingpong_mobilenet_v1_b1.txt).  Timed: the batched pairs only.
+        if (fmode != 2 && !fuse) {
             float ta, tb;
             if (time_fn(g, sa.fn, &ta) || time_fn(g, sb.fn, &tb)) return -1;
             fuse = best_ms < 0.97f * (ta + tb);
