@@ -480,7 +480,8 @@ def pmc_traffic(model, dtype, batch, family):
     same-session streaming-copy calibration -- tools/collect_profiles.sh, tools/traffic_summary.py); None when this
     workload has no PMC pass (counters cannot be collected from inside the timed process)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_%s_%s_b%d.json" % (model, dtype, batch))))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_%s_%s_b%d.json" % (model, dtype, batch)))
+                   + glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_traffic_%s_%s_b%d.json" % (model, dtype, batch))))      # (a second pass of a round: r05b_)
     if not found:
         return None
     path = found[-1]
