@@ -193,6 +193,8 @@ TAMD_API int tamd_graph_set_batch(tamd_graph* g, int batch);
  * Threading: the library may be used from several host threads, each graph by ONE thread at a time (a graph's run state --
  * I/O slots, runs in flight, its HSA queue, which is single-producer -- is not locked; the reference calls a subgraph's
  * interface from one scheduler thread as well, scheduler.c:95-213).  Different graphs never share run state.
+ * Enforced since round 5: a call that arrives while ANOTHER thread is inside a call on the same graph returns -1
+ * ("... one graph = one thread at a time"); calls from different threads one after the other are fine.
  * prerun  <- interface.pre_run   (device.h:46, called from scheduler.c:49-59; options may be NULL)
  * run     <- interface.run       (device.h:49, scheduler.c:134; must return with outputs complete)
  * destroy <- interface.post_run / release_graph (device.h:52-58, scheduler.c:201, subgraph.c:53-56) */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -139,6 +140,9 @@ struct DevArena { char* base = nullptr; size_t cap = 0, used = 0; };
     } while (0)
 
 struct tamd_graph {
+    // "one graph = one thread at a time" (include/tengine_amd.h), enforced: the token of the thread inside a call that changes the graph
+    // or touches its buffers (0: nobody).  A second thread's call fails with an error instead of racing (graph.hip: OneThread)
+    std::atomic<unsigned long> owner{0};
     std::vector<tamd::HTensor> tensors;
     std::vector<tamd::HNode> nodes;
     std::vector<tamd::IOBind> inputs, outputs;

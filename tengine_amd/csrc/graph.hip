@@ -1912,6 +1912,30 @@ static int direct_io_selfcheck(tamd_graph* g, DirectProgram* pio, int slot)
 // (include/tengine_amd.h "Threading": run state and the single-producer HSA queue are not locked) -- whose current HIP
 // device is whatever that thread used last (events, eager launches and temporary allocations would land on the wrong
 // device otherwise).  hipSetDevice is a thread-local assignment when nothing changes.
+// One graph = one thread at a time: every entry point that changes the graph or touches its buffers holds the graph for the
+// duration of the call (nested entry points of the SAME thread pass).  Calls from different threads one after the other are fine --
+// Tengine's scheduler does that -- two at once are a caller's bug that used to show up as corrupted launch lists; now the second
+// call fails with an error.
+namespace {
+struct OneThread {
+    tamd_graph* g;
+    bool ok = true, outer = false;
+    explicit OneThread(tamd_graph* g_) : g(g_)
+    {
+        static thread_local char marker;
+        const unsigned long me = (unsigned long)(uintptr_t)&marker;
+        if (!g) return;
+        unsigned long none = 0;
+        if (g->owner.compare_exchange_strong(none, me)) outer = true;
+        else if (none != me) ok = false;
+    }
+    ~OneThread() { if (g && outer) g->owner.store(0); }
+};
+}  // namespace
+#define TAMD_ONE_THREAD(g_)                                                                                                          \
+    OneThread one_thread_(g_);                                                                                                       \
+    if (!one_thread_.ok) { set_error("this tamd_graph is inside a call on another thread: one graph = one thread at a time (include/tengine_amd.h)"); return -1; }
+
 static int bind_device(tamd_graph* g)
 {
     if (!g) { set_error("null graph"); return -1; }
@@ -2141,6 +2165,7 @@ int tamd_graph_set_batch(tamd_graph* g, int batch)
 
 int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
 {
+    TAMD_ONE_THREAD(g);
     if (!g) return -1;
     if (g->prepared) return 0;
     std::lock_guard<std::mutex> lk(g_capture_mutex);
@@ -2344,6 +2369,7 @@ static bool close_on_last_packet()
 
 int tamd_graph_upload_inputs(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->inflight.empty()) { set_error("tamd_graph_upload_inputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
@@ -2374,6 +2400,7 @@ static int stage_from_pinned(tamd_graph* g)
 
 int tamd_graph_launch(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     g->out_fresh_in = 0;                       // the pass writes the staging buffers itself
@@ -2400,6 +2427,7 @@ double tamd_graph_prerun_ms(const tamd_graph* g) { return g ? g->prerun_ms : 0.0
 
 int tamd_graph_sync(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (direct_drain(g)) return -1;
     // asynchronous runs that were submitted and not collected yet are device work too (their outputs stay in the pinned slots
@@ -2412,6 +2440,7 @@ int tamd_graph_sync(tamd_graph* g)
 
 int tamd_graph_download_outputs(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->inflight.empty()) { set_error("tamd_graph_download_outputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
@@ -2429,6 +2458,7 @@ int tamd_graph_download_outputs(tamd_graph* g)
 
 int tamd_graph_run(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
     if (!g->inflight.empty()) { set_error("tamd_graph_run while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
     if (bind_device(g)) return -1;
@@ -2480,6 +2510,7 @@ int tamd_graph_run(tamd_graph* g)
 // stream: run k+1's H2D queues behind run k's D2H, results cannot mix.
 int tamd_graph_run_async(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
     if (bind_device(g)) return -1;
     if (g->inflight.size() >= 2) { set_error("two runs are already in flight: call tamd_graph_wait first"); return -1; }
@@ -2522,6 +2553,7 @@ int tamd_graph_run_async(tamd_graph* g)
 // blocks until the OLDEST run in flight is complete and its outputs are in the buffers that were set when it was submitted
 int tamd_graph_wait(tamd_graph* g)
 {
+    TAMD_ONE_THREAD(g);
     if (!g || g->inflight.empty()) { set_error("tamd_graph_wait: no run in flight"); return -1; }
     if (bind_device(g)) return -1;
     const Inflight f = g->inflight.front();
@@ -2546,6 +2578,7 @@ int tamd_graph_inflight(const tamd_graph* g) { return g ? (int)g->inflight.size(
 
 int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 {
+    TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->outputs.size() || !g->prepared) return -1;
     if (g->out_fresh_in && (bind_device(g) || stage_from_pinned(g))) return -1;
     *dptr = g->outputs[idx].stage;
@@ -2558,6 +2591,7 @@ void* tamd_graph_stream(tamd_graph* g) { g->stream_exposed = true; g->stream_dir
 
 int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (g->direct) {        // the passes are not on the stream: host clock around submit .. complete
         if (direct_drain(g)) return -1;
@@ -2587,6 +2621,7 @@ int tamd_graph_kernel_num(const tamd_graph* g) { return (int)g->steps.size(); }
 
 int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out)
 {
+    TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
     if (direct_drain(g)) return -1;
@@ -2636,6 +2671,7 @@ int tamd_graph_tensor_desc(const tamd_graph* g, int idx, int* dims8, int* dtype)
 
 int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
 {
+    TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
     if (bind_device(g)) return -1;
     HTensor& t = g->tensors[idx];

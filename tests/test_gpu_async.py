@@ -115,3 +115,53 @@ def test_blocking_run_variants_agree(monkeypatch):
         for o in outs[1:]:
             assert np.array_equal(outs[0], o)
         assert np.array_equal(outs[0].reshape(-1), oracle.run_graph(g, x)[0].reshape(-1))
+
+
+def test_two_threads_on_one_graph_are_refused_not_raced():
+    """include/tengine_amd.h: one graph = one thread at a time.  Enforced since round 5 (graph.hip: OneThread): while a thread is
+    inside a call, a second thread's call on the SAME graph fails with an error -- it does not interleave with the first one's
+    launch list.  Two threads hammer run() on one graph: every call either succeeds with the right bytes or fails with that
+    error; afterwards the graph is as usable as before.  (Calls from different threads one AFTER the other are fine: the last
+    part runs the graph from a third thread.)"""
+    import threading
+    g = models.build("mobilenet_v1", "int8", 1)
+    x = models.synth_input(g, 21)
+    gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True)
+    gr.set_input(x)
+    want = [o.copy() for o in gr.run()]
+    ok, refused, other = [0], [0], []
+    lock = threading.Lock()
+
+    def hammer():
+        mine = 0
+        for _ in range(200000):              # a refused call returns at once: attempts are cheap, successes are what is counted
+            if mine >= 60:
+                break
+            try:
+                out = gr.run()
+                good = all(np.array_equal(a, b) for a, b in zip(want, out))
+                mine += 1
+                with lock:
+                    ok[0] += 1
+                    if not good:
+                        other.append("a run that was let through returned other bytes")
+            except capi.TamdError as e:
+                with lock:
+                    if "one thread at a time" in str(e):
+                        refused[0] += 1
+                    else:
+                        other.append(str(e))
+
+    ts = [threading.Thread(target=hammer) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not other, other[:3]
+    assert ok[0] == 120, (ok[0], refused[0])          # both threads got their 60 runs through, between the other's calls
+    res = []
+    t = threading.Thread(target=lambda: res.append([o.copy() for o in gr.run()]))
+    t.start()
+    t.join()
+    assert all(np.array_equal(a, b) for a, b in zip(want, res[0]))
+    gr.close()
