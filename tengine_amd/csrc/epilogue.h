@@ -134,9 +134,15 @@ __device__ __attribute__((noinline)) static unsigned requant4_chain(int a0, int 
 // inlined behind a run-time test at every call site the kernels grew by 10-24 registers and the step got 12 % SLOWER
 // (profiles/r05_ab_window_runtime_branch_*.txt).
 // (`thr_of_test` = the threshold the caller's integer test stands for: 2^-13 <-> 8, the residual tail's 2^-12 <-> 16)
-__host__ __device__ __forceinline__ bool rq_window_is_one_binade(float ylo, float thr, float thr_of_test) { return ylo >= 128.f && thr == thr_of_test; }
-__host__ __device__ __forceinline__ bool rq_win(const RqArgs& r) { return rq_window_is_one_binade(r.ylo, r.thr, 0x1p-13f); }
-__host__ __device__ __forceinline__ bool elt_win(const EltFuse& e) { return rq_window_is_one_binade(e.ylo, e.thr, 0x1p-12f); }
+// The whole window must lie inside the binade: ylo >= 128 AND yhi < 256 (ylo <= yhi), both CHECKED here -- host_rq and the eltwise fold
+// clamp yhi to <= 255.75 today, but a window that ever reached 256 (or a NaN bound: every comparison below is false for it) would make
+// byte 2 / the low half mean something else, and the WIN instances must then not be selected.
+__host__ __device__ __forceinline__ bool rq_window_is_one_binade(float ylo, float yhi, float thr, float thr_of_test)
+{
+    return ylo >= 128.f && yhi < 256.f && ylo <= yhi && thr == thr_of_test;
+}
+__host__ __device__ __forceinline__ bool rq_win(const RqArgs& r) { return rq_window_is_one_binade(r.ylo, r.yhi, r.thr, 0x1p-13f); }
+__host__ __device__ __forceinline__ bool elt_win(const EltFuse& e) { return rq_window_is_one_binade(e.ylo, e.yhi, e.thr, 0x1p-12f); }
 
 __device__ __forceinline__ unsigned rq_pack_byte2(float y0, float y1, float y2, float y3)
 {

@@ -1164,7 +1164,10 @@ static int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, s
     Step& sb = g->steps[s0 + 1];
     const bool autotune = autotune_enabled() && sa.macs >= 4e6;
     size_t best = 0;
-    bool fuse = fmode == 2 || (double)a.N * a.H * a.W <= 32768.0;
+    // fused by construction (no race): a link of a LATENCY chain only -- batch 1, or a pair whose launches cannot fill the machine
+    // (<= 32 k pixels AND at most 256 pixel rows of 64, i.e. fewer blocks than CUs).  Batch 8 at 56x56 or batch 16 at 19x19 are
+    // throughput launches: they keep the race against the two-launch plan below
+    bool fuse = fmode == 2 || ((double)a.N * a.H * a.W <= 32768.0 && (a.N == 1 || (double)a.N * a.H * a.W <= 256.0 * 64.0));
     // cost model inputs below use the map the tail reads (a.H x a.W) and the reduction depth
     char ckey[256];
     snprintf(ckey, sizeof(ckey), "pwdw|%s|n%d %dx%d k%d m%d f%d c%zu", sa.node.c_str(), a.N, a.H, a.W, a.ktot, tmode, fmode, cfgs.size());
@@ -2158,6 +2161,8 @@ int tamd_graph_set_outputs(tamd_graph* g, int n, const int* ids)
 
 int tamd_graph_set_batch(tamd_graph* g, int batch)
 {
+    if (!g) { set_error("null graph"); return -1; }
+    TAMD_ONE_THREAD(g);
     if (g->prepared) { set_error("set_batch after prerun"); return -1; }
     for (auto& io : g->inputs) g->tensors[io.tensor].dims[0] = batch;
     return 0;
@@ -2321,8 +2326,12 @@ int tamd_graph_output_desc(const tamd_graph* g, int idx, int* dims8, int* dtype,
     return fill_desc(t, dims8, dtype);
 }
 
+// (the setters change io.host_in / io.host_out, which run / run_async / wait read: they hold the graph like every other entry point --
+//  a set_input from a second thread DURING a run is refused instead of racing)
 int tamd_graph_set_input(tamd_graph* g, int idx, const void* host, size_t bytes)
 {
+    if (!g) { set_error("null graph"); return -1; }
+    TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->inputs.size()) { set_error("bad input index"); return -1; }
     if (g->prepared && bytes != g->inputs[idx].bytes) { set_error("input %d: %zu bytes given, %zu expected", idx, bytes, g->inputs[idx].bytes); return -1; }
     g->inputs[idx].host_in = host;
@@ -2331,6 +2340,8 @@ int tamd_graph_set_input(tamd_graph* g, int idx, const void* host, size_t bytes)
 
 int tamd_graph_set_output(tamd_graph* g, int idx, void* host, size_t bytes)
 {
+    if (!g) { set_error("null graph"); return -1; }
+    TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->outputs.size()) { set_error("bad output index"); return -1; }
     if (g->prepared && bytes != g->outputs[idx].bytes) { set_error("output %d: %zu bytes given, %zu expected", idx, bytes, g->outputs[idx].bytes); return -1; }
     g->outputs[idx].host_out = host;
@@ -2578,6 +2589,7 @@ int tamd_graph_inflight(const tamd_graph* g) { return g ? (int)g->inflight.size(
 
 int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 {
+    if (!g) { set_error("null graph"); return -1; }
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->outputs.size() || !g->prepared) return -1;
     if (g->out_fresh_in && (bind_device(g) || stage_from_pinned(g))) return -1;
@@ -2624,7 +2636,9 @@ int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    if (!g->inflight.empty()) { set_error("tamd_graph_profile while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
+    g->out_fresh_in = 0;                       // the launches below (and the closing pass) write the staging buffers themselves
     int n = std::min((int)g->steps.size(), max_out);
     std::vector<hipEvent_t> ev(2 * g->steps.size());
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
@@ -2671,6 +2685,7 @@ int tamd_graph_tensor_desc(const tamd_graph* g, int idx, int* dims8, int* dtype)
 
 int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
 {
+    if (!g) { set_error("null graph"); return -1; }
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
     if (bind_device(g)) return -1;

@@ -883,8 +883,15 @@ __attribute__((visibility("default"))) int register_hip_device(void)
     }
     // the plugin hands contexts a pointer into this library (hip_scheduler): keep the library mapped for the life of the process, so
     // that a context which outlives unload_tengine_plugin still points at valid (then forwarding) code -- see g_sched_live
+    // (pinned ONCE: a second registration must not leak another handle -- ADVICE r5.  Between split_graph and the scheduler's prerun the
+    //  reference has no failing step for a device without optimize_graph (c_api.c:476-527), and hip_split_graph fails only BEFORE it
+    //  touches the context, so a context is never left on hip_scheduler by a failed split; graphs destroyed without postrun_graph and
+    //  graphs attached before an unregister / re-register keep their HipSchedState with a stale `attached`: the counts of g_sched_live
+    //  are a lower bound after that, which only means a context may go back to the reference's scheduler one graph early -- the forwarder
+    //  path of hip_scheduler handles every graph either way)
+    static std::atomic<bool> pinned{false};
     Dl_info me;
-    if (dladdr((void*)&register_hip_device, &me) && me.dli_fname) (void)dlopen(me.dli_fname, RTLD_NOW | RTLD_NODELETE);
+    if (!pinned.exchange(true) && dladdr((void*)&register_hip_device, &me) && me.dli_fname) (void)dlopen(me.dli_fname, RTLD_NOW | RTLD_NODELETE);
     g_sched_forward.store(false);
     TLOG_INFO("Tengine plugin device %s is registered.\n", hip_device.name);
     return 0;

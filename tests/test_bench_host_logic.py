@@ -100,3 +100,26 @@ def test_shipped_plan_seeds_a_copy_and_never_overwrites(tmp_path, monkeypatch):
     assert "mine" in open(dst).read() and "mine" not in open(src).read()
     assert plans.seed(str(tmp_path / "other.txt"), "resnet50", "int8", 32) is None
     assert not os.path.exists(str(tmp_path / "other.txt"))
+
+
+def test_timed_region_repeats():
+    """round 6: the region of exactly K steps is repeated until the regions add up to --min-seconds (the driver's K = 20 is a 1 ms region)"""
+    b = _bench()
+    assert b.repeats_for(0.00106, 0.05, 400) == 48          # the driver's invocation at batch 1
+    assert b.repeats_for(0.2, 0.05, 400) == 1               # a region that is long enough is timed once
+    assert b.repeats_for(1e-7, 0.05, 400) == 400            # capped
+    assert b.repeats_for(0.0, 0.05, 400) == 400
+    assert b.repeats_for(0.025, 0.05, 400) == 2
+
+
+def test_side_configs_have_a_reference_golden():
+    """every configuration bench.py times (headline + `configs`) has the real reference's output hashes committed, one per graph output"""
+    b = _bench()
+    gold = json.load(open(b.GOLDEN_SHA))
+    want_outputs = {"mobilenet_v1_int8_b1": 1, "mobilenet_v1_int8_b64": 1, "resnet50_int8_b32": 1, "yolov3_tiny_uint8_b8": 2, "mssd_uint8_b16": 2}
+    for name, dtype, batch, _ in b.SIDE_CONFIGS:
+        key = "%s_%s_b%d" % (name, dtype, batch)
+        sha = b.golden_sha(name, dtype, batch)
+        assert sha is not None and len(sha) == want_outputs[key] and all(len(h) == 64 for h in sha), key
+        assert gold[key]["seed"] == 1000 and gold[key]["outputs"][0]["shape"][0] == batch
+    assert b.golden_sha("no_such_model", "int8", 1) is None
