@@ -106,7 +106,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # every graph of this process (second timed region, concurrent streams) takes the plan the first one measured: the same kernels in
-    # every region, one plan-time autotune instead of one per graph (csrc/graph.hip: plan cache)
+    # every region, one plan-time autotune instead of one per graph (csrc/plan_cache.hip)
     plan_tmp = None
     shipped_plan = None
     if "TAMD_PLAN_CACHE" not in os.environ:
@@ -139,7 +139,7 @@ def main():
         # the plan the committed evidence was taken with (tengine_amd/plans/, written by tools/make_plans.py on the GPU box): a COPY
         # seeds this job's plan file, so the driver's run launches the kernels the layer tables name instead of re-rolling the
         # plan-time autotune.  The library ignores the file as a whole when its header names another build or candidate list, and
-        # re-checks every cached choice before using it (csrc/graph.hip: plan cache); layers the file does not hold are timed as usual.
+        # re-checks every cached choice before using it (csrc/plan_cache.hip); layers the file does not hold are timed as usual.
         shipped_plan = plans.seed(plan_tmp, args.model, args.dtype + ("_int" if args.u8_integer else ""), args.batch)
     max_shard = tdist.shard_range(total_images, world, 0)[1]
 
@@ -568,7 +568,7 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
     u8 = dtype == "uint8"
     plan = os.path.join(tempfile.gettempdir(), "tamd_plan_%d_%s_%s_b%d.txt" % (os.getpid(), model, dtype, batch))
     shipped = plans.seed(plan, model, dtype, batch)
-    os.environ["TAMD_PLAN_CACHE"] = plan          # (the library re-reads its table when the path changes: csrc/graph.hip plan cache)
+    os.environ["TAMD_PLAN_CACHE"] = plan          # (the library re-reads its table when the path changes: csrc/plan_cache.hip)
     gr = None
     try:
         g = models.build(model, dtype, batch)

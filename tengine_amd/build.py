@@ -1,6 +1,7 @@
 """Builds the in-tree native artefacts with hipcc for gfx950 (cross-compiles without a GPU):
 
   tengine_amd/lib/libtengine_amd.so      HIP kernels + planner/executor + tm2 loader, C ABI of include/tengine_amd.h
+  tengine_amd/lib/rccl_gather.bin        the C multi-GPU harness of INTEGRATION.md section F (tengine_amd/harness/rccl_gather.cpp)
   tengine_amd/lib/libtengine_hip_device.so   the Tengine device plugin (register_hip_device), only where the
                                          reference headers are present (it compiles against source/*.h; the
                                          prebuilt .so travels to the GPU box)
@@ -21,7 +22,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "pwdw_slices.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
+SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "pwdw_slices.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_infer.hip", "graph_plan.hip", "graph_plan_pairs.hip", "plan_cache.hip", "graph_exec.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 # int8 GEMM kernels: MFMA accumulators in architectural VGPRs.  hipcc's heuristic keeps them in AccVGPRs and every value
@@ -91,9 +92,23 @@ def build_plugin(ref="/root/reference", verbose=False, force=False):
     return lib
 
 
+def build_harness(force=False):
+    """tengine_amd/harness/rccl_gather.cpp -> tengine_amd/lib/rccl_gather.bin: the C-level multi-GPU program of INTEGRATION.md section F
+    (RCCL broadcast of the tmfile bytes -> native loader -> all-gather of every output), product code since round 6 (it used to live
+    under tools/exp although build() compiled it and tests/test_gpu_rccl_c.py ran it)."""
+    src = os.path.join(HERE, "harness", "rccl_gather.cpp")
+    out = os.path.join(LIBDIR, "rccl_gather.bin")
+    core = os.path.join(LIBDIR, "libtengine_amd.so")
+    if force or _newer(out, [src, core, os.path.join(ROOT, "include", "tengine_amd.h")]):
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+                               "-L" + LIBDIR, "-ltengine_amd", "-lrccl", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_all(verbose=False, force=False):
     core = build_core(verbose, force)
     plugin = build_plugin(verbose=verbose, force=force)
+    build_harness(force)
     return core, plugin
 
 

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_i8_kernel(ConvArgs a)
     igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
 
     // the launcher picks D so that the stage count needs little padding; padded stages multiply zeros (B reads the zero page
-    // once K is exhausted; the weight rows are followed by readable slack, graph.hip dev_alloc)
+    // once K is exhausted; the weight rows are followed by readable slack, graph_plan.hip dev_alloc)
     const int nk = ((a.kpad + BK - 1) / BK + D - 1) / D * D;
     gload(0, ra[0], rb[0]);
     if constexpr (D > 2) gload(1, ra[1], rb[1]);

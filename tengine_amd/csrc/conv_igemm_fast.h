@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_fast_i8_kernel(ConvArgs a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - shift), 0, (int)OOB, 0x00020000);
 
     const int ohw = a.OH * a.OW;
-    const unsigned long long mg_ohw = a.mg_ohw, mg_ow = a.mg_ow;                    // host-computed (graph.hip plan_conv)
+    const unsigned long long mg_ohw = a.mg_ohw, mg_ow = a.mg_ow;                    // host-computed (graph_plan.hip plan_conv)
     const int q = t & 3, r0 = t >> 2;
     unsigned voffA[PA], voffB[PB], inval[PB];      // inval: bit t set = tap t of this row is outside the image (or the row is)
     int ldsA[PA], ldsB[PB];

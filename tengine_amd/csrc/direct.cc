@@ -22,7 +22,7 @@
 // both ends of every pass, 57.0 with it at the ends of the burst, 61.8 for the hipGraph replay (profiles/r02_direct_dispatch.txt).
 //
 // Not covered, by construction: stream ordering with the graph's HIP stream (tamd_graph_sync / download / run wait for the
-// queue; graph.hip drains the stream before the first packet of a burst is written).  Kernels with a scratch frame pass their
+// queue; graph_exec.hip drains the stream before the first packet of a burst is written).  Kernels with a scratch frame pass their
 // private segment size in the packet; the runtime backs the queue's scratch on demand as it does for HIP's queues.
 #include <hip/hip_runtime.h>
 #include "env.h"
@@ -238,7 +238,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         // hidden arguments: at the offsets the kernel's own metadata lists (codeobj_meta.h).  Only where the code object is no
         // longer readable (or carries no note) the code-object-v5 defaults stand in -- block counts at the first 8-byte boundary
         // behind the explicit arguments, group sizes at +12, grid dimensionality at +64 -- and the prerun self-check
-        // (graph.hip direct_selfcheck) is what then vouches for them.  TAMD_DIRECT_META=0 forces the defaults (tests).
+        // (graph_exec.hip direct_selfcheck) is what then vouches for them.  TAMD_DIRECT_META=0 forces the defaults (tests).
         HiddenLayout hl;
         {
             static const bool use_meta = !(exp_env("TAMD_DIRECT_META") && atoi(exp_env("TAMD_DIRECT_META")) == 0);

@@ -74,7 +74,7 @@ __device__ __forceinline__ int round_div_sat(float f, float s, float inv)
 // clamp(R(f), R(lo), R(hi)) -- which clamping y to [128 + R(lo) + 0.25, 128 + R(hi) + 0.75] implements (values beyond the
 // window, including |d| >= 128.6 where the bound above no longer holds, are on the far side of the window by > 0.2); the
 // window's ends have fract 0.25 / 0.75, so a clamped value is never handed over.  M is folded only when every factor is a
-// normal number of moderate size (host_rq in graph.hip); otherwise thr = 2 sends every value down the reference chain.
+// normal number of moderate size (host_rq in graph_plan.hip); otherwise thr = 2 sends every value down the reference chain.
 // tests/csrc/fold_requant_check.c replays fast path and chain on the host (identical IEEE operations) over random layers and
 // boundary-hugging accumulators.
 #define TAMD_RQ_E 0x1p-14f

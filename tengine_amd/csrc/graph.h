@@ -73,7 +73,7 @@ struct Step {                  // one device launch of the compiled plan
     std::function<hipError_t(hipStream_t)> fn;
     bool once = false;         // every input is a prerun constant (PriorBox outputs): launched once at the end of prerun
     // rd / wr list EVERYTHING the step's launch reads / writes in device memory that another step may write (constants left
-    // out) -- only then is deps set, and only a step with deps may run beside its predecessors (graph.hip run_steps)
+    // out) -- only then is deps set, and only a step with deps may run beside its predecessors (graph_exec.hip run_steps)
     bool deps = false;
     std::vector<Access> rd, wr;
 };
@@ -141,7 +141,7 @@ struct DevArena { char* base = nullptr; size_t cap = 0, used = 0; };
 
 struct tamd_graph {
     // "one graph = one thread at a time" (include/tengine_amd.h), enforced: the token of the thread inside a call that changes the graph
-    // or touches its buffers (0: nobody).  A second thread's call fails with an error instead of racing (graph.hip: OneThread)
+    // or touches its buffers (0: nobody).  A second thread's call fails with an error instead of racing (graph_internal.h: OneThread)
     std::atomic<unsigned long> owner{0};
     std::vector<tamd::HTensor> tensors;
     std::vector<tamd::HNode> nodes;
@@ -194,7 +194,7 @@ struct tamd_graph {
 
 namespace tamd {
 
-// planner helpers shared by graph.hip (int8, NHWC) and graph_u8.hip (uint8, NCHW)
+// planner helpers shared by graph_plan.hip (int8, NHWC) and graph_u8.hip (uint8, NCHW)
 PoolGeom pool_geom(const tamd_pool_param& p, int h, int w);
 int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
 // plan-time autotune: candidates of a graph whose pass moves far more bytes than the L2s hold are timed COLD -- every timed
@@ -203,10 +203,10 @@ int dev_alloc(tamd_graph* g, void** p, size_t bytes, bool zero);
 constexpr size_t kL2FlushBytes = 64u << 20;
 void* l2_flush_buffer();
 bool autotune_cold(tamd_graph* g);
-// TAMD_PLAN_CACHE=<file>: "<site>|<node>|<shape>" -> what the plan-time autotune chose (graph.hip)
+// TAMD_PLAN_CACHE=<file>: "<site>|<node>|<shape>" -> what the plan-time autotune chose (plan_cache.hip)
 bool plan_cache_get(const std::string& key, std::string* v);
 void plan_cache_put(const std::string& key, const std::string& v);
-int time_cold(tamd_graph* g, void* flush, const std::function<hipError_t()>& launch, float* ms_out);      // graph.hip
+int time_cold(tamd_graph* g, void* flush, const std::function<hipError_t()>& launch, float* ms_out);      // graph_plan.hip
 void nhwc_geom(HTensor& t);
 int count_consumers(const tamd_graph* g, int tensor);
 int priorbox_count(const tamd_priorbox_param& p);

@@ -284,7 +284,7 @@ int plan_f32(tamd_graph* g)
             g->steps.push_back(st);
             break;
         }
-        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph.hip priorbox_eval); no launch at run
+        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph_infer.hip priorbox_eval); no launch at run
             const HTensor& img = g->tensors[n.in[1]];
             std::vector<float> boxes;
             priorbox_eval(n.p.priorbox, x.dims[2], x.dims[3], img.dims[2], img.dims[3], &boxes);

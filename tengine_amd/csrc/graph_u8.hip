@@ -810,7 +810,7 @@ int plan_u8(tamd_graph* g)
             g->steps.push_back(st);
             break;
         }
-        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph.hip priorbox_eval); no launch at run
+        case TAMD_OP_PRIORBOX: {          // shapes-only node: evaluated here, once (graph_infer.hip priorbox_eval); no launch at run
             HTensor& x = g->tensors[n.in[0]];
             HTensor& y = g->tensors[n.out[0]];
             const HTensor& img = g->tensors[n.in[1]];

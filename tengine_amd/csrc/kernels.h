@@ -25,7 +25,7 @@ struct EltFuse {              // eltwise (+ReLU) node applied in the conv epilog
     float mc, mr, k0, ylo, yhi, thr;
 };
 
-// Requantisation constants of one conv / FC node, folded by the planner (graph.hip: fold_requant + host_rq; the arithmetic and
+// Requantisation constants of one conv / FC node, folded by the planner (graph_plan.hip: fold_requant + host_rq; the arithmetic and
 // its exactness argument are in epilogue.h).  The kernels' per-channel vector `wscale[]` holds the FAST-path multiplier
 // M[c] = RN32(m1 * m2[c] / out_scale); the reference chain's own factors stay here for the values the fast path hands over.
 struct RqArgs {

@@ -29,7 +29,7 @@ extern thread_local bool g_launch_coherent;                     // direct.cc; se
 inline void launch_rec_coherent() { g_launch_coherent = true; }
 extern thread_local bool g_launch_beside;                       // direct.cc; set by launch_rec_beside() for the NEXT launch
 // the graph calls this before a step whose reads and writes touch nothing the launches since the last ordered launch write or
-// read (graph.hip run_steps): its first launch may start while they still run -- its packet goes out without the barrier bit
+// read (graph_exec.hip run_steps): its first launch may start while they still run -- its packet goes out without the barrier bit
 inline void launch_rec_beside() { g_launch_beside = true; }
 // both flags belong to ONE step: a step that launched nothing (or failed before its launch) must not hand them to the next one
 inline void launch_rec_clear_flags() { g_launch_coherent = false; g_launch_beside = false; }

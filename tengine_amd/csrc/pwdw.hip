@@ -171,7 +171,7 @@ __device__ __forceinline__ void pwdw_block(const PwDwArgs& a, unsigned* __restri
     const int VW = vx1 - vx0, VP = (vy1 - vy0) * VW;
     const float inv_vw = __builtin_amdgcn_rcpf((float)VW);
     const int ntiles = (VP + 15) >> 4;
-    const Rq rq = a.rq;                  // folded on the host (graph.hip: host_rq)
+    const Rq rq = a.rq;                  // folded on the host (graph_plan.hip: host_rq)
     const int8_t* xn = PROD == 0 ? a.x + (size_t)n * a.H * a.W * a.cs_in + kb * 16
                                  : a.x + (size_t)n * a.in_C * a.in_H * a.in_W;
     // PROD 1: the four patch rows (c, ky) of this lane's 16 K bytes: k = row * 4 + kx, a row is FOUR consecutive input bytes

@@ -517,7 +517,7 @@ hipError_t launch_conv_u8i_rgb(const U8ConvArgs& a, hipStream_t s)
 // stream through the same fragment order (and the same 8-deep register ring) as conv_u8i_k.  Arithmetic and epilogue: identical
 // to conv_u8i_k (exact int32 sums, column sums by v_dot4, cvec, the reference's requantisation).
 // A quad that hangs over the end of an image plane reads up to 3 bytes of whatever follows (the next channel, the next tensor or
-// the allocation's slack -- graph.hip: dev_alloc) and stores byte-wise.
+// the allocation's slack -- graph_plan.hip: dev_alloc) and stores byte-wise.
 // =================================================================================================================
 template <int WP, int WC, int TMC>
 __global__ __launch_bounds__(256) void conv_u8i_pw_k(const U8ConvArgs a)

@@ -627,7 +627,7 @@ void resplit_around_unsupported(struct graph* ir, struct device* hip)
 // reference's own shape (struct scheduler, scheduler.h:34-43) and installs it on the context of every graph it splits:
 //   prerun / postrun / run(block = 1): the reference's sync scheduler, unchanged (find_default_scheduler());
 //   run(block = 0): a graph that is ONE subgraph on "HIP" is submitted with interface.async_run and the call returns -- up to two
-//                   runs in flight (the device pipelines run k+1's upload behind run k's download, csrc/graph.hip); any other
+//                   runs in flight (the device pipelines run k+1's upload behind run k's download, csrc/graph_exec.hip); any other
 //                   graph (CPU pieces in between) runs to completion right here, which keeps the API's promise trivially;
 //   wait:           interface.async_wait for the oldest run in flight; outputs land in the output tensors' buffers then.
 // Reference defect to know about: wait_graph() itself can never reach a scheduler -- its status test

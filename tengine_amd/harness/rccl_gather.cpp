@@ -11,7 +11,7 @@
 //   `steps` passes with no collective (independent images), then ONE ncclAllGather per graph output, shards padded to the largest;
 //   rank 0 prints a line per output: bytes per image, FNV-1a of the gathered results in global image order.
 // tests/test_gpu_rccl_c.py runs it with world 1 on the GPU box and compares the hashes with the Python binding's results.
-// build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -I../../include -o rccl_gather.bin rccl_gather.cpp -L../../tengine_amd/lib -ltengine_amd -lrccl -Wl,-rpath,'$ORIGIN/../../tengine_amd/lib'
+// build: tengine_amd/build.py build_harness() -> tengine_amd/lib/rccl_gather.bin (hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include ... -ltengine_amd -lrccl -Wl,-rpath,'$ORIGIN')
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>

@@ -1,6 +1,6 @@
 """Shipped launch plans: what the plan-time autotune chose for the BASELINE configurations on the box the committed evidence
 was taken on (tengine_amd/plans/<model>_<dtype>_b<batch>.txt, the library's own TAMD_PLAN_CACHE format, written by
-tools/make_plans.py).  Nothing here decides anything: a plan file only pre-answers the timing races (csrc/graph.hip: plan
+tools/make_plans.py).  Nothing here decides anything: a plan file only pre-answers the timing races (csrc/plan_cache.hip: plan
 cache) -- a header that names another build or candidate list voids the whole file, every cached choice is re-checked for
 applicability before it is used, and layers the file does not hold are timed as they always were."""
 import os

@@ -118,7 +118,7 @@ def test_blocking_run_variants_agree(monkeypatch):
 
 
 def test_two_threads_on_one_graph_are_refused_not_raced():
-    """include/tengine_amd.h: one graph = one thread at a time.  Enforced since round 5 (graph.hip: OneThread): while a thread is
+    """include/tengine_amd.h: one graph = one thread at a time.  Enforced since round 5 (graph_internal.h: OneThread): while a thread is
     inside a call, a second thread's call on the SAME graph fails with an error -- it does not interleave with the first one's
     launch list.  Two threads hammer run() on one graph: every call either succeeds with the right bytes or fails with that
     error; afterwards the graph is as usable as before.  (Calls from different threads one AFTER the other are fine: the last

@@ -100,7 +100,7 @@ def test_fused_eltwise_tail_is_exact_in_every_member(member, etype, own_relu_sca
 @pytest.mark.parametrize("variant", ["sum_relu_fold", "sum_norelu_fold", "sum_relu_scales_too_wide", "sum_relu_fold_disabled"])
 def test_residual_tail_two_fma_form_and_its_fallbacks(member, variant, monkeypatch):
     """the SUM (+ scale-keeping ReLU) tail runs as two fused multiply-adds per value when (s_conv + s_res) / s_out <= 2
-    (epilogue.h: elt_sum4_fold, planner fold in graph.hip); wider scale ratios and TAMD_PIN elt_fold=0 take the general tail.
+    (epilogue.h: elt_sum4_fold, planner fold in graph_plan.hip); wider scale ratios and TAMD_PIN elt_fold=0 take the general tail.
     Same bytes either way, all against the oracle."""
     from helpers import eltwise_relu_graph
     g, x = eltwise_relu_graph(41, 6, 64, 28, 28, variant != "sum_norelu_fold", tm2.ELT_SUM)

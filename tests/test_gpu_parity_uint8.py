@@ -367,7 +367,7 @@ GOLDEN_PRIORBOX = os.path.join(os.path.dirname(__file__), "golden", "priorbox_ca
 
 @pytest.mark.parametrize("case", sorted(PRIORBOX_CASES))
 def test_priorbox_uint8_is_a_prerun_constant(case):
-    """PriorBox depends on shapes only -- evaluated once at prerun (graph.hip priorbox_eval), its Concat runs
+    """PriorBox depends on shapes only -- evaluated once at prerun (graph_infer.hip priorbox_eval), its Concat runs
     once at prerun too; a run launches nothing for them.  Bytes == oracle == the real reference's (golden fixture)."""
     g, x = priorbox_graph(dtype=tm2.DT_UINT8, **PRIORBOX_CASES[case])
     want = oracle.run_graph(g, x)[0]

@@ -1,4 +1,4 @@
-"""TAMD_PLAN_CACHE (graph.hip / graph_u8.hip): the first prerun of a model measures its candidates and writes what it chose,
+"""TAMD_PLAN_CACHE (plan_cache.hip; used by graph_plan*.hip / graph_u8.hip): the first prerun of a model measures its candidates and writes what it chose,
 later preruns take the recorded choices without launching anything -- same kernels, same bytes, a shorter prerun; a line that
 names nothing known is ignored (the site is measured again)."""
 import numpy as np

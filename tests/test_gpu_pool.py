@@ -1,4 +1,4 @@
-"""Activation buffers shared between tensors of disjoint lifetimes (graph.hip plan(): tamd_options.keep_tensors = 0, the default)
+"""Activation buffers shared between tensors of disjoint lifetimes (graph_plan.hip plan_i8(): tamd_options.keep_tensors = 0, the default)
 and device memory carved out of a few large arenas (dev_alloc): same bytes as one buffer per tensor, intermediate tensors are
 refused by read_tensor unless the graph was pre-run with keep_tensors."""
 import numpy as np

@@ -60,6 +60,14 @@ def main():
         us, n, best = min(results)
         shutil.copyfile(best, path)
         lines = sum(1 for _ in open(path)) - 1
+        # the selection is visible in the shipped file itself (a best-of-N plan carries selection bias): every candidate's
+        # step time, which one shipped, how many differ.  Lines without a tab are not entries (plan_cache.hip: plan_cache_read skips them)
+        distinct = len({open(r[2]).read() for r in results})
+        with open(path, "a") as f:
+            f.write("# make_plans: best of %d plan-time runs on one box, step us of each (device-resident, direct dispatch): %s; shipped: run %d (%.2f us, %d launches); "
+                    "%d distinct plan(s) among them; spread %.1f %%\n"
+                    % (tries, " ".join("%.2f" % r[0] for r in results), results.index(min(results)), us, n, distinct,
+                       100.0 * (max(r[0] for r in results) - us) / us))
         print("%-14s %-6s b%-3d %s: %d launches, %.1f us/step (the %d plans: %s), %d cached choices -> %s" % (
             name, dtype, batch, "integer" if integer else "       ", n, us, tries, " ".join("%.1f" % r[0] for r in results), lines, os.path.relpath(path, ROOT)))
     shutil.rmtree(tmp, ignore_errors=True)
