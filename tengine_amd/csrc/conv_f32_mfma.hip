@@ -1,6 +1,6 @@
 // fp32 GEMM-convolution on the matrix cores with the reference's summation order -- asynchronous version.
 //
-// Arithmetic contract (same as u8_kernels.hip, which holds the register-staged version of this kernel):
+// Arithmetic contract (same as u8_conv_gemm.hip, which holds the register-staged version of this kernel):
 // conv/x86/conv_kernel_x86.c:126-185 (im2col, k = (c,ky,kx), 0.0f outside the image), :322-960 sgemm_fp:
 //   pixel j <  (OH*OW)&~7 : one fused chain s = fma(x[k], w[k], s), k ascending        -> "main" blocks
 //   pixel j >= (OH*OW)&~7 : four fused chains over k = r (mod 4), k < K&~3, combined ((0+(s0+s1))+(s2+s3)) for
@@ -15,7 +15,7 @@
 //     models need none) -- so a K stage is a pure copy and travels global -> LDS with LDS-DMA
 //     (global_load_lds_dword): no VGPR round trip, no ds_write, and above all NO register results for the
 //     compiler's s_waitcnt insertion to serialise: STAGES-1 stages stay in flight behind counted vmcnt waits
-//     (the register ring of u8_kernels.hip is drained by hipcc at every loop back-edge);
+//     (the register ring of u8_conv_gemm.hip is drained by hipcc at every loop back-edge);
 //   * LDS is k-major: row k holds the 16/32/64 channels (pixels) of the tile, so a DMA instruction's 64 lanes are
 //     64 consecutive channels of the packed weights / 64 consecutive pixels of the image (coalesced), and an MFMA
 //     operand read is 16 consecutive dwords per k; row groups are spaced 80 dwords so the four k rows of an MFMA

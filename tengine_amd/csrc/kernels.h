@@ -291,7 +291,7 @@ hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);
 // whose per-element summation order is fixed by the reference's register tiling, and only the result is
 // requantised.  Byte-identical outputs therefore need the same fp32 operations in the same order: one fused
 // multiply-add chain per output element -- which is exactly how v_mfma_f32_16x16x4f32 accumulates (measured,
-// profiles/r01_mfma_f32_is_sequential_fma_chain.txt), so the path runs on the matrix cores (u8_kernels.hip).
+// profiles/r01_mfma_f32_is_sequential_fma_chain.txt), so the path runs on the matrix cores (u8_conv_*.hip, u8_kernels.hip).
 // uint8 activations stay in the reference's dense NCHW order on the device.
 struct U8Q { float scale; int zp; };
 // a ReLU node folded into the producing conv: applied to the conv's own uint8 result in registers
@@ -307,7 +307,7 @@ struct U8PoolFuse {            // a 2x2 / stride 2 / unpadded MAX-pool node appl
     U8Q in, out;               // quantisation of the pool node's input (== what the conv epilogue produced) and output
 };
 
-struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_kernels.hip: conv_u8_gemm)
+struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (u8_conv_gemm.hip: conv_u8_gemm)
     const uint8_t* x;          // NCHW
     const uint8_t* wq;         // raw uint8 weights, [cout tile of BM][stage of 32 k][BM rows][32 slots]; BM =
                                // conv_u8_gemm_bm(cfg); slot of k inside its stage: (k%4)*8 + (k%32)/4 (class-major);
@@ -330,7 +330,7 @@ struct U8ConvArgs {            // group == 1: conv_kernel_x86.c sgemm_fp order (
     const float* wf;           // conv_u8_rgb3x3 only: dequantised weights, [cout][wf_ld] rows in OIHW k order
     int wf_ld;
     U8PoolFuse pool;           // fused max-pool node (conv_u8_gemm main tiles and conv_u8_rgb3x3)
-    // conv_u8_patch (u8_kernels.hip): the main pixels (j < (OH*OW)&~7) from an LDS-resident fp32 input patch
+    // conv_u8_patch (u8_conv_patch.hip): the main pixels (j < (OH*OW)&~7) from an LDS-resident fp32 input patch
     const uint8_t* wpk;        // DEQUANTISED weights (floats) in MFMA A-fragment order, [16-row tile][super-step of 4*SS k][float4 group][lane]
     int pk_cfg;                // -1: not used; else tile configuration of launch_conv_u8_patch
     int pk_npad, pk_wp;        // floats per channel plane of the patch (3x3: 256 | 512, 1x1: the pixel tile) / patch row pitch (input columns incl. halo)

@@ -1,4 +1,4 @@
-"""GPU parity of the lane-level chains for SMALL uint8 layers (u8_kernels.hip: conv_u8_lanes_k = conv_u8_patch_lane_main +
+"""GPU parity of the lane-level chains for SMALL uint8 layers (u8_conv_patch.hip: conv_u8_lanes_k = conv_u8_patch_lane_main +
 conv_u8_patch_tail): the 5x5 .. 1x1 ends of an SSD pyramid, where a GEMM launch is all set-up around a handful of live MFMA
 columns.  Every output is one lane's fmaf chain in the reference's order -- the single chain over k for pixels j < (OH*OW)&~7,
 the four k%4 chains + combine for the tail pixels (conv_kernel_x86.c:322-960) -- so the bytes must equal the oracle's (pinned

@@ -1,4 +1,4 @@
-"""GPU parity of the uint8 patch convolution (u8_kernels.hip: conv_u8_patch_k) -- the 3x3 / 1x1 member that dequantises the
+"""GPU parity of the uint8 patch convolution (u8_conv_patch.hip: conv_u8_patch_k) -- the 3x3 / 1x1 member that dequantises the
 input patch of a pixel tile once into LDS and walks the reference's k order (channel-major, tap-minor; conv_kernel_x86.c im2col)
 through the fp32 MFMA chain.  It is an autotune candidate next to conv_u8_mfma_*; here TAMD_PIN u8_patch=1 pins it wherever it
 applies, and the bytes must equal the oracle's (pinned to the real reference by tests/test_uint8_oracle.py) and the GEMM member's."""

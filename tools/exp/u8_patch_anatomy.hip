@@ -1,9 +1,9 @@
-// Where the time of conv_u8_patch_k (u8_kernels.hip) goes: the product kernel compiled with parts removed (TAMD_U8P_ABLATE bits:
+// Where the time of conv_u8_patch_k (u8_conv_patch.hip) goes: the product kernel compiled with parts removed (TAMD_U8P_ABLATE bits:
 // 1 no MFMA, 2 no B reads from the patch, 4 no weight-fragment fetch after the prologue, 8 no patch refresh, 16 no epilogue),
 // main-pixel launch only (the tail pixels' GEMM launch is not part of this), YOLOv3-tiny / MobileNet-SSD layer shapes, random
 // operands, 20 launches back to back.  One binary per ablation mask: tools/exp/build_u8_patch_anatomy.sh.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -DTAMD_U8P_ABLATE=<mask> -I../../tengine_amd/csrc -o u8_patch_anatomy_<mask>.bin u8_patch_anatomy.hip ../../tengine_amd/csrc/direct.cc -lhsa-runtime64
-#include "../../tengine_amd/csrc/u8_kernels.hip"
+#include "../../tengine_amd/csrc/u8_conv_patch.hip"
 
 #include <stdio.h>
 #include <stdlib.h>
