@@ -212,6 +212,7 @@ int count_consumers(const tamd_graph* g, int tensor);
 int priorbox_count(const tamd_priorbox_param& p);
 void priorbox_eval(const tamd_priorbox_param& p, int feat_h, int feat_w, int data_h, int data_w, std::vector<float>* out);
 void priorbox_quant_u8(const std::vector<float>& f, float scale, int zp, std::vector<uint8_t>* q);
+void priorbox_quant_i8(const std::vector<float>& f, float scale, std::vector<int8_t>* q);
 int plan_u8(tamd_graph* g);        // graph_u8.hip: every activation tensor is uint8
 int plan_f32(tamd_graph* g);       // graph_f32.hip: every activation tensor is fp32
 

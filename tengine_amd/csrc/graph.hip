@@ -75,9 +75,9 @@ int tamd_op_supported(int op, int dtype)
     if (dtype != TAMD_DT_INT8 && dtype != TAMD_DT_UINT8 && dtype != TAMD_DT_FP32) return 0;
     if (op == TAMD_OP_UPSAMPLE) return dtype != TAMD_DT_INT8;      // nearest upsample: uint8 / fp32 graphs
     if (op == TAMD_OP_RELU6) return dtype == TAMD_DT_FP32;
-    if (op == TAMD_OP_SOFTMAX) return 1;                           // int8: over the channel axis only (tamd_node_supported)
-    if (op == TAMD_OP_RESHAPE || op == TAMD_OP_PRIORBOX) return dtype != TAMD_DT_INT8;   // dense NCHW device tensors: uint8 / fp32 graphs
-    if (op == TAMD_OP_PERMUTE) return dtype == TAMD_DT_UINT8;      // SSD heads (Permute -> Flatten -> Concat), uint8 graphs
+    if (op == TAMD_OP_SOFTMAX) return 1;                           // (which axes: tamd_node_supported)
+    if (op == TAMD_OP_RESHAPE || op == TAMD_OP_PRIORBOX) return 1; // dense device tensors: uint8 / fp32 graphs; int8 since round 6 (graph_plan.hip)
+    if (op == TAMD_OP_PERMUTE) return dtype != TAMD_DT_FP32;       // SSD heads (Permute -> Flatten -> Concat): uint8, and int8 since round 6
     switch (op) {
     case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_CONV: case TAMD_OP_FC: case TAMD_OP_POOL: case TAMD_OP_RELU:
     case TAMD_OP_ELTWISE: case TAMD_OP_CONCAT: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
@@ -134,16 +134,25 @@ int tamd_node_supported(const tamd_node_desc* n, const tamd_tensor_desc* in, int
     case TAMD_OP_CONCAT: {
         int ax = n->param ? ((const tamd_concat_param*)n->param)->axis : 1;
         if (ax < 0) ax += out[0].dim_num;
-        if (dt == TAMD_DT_INT8) return ax == 1 && out[0].dim_num >= 2;       // NHWC device tensors: channel concat
+        if (dt == TAMD_DT_INT8) {
+            // NHWC device tensors: the channel concat; any other axis only for what is dense on the device anyway -- the PriorBox layout
+            // [1][2][K][1] (priorbox.c:33-75: mbox_priorbox is a Concat on axis 2) and tensors of other ranks (Reshape / Flatten results)
+            if (ax == 1) return out[0].dim_num >= 2;
+            if (ax < 0 || ax >= out[0].dim_num) return 0;
+            return out[0].dim_num != 4 || (out[0].dims[0] == 1 && out[0].dims[1] == 2 && out[0].dims[3] == 1);
+        }
         return ax >= 0 && ax < out[0].dim_num;                               // dense NCHW: any axis
     }
     case TAMD_OP_SOFTMAX: {
         if (dt != TAMD_DT_INT8) return 1;
-        // int8 tensors are NHWC on the device: the channel axis of a 2-D / 4-D tensor is the contiguous one (softmax_i8_kernel)
-        if (n_in < 1 || (in[0].dim_num != 2 && in[0].dim_num != 4) || in[0].ttype == TAMD_TT_CONST) return 0;
+        // int8 tensors are NHWC on the device: the channel axis of a 2-D / 4-D tensor is the contiguous one; since round 6 the spatial axes
+        // of a 4-D tensor and any axis >= 1 of a 3-D tensor (a Reshape result: dense on the device) run through the same kernel, strided
+        if (n_in < 1 || in[0].dim_num < 2 || in[0].dim_num > 4 || in[0].ttype == TAMD_TT_CONST) return 0;
         int ax = n->param ? ((const tamd_softmax_param*)n->param)->axis : 1;
         if (ax < 0) ax += in[0].dim_num;
-        return ax == 1 && in[0].dims[1] >= 1 && in[0].dims[1] <= kSoftmaxI8MaxC;
+        if (ax < 1 || ax >= in[0].dim_num) return 0;
+        if (in[0].dim_num == 2 && ax != 1) return 0;
+        return in[0].dims[ax] >= 1 && in[0].dims[ax] <= kSoftmaxI8MaxC;
     }
     case TAMD_OP_PRIORBOX: {
         if (!n->param || n_in < 2 || in[0].dim_num != 4 || in[1].dim_num != 4 || out[0].dim_num < 1 || out[0].dims[0] != 1) return 0;

@@ -146,6 +146,16 @@ void priorbox_quant_u8(const std::vector<float>& f, float scale, int zp, std::ve
     }
 }
 
+// priorbox_ref.c:195-210: round(f / scale) -- C `round` on the float quotient promoted to double -- clamped to +-127
+void priorbox_quant_i8(const std::vector<float>& f, float scale, std::vector<int8_t>* q)
+{
+    q->resize(f.size());
+    for (size_t i = 0; i < f.size(); i++) {
+        const int v = (int)round((double)(f[i] / scale));
+        (*q)[i] = (int8_t)std::min(std::max(v, -127), 127);
+    }
+}
+
 int infer_shapes(tamd_graph* g)
 {
     for (auto& n : g->nodes) {

@@ -598,10 +598,96 @@ int plan_i8(tamd_graph* g)
     // channel count / offset not a multiple of 16; produced or also consumed by a kernel that does not address channel
     // slices; a graph input) keeps its own buffer and is copied by concat_copy_i8 at the concat's position.
     std::vector<int> view_of(g->tensors.size(), -1), view_off(g->tensors.size(), 0);
+    std::vector<int> alias_of(g->tensors.size(), -1);
+    // ---- DENSE tensors (round 6: the SSD head plumbing of an int8 graph).  The convolution stack lives in NHWC buffers
+    // with padded channels; what Permute(0,2,3,1) / PriorBox produce, and everything that is only a re-reading of it (Flatten, Reshape,
+    // Concat on any axis, Softmax on any axis), lives in the reference's own dense element order (HTensor::nchw_raw, cs = 0): those ops
+    // are byte copies / views there (permute_ref.c:305-343, flatten_ref.c:74-80, reshape_ref.c:76-90), and a graph output needs no
+    // layout pass.  perm_src[t] >= 0: t is NHWC tensor perm_src[t] seen through Permute(0,2,3,1) (+ views) -- a Concat reads the NHWC
+    // buffer itself (flatcat_i8, kind 1) and the permuted copy is never written unless something else reads it too.
+    const size_t NT = g->tensors.size();
+    std::vector<char> dense(NT, 0), flat_concat(g->nodes.size(), 0), need_buf(NT, 0);
+    std::vector<int> perm_src(NT, -1);
+    {
+        auto root = [&](int t) { for (int hop = 0; hop < 16 && alias_of[t] >= 0; hop++) t = alias_of[t]; return t; };
+        for (size_t ni = 0; ni < g->nodes.size(); ni++) {
+            HNode& n = g->nodes[ni];
+            if (n.op == TAMD_OP_INPUT || n.op == TAMD_OP_CONST || n.in.empty() || n.out.empty()) continue;
+            HTensor& x = g->tensors[n.in[0]];
+            const int yo = n.out[0];
+            switch (n.op) {
+            case TAMD_OP_PERMUTE: {
+                const int* o = n.p.perm.order;
+                if (x.dims.size() != 4 || dense[n.in[0]] || !(o[0] == 0 && o[1] == 2 && o[2] == 3 && o[3] == 1)) {
+                    set_error("permute %s: only order (0, 2, 3, 1) of a 4-D convolution-stack tensor runs on the device", n.name.c_str());
+                    return -1;
+                }
+                dense[yo] = 1; perm_src[yo] = n.in[0];
+                break;
+            }
+            case TAMD_OP_PRIORBOX: dense[yo] = 1; break;
+            case TAMD_OP_RESHAPE: dense[yo] = 1; if (dense[n.in[0]]) { alias_of[yo] = n.in[0]; perm_src[yo] = perm_src[n.in[0]]; } break;
+            case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
+                if (dense[n.in[0]]) { dense[yo] = 1; alias_of[yo] = n.in[0]; perm_src[yo] = perm_src[n.in[0]]; }
+                else {
+                    // Flatten of an H x W map: the [N, C*H*W] result is the SAME NCHW element order; on the device it stays the NHWC
+                    // buffer and keeps the 4-D geometry, so a following FC (== conv whose kernel covers the map), the NCHW output
+                    // conversion and a flat Concat (kind 2) all see (c, h, w).  Set HERE, in node order: the Concat case below looks
+                    // at the geometry of its inputs (a 2-D tensor that is a flattened MAP must not take the channel-concat path --
+                    // it did until round 6 and wrote N*H*W rows into an N-row output)
+                    alias_of[yo] = n.in[0];
+                    HTensor& yy = g->tensors[yo];
+                    yy.n = x.n; yy.c = x.c; yy.h = x.h; yy.w = x.w;
+                }
+                break;
+            case TAMD_OP_SOFTMAX: if (dense[n.in[0]]) dense[yo] = 1; break;
+            case TAMD_OP_CONCAT: {
+                HTensor& y = g->tensors[yo];
+                const int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+                bool any_dense = false, any_map = false;
+                for (int i : n.in) { any_dense |= dense[i] != 0; any_map |= g->tensors[i].h * g->tensors[i].w > 1; }
+                if (any_dense || ax != 1 || (y.dims.size() != 4 && any_map)) {
+                    flat_concat[ni] = 1; dense[yo] = 1;
+                }
+                break;
+            }
+            default:
+                for (int i : n.in)
+                    if (g->tensors[i].ttype != TAMD_TT_CONST && dense[i]) {
+                        set_error("%s reads %s, a tensor in dense (permuted / flattened) order: only Flatten, Reshape, Concat and Softmax do on the device", n.name.c_str(), g->tensors[i].name.c_str());
+                        return -1;
+                    }
+            }
+        }
+        // who needs the bytes of a dense tensor in memory: everything but the flat Concat of a lazily permuted tensor (and its views)
+        for (size_t ni = 0; ni < g->nodes.size(); ni++) {
+            const HNode& n = g->nodes[ni];
+            for (int i : n.in) {
+                if (g->tensors[i].ttype == TAMD_TT_CONST || !dense[i]) continue;
+                const bool is_alias_op = !n.out.empty() && alias_of[n.out[0]] == i;
+                if (is_alias_op) continue;
+                if (!(flat_concat[ni] && perm_src[i] >= 0)) need_buf[root(i)] = 1;
+            }
+        }
+        for (auto& io : g->outputs) if (dense[io.tensor]) need_buf[root(io.tensor)] = 1;
+        for (size_t t = 0; t < NT; t++) {
+            if (!dense[t]) continue;
+            if (need_buf[root((int)t)]) perm_src[t] = -1;              // materialised: its readers take the dense bytes
+            HTensor& d = g->tensors[t];
+            d.nchw_raw = true; d.cs = 0; d.c_off = 0;
+        }
+        for (size_t t = 0; t < NT; t++) {
+            HTensor& d = g->tensors[t];
+            if (!dense[t] || alias_of[t] >= 0) continue;
+            if (d.dtype != TAMD_DT_INT8) { set_error("tensor %s: dtype %d not supported on the device yet", d.name.c_str(), d.dtype); return -1; }
+            if (perm_src[t] >= 0) continue;                             // never written: read through its NHWC source
+            if (dev_alloc(g, &d.dptr, d.elems(), true)) return -1;
+        }
+    }
     auto producer_op = [&](int t) { for (auto& n : g->nodes) if (!n.out.empty() && n.out[0] == t) return n.op; return -1; };
     auto slice_capable = [](int op) { return op == TAMD_OP_CONV || op == TAMD_OP_FC || op == TAMD_OP_POOL; };
     for (auto& n : g->nodes) {
-        if (n.op != TAMD_OP_CONCAT) continue;
+        if (n.op != TAMD_OP_CONCAT || flat_concat[&n - g->nodes.data()]) continue;
         HTensor& y = g->tensors[n.out[0]];
         int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
         if (ax != 1 || y.dims.size() < 2) { set_error("concat %s: only the channel axis is supported on the device", n.name.c_str()); return -1; }
@@ -622,19 +708,7 @@ int plan_i8(tamd_graph* g)
             off += x.c;
         }
     }
-    // identity ops alias their input
-    std::vector<int> alias_of(g->tensors.size(), -1);
-    for (auto& n : g->nodes) {
-        if (n.op == TAMD_OP_DROPOUT || n.op == TAMD_OP_FLATTEN) {
-            HTensor& x = g->tensors[n.in[0]];
-            // Flatten of an H x W map: the [N, C*H*W] result is the SAME NCHW element order; on the device it stays the NHWC
-            // buffer and keeps the 4-D geometry, so a following FC (== conv whose kernel covers the map) and the NCHW
-            // output conversion both see (c, h, w)
-            alias_of[n.out[0]] = n.in[0];
-            HTensor& yy = g->tensors[n.out[0]];
-            yy.n = x.n; yy.c = x.c; yy.h = x.h; yy.w = x.w;
-        }
-    }
+    // (identity ops -- Dropout, Flatten -- alias their input: alias_of, set by the dense analysis above)
     // graph inputs: NCHW staging; first conv with <=4 channels reads NCHW directly
     for (auto& io : g->inputs) {
         HTensor& t = g->tensors[io.tensor];
@@ -695,6 +769,11 @@ int plan_i8(tamd_graph* g)
             for (int o : n.out) { const int r = root_of(o); birth[r] = std::min(birth[r], e); death[r] = std::max(death[r], ni); }
             for (int i : n.in) if (g->tensors[i].ttype != TAMD_TT_CONST) { const int r = root_of(i); death[r] = std::max(death[r], ni); }
         }
+        // an NHWC tensor that a flat Concat reads THROUGH its Permute (perm_src) is read at the Concat's position, not at the Permute's
+        for (int ni = 0; ni < NN; ni++)
+            if (flat_concat[ni])
+                for (int i : g->nodes[ni].in)
+                    if (perm_src[i] >= 0) { const int r = root_of(perm_src[i]); death[r] = std::max(death[r], ni); }
         std::vector<char> pinned(g->tensors.size(), 0);
         for (auto& io : g->inputs) pinned[root_of(io.tensor)] = 1;
         for (auto& io : g->outputs) pinned[root_of(io.tensor)] = 1;
@@ -799,8 +878,93 @@ int plan_i8(tamd_graph* g)
         switch (n.op) {
         case TAMD_OP_INPUT: case TAMD_OP_CONST: case TAMD_OP_DROPOUT: case TAMD_OP_FLATTEN:
             break;
+        case TAMD_OP_PERMUTE: {            // permute_ref.c:305-343, order (0, 2, 3, 1): a byte permutation -- written only when somebody reads it
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            if (perm_src[n.out[0]] >= 0) { g->fused_away[n.out[0]] = 1; break; }       // its Concat reads the NHWC buffer itself
+            FlatCatI8Args a{};
+            a.nsrc = 1; a.y = (int8_t*)y.dptr; a.outer = x.n; a.out_row = x.c * x.h * x.w; a.row_begin = 0; a.row_len = a.out_row;
+            a.src[0] = FlatCatI8Src{(const int8_t*)x.dptr + x.c_off, 1, a.out_row, x.c, x.h * x.w, x.cs, 0, 1.f, 1};
+            Step st; st.node = n.name; st.kernel = "permute_i8"; st.bytes = 2.0 * x.elems();
+            st.fn = [a](hipStream_t s) { return launch_flatcat_i8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_RESHAPE: {            // reshape_ref.c:76-90 (NCHW): the same bytes under another shape
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            if (alias_of[n.out[0]] >= 0) { if (perm_src[n.out[0]] >= 0) g->fused_away[n.out[0]] = 1; break; }     // dense input: a view
+            FlatCatI8Args a{};              // convolution-stack input: its NCHW element order, written once
+            a.nsrc = 1; a.y = (int8_t*)y.dptr; a.outer = x.n; a.out_row = x.c * x.h * x.w; a.row_begin = 0; a.row_len = a.out_row;
+            a.src[0] = FlatCatI8Src{(const int8_t*)x.dptr + x.c_off, 2, a.out_row, x.c, x.h * x.w, x.cs, 0, 1.f, 1};
+            Step st; st.node = n.name; st.kernel = "reshape_i8"; st.bytes = 2.0 * x.elems();
+            st.fn = [a](hipStream_t s) { return launch_flatcat_i8(a, s); };
+            g->steps.push_back(st);
+            break;
+        }
+        case TAMD_OP_PRIORBOX: {           // shapes only: evaluated here, once (graph_infer.hip priorbox_eval), quantised as priorbox_ref.c:195-210
+            HTensor& x = g->tensors[n.in[0]];
+            HTensor& y = g->tensors[n.out[0]];
+            const HTensor& img = g->tensors[n.in[1]];
+            if (y.scales.empty()) { set_error("priorbox %s: missing quant params", n.name.c_str()); return -1; }
+            std::vector<float> boxes;
+            std::vector<int8_t> q;
+            priorbox_eval(n.p.priorbox, x.dims[2], x.dims[3], img.dims[2], img.dims[3], &boxes);
+            if (boxes.size() != y.elems()) { set_error("priorbox %s: output shape mismatch", n.name.c_str()); return -1; }
+            priorbox_quant_i8(boxes, y.scales[0], &q);
+            HIPCHK(hipMemcpyAsync(y.dptr, q.data(), q.size(), hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+            y.prerun_const = true;
+            break;
+        }
         case TAMD_OP_CONCAT: {
             HTensor& y = g->tensors[n.out[0]];
+            if (flat_concat[ni]) {
+                // dense output: for every index in front of the axis each input is one contiguous run of the output's run; up to
+                // kFlatCatMax inputs per launch (the six SSD heads of a Concat: one launch), each read in the reference's element order
+                const int ax = n.p.concat.axis < 0 ? n.p.concat.axis + (int)y.dims.size() : n.p.concat.axis;
+                if (y.scales.empty()) { set_error("concat %s: missing quant params", n.name.c_str()); return -1; }
+                long outer = 1, inner = 1;
+                for (int d = 0; d < ax; d++) outer *= y.dims[d];
+                for (size_t d = ax + 1; d < y.dims.size(); d++) inner *= y.dims[d];
+                const int out_row = (int)(y.dims[ax] * inner);
+                bool all_const = true;
+                for (int i : n.in) all_const &= g->tensors[i].prerun_const;
+                int begin = 0;
+                for (size_t k0 = 0; k0 < n.in.size(); k0 += kFlatCatMax) {
+                    FlatCatI8Args a{};
+                    a.y = (int8_t*)y.dptr; a.outer = outer; a.out_row = out_row; a.row_begin = begin;
+                    Step st; st.node = n.name; st.kernel = "flatcat_i8"; st.once = all_const;
+                    for (size_t k = k0; k < std::min(n.in.size(), k0 + (size_t)kFlatCatMax); k++) {
+                        HTensor& x = g->tensors[n.in[k]];
+                        if (x.dtype != y.dtype || x.scales.empty()) { set_error("concat %s: input %s: dtype / quant params", n.name.c_str(), x.name.c_str()); return -1; }
+                        FlatCatI8Src s{};
+                        s.begin = begin; s.identity = n.in.size() == 1;            // concat_kernel_ref_int8.c:47-57: a single input is copied as it is
+                        volatile float rs = x.scales[0] / y.scales[0];             // :70 rescale = in_scale / out_scale
+                        s.rescale = rs;
+                        if (perm_src[n.in[k]] >= 0) {                              // Permute(0,2,3,1) (-> Flatten) of an NHWC tensor, read in place
+                            HTensor& p = g->tensors[perm_src[n.in[k]]];
+                            s.x = (const int8_t*)p.dptr + p.c_off; s.kind = 1; s.C = p.c; s.HW = p.h * p.w; s.cs = p.cs; s.chunk = p.c * p.h * p.w;
+                            if (p.n != outer) { set_error("concat %s: a permuted input on axis %d", n.name.c_str(), ax); return -1; }
+                            st.kernel = "permute_concat_i8";
+                        } else if (dense[n.in[k]]) {
+                            s.x = (const int8_t*)x.dptr; s.kind = 0; s.chunk = (int)(x.dims[ax] * inner);
+                        } else {                                                   // a convolution-stack tensor, read in NCHW element order
+                            s.x = (const int8_t*)x.dptr + x.c_off; s.kind = 2; s.C = x.c; s.HW = x.h * x.w; s.cs = x.cs;
+                            s.chunk = (int)((size_t)x.n * x.c * x.h * x.w / (size_t)outer);
+                        }
+                        a.src[a.nsrc++] = s;
+                        begin += s.chunk;
+                        st.bytes += 2.0 * outer * s.chunk;
+                    }
+                    a.row_len = begin - a.row_begin;
+                    st.fn = [a](hipStream_t s) { return launch_flatcat_i8(a, s); };
+                    g->steps.push_back(st);
+                }
+                if (begin != out_row) { set_error("concat %s: the inputs do not add up to the output", n.name.c_str()); return -1; }
+                y.prerun_const = all_const;
+                break;
+            }
             int off = 0;
             for (int i : n.in) {
                 HTensor& x = g->tensors[i];
@@ -924,6 +1088,36 @@ int plan_i8(tamd_graph* g)
             HTensor& x = g->tensors[n.in[0]];
             HTensor& y = g->tensors[n.out[0]];
             int ax = n.p.softmax.axis < 0 ? n.p.softmax.axis + (int)x.dims.size() : n.p.softmax.axis;
+            if (x.scales.empty() || y.scales.empty()) { set_error("softmax %s: missing quant params", n.name.c_str()); return -1; }
+            const bool general = dense[n.in[0]] || (x.dims.size() == 4 && (ax == 2 || ax == 3));
+            if (general) {
+                // round 6: any axis of a dense tensor (the SSD tail: Reshape -> Softmax(axis 2) on [N, priors, classes]) and the spatial
+                // axes of an NHWC tensor -- the same kernel with strided addressing (kernels.h: SoftmaxI8Args)
+                if (ax < 0 || ax >= (int)x.dims.size() || x.dims[ax] < 1 || x.dims[ax] > kSoftmaxI8MaxC) {
+                    set_error("softmax %s: axis %d of at most %d values", n.name.c_str(), ax, kSoftmaxI8MaxC);
+                    return -1;
+                }
+                SoftmaxI8Args a{};
+                a.x = (const int8_t*)x.dptr + x.c_off; a.y = (int8_t*)y.dptr + y.c_off;
+                a.C = x.dims[ax]; a.in_scale = x.scales[0]; a.out_scale = y.scales[0];
+                if (dense[n.in[0]]) {
+                    long outer = 1, inner = 1;
+                    for (int d = 0; d < ax; d++) outer *= x.dims[d];
+                    for (size_t d = ax + 1; d < x.dims.size(); d++) inner *= x.dims[d];
+                    a.positions = outer * inner; a.d1 = a.d2 = inner; a.is1 = a.os1 = (long)a.C * inner; a.is2 = a.os2 = 0; a.istride = a.ostride = inner;
+                } else if (ax == 3) {
+                    a.positions = (long)x.n * x.h * x.c; a.d1 = a.d2 = x.c;
+                    a.is1 = (long)x.w * x.cs; a.os1 = (long)y.w * y.cs; a.is2 = a.os2 = 0; a.istride = x.cs; a.ostride = y.cs;
+                } else {
+                    a.positions = (long)x.n * x.w * x.c; a.d1 = (long)x.w * x.c; a.d2 = x.c;
+                    a.is1 = (long)x.h * x.w * x.cs; a.os1 = (long)y.h * y.w * y.cs; a.is2 = x.cs; a.os2 = y.cs;
+                    a.istride = (long)x.w * x.cs; a.ostride = (long)y.w * y.cs;
+                }
+                Step st; st.node = n.name; st.kernel = "softmax_i8"; st.bytes = 2.0 * (double)x.elems();
+                st.fn = [a](hipStream_t s) { return launch_softmax_i8(a, s); };
+                g->steps.push_back(st);
+                break;
+            }
             if (ax != 1 || (x.dims.size() != 2 && x.dims.size() != 4) || x.c < 1 || x.c > kSoftmaxI8MaxC) {
                 set_error("softmax %s is not supported on the device: int8 softmax runs over the channel axis of a 2-D / 4-D tensor of at most %d channels",
                           n.name.c_str(), kSoftmaxI8MaxC);
@@ -997,6 +1191,7 @@ int plan_i8(tamd_graph* g)
         HTensor& t = g->tensors[io.tensor];
         io.bytes = t.elems() * esize(t.dtype);
         HIPCHK(hipHostMalloc(&io.pinned, io.bytes, hipHostMallocDefault));
+        if (t.nchw_raw) { io.stage = t.dptr; continue; }                 // dense tensors are the reference's element order already
         if (t.h * t.w == 1 && t.cs == t.c && t.c_off == 0) { io.stage = t.dptr; continue; }
         if (dev_alloc(g, &io.stage, io.bytes, true)) return -1;
         LayoutArgs a{(const int8_t*)t.dptr + t.c_off, io.stage, t.n, t.c, t.h, t.w, t.cs, esize(t.dtype)};

@@ -208,11 +208,19 @@ struct ReluArgs {
     const int8_t* x; int8_t* y; size_t count; float slope, in_scale, out_scale;
 };
 
-struct SoftmaxI8Args {     // softmax over the channels of an NHWC int8 tensor (a view's channel slice included)
+struct SoftmaxI8Args {     // softmax over ONE axis of an int8 tensor: the channels of an NHWC tensor (a view's channel slice included), or --
+                           // round 6 -- any axis of a dense (reference-order) or NHWC tensor
     const int8_t* x; int8_t* y;
-    long positions;        // N * H * W
-    int C, cs_in, cs_out;
+    long positions;        // the (outer, inner) index pairs: N * H * W for the channel axis
+    int C, cs_in, cs_out;  // C = length of the axis.  Position p starts at p * cs_in / p * cs_out ...
     float in_scale, out_scale;
+    // ... unless d1 > 0 (the general form): start = (p / d1) * s1 + ((p % d1) / d2) * s2 + (p % d2), element j of the axis `stride`
+    // bytes further on; i-fields for the input, o-fields for the output.  Dense [outer][A][inner]: d1 = d2 = inner, s1 = A * inner, s2 = 0,
+    // stride = inner.  NHWC over W: d1 = d2 = C, s1 = W * cs, stride = cs.  NHWC over H: d1 = W * C, d2 = C, s1 = H * W * cs, s2 = cs,
+    // stride = W * cs.
+    long d1, d2;
+    long is1, is2, os1, os2;
+    long istride, ostride;
 };
 constexpr int kSoftmaxI8MaxC = 16000;      // the axis' exponentials live in LDS as floats (<= 64 KB with the chain's padding)
 
@@ -222,6 +230,30 @@ struct CatCopyArgs {       // one concat input that cannot be written in place: 
     int C, cs_in, ldc, c_off;
     float rescale;         // in_scale / out_scale
     int identity;          // plain byte copy (single-input concat)
+};
+
+// ---- int8 tensors in the reference's DENSE element order (round 6: the SSD head plumbing of an int8 graph -- Permute(0,2,3,1), Flatten,
+// Reshape, Concat on any axis, PriorBox).  One launch copies up to kFlatCatMax inputs of a Concat into their slots of every outer slice
+// of the dense output, each read in the element order the reference sees and re-scaled as concat_kernel_ref_int8.c does.
+struct FlatCatI8Src {
+    const int8_t* x;
+    int kind;              // 0: dense, element e of outer slice o at o * chunk + e
+                           // 1: NHWC tensor seen through Permute(0,2,3,1) (+ Flatten): e = p * C + c   -> (o * HW + p) * cs + c
+                           // 2: NHWC tensor in NCHW element order: L = o * chunk + e = (n * C + c) * HW + p   -> (n * HW + p) * cs + c
+    int chunk;             // elements per outer slice
+    int C, HW, cs;
+    int begin;             // first element of this input inside an output slice
+    float rescale;         // in_scale / out_scale
+    int identity;          // plain byte copy (single-input concat, a lone Permute / layout copy)
+};
+constexpr int kFlatCatMax = 8;
+struct FlatCatI8Args {
+    FlatCatI8Src src[kFlatCatMax];
+    int nsrc;
+    int8_t* y;
+    long outer;
+    int out_row;           // elements of one outer slice of the output
+    int row_begin, row_len;   // this launch covers [row_begin, row_begin + row_len) of every slice
 };
 
 struct LayoutArgs {        // NCHW <-> NHWC(cs) int8 / generic element size
@@ -282,6 +314,7 @@ hipError_t launch_eltwise(const EltArgs& a, hipStream_t s);
 hipError_t launch_relu(const ReluArgs& a, hipStream_t s);
 hipError_t launch_softmax_i8(const SoftmaxI8Args& a, hipStream_t s);
 hipError_t launch_concat_copy_i8(const CatCopyArgs& a, hipStream_t s);
+hipError_t launch_flatcat_i8(const FlatCatI8Args& a, hipStream_t s);
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // 16-byte aligned buffers
 hipError_t launch_nchw_to_nhwc(const LayoutArgs& a, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const LayoutArgs& a, hipStream_t s);

@@ -221,6 +221,48 @@ hipError_t launch_concat_copy_i8(const CatCopyArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- dense int8 tensors (round 6): Permute(0,2,3,1) (permute_ref.c:305-343, a byte permutation), Flatten (flatten_ref.c:74-80) and
+// Reshape (reshape_ref.c, NCHW: byte copies) are views of what this kernel writes; Concat re-scales like concat_copy_i8 above
+// (concat_kernel_ref_int8.c: the same text at every rank / axis, the +127 lower clamp included).  One thread per output byte.
+__global__ __launch_bounds__(256) void flatcat_i8_kernel(FlatCatI8Args a)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.outer * a.row_len) return;
+    const long o = idx / a.row_len;
+    const int r = a.row_begin + (int)(idx - o * a.row_len);
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kFlatCatMax; k++)
+        if (k < a.nsrc && r >= a.src[k].begin) si = k;
+    const FlatCatI8Src& s = a.src[si];
+    const int e = r - s.begin;
+    size_t at;
+    if (s.kind == 0) at = (size_t)o * s.chunk + e;
+    else if (s.kind == 1) at = ((size_t)o * s.HW + e / s.C) * s.cs + e % s.C;
+    else {
+        const size_t L = (size_t)o * s.chunk + e, img = (size_t)s.C * s.HW;
+        const size_t n = L / img, rem = L - n * img;
+        at = (n * s.HW + rem % s.HW) * s.cs + rem / s.HW;
+    }
+    const int x = s.x[at];
+    int q = x;
+    if (!s.identity) {
+        q = (int)roundf(__fmul_rn((float)x, s.rescale));
+        if (q > 127) q = 127;
+        else if (q < -127) q = 127;
+    }
+    a.y[(size_t)o * a.out_row + r] = (int8_t)q;
+}
+
+hipError_t launch_flatcat_i8(const FlatCatI8Args& a, hipStream_t s)
+{
+    if (a.nsrc < 1 || a.nsrc > kFlatCatMax) return hipErrorInvalidValue;
+    const long total = a.outer * a.row_len;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(flatcat_i8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- relu / leaky relu: relu/relu_kernel_ref_int8.c:40-94 -------------------------------------------
 __global__ __launch_bounds__(256) void relu_i8_kernel(ReluArgs a)
 {
@@ -283,10 +325,12 @@ __global__ __launch_bounds__(64 * TW * TPB) void softmax_i8_kernel(SoftmaxI8Args
             __syncthreads();
         }
     };
-    const int8_t* x = a.x + (size_t)p * a.cs_in;
-    int8_t* y = a.y + (size_t)p * a.cs_out;
+    // where position p starts and how far apart the axis' elements are (kernels.h: SoftmaxI8Args; d1 == 0: the contiguous channel axis)
+    const long xs = a.d1 > 0 ? a.istride : 1, ys = a.d1 > 0 ? a.ostride : 1;
+    const int8_t* x = a.d1 > 0 ? a.x + (size_t)((p / a.d1) * a.is1 + ((p % a.d1) / a.d2) * a.is2 + (p % a.d2)) : a.x + (size_t)p * a.cs_in;
+    int8_t* y = a.d1 > 0 ? a.y + (size_t)((p / a.d1) * a.os1 + ((p % a.d1) / a.d2) * a.os2 + (p % a.d2)) : a.y + (size_t)p * a.cs_out;
     float mx = -__builtin_inff();
-    for (int j = tid; j < a.C; j += T) mx = fmaxf(mx, __fmul_rn((float)x[j], a.in_scale));
+    for (int j = tid; j < a.C; j += T) mx = fmaxf(mx, __fmul_rn((float)x[j * xs], a.in_scale));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     if constexpr (TW > 1) {
@@ -296,7 +340,7 @@ __global__ __launch_bounds__(64 * TW * TPB) void softmax_i8_kernel(SoftmaxI8Args
         for (int w = 0; w < TW; w++) mx = fmaxf(mx, red[w]);
     }
     for (int j = tid; j < pitch; j += T)
-        e[j] = j < a.C ? (float)exp((double)__fsub_rn(__fmul_rn((float)x[j], a.in_scale), mx)) : 0.f;
+        e[j] = j < a.C ? (float)exp((double)__fsub_rn(__fmul_rn((float)x[j * xs], a.in_scale), mx)) : 0.f;
     team_sync();
     float sum = 0.f;
     if (tid == 0) {
@@ -322,7 +366,7 @@ __global__ __launch_bounds__(64 * TW * TPB) void softmax_i8_kernel(SoftmaxI8Args
     }
     if constexpr (TW == 1) sum = __shfl(sum, 0, 64);
     else { __syncthreads(); sum = red[TW]; }
-    for (int j = tid; j < a.C; j += T) y[j] = (int8_t)round_sat(__fdiv_rn(__fdiv_rn(e[j], sum), a.out_scale));
+    for (int j = tid; j < a.C; j += T) y[j * ys] = (int8_t)round_sat(__fdiv_rn(__fdiv_rn(e[j], sum), a.out_scale));
 }
 
 hipError_t launch_softmax_i8(const SoftmaxI8Args& a, hipStream_t s)

@@ -93,10 +93,10 @@ int map_op(int op)
 const int kSupportedOps[] = {OP_INPUT, OP_CONST, OP_CONV, OP_FC, OP_POOL, OP_RELU, OP_ELTWISE, OP_CONCAT, OP_DROPOUT, OP_UPSAMPLE,
                              OP_SOFTMAX, OP_RELU6};
 
-// SSD head plumbing (Permute -> Flatten -> Concat): on the device for uint8 graphs only, so these two are added to
-// the allowed list per graph (hip_split_graph) instead of globally -- an int8 / fp32 graph keeps them on the CPU
-// without dragging the convolutions around them back there
-const int kUint8OnlyOps[] = {OP_PERMUTE, OP_FLATTEN, OP_RESHAPE, OP_PRIORBOX};
+// SSD head plumbing (Permute -> Flatten -> Concat, Reshape, PriorBox): on the device for the QUANTISED graphs (uint8 since round 3,
+// int8 since round 6: csrc/graph_plan.hip "dense tensors"), so these are added to the allowed list per graph (hip_split_graph)
+// instead of globally -- an fp32 graph keeps them on the CPU without dragging the convolutions around them back there
+const int kQuantisedOnlyOps[] = {OP_PERMUTE, OP_FLATTEN, OP_RESHAPE, OP_PRIORBOX};
 
 // struct priorbox_param (priorbox_param.h:28-52, float vectors on the heap) -> the inline-array form of the C ABI
 bool translate_priorbox(const struct priorbox_param* p, tamd_priorbox_param* q)
@@ -118,8 +118,8 @@ bool op_supported(int op, int dtype)
 {
     for (int o : kSupportedOps)
         if (o == op) return true;
-    if (dtype == TENGINE_DT_UINT8)
-        for (int o : kUint8OnlyOps)
+    if (dtype == TENGINE_DT_UINT8 || dtype == TENGINE_DT_INT8)
+        for (int o : kQuantisedOnlyOps)
             if (o == op) return true;
     return false;
 }
@@ -833,7 +833,7 @@ int hip_split_graph(struct graph* ir_graph)
         struct node* in_node = get_ir_graph_node(ir_graph, ir_graph->input_nodes[0]);
         if (in_node->output_num > 0) graph_dt = get_ir_graph_tensor(ir_graph, in_node->output_tensors[0])->data_type;
     }
-    if (graph_dt == TENGINE_DT_UINT8) {          // the uint8-only operators join the allowed list for this graph
+    if (graph_dt == TENGINE_DT_UINT8 || graph_dt == TENGINE_DT_INT8) {          // the quantised-only operators join the allowed list for this graph
         release_vector(allowed_ops);
         release_vector(blocked_ops);
         allowed_ops = create_vector(sizeof(int), nullptr);

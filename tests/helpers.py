@@ -405,7 +405,9 @@ def priorbox_graph(seed, dtype, img_h, img_w, feats, min_sizes, max_sizes, ratio
     rng = np.random.default_rng(seed)
     g = Graph(name="priorbox_case")
     u8 = dtype == tm2.DT_UINT8
-    qa = dict(scales=[float(np.float32(0.02))], zps=[int(rng.integers(100, 150))]) if u8 else dict(scales=None, zps=None)
+    if dtype == tm2.DT_INT8:         # round 6: symmetric int8 (priorbox_ref.c:195-210 rounds, the uint8 form truncates); q[0] doubles as its scale
+        u8, q = True, (float(np.float32(1.0 / 127.0)) * (q[0] * 255.0 / 2.0), 0)
+    qa = dict(scales=[float(np.float32(0.02))], zps=[int(rng.integers(100, 150)) if dtype != tm2.DT_INT8 else 0]) if u8 else dict(scales=None, zps=None)
     x = g.add_input("data", [1, 3, img_h, img_w], dtype, qa["scales"], qa["zps"])
     pbs = []
     for i, (fh, fw) in enumerate(feats):
@@ -428,9 +430,11 @@ def priorbox_graph(seed, dtype, img_h, img_w, feats, min_sizes, max_sizes, ratio
         total = sum(g.tensors[t].dims[2] for t in pbs)
         # a different output scale on purpose: the (once-only) concat launch requantises like any other uint8 concat
         cat = g.add_tensor("mbox_priorbox", [1, 2, total, 1], dtype, tm2.TT_VAR, None,
-                           [float(np.float32(q[0] * 1.25))] if u8 else None, [int(q[1]) - 9] if u8 else None)
+                           [float(np.float32(q[0] * 1.25))] if u8 else None, [int(q[1]) - 9 if dtype != tm2.DT_INT8 else 0] if u8 else None)
         ni = g.add_node("mbox_priorbox", "Concat", pbs, [cat], axis=2)
         g.output_nodes = [ni]
+    if dtype == tm2.DT_INT8:
+        return g, rng.integers(-127, 128, size=(1, 3, img_h, img_w)).astype(np.int8)
     xin = rng.integers(0, 256, size=(1, 3, img_h, img_w)).astype(np.uint8) if u8 else \
         rng.uniform(-1, 1, size=(1, 3, img_h, img_w)).astype(np.float32)
     return g, xin
@@ -583,3 +587,72 @@ class pinned:
 
     def __exit__(self, *a):
         restore_pins(self.old)
+
+
+# ---- int8 head plumbing (round 6): Permute / Flatten / Reshape / Concat / Softmax behind a convolution ----------------------------
+def i8_head_graph(seed, n, cin, h, w, couts=(12, 21), tail="concat", same_q=False, softmax_axis=None):
+    """int8: data -> len(couts) 1x1 convolutions (channel counts that are NOT multiples of 16, like the SSD heads) -> per head
+    `tail`:
+      "concat"   Permute(0,2,3,1) -> Flatten -> ONE Concat on axis 1 (per-input rescale unless same_q)      [the SSD head]
+      "permute"  the graph ends at the first head's Permute
+      "flatcat"  Flatten (NCHW order, no Permute) -> Concat on axis 1
+      "reshape"  Reshape of the first head to [n, h*w, cout] (after Permute) -> Softmax over `softmax_axis` (1 | 2) -> Flatten
+      "softmax4" Softmax over axis `softmax_axis` (1 | 2 | 3) of the first head's 4-D map"""
+    rng = np.random.default_rng(seed)
+    g = Graph(name="i8_head_case")
+    xs = float(np.float32(rng.uniform(0.01, 0.05)))
+    x = g.add_input("data", [n, cin, h, w], DT_INT8, [xs], [0])
+    cat_s = float(np.float32(xs * 7.0))
+    flats = []
+    for i, cout in enumerate(couts):
+        wq = rng.integers(-127, 128, size=(cout, cin, 1, 1)).astype(np.int8)
+        ws = _scales(rng, cout)
+        bq = rng.integers(-2000, 2000, size=(cout,)).astype(np.int32)
+        ins = [x, g.add_const("w%d" % i, wq, DT_INT8, ws, [0] * cout), g.add_const("b%d" % i, bq, DT_INT32, [1.0], [0])]
+        os_ = cat_s if same_q else float(np.float32(xs * np.mean(ws) * 73.0 * np.sqrt(cin) * 73.0 / 60.0 * (1.0 + 0.4 * i)))
+        y = g.add_tensor("head%d" % i, [n, cout, h, w], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        g.add_node("head%d" % i, "Convolution", ins, [y], kernel_h=1, kernel_w=1, stride_h=1, stride_w=1, dilation_h=1, dilation_w=1,
+                   input_channel=cin, output_channel=cout, group=1, activation=-1, pad_h0=0, pad_w0=0, pad_h1=0, pad_w1=0)
+        if tail == "softmax4":
+            sm = g.add_tensor("prob", [n, cout, h, w], DT_INT8, tm2.TT_VAR, None, [float(np.float32(1.0 / 127.0))], [0])
+            g.output_nodes = [g.add_node("prob", "Softmax", [y], [sm], axis=softmax_axis)]
+            return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+        if tail == "flatcat":
+            fl = g.add_tensor("flat%d" % i, [n, cout * h * w], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+            g.add_node("flat%d" % i, "Flatten", [y], [fl], axis=1, end_axis=3)
+            flats.append(fl)
+            continue
+        pm = g.add_tensor("perm%d" % i, [n, h, w, cout], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        pi = g.add_node("perm%d" % i, "Permute", [y], [pm], flag=0, order=[0, 2, 3, 1])
+        if tail == "permute":
+            g.output_nodes = [pi]
+            return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+        if tail == "reshape":
+            rs = g.add_tensor("rs", [n, h * w, cout], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+            g.add_node("rs", "Reshape", [pm], [rs], is_mxnet=0, reverse=0, is_onnx=1, re_shape=[0, -1, cout])
+            sm = g.add_tensor("prob", [n, h * w, cout], DT_INT8, tm2.TT_VAR, None, [float(np.float32(1.0 / 127.0))], [0])
+            g.add_node("prob", "Softmax", [rs], [sm], axis=softmax_axis)
+            fl = g.add_tensor("prob_flat", [n, h * w * cout], DT_INT8, tm2.TT_VAR, None, [float(np.float32(1.0 / 127.0))], [0])
+            g.output_nodes = [g.add_node("prob_flat", "Flatten", [sm], [fl], axis=1, end_axis=2)]
+            return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+        fl = g.add_tensor("flat%d" % i, [n, h * w * cout], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+        g.add_node("flat%d" % i, "Flatten", [pm], [fl], axis=1, end_axis=3)
+        flats.append(fl)
+    total = sum(g.tensors[f].dims[1] for f in flats)
+    cc = g.add_tensor("mbox", [n, total], DT_INT8, tm2.TT_VAR, None, [cat_s], [0])
+    g.output_nodes = [g.add_node("mbox", "Concat", flats, [cc], axis=1)]
+    return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
+
+
+I8_HEAD_CASES = {
+    "ssd_head_two_maps": dict(seed=1, n=2, cin=24, h=5, w=7, couts=(12, 21), tail="concat"),
+    "ssd_head_same_scale_ten_inputs": dict(seed=2, n=1, cin=16, h=3, w=3, couts=(4, 6, 12, 5, 7, 9, 3, 8, 10, 11), tail="concat", same_q=True),
+    "ssd_head_rescaled_ten_inputs": dict(seed=3, n=3, cin=16, h=2, w=3, couts=(4, 6, 12, 5, 7, 9, 3, 8, 10, 11), tail="concat"),
+    "standalone_permute": dict(seed=4, n=2, cin=8, h=4, w=6, couts=(20,), tail="permute"),
+    "flatten_maps_then_concat": dict(seed=5, n=2, cin=8, h=3, w=5, couts=(12, 32), tail="flatcat"),
+    "reshape_softmax_last_axis": dict(seed=6, n=2, cin=8, h=4, w=5, couts=(21,), tail="reshape", softmax_axis=2),
+    "reshape_softmax_middle_axis": dict(seed=7, n=1, cin=8, h=3, w=4, couts=(6,), tail="reshape", softmax_axis=1),
+    "softmax_over_h": dict(seed=8, n=2, cin=8, h=6, w=5, couts=(12,), tail="softmax4", softmax_axis=2),
+    "softmax_over_w": dict(seed=9, n=2, cin=8, h=4, w=9, couts=(32,), tail="softmax4", softmax_axis=3),
+    "softmax_over_c_padded": dict(seed=10, n=2, cin=8, h=4, w=3, couts=(21,), tail="softmax4", softmax_axis=1),
+}

@@ -84,12 +84,12 @@ def test_wrong_input_size_is_an_error():
 
 
 def test_unsupported_op_fails_loudly_at_prerun():
-    """an int8 Softmax over a spatial axis has no device kernel (NHWC tensors: only the channel axis is contiguous): prerun must
-    fail with a message, never run something else."""
+    """an int8 Softmax over the batch axis has no device kernel (until round 5 this test used a spatial axis; those run since round 6):
+    prerun must fail with a message, never run something else."""
     g, x = conv_graph(5, 1, 32, 6, 6, 10, 1, act=-1)
     y = g.nodes[-1].outputs[0]
     o = g.add_tensor("prob", list(g.tensors[y].dims), tm2.DT_INT8, tm2.TT_VAR, None, [1.0 / 127.0], [0])
-    ni = g.add_node("softmax", "Softmax", [y], [o], axis=2)
+    ni = g.add_node("softmax", "Softmax", [y], [o], axis=0)
     g.output_nodes = [ni]
     with pytest.raises(RuntimeError) as e:
         capi.Graph(tm2.write_tm2(g))
