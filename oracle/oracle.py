@@ -371,6 +371,10 @@ def run_graph(g, x, keep_all=False, teacher=None, report=None):
             y = softmax_int8(a, p.get("axis", 1), sc(i0), sc(o0))
         elif op == "Flatten":       # flatten/flatten_ref.c:53-77: element copy; shape [n, prod(rest)] (flatten.c:34-61)
             y = a.reshape(a.shape[0], -1)
+        elif op == "Concat" and dt in (DT_UINT8, DT_INT8) and len(n.inputs) == 1:
+            # concat_kernel_ref_int8.c:47-57 / concat_kernel_ref_uint8.c:47-58: a SINGLE input is copied byte for byte, whatever the
+            # two tensors' quantisation says (found in round 6 by tools/fuzz_heads.py --ref: the restatement used to rescale it)
+            y = vals[n.inputs[0]].reshape(g.tensors[o0].dims).copy()
         elif op == "Concat" and dt == DT_UINT8:
             y = np.concatenate([requant_copy_uint8(vals[i], qp(i), qp(o0)) for i in n.inputs], axis=p.get("axis", 1))
         elif op == "Concat" and dt == DT_INT8:

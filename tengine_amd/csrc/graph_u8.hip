@@ -852,7 +852,9 @@ int plan_u8(tamd_graph* g)
                 a.N = (int)outer; a.in_img = in_img; a.out_img = out_img; a.out_off = off;
                 if (q_of(x, &a.in, "tensor") || q_of(y, &a.out, "tensor")) return -1;
                 // roundf((u - zp) * 1 + zp) == u: equal parameters make the rescale a copy
-                a.identity = a.in.scale == a.out.scale && a.in.zp == a.out.zp;
+                // (.. and a SINGLE input is copied byte for byte whatever the quantisation says: concat_kernel_ref_uint8.c:47-58 --
+                //  round 6, found by tools/fuzz_heads.py on the int8 twin of this rule)
+                a.identity = (a.in.scale == a.out.scale && a.in.zp == a.out.zp) || n.in.size() == 1;
                 const char* kname = "concat_u8";
                 if (perm_src[i] >= 0) {                                  // Permute(0,2,3,1) -> Flatten -> this concat
                     HTensor& s = g->tensors[perm_src[i]];

@@ -656,3 +656,22 @@ I8_HEAD_CASES = {
     "softmax_over_w": dict(seed=9, n=2, cin=8, h=4, w=9, couts=(32,), tail="softmax4", softmax_axis=3),
     "softmax_over_c_padded": dict(seed=10, n=2, cin=8, h=4, w=3, couts=(21,), tail="softmax4", softmax_axis=1),
 }
+
+
+def single_input_concat_graph(seed, dtype, dims=(2, 12, 5, 4)):
+    """data -> leaky ReLU (own quantisation) -> Concat of that ONE tensor into an output with ANOTHER scale / zero point: the reference
+    copies the bytes as they are (concat_kernel_ref_int8.c:47-57, concat_kernel_ref_uint8.c:47-58) -- it does not rescale a lone input"""
+    rng = np.random.default_rng(seed)
+    u8 = dtype == tm2.DT_UINT8
+    g = Graph(name="single_input_concat_case")
+    x = g.add_input("data", list(dims), dtype, [0.03], [120 if u8 else 0])
+    r = g.add_tensor("r", list(dims), dtype, tm2.TT_VAR, None, [0.041], [97 if u8 else 0])
+    g.add_node("relu", "ReLU", [x], [r], negative_slope=0.25)
+    y = g.add_tensor("cat", list(dims), dtype, tm2.TT_VAR, None, [0.07], [131 if u8 else 0])
+    g.output_nodes = [g.add_node("cat", "Concat", [r], [y], axis=1)]
+    xin = rng.integers(0, 256, size=dims).astype(np.uint8) if u8 else rng.integers(-127, 128, size=dims).astype(np.int8)
+    return g, xin
+
+
+I8_HEAD_CASES["single_head_concat_is_a_copy"] = dict(seed=11, n=2, cin=16, h=3, w=4, couts=(21,), tail="concat")
+I8_HEAD_CASES["single_flattened_map_concat_is_a_copy"] = dict(seed=12, n=2, cin=16, h=3, w=4, couts=(24,), tail="flatcat")

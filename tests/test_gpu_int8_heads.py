@@ -5,7 +5,7 @@ Device against the oracle (tests/test_int8_heads_oracle.py pins the oracle to th
 import numpy as np
 import pytest
 
-from helpers import I8_HEAD_CASES, PRIORBOX_CASES, i8_head_graph, priorbox_graph
+from helpers import I8_HEAD_CASES, PRIORBOX_CASES, i8_head_graph, priorbox_graph, single_input_concat_graph
 from oracle import oracle
 from tengine_amd import capi, models, tm2
 
@@ -103,3 +103,14 @@ def test_int8_priorbox_cases(case):
     for w, o in zip(want, got):
         assert np.array_equal(np.asarray(w).ravel(), o.ravel()), case
     assert "flatcat_i8" not in kernels, kernels
+
+
+@pytest.mark.parametrize("dtype", ["int8", "uint8"])
+def test_a_single_input_concat_is_a_byte_copy_on_the_device(dtype):
+    """concat_kernel_ref_int8.c:47-57 / concat_kernel_ref_uint8.c:47-58: a lone input is copied as it is, not rescaled (the uint8 planner
+    rescaled it until round 6; tests/test_int8_heads_oracle.py pins the oracle's side of this to the real reference)"""
+    dt = tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8
+    g, x = single_input_concat_graph(3, dt)
+    want = oracle.run_graph(g, x)[0]
+    got, _ = run_device(g, x)
+    assert np.array_equal(np.asarray(want).ravel(), got[0].ravel())
