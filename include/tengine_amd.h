@@ -58,12 +58,14 @@ enum {
     TAMD_OP_UPSAMPLE = 9,/* param: tamd_upsample_param */
     TAMD_OP_RELU6 = 10,
     TAMD_OP_FLATTEN = 11,
-    TAMD_OP_SOFTMAX = 12, /* param: tamd_softmax_param (NULL: axis 1); fp32 / uint8 graphs: any axis; int8 graphs (NHWC on the
-                           * device): the channel axis of a 2-D / 4-D tensor, <= 16000 channels (softmax_kernel_ref_int8.c)   */
-    TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 graphs, order (0,2,3,1) -- the SSD head permute */
-    TAMD_OP_RESHAPE = 14, /* param: tamd_reshape_param; uint8 / fp32 graphs (dense NCHW on the device: a view)        */
-    TAMD_OP_PRIORBOX = 15,/* param: tamd_priorbox_param; uint8 / fp32 graphs, batch 1.  Depends on shapes only: evaluated ONCE
-                           * at prerun (priorbox_ref.c:53-199 re-computes the same numbers at every run), no launch at run   */
+    TAMD_OP_SOFTMAX = 12, /* param: tamd_softmax_param (NULL: axis 1); fp32 / uint8 graphs: any axis; int8 graphs: any axis >= 1 of a
+                           * 2-D / 3-D / 4-D tensor, <= 16000 values along it (softmax_kernel_ref_int8.c:41-117; the spatial axes of an
+                           * NHWC tensor and the axes of a dense tensor since round 6)                                               */
+    TAMD_OP_PERMUTE = 13, /* param: tamd_permute_param; uint8 and (round 6) int8 graphs, order (0,2,3,1) -- the SSD head permute */
+    TAMD_OP_RESHAPE = 14, /* param: tamd_reshape_param; a view of a dense tensor (uint8 / fp32 graphs; int8 since round 6: what a
+                           * Permute / Flatten / Reshape / PriorBox / flat Concat produces is dense on the device)                  */
+    TAMD_OP_PRIORBOX = 15,/* param: tamd_priorbox_param; uint8 / fp32 and (round 6) int8 graphs, batch 1.  Depends on shapes only:
+                           * evaluated ONCE at prerun (priorbox_ref.c:53-213 re-computes the same numbers at every run), no launch   */
     TAMD_OP_NUM
 };
 

@@ -213,10 +213,11 @@ int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, size_t s
     Step& sb = g->steps[s0 + 1];
     const bool autotune = autotune_enabled() && sa.macs >= 4e6;
     size_t best = 0;
-    // fused by construction (no race): a link of a LATENCY chain only -- batch 1, or a pair whose launches cannot fill the machine
-    // (<= 32 k pixels AND at most 256 pixel rows of 64, i.e. fewer blocks than CUs).  Batch 8 at 56x56 or batch 16 at 19x19 are
-    // throughput launches: they keep the race against the two-launch plan below
-    bool fuse = fmode == 2 || ((double)a.N * a.H * a.W <= 32768.0 && (a.N == 1 || (double)a.N * a.H * a.W <= 256.0 * 64.0));
+    // fused by construction (no race): a link of a LATENCY chain only -- batch 1.  Everything batched keeps the race against the two-launch
+    // plan below (batch 8 at 56x56 or batch 16 at 19x19 are throughput launches; round 6's first evidence pass showed what the
+    // wider rule costs where the race is skipped: MobileNet-v1 b64's 7x7 tail fused by construction ran conv6/sep + pool6 in 34.9 us
+    // against 9.9 + 3.5 us as two launches, and conv5_6/sep + conv6/dw in 18.5 against 7.5 + 5.8 -- 287 instead of 265 us per step)
+    bool fuse = fmode == 2 || (a.N == 1 && (double)a.N * a.H * a.W <= 32768.0);
     // cost model inputs below use the map the tail reads (a.H x a.W) and the reduction depth
     char ckey[256];
     snprintf(ckey, sizeof(ckey), "pwdw|%s|n%d %dx%d k%d m%d f%d c%zu", sa.node.c_str(), a.N, a.H, a.W, a.ktot, tmode, fmode, cfgs.size());

@@ -597,7 +597,8 @@ def i8_head_graph(seed, n, cin, h, w, couts=(12, 21), tail="concat", same_q=Fals
       "permute"  the graph ends at the first head's Permute
       "flatcat"  Flatten (NCHW order, no Permute) -> Concat on axis 1
       "reshape"  Reshape of the first head to [n, h*w, cout] (after Permute) -> Softmax over `softmax_axis` (1 | 2) -> Flatten
-      "softmax4" Softmax over axis `softmax_axis` (1 | 2 | 3) of the first head's 4-D map"""
+      "softmax4" Softmax over axis `softmax_axis` (1 | 2 | 3) of the first head's 4-D map
+      "reshape_map" Reshape of the first head's NCHW map (no Permute) to [n, cout*h, w] -> Softmax over `softmax_axis`"""
     rng = np.random.default_rng(seed)
     g = Graph(name="i8_head_case")
     xs = float(np.float32(rng.uniform(0.01, 0.05)))
@@ -622,6 +623,12 @@ def i8_head_graph(seed, n, cin, h, w, couts=(12, 21), tail="concat", same_q=Fals
             g.add_node("flat%d" % i, "Flatten", [y], [fl], axis=1, end_axis=3)
             flats.append(fl)
             continue
+        if tail == "reshape_map":       # Reshape of the NCHW map itself (no Permute): [n, cout * h, w] -> Softmax over the last axis -> graph output
+            rs = g.add_tensor("rs", [n, cout * h, w], DT_INT8, tm2.TT_VAR, None, [os_], [0])
+            g.add_node("rs", "Reshape", [y], [rs], is_mxnet=0, reverse=0, is_onnx=1, re_shape=[0, -1, w])
+            sm = g.add_tensor("prob", [n, cout * h, w], DT_INT8, tm2.TT_VAR, None, [float(np.float32(1.0 / 127.0))], [0])
+            g.output_nodes = [g.add_node("prob", "Softmax", [rs], [sm], axis=softmax_axis)]
+            return g, rng.integers(-127, 128, size=(n, cin, h, w)).astype(np.int8)
         pm = g.add_tensor("perm%d" % i, [n, h, w, cout], DT_INT8, tm2.TT_VAR, None, [os_], [0])
         pi = g.add_node("perm%d" % i, "Permute", [y], [pm], flag=0, order=[0, 2, 3, 1])
         if tail == "permute":
@@ -675,3 +682,5 @@ def single_input_concat_graph(seed, dtype, dims=(2, 12, 5, 4)):
 
 I8_HEAD_CASES["single_head_concat_is_a_copy"] = dict(seed=11, n=2, cin=16, h=3, w=4, couts=(21,), tail="concat")
 I8_HEAD_CASES["single_flattened_map_concat_is_a_copy"] = dict(seed=12, n=2, cin=16, h=3, w=4, couts=(24,), tail="flatcat")
+I8_HEAD_CASES["reshape_of_a_map_softmax"] = dict(seed=13, n=2, cin=8, h=3, w=7, couts=(12,), tail="reshape_map", softmax_axis=2)
+I8_HEAD_CASES["reshape_of_a_map_softmax_middle"] = dict(seed=14, n=2, cin=8, h=2, w=5, couts=(20,), tail="reshape_map", softmax_axis=1)
