@@ -136,17 +136,22 @@ def test_node_supported_query():
     elt = (C.c_int * 5)(9, 0, 0, 0, 0)                                          # an eltwise type the device does not run
     assert ask(6, [a, a], [a], elt) == 0
     assert ask(12, [a], [a]) == 1                                               # softmax int8: over the channel axis (NHWC on the device)
-    assert ask(12, [a], [a], (C.c_int * 1)(2)) == 0                             # .. any other axis stays on the CPU
+    assert ask(12, [a], [a], (C.c_int * 1)(2)) == 1                             # .. the spatial axes too since round 6 (strided addressing)
+    assert ask(12, [a], [a], (C.c_int * 1)(0)) == 0                             # .. the batch axis stays on the CPU
     assert ask(12, [a], [a], (C.c_int * 1)(-3)) == 1
     assert ask(12, [t(I8, VAR, [2, 1000])], [t(I8, VAR, [2, 1000])], (C.c_int * 1)(-1)) == 1
-    assert ask(12, [t(I8, VAR, [2, 5, 1000])], [t(I8, VAR, [2, 5, 1000])], (C.c_int * 1)(1)) == 0     # 3-D: no NHWC geometry
+    assert ask(12, [t(I8, VAR, [2, 5, 1000])], [t(I8, VAR, [2, 5, 1000])], (C.c_int * 1)(1)) == 1     # 3-D (a Reshape result: dense on the device), round 6
+    assert ask(12, [t(I8, VAR, [2, 5, 1000])], [t(I8, VAR, [2, 5, 1000])], (C.c_int * 1)(2)) == 1
     assert ask(12, [t(I8, VAR, [1, 20000])], [t(I8, VAR, [1, 20000])]) == 0     # the axis must fit a wave's LDS slice
     assert ask(12, [t(F32, VAR, [1, 8], 0)], [t(F32, VAR, [1, 8], 0)]) == 1
-    # uint8 / fp32 device tensors are dense NCHW: concat on any axis; int8 (NHWC blocks): channels only
+    # uint8 / fp32 device tensors are dense NCHW: concat on any axis; int8 (NHWC blocks): channels -- and, since round 6, the PriorBox layout
+    # [1][2][K][1] on axis 2 and tensors of other ranks (dense on the device)
     cat2 = (C.c_int * 1)(2)
     ua = t(U8, VAR, [1, 2, 100, 1])
     assert ask(7, [ua, ua], [t(U8, VAR, [1, 2, 200, 1])], cat2) == 1
-    assert ask(7, [t(I8, VAR, [1, 2, 100, 1])] * 2, [t(I8, VAR, [1, 2, 200, 1])], cat2) == 0
+    assert ask(7, [t(I8, VAR, [1, 2, 100, 1])] * 2, [t(I8, VAR, [1, 2, 200, 1])], cat2) == 1
+    assert ask(7, [t(I8, VAR, [2, 8, 4, 4])] * 2, [t(I8, VAR, [2, 8, 8, 4])], cat2) == 0                  # rows of a convolution-stack map: CPU
+    assert ask(7, [t(I8, VAR, [2, 30, 7])] * 2, [t(I8, VAR, [2, 30, 14])], cat2) == 1
 
     class PB(C.Structure):         # tamd_priorbox_param
         _fields_ = [("min_size_num", C.c_int), ("max_size_num", C.c_int), ("aspect_ratio_num", C.c_int), ("min_size", C.c_float * 8),
@@ -159,7 +164,11 @@ def test_node_supported_query():
     assert ask(15, [feat, img], [t(U8, VAR, [1, 2, 600, 1])], pb) == 1
     assert ask(15, [feat, img], [t(U8, VAR, [2, 2, 600, 1])], pb) == 0           # batch > 1: undefined in the reference
     assert ask(15, [feat], [t(U8, VAR, [1, 2, 600, 1])], pb) == 0                # needs the image tensor too
-    assert ask(15, [t(I8, VAR, [1, 64, 5, 5]), t(I8, VAR, [1, 3, 80, 80])], [t(I8, VAR, [1, 2, 600, 1])], pb) == 0   # int8 graphs: CPU
+    assert ask(15, [t(I8, VAR, [1, 64, 5, 5]), t(I8, VAR, [1, 3, 80, 80])], [t(I8, VAR, [1, 2, 600, 1])], pb) == 1   # int8 graphs too since round 6
+    perm = (C.c_int * 4)(0, 2, 3, 1)
+    assert ask(13, [t(I8, VAR, [1, 12, 5, 5])], [t(I8, VAR, [1, 5, 5, 12])], perm) == 1                              # the SSD head permute, int8 since round 6
+    assert ask(13, [t(I8, VAR, [1, 12, 5, 5])], [t(I8, VAR, [1, 5, 12, 5])], (C.c_int * 4)(0, 3, 1, 2)) == 0
+    assert ask(13, [t(F32, VAR, [1, 12, 5, 5], 0)], [t(F32, VAR, [1, 5, 5, 12], 0)], perm) == 0
     pb.max_size_num = 2
     assert ask(15, [feat, img], [t(U8, VAR, [1, 2, 600, 1])], pb) == 0           # max sizes must pair with min sizes (priorbox.c:48-61)
 
