@@ -229,6 +229,13 @@ TAMD_API int tamd_graph_direct_packets(const tamd_graph* g);
 /* of those packets, how many carry hidden arguments placed at the offsets the kernel's own code-object metadata lists (the rest
  * use the code-object-v5 default layout, vouched for by the prerun self-check) */
 TAMD_API int tamd_graph_direct_meta_packets(const tamd_graph* g);
+/* MEASUREMENT (round 6): `passes` back-to-back passes of the directly dispatched launch list with every packet stamped by the HSA
+ * runtime's own dispatch profiling (hsa_amd_profiling_get_dispatch_time -- the timestamps a kernel trace reports, without a tool
+ * intercepting the queue): dur_us[i] = mean duration of packet i, gap_us[i] = mean time from its end to the next packet's start
+ * (the last packet: to the first packet of the next pass).  Returns the packet count (<= max_packets), -1 when the graph does not
+ * dispatch directly.  tamd_graph_direct_packet_name(g, i): kernel symbol of packet i. */
+TAMD_API int tamd_graph_direct_timestamps(tamd_graph* g, int passes, double* dur_us, double* gap_us, int max_packets);
+TAMD_API const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i);
 TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
 /* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather).  Valid after any pass: a
  * direct-dispatch tamd_graph_run / tamd_graph_wait leaves its outputs in the pinned host buffers only (zero-copy lists) and this

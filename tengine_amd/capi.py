@@ -32,7 +32,7 @@ EXPORTS = [
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
     "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
     "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_direct_meta_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
-    "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_prerun_ms", "tamd_graph_kernel_num", "tamd_graph_profile",
+    "tamd_graph_direct_timestamps", "tamd_graph_direct_packet_name", "tamd_graph_stream", "tamd_graph_time_launches", "tamd_graph_prerun_ms", "tamd_graph_kernel_num", "tamd_graph_profile",
     "tamd_graph_read_tensor", "tamd_graph_tensor_num", "tamd_graph_tensor_desc", "tamd_graph_destroy",
 ]
 
@@ -61,6 +61,9 @@ def lib():
         L.tamd_graph_load_tm2.restype = vp
         L.tamd_graph_load_tm2.argtypes = [vp, C.c_size_t]
         L.tamd_graph_stream.restype = vp
+        L.tamd_graph_direct_packet_name.restype = C.c_char_p
+        L.tamd_graph_direct_packet_name.argtypes = [vp, ci]
+        L.tamd_graph_direct_timestamps.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), ci]
         L.tamd_graph_prerun_ms.restype = C.c_double
         L.tamd_graph_prerun_ms.argtypes = [vp]
         for name, args in {
@@ -192,6 +195,13 @@ class Graph:
     def direct_packets(self):
         """AQL packets per launch() when direct dispatch is active, else 0"""
         return lib().tamd_graph_direct_packets(self._h)
+
+    def direct_timestamps(self, passes=200):
+        """the directly dispatched pass under the HSA runtime's dispatch profiling: [(kernel symbol, mean us, mean gap to the next packet us)]"""
+        n = lib().tamd_graph_direct_packets(self._h)
+        dur, gap = (C.c_double * n)(), (C.c_double * n)()
+        _check(lib().tamd_graph_direct_timestamps(self._h, passes, dur, gap, n), "direct_timestamps")
+        return [(lib().tamd_graph_direct_packet_name(self._h, i).decode(), dur[i], gap[i]) for i in range(n)]
 
     def direct_meta_packets(self):
         return lib().tamd_graph_direct_meta_packets(self._h)

@@ -206,6 +206,8 @@ struct DirectProgram {
     void* kernargs = nullptr;
     uint16_t h_open = 0, h_close = 0, h_wrap = 0;        // first packet of a burst / closing barrier packet / first packet of a later pass
     int n_meta = 0;                                      // packets whose hidden-argument offsets were read from code-object metadata
+    hsa_agent_t agent{};                                 // direct_timestamps: the agent whose clock the dispatch times are in
+    std::vector<std::string> names;                      // kernel symbol of packet i (direct_packet_name)
 };
 
 DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<LaunchRec>& recs, const char** why, DirectProgram* share)
@@ -279,6 +281,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         pk.group_segment_size = k.group + r.shmem;
         pk.kernel_object = k.object;
         p->pkts.push_back(pk);
+        p->names.push_back(nm);
         // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores): flagged by their launcher
         const bool allow_none = tamd_pin_int("direct_coherent", 1) != 0;      // (read at every prerun: a test flips it inside one process)
         coherent.push_back(allow_none && r.coherent);
@@ -319,6 +322,7 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         }
     }
     p->dq->refs++;
+    p->agent = ctx->agent;
     if (p->pkts.size() * 2 > p->dq->q->size) { *why = "launch list longer than the shared queue"; direct_destroy(p); return nullptr; }
     auto header = [](int type, int acq, int rel, bool barrier = true) {
         return (uint16_t)((type << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) | (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE)
@@ -356,6 +360,82 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
 }
 
 int direct_packets(const DirectProgram* p) { return p ? (int)p->pkts.size() : 0; }
+const char* direct_packet_name(const DirectProgram* p, int i) { return (p && i >= 0 && i < (int)p->names.size()) ? p->names[i].c_str() : ""; }
+
+// The directly dispatched pass under the HSA runtime's OWN dispatch profiling (hsa_amd_profiling_set_profiler_enabled +
+// hsa_amd_profiling_get_dispatch_time: the packet processor stamps the start and the end of every dispatch into its completion
+// signal -- the very timestamps rocprofv3's kernel trace reports, without the tool's queue interception, which does not survive
+// packets it did not see HIP write).  `passes` passes of the program, each packet with a completion signal of its own (that is
+// the only change to the packets: same headers, same fences, same barrier bits), one burst per pass.
+//   dur_us[i]  mean duration of packet i (end - start)
+//   gap_us[i]  mean time from the end of packet i to the start of packet i + 1 (the launch boundary as the device saw it);
+//              gap_us[n - 1] = from the end of the last packet to the start of the first packet of the NEXT pass (0 for the last pass)
+// A measurement entry point (round 6: the timed path had never been seen by anything but the host's clock); not used by a run.
+int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_us)
+{
+    const int n = (int)p->pkts.size();
+    if (n == 0 || passes < 1) return -1;
+    DirectQueue* dq = p->dq;
+    if (direct_wait_all(p)) return -1;
+    uint64_t freq = 0;
+    if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) != HSA_STATUS_SUCCESS || !freq) { direct_err("no timestamp frequency", 0); return -1; }
+    if (hsa_amd_profiling_set_profiler_enabled(dq->q, 1) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_set_profiler_enabled", 0); return -1; }
+    std::vector<hsa_signal_t> sig((size_t)n * passes);
+    for (auto& s : sig)
+        if (hsa_signal_create(1, 0, nullptr, &s) != HSA_STATUS_SUCCESS) { direct_err("hsa_signal_create", 0); return -1; }
+    int rc = 0;
+    hsa_queue_t* q = dq->q;
+    hsa_kernel_dispatch_packet_t* base = (hsa_kernel_dispatch_packet_t*)q->base_address;
+    const uint64_t mask = q->size - 1;
+    for (int ps = 0; ps < passes && !rc; ps++) {
+        // all passes go out back to back (one burst), as the timed loop of bench.py submits them
+        const uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, (uint64_t)n);
+        while (idx0 + n - hsa_queue_load_read_index_scacquire(q) > q->size)
+            if (dq->fault.load()) { rc = -1; break; }
+        for (int i = 0; i < n && !rc; i++) {
+            hsa_kernel_dispatch_packet_t* d = base + ((idx0 + i) & mask);
+            const hsa_kernel_dispatch_packet_t& s = p->pkts[i];
+            d->setup = s.setup;
+            d->workgroup_size_x = s.workgroup_size_x; d->workgroup_size_y = s.workgroup_size_y; d->workgroup_size_z = s.workgroup_size_z;
+            d->reserved0 = 0;
+            d->grid_size_x = s.grid_size_x; d->grid_size_y = s.grid_size_y; d->grid_size_z = s.grid_size_z;
+            d->private_segment_size = s.private_segment_size; d->group_segment_size = s.group_segment_size;
+            d->kernel_object = s.kernel_object; d->kernarg_address = s.kernarg_address; d->reserved2 = 0;
+            d->completion_signal = sig[(size_t)ps * n + i];
+            const uint16_t h = i == 0 ? (dq->open ? p->h_wrap : p->h_open) : p->hdr[i];
+            __atomic_store_n(&d->header, h, __ATOMIC_RELEASE);
+        }
+        const uint64_t to_end = q->size - (idx0 & mask);
+        if (to_end < (uint64_t)n) hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + to_end - 1));
+        hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + n - 1));
+        dq->open = true;
+    }
+    if (!rc) rc = direct_wait(p);
+    std::vector<double> t0((size_t)n * passes, 0.0), t1((size_t)n * passes, 0.0);
+    for (size_t k = 0; k < sig.size() && !rc; k++) {
+        hsa_amd_profiling_dispatch_time_t t{};
+        if (hsa_amd_profiling_get_dispatch_time(p->agent, sig[k], &t) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_get_dispatch_time", (int)k); rc = -1; break; }
+        uint64_t s0 = t.start, s1 = t.end;
+        (void)hsa_amd_profiling_convert_tick_to_system_domain(p->agent, t.start, &s0);
+        (void)hsa_amd_profiling_convert_tick_to_system_domain(p->agent, t.end, &s1);
+        t0[k] = 1e6 * (double)s0 / (double)freq; t1[k] = 1e6 * (double)s1 / (double)freq;
+    }
+    (void)hsa_amd_profiling_set_profiler_enabled(dq->q, 0);
+    for (auto& s : sig) (void)hsa_signal_destroy(s);
+    if (rc) return -1;
+    for (int i = 0; i < n; i++) {
+        double d = 0, g = 0;
+        int ng = 0;
+        for (int ps = 0; ps < passes; ps++) {
+            const size_t k = (size_t)ps * n + i;
+            d += t1[k] - t0[k];
+            if (k + 1 < sig.size()) { g += t0[k + 1] - t1[k]; ng++; }
+        }
+        dur_us[i] = d / passes;
+        gap_us[i] = ng ? g / ng : 0.0;
+    }
+    return n;
+}
 int direct_meta_packets(const DirectProgram* p) { return p ? p->n_meta : 0; }
 
 // close_burst: this pass is the last of its burst and its LAST packet closes it -- it releases at system scope and carries the

@@ -338,6 +338,24 @@ int tamd_graph_launch(tamd_graph* g)
 
 int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->direct ? direct_packets(g->direct) : 0; }
 int tamd_graph_direct_meta_packets(const tamd_graph* g) { return g && g->direct ? direct_meta_packets(g->direct) : 0; }
+const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i) { return g && g->direct ? direct_packet_name(g->direct, i) : ""; }
+
+int tamd_graph_direct_timestamps(tamd_graph* g, int passes, double* dur_us, double* gap_us, int max_packets)
+{
+    if (!g) { set_error("null graph"); return -1; }
+    TAMD_ONE_THREAD(g);
+    if (bind_device(g)) return -1;
+    if (!g->prepared || !g->direct) { set_error("tamd_graph_direct_timestamps: the graph does not dispatch directly (tamd_options.direct_dispatch)"); return -1; }
+    if (!g->inflight.empty()) { set_error("tamd_graph_direct_timestamps while asynchronous runs are in flight"); return -1; }
+    if (max_packets < direct_packets(g->direct)) { set_error("tamd_graph_direct_timestamps: %d packets, room for %d", direct_packets(g->direct), max_packets); return -1; }
+    if (direct_drain(g)) return -1;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->stream_dirty = false;
+    g->out_fresh_in = 0;                       // the passes write the staging buffers themselves
+    const int n = direct_timestamps(g->direct, passes, dur_us, gap_us);
+    if (n < 0) { set_error("direct dispatch: %s", direct_last_error()); return -1; }
+    return n;
+}
 double tamd_graph_prerun_ms(const tamd_graph* g) { return g ? g->prerun_ms : 0.0; }
 
 int tamd_graph_sync(tamd_graph* g)

@@ -77,6 +77,10 @@ int direct_wait(DirectProgram* p);          // direct_close + direct_wait_burst:
 int direct_wait_all(DirectProgram* p);      // .. and every burst closed earlier without a wait (asynchronous runs)
 const char* direct_last_error();            // what the last -1 of this thread was about
 int direct_packets(const DirectProgram* p);
+const char* direct_packet_name(const DirectProgram* p, int i);       // kernel symbol of packet i
+// `passes` back-to-back passes with every packet stamped by the HSA runtime's dispatch profiling: mean duration of packet i and mean
+// gap to the next packet's start, microseconds (direct.cc); returns the packet count, -1 on error
+int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_us);
 int direct_meta_packets(const DirectProgram* p);      // of those, how many took their hidden-argument offsets from code-object metadata
 void direct_destroy(DirectProgram* p);
 

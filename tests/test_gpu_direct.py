@@ -198,3 +198,28 @@ def test_device_copy_of_the_outputs_after_a_zero_copy_run(name, dtype, batch):
     for a, c in zip(got, gr.download()):
         assert np.array_equal(a, c)
     gr.close()
+
+
+def test_direct_timestamps_account_for_the_step():
+    """round 6: the directly dispatched pass under the HSA runtime's own dispatch profiling (tamd_graph_direct_timestamps) -- one stamp
+    pair per packet, no tool in the process.  The packets' durations and the gaps between them add up to (about) the step the host's
+    clock sees, every duration is positive, and the passes leave the same bytes behind as any other pass."""
+    g = models.build("mobilenet_v1", "int8", 1)
+    x = models.synth_input(g, 5, DT_INT8)
+    want = oracle.run_graph(g, x)
+    gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True)
+    _resident(gr, x, 2)
+    gr.time_launches(50)
+    step_us = min(1e3 * gr.time_launches(300) / 300 for _ in range(3))
+    rows = gr.direct_timestamps(100)
+    assert len(rows) == gr.direct_packets() > 0
+    assert all(d > 0.2 for _, d, _ in rows), rows
+    assert all(gp > -0.05 for _, _, gp in rows), rows                    # in-order, barrier bit on every packet: no overlap
+    total = sum(d + gp for _, d, gp in rows)
+    print("direct path, HSA stamps: %.2f us per pass (durations %.2f + gaps %.2f); host clock %.2f us" % (total, sum(r[1] for r in rows), sum(r[2] for r in rows), step_us))
+    assert 0.7 * step_us < total < 1.5 * step_us, (total, step_us)
+    gr.sync()
+    got = gr.download()
+    gr.close()
+    for w, o in zip(want, got):
+        assert np.array_equal(o.reshape(w.shape), w)
