@@ -530,7 +530,24 @@ def roofline_of(gr, model, dtype, batch, u8_integer, step_s):
                                          "(tamd_graph_profile) -- the figure rocprofv3 --kernel-trace agrees with"})
     if gr.direct_packets():
         # the timed loop dispatched the same launches as AQL packets with cheaper boundaries (csrc/direct.cc): HIP events do not see
-        # that queue.  The step's own clock bounds what a launch of the dominant family cost there: its share of the step
+        # that queue.  Round 6: the HSA runtime's own dispatch profiling does (tamd_graph_direct_timestamps: start / end stamp of every
+        # packet of back-to-back direct passes, no tool in the process) -- the dominant family's launch duration ON THE TIMED PATH
+        try:
+            rows = gr.direct_timestamps(100 if step_s < 2e-4 else 30)
+            famrows = [r for r in rows if symbol_in_family(r[0], dom)]
+            if famrows:
+                us = sum(r[1] for r in famrows) / len(famrows)
+                per = (d["bytes"] / d["launches"]) / 1e9 / HBM_PEAK_GBS if t_hbm >= t_mfma else (2.0 * d["macs"] / d["launches"]) / 1e12 / mfma_peak
+                roofline["hsa_dispatch_stamps"] = {
+                    "avg_launch_us": us, "launches_matched": len(famrows), "frac": per / (us * 1e-6),
+                    "avg_gap_to_next_packet_us": sum(r[2] for r in rows) / len(rows),
+                    "sum_durations_us_per_pass": sum(r[1] for r in rows), "sum_gaps_us_per_pass": sum(r[2] for r in rows),
+                    "what": "direct AQL passes with every packet stamped by hsa_amd_profiling_get_dispatch_time (the timestamps a kernel trace "
+                            "reports, read without a tool): mean duration of the dominant family's packets on the path the timed loop runs, "
+                            "and the device-side gap between consecutive packets"}
+        except Exception as e:       # noqa: BLE001 -- a measurement extra must never take the line down
+            roofline["hsa_dispatch_stamps"] = {"error": str(e)[:200]}
+        # The step's own clock bounds what a launch of the dominant family cost there: its share of the step
         est_us = 1e3 * (d["ms"] / sum_ms) * (step_s * 1e3) / d["launches"]
         roofline["direct_dispatch"] = {
             "avg_launch_us_from_step_clock": est_us,
@@ -615,6 +632,20 @@ def kernel_family(step_kernel):
     return re.sub(r"_\d+x\d+(x\d+)?(k\d+)?$", "", step_kernel.split("<")[0].split("+")[0])
 
 
+def symbol_in_family(name, family):
+    """does the kernel SYMBOL `name` (rocprofv3 / HSA packet name) belong to the step family `family` (kernel_family of a step name)?"""
+    # the pwdw_i8_kernel<STEPS, MODE, CHUNKED, PROD[, WIN]> template serves four step families: tell them apart by MODE / PROD
+    m = re.search(r"pwdw_i8(?:_coh)?_kernel<\s*\d+,\s*(\d+),\s*\w+,\s*(\d+)(?:,\s*\d+)*>", name)
+    if m:
+        mode, prod = int(m.group(1)), int(m.group(2))
+        fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"
+        return fam == family
+    # step names vs kernel symbols where they differ
+    alias = {"conv_u8_mfma": "conv_u8_gemm_k", "conv_u8_patch": "conv_u8_patch_k", "conv_pgemm_i8": "conv_pgemm", "conv_igemm_i8": "conv_igemm",
+             "conv_u8i": "conv_u8i_k"}
+    return alias.get(family, family) in name
+
+
 def pmc_traffic(model, dtype, batch, family):
     """HBM bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC summary of this workload
     (profiles/rNN_traffic_<model>_<dtype>_b<batch>.json, the newest round's: separate --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by the
@@ -628,19 +659,9 @@ def pmc_traffic(model, dtype, batch, family):
     path = found[-1]
     ks = json.load(open(path))["kernels"]
     tot, n = 0.0, 0
-    import re
 
     def member(name):
-        # the pwdw_i8_kernel<STEPS, MODE, CHUNKED, PROD[, WIN]> template serves four step families: tell them apart by MODE / PROD
-        m = re.search(r"pwdw_i8(?:_coh)?_kernel<\s*\d+,\s*(\d+),\s*\w+,\s*(\d+)(?:,\s*\d+)?>", name)
-        if m:
-            mode, prod = int(m.group(1)), int(m.group(2))
-            fam = "firstdw_i8" if prod == 1 else "pwpool_i8" if mode == 0 else "pw_small_i8" if mode == 4 else "pwdw_i8"
-            return fam == family
-        # step names vs kernel symbols where they differ
-        alias = {"conv_u8_mfma": "conv_u8_gemm_k", "conv_u8_patch": "conv_u8_patch_k", "conv_pgemm_i8": "conv_pgemm", "conv_igemm_i8": "conv_igemm",
-                 "conv_u8i": "conv_u8i_k"}
-        return alias.get(family, family) in name
+        return symbol_in_family(name, family)
 
     for name, v in ks.items():
         if member(name) and v["hbm_read_bytes_per_launch"] is not None:

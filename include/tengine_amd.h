@@ -232,7 +232,9 @@ TAMD_API int tamd_graph_direct_meta_packets(const tamd_graph* g);
 /* MEASUREMENT (round 6): `passes` back-to-back passes of the directly dispatched launch list with every packet stamped by the HSA
  * runtime's own dispatch profiling (hsa_amd_profiling_get_dispatch_time -- the timestamps a kernel trace reports, without a tool
  * intercepting the queue): dur_us[i] = mean duration of packet i, gap_us[i] = mean time from its end to the next packet's start
- * (the last packet: to the first packet of the next pass).  Returns the packet count (<= max_packets), -1 when the graph does not
+ * (the last packet: to the first packet of the next pass).  On this stack the stamps of consecutive barrier-bit packets ABUT (gap 0): a
+ * packet's "duration" is its kernel plus the launch boundary in front of it, and the per-packet completion signals the stamps need cost
+ * ~0.6 us per packet -- the sums equal the host's clock of an unstamped pass within 0.5 % on the batched configs, +18 % at batch 1.  Returns the packet count (<= max_packets), -1 when the graph does not
  * dispatch directly.  tamd_graph_direct_packet_name(g, i): kernel symbol of packet i. */
 TAMD_API int tamd_graph_direct_timestamps(tamd_graph* g, int passes, double* dur_us, double* gap_us, int max_packets);
 TAMD_API const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i);

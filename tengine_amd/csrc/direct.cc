@@ -29,6 +29,7 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
+#include <cxxabi.h>
 
 #include <atomic>
 #include <chrono>
@@ -281,7 +282,12 @@ DirectProgram* direct_build(int gpu, hipStream_t stream, const std::vector<Launc
         pk.group_segment_size = k.group + r.shmem;
         pk.kernel_object = k.object;
         p->pkts.push_back(pk);
-        p->names.push_back(nm);
+        {                                                // readable kernel name for direct_packet_name (measurement output)
+            int st = 0;
+            char* dm = abi::__cxa_demangle(nm, nullptr, nullptr, &st);
+            p->names.push_back(st == 0 && dm ? std::string(dm) : std::string(nm));
+            free(dm);
+        }
         // kernels that exchange their tensors with agent-scope accesses (sc1 loads, write-through stores): flagged by their launcher
         const bool allow_none = tamd_pin_int("direct_coherent", 1) != 0;      // (read at every prerun: a test flips it inside one process)
         coherent.push_back(allow_none && r.coherent);
@@ -377,9 +383,16 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
     if (n == 0 || passes < 1) return -1;
     DirectQueue* dq = p->dq;
     if (direct_wait_all(p)) return -1;
+    // On this stack (ROCm 7.x) hsa_amd_profiling_get_dispatch_time hands out SYSTEM-domain ticks already (HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY =
+    // 1 GHz): measured in round 6, calls 9 / 10 -- the sums of the stamps of a batched pass equal the host's clock within 0.5 % in that unit
+    // (10.0 x off with the agent's 100 MHz figure), and hsa_amd_profiling_convert_tick_to_system_domain applied on top returns non-monotonic
+    // values.  So: no conversion, system frequency.
     uint64_t freq = 0;
     if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) != HSA_STATUS_SUCCESS || !freq) { direct_err("no timestamp frequency", 0); return -1; }
     if (hsa_amd_profiling_set_profiler_enabled(dq->q, 1) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_set_profiler_enabled", 0); return -1; }
+    // the first pass after profiling is switched on is not stamped (the packet processor picks the queue property up with the next
+    // doorbell: call 10 read start == end == a constant for all of its packets): one extra pass in front, dropped below
+    passes += 1;
     std::vector<hsa_signal_t> sig((size_t)n * passes);
     for (auto& s : sig)
         if (hsa_signal_create(1, 0, nullptr, &s) != HSA_STATUS_SUCCESS) { direct_err("hsa_signal_create", 0); return -1; }
@@ -415,10 +428,12 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
     for (size_t k = 0; k < sig.size() && !rc; k++) {
         hsa_amd_profiling_dispatch_time_t t{};
         if (hsa_amd_profiling_get_dispatch_time(p->agent, sig[k], &t) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_get_dispatch_time", (int)k); rc = -1; break; }
-        uint64_t s0 = t.start, s1 = t.end;
-        (void)hsa_amd_profiling_convert_tick_to_system_domain(p->agent, t.start, &s0);
-        (void)hsa_amd_profiling_convert_tick_to_system_domain(p->agent, t.end, &s1);
-        t0[k] = 1e6 * (double)s0 / (double)freq; t1[k] = 1e6 * (double)s1 / (double)freq;
+        if (getenv("TAMD_DEBUG") && k >= (size_t)n && k < (size_t)n + 4)
+            fprintf(stderr, "[tamd] stamp %zu: start %llu end %llu (%lld ticks), system timestamp frequency %llu Hz\n", k, (unsigned long long)t.start,
+                    (unsigned long long)t.end, (long long)(t.end - t.start), (unsigned long long)freq);
+        if (k >= (size_t)n && t.end <= t.start) { direct_err("a packet carries no dispatch stamps (start >= end)", (int)k); rc = -1; break; }
+        const uint64_t origin = 0;
+        t0[k] = 1e6 * (double)(t.start - origin) / (double)freq; t1[k] = 1e6 * (double)(t.end - origin) / (double)freq;
     }
     (void)hsa_amd_profiling_set_profiler_enabled(dq->q, 0);
     for (auto& s : sig) (void)hsa_signal_destroy(s);
@@ -426,12 +441,12 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
     for (int i = 0; i < n; i++) {
         double d = 0, g = 0;
         int ng = 0;
-        for (int ps = 0; ps < passes; ps++) {
+        for (int ps = 1; ps < passes; ps++) {            // (pass 0: the unstamped warm-up)
             const size_t k = (size_t)ps * n + i;
             d += t1[k] - t0[k];
             if (k + 1 < sig.size()) { g += t0[k + 1] - t1[k]; ng++; }
         }
-        dur_us[i] = d / passes;
+        dur_us[i] = d / (passes - 1);
         gap_us[i] = ng ? g / ng : 0.0;
     }
     return n;

@@ -36,7 +36,6 @@ def main():
     gr.time_launches(50)
     step_us = min(1e3 * gr.time_launches(passes) / passes for _ in range(3))
     rows = gr.direct_timestamps(passes)
-    rows = gr.direct_timestamps(passes)
     step_us2 = min(1e3 * gr.time_launches(passes) / passes for _ in range(3))
     gr.close()
     print("%s %s batch %d: %d packets per pass, %d passes back to back; host clock %.2f us per step before, %.2f after the stamped passes" % (name, dtype, batch, len(rows), passes, step_us, step_us2))
