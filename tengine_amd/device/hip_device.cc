@@ -528,6 +528,27 @@ static bool node_supported(struct graph* ir, struct node* n)
 // last asked of the backend itself (tamd_node_supported: the planners' conditions), so that the splitter and pre_run cannot
 // disagree.  (Round 2 also kept two leftover guards here -- Concat axis != 1, Permute order -- from before the backend learnt
 // them; the Concat one silently sent the whole of MobileNet-SSD-with-priors to the CPU device.  They are gone.)
+// int8 graphs (round 6): what a Permute / PriorBox produces -- and every Flatten / Reshape / Dropout / Concat / Softmax result that is only a
+// re-reading of it -- lives in the reference's DENSE element order on the device (csrc/graph_plan.hip "dense tensors"), not in the NHWC
+// layout the convolution stack reads.  Only those re-reading operators may consume such a tensor there; anything else (an FC behind
+// Permute -> Flatten, say) is left to the CPU device here, so that the splitter and the planner cannot disagree (the planner would
+// refuse the graph by name at pre_run otherwise).
+bool int8_tensor_is_dense_on_device(struct graph* ir, struct tensor* t, int depth = 0)
+{
+    if (!t || t->producer < 0 || depth > 16) return false;
+    struct node* pn = get_ir_graph_node(ir, t->producer);
+    switch (pn->op.type) {
+    case OP_PERMUTE: case OP_PRIORBOX: case OP_RESHAPE: return true;
+    case OP_FLATTEN: case OP_DROPOUT: case OP_SOFTMAX:
+        return pn->input_num >= 1 && int8_tensor_is_dense_on_device(ir, get_ir_graph_tensor(ir, pn->input_tensors[0]), depth + 1);
+    case OP_CONCAT:
+        for (int i = 0; i < pn->input_num; i++)
+            if (int8_tensor_is_dense_on_device(ir, get_ir_graph_tensor(ir, pn->input_tensors[i]), depth + 1)) return true;
+        return false;
+    default: return false;
+    }
+}
+
 bool node_runs_on_device(struct graph* ir, struct node* n)
 {
     const int out_dt = n->output_num ? get_ir_graph_tensor(ir, n->output_tensors[0])->data_type : -1;
@@ -557,6 +578,12 @@ bool node_runs_on_device(struct graph* ir, struct node* n)
             if (t->dim_num == 4 && t->dims[2] * t->dims[3] != 1) return false;
         }
     }
+    if (out_dt == TENGINE_DT_INT8 && n->op.type != OP_FLATTEN && n->op.type != OP_RESHAPE && n->op.type != OP_DROPOUT && n->op.type != OP_CONCAT
+        && n->op.type != OP_SOFTMAX && n->op.type != OP_PRIORBOX)
+        for (int i = 0; i < n->input_num; i++) {
+            struct tensor* t = get_ir_graph_tensor(ir, n->input_tensors[i]);
+            if (t->tensor_type != TENSOR_TYPE_CONST && int8_tensor_is_dense_on_device(ir, t)) return false;
+        }
     return node_supported(ir, n);
 }
 

@@ -121,6 +121,28 @@ def test_split_keeps_whole_int8_ssd_on_the_device(ref):
     assert ops.count("Convolution") == 47, pl
 
 
+def test_split_leaves_a_consumer_of_a_dense_int8_tensor_to_the_cpu(ref):
+    """round 6: conv -> Permute -> Flatten -> FullyConnected (int8).  Permute / Flatten run on the device and leave a DENSE tensor there; an
+    FC is not one of the operators that may re-read it (csrc/graph_plan.hip), so the splitter keeps it on the CPU device instead of
+    handing the planner a graph it refuses"""
+    from helpers import I8_HEAD_CASES, i8_head_graph
+    _load_plugin(ref)
+    g, x = i8_head_graph(**dict(I8_HEAD_CASES["standalone_permute"], n=1))
+    pm = g.nodes[g.output_nodes[0]].outputs[0]
+    d = g.tensors[pm].dims
+    hidden = d[1] * d[2] * d[3]
+    fl = g.add_tensor("flat", [d[0], hidden], tm2.DT_INT8, tm2.TT_VAR, None, list(g.tensors[pm].scales), [0])
+    g.add_node("flat", "Flatten", [pm], [fl], axis=1, end_axis=3)
+    rng = np.random.default_rng(2)
+    w = g.add_const("fc_w", rng.integers(-127, 128, size=(10, hidden)).astype(np.int8), tm2.DT_INT8, [0.01] * 10, [0] * 10)
+    y = g.add_tensor("fc", [d[0], 10], tm2.DT_INT8, tm2.TT_VAR, None, [0.5], [0])
+    g.output_nodes = [g.add_node("fc", "FullyConnected", [fl, w], [y], num_output=10)]
+    pl = _split_only(ref, g, x, ref.MODE_INT8)
+    hip_ops = [o for dev, _, _, ops in pl if dev == "HIP" for o in ops if o not in ("InputOp", "Const")]
+    cpu_ops = [o for dev, _, _, ops in pl if dev != "HIP" for o in ops if o not in ("InputOp", "Const")]
+    assert "FullyConnected" in cpu_ops and "Convolution" in hip_ops and "Permute" in hip_ops, pl
+
+
 def test_split_keeps_whole_resnet50_int8_on_the_device(ref):
     """round 4: the benchmark graph of BASELINE configs[2] ends in an int8 Softmax; with softmax_i8 on the
     device it is ONE "HIP" subgraph -- no CPU tail, so run_graph(g, 0) pipelines it like MobileNet"""
