@@ -18,6 +18,15 @@
 //     v_mfma_i32_32x32x32_i8 per stage, A fragments straight from global memory in fragment order ([32-cout tile][32-k step][lane][16 B],
 //     packed by the planner), requested behind the MFMAs of the previous stage; two B buffers, one barrier per stage;
 //   * epilogue: requant4 + half-wave regroup -> one 16-byte store per lane and tile (gemm_epilogue.h's scheme on this tile's pixel map).
+//
+// Round 6 (the ISA of round 4's form, `s_waitcnt` by `s_waitcnt`): every stage fetched the depthwise weights / bias / multipliers of its 128
+// channels from global memory at the top of its depthwise phase, BEHIND the eight A-fragment loads it had just issued -- loads return in
+// order, so the `vmcnt(0)` in front of the first requantisation waited for the fragments too: one exposed L2 round trip of 8 KB per wave
+// and stage; and the epilogue fetched the pointwise multipliers one vector at a time, sixteen `global_load_dwordx4` + `vmcnt(0)` pairs
+// in a row.  Now the per-channel constants of BOTH nodes are copied into LDS once (20 bytes per depthwise channel + 4 per output
+// channel, requested before anything else), every global load of the stage loop is unconditional (a stage index past the end is
+// clamped: the compiler's wait counting then knows how many younger loads are in flight instead of falling back to vmcnt(0)), and
+// the A fragments of stage s + 1 are requested k step by k step right behind the MFMAs that read stage s's.
 #include <type_traits>
 
 #include "dw_common.h"
@@ -33,14 +42,35 @@ typedef int v16i_dp __attribute__((ext_vector_type(16)));
 constexpr int DWPW_KST = 128;                            // channels per stage
 typedef int8_t dwpw_bs_t[DWPW_KST / 16][64][16];         // one B buffer: [channel granule][pixel][16 B]
 
+// dynamic LDS of a block: [2 B buffers][dw weights 3 x cw dwords][dw bias cw][dw multipliers cw][pw multipliers 64 NW]
+__host__ __device__ inline size_t dwpw_lds_bytes(int cw, int nw) { return 2 * sizeof(dwpw_bs_t) + (size_t)20 * cw + (size_t)256 * nw; }
+
 // WIN: both requantisations (the depthwise node's and the pointwise node's) in the one-binade form of epilogue.h; checked once by the kernel
 template <int NW, int WIN>
-__device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
+__device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
 {
     constexpr int KST = DWPW_KST;
+    dwpw_bs_t* bs = reinterpret_cast<dwpw_bs_t*>(smem);
+    int8_t* const cW = smem + 2 * sizeof(dwpw_bs_t);     // depthwise weights, DwArgs::w's own layout: [3 rows][cw channels][4 B]
+    int8_t* const cB = cW + (size_t)12 * a.cw;           // depthwise bias [cw] int32
+    int8_t* const cS = cB + (size_t)4 * a.cw;            // depthwise multipliers [cw] float
+    int8_t* const pS = cS + (size_t)4 * a.cw;            // pointwise multipliers [64 NW] float
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
     const int rows_total = a.N * a.OH;
     const int gr0 = blockIdx.x * 4;                      // first row (image * OH + oy) of the tile
+
+    // ---- the per-channel constants of both nodes -> LDS: requested before everything else (they are needed first), stored once the
+    // other loads of the prologue are on their way.  16-byte unit i of the LDS block [cW | cB | cS | pS] comes from one of four arrays
+    const int nw4 = 3 * a.cw / 4, nb4 = a.cw / 4, cunits = nw4 + 2 * nb4 + NW * 16;      // (cw is a multiple of 16)
+    auto const_unit = [&](int i) {
+        i = min(i, cunits - 1);                          // unconditional load; units past the end are not stored
+        const uint4* src = i < nw4 ? reinterpret_cast<const uint4*>(a.dw_w) + i
+                         : i < nw4 + nb4 ? reinterpret_cast<const uint4*>(a.dw_bias) + (i - nw4)
+                         : i < nw4 + 2 * nb4 ? reinterpret_cast<const uint4*>(a.dw_wscale) + (i - nw4 - nb4)
+                         : reinterpret_cast<const uint4*>(a.pw_wscale) + (i - nw4 - 2 * nb4);
+        return *src;
+    };
+    const uint4 cu0 = const_unit(t), cu1 = const_unit(t + 512);
 
     // ---- this thread's depthwise unit: pixels (row ur, columns 4 ucg .. 4 ucg + 3), channels 4 cq .. 4 cq + 3 of the stage ----
     const int cq = t & 31, pq = t >> 5, ur = pq >> 2, ucg = pq & 3;
@@ -70,11 +100,12 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
     const int nst = (a.C + KST - 1) / KST;
 
     // depthwise of stage `st` -> B buffer `buf`.  Channels past C (a ragged last stage) read the tensor's zero padding / repeat: their
-    // weights are zero rows of the pointwise fragments, so whatever they hold is multiplied by 0.
+    // weights are zero rows of the pointwise fragments, so whatever they hold is multiplied by 0.  A stage index past the end repeats the
+    // last stage's addresses (requested, never used): every load of the loop is unconditional.
     unsigned raw[2][3][6];                               // two sets: the taps of stage s + 2 are requested before stage s + 1 is computed
     auto dw_load = [&](auto D, int st) {
         constexpr int d = decltype(D)::value;
-        const int c0 = min(st * KST + 4 * cq, a.cw - 4) - 4 * cq;      // keep the dword inside the padded channel row
+        const int c0 = min(min(st, nst - 1) * KST + 4 * cq, a.cw - 4) - 4 * cq;      // keep the dword inside the padded channel row
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -86,11 +117,11 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
         unsigned wrow[3][4];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const uint4 v = *reinterpret_cast<const uint4*>(a.dw_w + ((size_t)r * a.cw + c) * 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(cW + ((size_t)r * a.cw + c) * 4);
             wrow[r][0] = v.x; wrow[r][1] = v.y; wrow[r][2] = v.z; wrow[r][3] = v.w;
         }
-        const int4 b4 = *reinterpret_cast<const int4*>(a.dw_bias + c);
-        const float4 s4 = *reinterpret_cast<const float4*>(a.dw_wscale + c);
+        const int4 b4 = *reinterpret_cast<const int4*>(cB + (size_t)c * 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(cS + (size_t)c * 4);
         int acc[4][4];
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -126,13 +157,10 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
     const int nk32 = nst * (KST / 32);
     const int8_t* wf = a.pw_wfrag + ((size_t)(wave * 2) * nk32 * 64 + lane) * 16;       // tile 2w, step 0, this lane
     v4i_dp af[2][KST / 32];                              // [cout tile][k step]: ONE stage of fragments
-    auto a_load = [&](int st) {
-        if (wave >= NW) return;
+    auto a_load_ks = [&](int st, int ks) {
 #pragma unroll
         for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int ks = 0; ks < KST / 32; ks++)
-                af[i][ks] = *reinterpret_cast<const v4i_dp*>(wf + ((size_t)i * nk32 + (size_t)(st < nst ? st : nst - 1) * (KST / 32) + ks) * 1024);
+            af[i][ks] = *reinterpret_cast<const v4i_dp*>(wf + ((size_t)i * nk32 + (size_t)min(st, nst - 1) * (KST / 32) + ks) * 1024);
     };
     // the accumulators start at the pointwise bias (C/D layout of the 32x32 MFMA: register e of lane (pixel, hi) is channel
     // 8 (e >> 2) + 4 hi + (e & 3) of the tile): the epilogue requantises them as they are
@@ -145,7 +173,9 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
 #pragma unroll
             for (int j = 0; j < 2; j++) { acc[i][j][4 * g4 + 0] = b4.x; acc[i][j][4 * g4 + 1] = b4.y; acc[i][j][4 * g4 + 2] = b4.z; acc[i][j][4 * g4 + 3] = b4.w; }
         }
-    auto mma = [&](int buf) {
+    // stage `buf` multiplied; NEXT >= 0: the fragments of stage NEXT requested into the same registers, k step by k step, right behind
+    // the MFMAs that read them (the hardware orders the overwrite behind the read; the fetch then has the rest of the stage to land)
+    auto mma = [&](int buf, int next) {
         if (wave >= NW) return;
 #pragma unroll
         for (int ks = 0; ks < KST / 32; ks++) {
@@ -156,41 +186,48 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i][ks], bf[j], acc[i][j], 0, 0, 0);
+            if (next >= 0) a_load_ks(next, ks);
         }
     };
 
-    // ---- the stages: stage s multiplies, then the fragments of stage s + 1 are requested into the same registers (behind the MFMAs that
-    // read them) and the depthwise layer of stage s + 1 is computed into the other B buffer -- its ~150 VALU instructions hide the
-    // fragment fetch and run beside the matrix pipe; one barrier per stage
+    // ---- the stages: stage s multiplies while the fragments of stage s + 1 are on their way, then the depthwise layer of stage s + 1 is
+    // computed into the other B buffer -- its ~150 VALU instructions run beside the matrix pipe -- and the taps of stage s + 3 are
+    // requested; one barrier per stage
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    a_load(0);
-    dw_load(I0{}, 0);
-    if (nst > 1) dw_load(I1{}, 1);
-    dw_compute(I0{}, 0, 0);
-    if (nst > 2) dw_load(I0{}, 2);
-    __syncthreads();
-    for (int st = 0; st < nst; st += 2) {
-        mma(0);
-        if (st + 1 < nst) {
-            a_load(st + 1);
-            dw_compute(I1{}, st + 1, 1);
-            if (st + 3 < nst) dw_load(I1{}, st + 3);
-        }
-        __syncthreads();
-        if (st + 1 >= nst) break;
-        mma(1);
-        if (st + 2 < nst) {
-            a_load(st + 2);
-            dw_compute(I0{}, st + 2, 0);
-            if (st + 4 < nst) dw_load(I0{}, st + 4);
-        }
-        __syncthreads();
+    if (wave < NW) {
+#pragma unroll
+        for (int ks = 0; ks < KST / 32; ks++) a_load_ks(0, ks);
     }
+    dw_load(I0{}, 0);
+    dw_load(I1{}, 1);
+    if (t < cunits) reinterpret_cast<uint4*>(cW)[t] = cu0;
+    if (t + 512 < cunits) reinterpret_cast<uint4*>(cW)[t + 512] = cu1;
+    for (int i = t + 1024; i < cunits; i += 512) reinterpret_cast<uint4*>(cW)[i] = const_unit(i);      // more than 768 depthwise channels
+    __syncthreads();                                     // the constants are in LDS
+    dw_compute(I0{}, 0, 0);
+    dw_load(I0{}, 2);
+    __syncthreads();
+    // half(st, D, buf): stage st (B buffer buf) multiplied, stage st + 1 produced from tap set D into the other buffer
+    auto half = [&](int st, auto D, int buf) {
+        mma(buf, st + 1);
+        dw_compute(D, st + 1, buf ^ 1);
+        dw_load(D, st + 3);
+        __syncthreads();
+    };
+    int st = 0;
+    for (; st + 2 < nst; st += 2) { half(st, I1{}, 0); half(st + 1, I0{}, 1); }
+    if (st + 1 < nst) { half(st, I1{}, 0); mma(1, -1); }
+    else mma(0, -1);
     if (wave >= NW) return;
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cout) ----
     const Rq prq = a.pw_rq;
+    float4 s4s[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) s4s[i][g4] = *reinterpret_cast<const float4*>(pS + (size_t)((wave * 2 + i) * 32 + 8 * g4 + 4 * hi) * 4);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int p = j * 32 + l31, pr = p >> 4, pc = p & 15;
@@ -204,8 +241,7 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const int c = cb + 8 * g4 + 4 * hi;
-                const float4 s4 = *reinterpret_cast<const float4*>(a.pw_wscale + c);
-                pk[g4] = requant4<WIN>(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3], s4, c, prq);
+                pk[g4] = requant4<WIN>(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3], s4s[i][g4], c, prq);
             }
             half_wave_regroup(pk);
             const int c16 = cb + hi * 16;
@@ -217,16 +253,17 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, dwpw_bs_t* bs)
 template <int NW>
 __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
 {
-    __shared__ __attribute__((aligned(16))) dwpw_bs_t bs[2];
-    if (rq_win(a.dw_rq) && rq_win(a.pw_rq)) dwpw_body<NW, 1>(a, bs);
-    else dwpw_body<NW, 0>(a, bs);
+    extern __shared__ __attribute__((aligned(16))) int8_t dwpw_smem[];
+    if (rq_win(a.dw_rq) && rq_win(a.pw_rq)) dwpw_body<NW, 1>(a, dwpw_smem);
+    else dwpw_body<NW, 0>(a, dwpw_smem);
 }
 
 // depthwise 3x3 stride 1 (any padding the map allows) feeding a pointwise 1x1 stride-1 convolution with no padding; output channels
-// in whole 64-channel wave slices up to 512, destination on 16-channel granularity (16-byte stores); OW <= 16 (one tile row spans the map)
+// in whole 64-channel wave slices up to 512, destination on 16-channel granularity (16-byte stores); OW <= 16 (one tile row spans the map);
+// at most 2048 (padded) channels: their constants live in LDS (dwpw_lds_bytes <= 64 KB)
 bool dwpw_applicable(const DwArgs& d, const ConvArgs& p)
 {
-    if (d.S != 1 || d.OW > 16 || d.C % 4 != 0 || d.cw < 4) return false;
+    if (d.S != 1 || d.OW > 16 || d.C % 4 != 0 || d.cw < 16 || d.cw % 16 != 0 || d.cw > 2048) return false;
     if (p.KH != 1 || p.KW != 1 || p.SH != 1 || p.SW != 1 || p.PH != 0 || p.PW != 0 || p.elt.res) return false;
     if (p.cout % 64 != 0 || p.cout > 512 || p.cin != d.C) return false;
     if (((p.c_limit | p.c_off | p.ldc) & 15) != 0 || p.c_limit < p.cout) return false;
@@ -251,14 +288,14 @@ hipError_t launch_dwpw(const DwPwArgs& a, hipStream_t s)
 {
     const int blocks = (a.N * a.OH + 3) / 4;
     switch (a.cout / 64) {
-    case 1: hipLaunchKernelGGL(dwpw_i8_kernel<1>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(dwpw_i8_kernel<2>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(dwpw_i8_kernel<3>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(dwpw_i8_kernel<4>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(dwpw_i8_kernel<5>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(dwpw_i8_kernel<6>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(dwpw_i8_kernel<7>, dim3(blocks), dim3(512), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(dwpw_i8_kernel<8>, dim3(blocks), dim3(512), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(dwpw_i8_kernel<1>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 1), s, a); break;
+    case 2: hipLaunchKernelGGL(dwpw_i8_kernel<2>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 2), s, a); break;
+    case 3: hipLaunchKernelGGL(dwpw_i8_kernel<3>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 3), s, a); break;
+    case 4: hipLaunchKernelGGL(dwpw_i8_kernel<4>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 4), s, a); break;
+    case 5: hipLaunchKernelGGL(dwpw_i8_kernel<5>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 5), s, a); break;
+    case 6: hipLaunchKernelGGL(dwpw_i8_kernel<6>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 6), s, a); break;
+    case 7: hipLaunchKernelGGL(dwpw_i8_kernel<7>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 7), s, a); break;
+    case 8: hipLaunchKernelGGL(dwpw_i8_kernel<8>, dim3(blocks), dim3(512), dwpw_lds_bytes(a.cw, 8), s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
