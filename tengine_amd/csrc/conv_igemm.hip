@@ -144,10 +144,6 @@ __global__ __launch_bounds__(256) void conv_igemm_i8_kernel(ConvArgs a)
 
     v16i acc[TN][TM];
     igemm_acc_from_bias<TM, TN>(acc, a.bias, n0, wn, hi);      // the epilogue adds nothing (gemm_epilogue.h)
-    // small tiles (the shallow pointwise layers, one to four K steps): multipliers and residual operand requested NOW, gemm_epilogue.h
-    constexpr bool PRE = TM * TN <= 2;
-    EpiPre<TM, TN> pre;
-    if constexpr (PRE) igemm_epilogue_prefetch<TM, TN>(a, pre, m0, n0, wm, wn, l31, hi);
 
     // ceil: a stage may run past kpad -- the activation operand is zero there (k >= ktot / tap >= ntaps) and the
     // weight rows are followed by readable memory (next row, or the planner's 256-byte tail), so it adds exact zeros
@@ -179,8 +175,7 @@ __global__ __launch_bounds__(256) void conv_igemm_i8_kernel(ConvArgs a)
         __syncthreads();
     }
 
-    if constexpr (PRE) igemm_epilogue_pre<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi, pre);
-    else igemm_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi);
+    igemm_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, l31, hi);
 }
 
 // ---- the same GEMM with a software pipeline that really runs ahead (the one-stage register prefetch above

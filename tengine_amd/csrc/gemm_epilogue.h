@@ -49,46 +49,12 @@ __device__ __forceinline__ void igemm_acc_from_bias(V (&acc)[TN][TM], const int3
         }
 }
 
-// ---- what the epilogue needs from memory, requested at the TOP of the kernel (round 6) ------------------------------------------------
-// The ISA of the 64x64 instance on ResNet-50's `branch2c + eltwise` layers (K = 64 .. 256: one to four K steps) showed three dependent
-// memory round trips per block: operands -> LDS -> MFMA, THEN the multipliers (global_load x4, vmcnt), THEN the residual operand
-// (global_load_dwordx4, vmcnt(0)), then the store.  Which multipliers and which 16 residual bytes a lane needs is known from its
-// tile coordinates alone, so small-tile kernels request them before their main loop (TN * (16 + 4 TM) registers held across it) and the
-// epilogue finds them landed.  Every load is unconditional: a lane without a residual operand (no eltwise tail, a pixel past M, a
-// channel granule past c_limit, a destination that is not 16-channel granular) reads the planner's zero page instead.
-template <int TM, int TN>
-struct EpiPre {
-    float4 s4s[TN][4];       // multipliers of the lane's channels, per cout tile and 8-channel group (C/D layout of the 32x32 MFMA)
-    uint4 res[TN][TM];       // the residual operand's 16 channels the lane holds AFTER half_wave_regroup, per tile
-};
-
-template <int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue_prefetch(const ConvArgs& a, EpiPre<TM, TN>& pre, int m0, int n0, int wm, int wn, int l31, int hi)
-{
-    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0 && (!a.elt.res || ((a.elt.res_ldc | a.elt.res_c_off) & 15) == 0);
-    const bool has_res = wide && a.elt.res;
-#pragma unroll
-    for (int i = 0; i < TN; i++) {
-        const int cb = n0 + (wn * TN + i) * 32;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) pre.s4s[i][g4] = *reinterpret_cast<const float4*>(a.wscale + cb + 8 * g4 + 4 * hi);
-#pragma unroll
-        for (int j = 0; j < TM; j++) {
-            const int m = m0 + (wm * TM + j) * 32 + l31, c16 = cb + hi * 16;
-            const int8_t* src = (has_res && m < a.M && c16 < a.c_limit) ? a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16 : a.zeros;
-            pre.res[i][j] = *reinterpret_cast<const uint4*>(src);
-        }
-    }
-}
-
 // FORM 0: everything (any destination granularity, any fused eltwise tail, the general requantisation).  FORM 1 / 2: the one-binade
 // requantisation of epilogue.h for the two common nodes, as SMALL instances (16-channel-granular destination only): 1 = a conv with
 // a fused ReLU and no eltwise tail, its own window in the one-binade form; 2 = a conv (general form) + the folded SUM tail whose
 // ReLU puts the tail's window there.  igemm_epilogue_src checks the node's constants and picks the instance.
-// PRE: multipliers and residual operand come from `pre` (igemm_epilogue_prefetch; the accumulators then hold the bias already)
-template <int TM, int TN, int FORM, typename Src, bool PRE = false>
-__device__ __forceinline__ void igemm_epilogue_form(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi, const Src src,
-                                                    const EpiPre<TM, TN>* pre = nullptr)
+template <int TM, int TN, int FORM, typename Src>
+__device__ __forceinline__ void igemm_epilogue_form(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi, const Src src)
 {
     // C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
     const Rq rq = a.rq;
@@ -107,8 +73,7 @@ __device__ __forceinline__ void igemm_epilogue_form(const ConvArgs& a, v16i_t (&
         for (int g4 = 0; g4 < 4; g4++) {
             const int c = n0 + (wn * TN + i) * 32 + 8 * g4 + 4 * hi;
             b4s[i][g4] = src.bias4(c);
-            if constexpr (PRE) s4s[i][g4] = pre->s4s[i][g4];
-            else s4s[i][g4] = src.scale4(c);
+            s4s[i][g4] = src.scale4(c);
         }
     static_for<0, TN>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -129,9 +94,7 @@ __device__ __forceinline__ void igemm_epilogue_form(const ConvArgs& a, v16i_t (&
                 const int c16 = cb + hi * 16;
                 if (m < a.M && c16 < a.c_limit) {
                     if (FORM == 2 || (FORM == 0 && a.elt.res)) {      // eltwise (+ReLU) tail on the 16 channels this lane now holds
-                        uint4 r;
-                        if constexpr (PRE) r = pre->res[i][j];
-                        else r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16);
+                        const uint4 r = *reinterpret_cast<const uint4*>(a.elt.res + (size_t)m * a.elt.res_ldc + a.elt.res_c_off + c16);
                         if (FORM == 2) {
                             elt_sum16_fold<1>(p, r, a.elt);
                         } else if (a.elt.thr > 0.f) {
@@ -169,19 +132,6 @@ __device__ __forceinline__ void igemm_epilogue_src(const ConvArgs& a, v16i_t (&a
     if (form == 1) igemm_epilogue_form<TM, TN, 1>(a, acc, m0, n0, wm, wn, l31, hi, src);
     else if (form == 2) igemm_epilogue_form<TM, TN, 2>(a, acc, m0, n0, wm, wn, l31, hi, src);
     else igemm_epilogue_form<TM, TN, 0>(a, acc, m0, n0, wm, wn, l31, hi, src);
-}
-
-// the same choice for a kernel that called igemm_epilogue_prefetch at its top (accumulators from igemm_acc_from_bias)
-template <int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue_pre(const ConvArgs& a, v16i_t (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int hi, const EpiPre<TM, TN>& pre)
-{
-    const bool wide = ((a.c_limit | a.c_off | a.ldc) & 15) == 0 && (!a.elt.res || ((a.elt.res_ldc | a.elt.res_c_off) & 15) == 0);
-    const int form = !wide ? 0 : a.elt.res ? ((a.elt.thr > 0.f && elt_win(a.elt)) ? 2 : 0) : (rq_win(a.rq) ? 1 : 0);
-    const EpiScaleFromGlobal src{a.wscale};
-    if (form == 1) igemm_epilogue_form<TM, TN, 1, EpiScaleFromGlobal, true>(a, acc, m0, n0, wm, wn, l31, hi, src, &pre);
-    else if (form == 2) igemm_epilogue_form<TM, TN, 2, EpiScaleFromGlobal, true>(a, acc, m0, n0, wm, wn, l31, hi, src, &pre);
-    else if (wide) igemm_epilogue_form<TM, TN, 0, EpiScaleFromGlobal, true>(a, acc, m0, n0, wm, wn, l31, hi, src, &pre);
-    else igemm_epilogue_form<TM, TN, 0>(a, acc, m0, n0, wm, wn, l31, hi, src);      // dword-granular destination: the general path loads for itself
 }
 
 template <int TM, int TN>
