@@ -38,6 +38,14 @@ namespace tamd {
 typedef int v4i_dp __attribute__((ext_vector_type(4)));
 typedef int v16i_dp __attribute__((ext_vector_type(16)));
 
+#ifdef TAMD_DWPW_STAMPS      // tools/exp/dwpw_anatomy.hip: stage time stamps (100 MHz wall clock) of wave 0 of every block, ablation switches
+#define DWPW_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define DWPW_ON(bit) (!(a.ablate & (bit)))
+#else
+#define DWPW_STAMP(i) do { } while (0)
+#define DWPW_ON(bit) true
+#endif
+
 // NW = waves along the output channels (cout <= 64 * NW); 512 threads always (the depthwise stage needs 512 units per 128 channels)
 constexpr int DWPW_KST = 128;                            // channels per stage
 typedef int8_t dwpw_bs_t[DWPW_KST / 16][64][16];         // one B buffer: [channel granule][pixel][16 B]
@@ -58,6 +66,7 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
     const int rows_total = a.N * a.OH;
     const int gr0 = blockIdx.x * 4;                      // first row (image * OH + oy) of the tile
+    DWPW_STAMP(0);
 
     // ---- the per-channel constants of both nodes -> LDS: requested before everything else (they are needed first), stored once the
     // other loads of the prologue are on their way.  16-byte unit i of the LDS block [cW | cB | cS | pS] comes from one of four arrays
@@ -73,10 +82,13 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
     const uint4 cu0 = const_unit(t), cu1 = const_unit(t + 512);
 
     // ---- this thread's depthwise unit: pixels (row ur, columns 4 ucg .. 4 ucg + 3), channels 4 cq .. 4 cq + 3 of the stage ----
-    const int cq = t & 31, pq = t >> 5, ur = pq >> 2, ucg = pq & 3;
+    // t >> 5 = 2 wave + hi: the tile row ur = wave >> 1 is the same for the whole wave, so everything that hangs on it -- image, input
+    // rows, their validity -- is scalar: a tap's address is (scalar row pointer + stage offset) + (per-lane pixel / channel offset), the
+    // form a global load takes as SGPR base + 32-bit VGPR offset with no vector address arithmetic per load
+    const int cq = t & 31, ur = wave >> 1, ucg = 2 * (wave & 1) + hi;
     const int ugr = min(gr0 + ur, rows_total - 1);       // (a dead row repeats the last live one: computed, never stored)
     const int un = ugr / a.OH, uoy = ugr - un * a.OH;
-    const int8_t* xn = a.x + (size_t)un * a.H * a.W * a.cs_in + 4 * cq;
+    const int8_t* xn = a.x + (size_t)un * a.H * a.W * a.cs_in;
     const int ixb = 4 * ucg - a.PW;
     int pixoff[6];
     unsigned colok = 0;
@@ -87,13 +99,13 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
         pixoff[p] = (ok ? ix : 0) * a.cs_in;
         colok |= ok ? 1u << p : 0u;
     }
-    int rowoff[3];
+    const int8_t* xrow[3];
     unsigned rowok = 0;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int iy = uoy - a.PH + r;
         const bool ok = (unsigned)iy < (unsigned)a.H;
-        rowoff[r] = (ok ? iy : 0) * a.W * a.cs_in;
+        xrow[r] = xn + (size_t)((ok ? iy : 0) * a.W) * a.cs_in;
         rowok |= ok ? 1u << r : 0u;
     }
     const Rq drq = a.dw_rq;
@@ -105,11 +117,15 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
     unsigned raw[2][3][6];                               // two sets: the taps of stage s + 2 are requested before stage s + 1 is computed
     auto dw_load = [&](auto D, int st) {
         constexpr int d = decltype(D)::value;
-        const int c0 = min(min(st, nst - 1) * KST + 4 * cq, a.cw - 4) - 4 * cq;      // keep the dword inside the padded channel row
+        const int sb = min(st, nst - 1) * KST;                                      // scalar
+        const int lc = min(sb + 4 * cq, a.cw - 4) - sb;                             // keep the dword inside the padded channel row
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+        for (int p = 0; p < 6; p++) {
+            const unsigned vo = (unsigned)(pixoff[p] + lc);
+            if (!DWPW_ON(16)) continue;
 #pragma unroll
-            for (int p = 0; p < 6; p++) raw[d][r][p] = *reinterpret_cast<const unsigned*>(xn + rowoff[r] + pixoff[p] + c0);
+            for (int r = 0; r < 3; r++) raw[d][r][p] = *reinterpret_cast<const unsigned*>(xrow[r] + sb + vo);
+        }
     };
     auto dw_compute = [&](auto D, int st, int buf) {
         constexpr int d = decltype(D)::value;
@@ -129,6 +145,7 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
             for (int k = 0; k < 4; k++) acc[j][k] = k == 0 ? b4.x : k == 1 ? b4.y : k == 2 ? b4.z : b4.w;      // the dot chain starts at the bias
 #pragma unroll
         for (int r = 0; r < 3; r++) {
+            if (!DWPW_ON(2)) { acc[0][0] += (int)(raw[d][r][0] ^ raw[d][r][1] ^ raw[d][r][2] ^ raw[d][r][3] ^ raw[d][r][4] ^ raw[d][r][5]); continue; }
             unsigned d0[4], d1[4], f0[4], f1[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) d0[q] = ((rowok >> r) & (colok >> q) & 1u) ? raw[d][r][q] : 0u;
@@ -158,6 +175,7 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
     const int8_t* wf = a.pw_wfrag + ((size_t)(wave * 2) * nk32 * 64 + lane) * 16;       // tile 2w, step 0, this lane
     v4i_dp af[2][KST / 32];                              // [cout tile][k step]: ONE stage of fragments
     auto a_load_ks = [&](int st, int ks) {
+        if (!DWPW_ON(8) && st > 0) return;
 #pragma unroll
         for (int i = 0; i < 2; i++)
             af[i][ks] = *reinterpret_cast<const v4i_dp*>(wf + ((size_t)i * nk32 + (size_t)min(st, nst - 1) * (KST / 32) + ks) * 1024);
@@ -179,9 +197,10 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
         if (wave >= NW) return;
 #pragma unroll
         for (int ks = 0; ks < KST / 32; ks++) {
+            if (!DWPW_ON(1)) { if (next >= 0) a_load_ks(next, ks); continue; }
             v4i_dp bf[2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) bf[j] = *reinterpret_cast<const v4i_dp*>(&bs[buf][ks * 2 + hi][j * 32 + l31][0]);
+            for (int j = 0; j < 2; j++) bf[j] = DWPW_ON(32) ? *reinterpret_cast<const v4i_dp*>(&bs[buf][ks * 2 + hi][j * 32 + l31][0]) : af[j][ks];
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -205,20 +224,25 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
     if (t + 512 < cunits) reinterpret_cast<uint4*>(cW)[t + 512] = cu1;
     for (int i = t + 1024; i < cunits; i += 512) reinterpret_cast<uint4*>(cW)[i] = const_unit(i);      // more than 768 depthwise channels
     __syncthreads();                                     // the constants are in LDS
+    DWPW_STAMP(1);
     dw_compute(I0{}, 0, 0);
     dw_load(I0{}, 2);
     __syncthreads();
+    DWPW_STAMP(2);
     // half(st, D, buf): stage st (B buffer buf) multiplied, stage st + 1 produced from tap set D into the other buffer
     auto half = [&](int st, auto D, int buf) {
         mma(buf, st + 1);
+        DWPW_STAMP(8 + st);
         dw_compute(D, st + 1, buf ^ 1);
         dw_load(D, st + 3);
         __syncthreads();
+        DWPW_STAMP(3 + st);
     };
     int st = 0;
     for (; st + 2 < nst; st += 2) { half(st, I1{}, 0); half(st + 1, I0{}, 1); }
     if (st + 1 < nst) { half(st, I1{}, 0); mma(1, -1); }
     else mma(0, -1);
+    DWPW_STAMP(6);
     if (wave >= NW) return;
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cout) ----
@@ -241,6 +265,7 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const int c = cb + 8 * g4 + 4 * hi;
+                if (!DWPW_ON(4)) { pk[g4] = (unsigned)(acc[i][j][4 * g4 + 0] ^ acc[i][j][4 * g4 + 1] ^ acc[i][j][4 * g4 + 2] ^ acc[i][j][4 * g4 + 3]); continue; }
                 pk[g4] = requant4<WIN>(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3], s4s[i][g4], c, prq);
             }
             half_wave_regroup(pk);
@@ -248,8 +273,13 @@ __device__ __forceinline__ void dwpw_body(const DwPwArgs& a, int8_t* smem)
             if (live && c16 < a.c_limit) *reinterpret_cast<uint4*>(yp + c16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
     }
+    DWPW_STAMP(7);
 }
 
+// (Round 6 also built the depthwise layer as diagonal-weight MFMAs -- v_mfma_i32_16x16x64_i8, k = kx * 16 + channel, the B operand one
+// ds_read_b128 of an LDS copy of the input patch per tap row -- bit-exact, ~105 instead of ~260 vector instructions per wave and stage, and
+// 8 % SLOWER in the graph: the patch is re-read from LDS 12 KB per wave and stage on top of the pointwise B reads, and this kernel's
+// phases add up instead of overlapping.  tools/exp/patches/r06_dwpw_depthwise_on_mfma.patch, profiles/r06_ab_dwpw_depthwise_on_mfma_*.)
 template <int NW>
 __global__ __launch_bounds__(512) void dwpw_i8_kernel(DwPwArgs a)
 {

@@ -98,6 +98,10 @@ struct DwPwArgs {          // depthwise 3x3 (stride 1) -> pointwise 1x1 in one l
     int8_t* y;             // NHWC output of the pointwise conv
     int N, H, W, C, cs_in, cw, OH, OW, PH, PW;     // depthwise geometry (C channels in and out, cw = roundup(C, 16))
     int cout, ldc, c_off, c_limit;                 // pointwise output
+#ifdef TAMD_DWPW_STAMPS
+    unsigned long long* stamps;                    // tools/exp/dwpw_anatomy.hip only: 16 per block
+    int ablate;                                    // .. 1: no MFMAs, 2: no depthwise arithmetic, 4: no epilogue requantisation, 8: no A-fragment loads after stage 0, 16: no tap loads, 32: no B-fragment reads
+#endif
 };
 
 struct PwDwArgs {          // pointwise conv + its consumer in one launch (pwdw.hip)
