@@ -255,7 +255,7 @@ int time_fn(tamd_graph* g, const std::function<hipError_t(hipStream_t)>& fn, flo
 
 bool autotune_enabled()
 {
-    static const char* at_env = getenv("TAMD_AUTOTUNE");
+    const char* at_env = getenv("TAMD_AUTOTUNE");
     return !(at_env && atoi(at_env) == 0);
 }
 
@@ -839,7 +839,7 @@ int plan_i8(tamd_graph* g)
     // folded into the LATER of its two producers when that one is a group-1 GEMM conv whose output feeds nothing else
     std::vector<FusedElt> fuse_at(g->nodes.size());
     std::vector<char> has_fuse(g->nodes.size(), 0);
-    static const char* fuse_env = getenv("TAMD_FUSE_ELTWISE");
+    const char* fuse_env = getenv("TAMD_FUSE_ELTWISE");
     auto producer = [&](int t) { for (size_t i = 0; i < g->nodes.size(); i++) if (!g->nodes[i].out.empty() && g->nodes[i].out[0] == t) return (int)i; return -1; };
     for (size_t ei = 0; ei < g->nodes.size() && !(fuse_env && atoi(fuse_env) == 0); ei++) {
         HNode& e = g->nodes[ei];

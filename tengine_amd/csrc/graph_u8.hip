@@ -270,7 +270,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
                         if (!done && bl > most) { most = bl; pick = c; }
                     }
                 }
-                static const char* iat_env = getenv("TAMD_AUTOTUNE");
+                const char* iat_env = getenv("TAMD_AUTOTUNE");
                 char ikey[256];
                 snprintf(ikey, sizeof(ikey), "u8iconv|%s|%dx%dx%dx%d>%d k%dx%d s%d d%d%s%s", n.name.c_str(), x.n, x.c, x.h, x.w, cout, p.kernel_h, p.kernel_w,
                          p.stride_h, p.dilation_h, relu ? "+relu" : "", pool ? "+pool" : "");
@@ -383,7 +383,7 @@ static int plan_conv_u8(tamd_graph* g, HNode& n, const HNode* relu = nullptr, co
         };
         bool use_rgb = false, use_pw = false;           // conv_u8_rgb3x3 / conv_u8_pw (shallow pointwise layers of large maps)
         const char* pw_env = tamd_pin("u8_pw");                     // 0: never, 1: wherever it applies (tests)
-        static const char* at_env = getenv("TAMD_AUTOTUNE");
+        const char* at_env = getenv("TAMD_AUTOTUNE");
         const bool tune = !(at_env && atoi(at_env) == 0) && st.macs >= 4e6 && !tamd_pin("u8_cfg");
         // what the autotune decided last time (TAMD_PLAN_CACHE): "g<cfg>" GEMM family, "p<cfg>" patch kernel, "rgb"
         char ckey[256];

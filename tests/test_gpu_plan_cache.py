@@ -64,3 +64,25 @@ def test_plan_file_of_another_build_is_ignored_and_foreign_entries_survive_a_flu
     after = cache.read_text().splitlines()
     assert any(ln.startswith("gemm|some_other_model_layer|") for ln in after) and any(ln.startswith("gemm|res") for ln in after)
     assert not [f for f in tmp_path.iterdir() if ".tmp." in f.name]
+
+
+def test_autotune_switch_is_read_at_every_prerun(tmp_path, monkeypatch):
+    """round 6 (found by the suite's seed-7 file order): TAMD_AUTOTUNE / TAMD_FUSE_ELTWISE were read ONCE per process (function-local
+    statics), so whichever test planned first decided for every later graph -- after tests/test_gpu_pgemm.py's TAMD_AUTOTUNE=0 case no plan
+    file was written any more.  Both orders in one process: off (nothing timed, nothing recorded), then on (the file appears), then off."""
+    g = models.build("mobilenet_v1", "int8", 2)
+    x = models.synth_input(g, 5)
+    outs = []
+    for i, off in enumerate([True, False, True]):
+        cache = tmp_path / ("plan%d.txt" % i)
+        monkeypatch.setenv("TAMD_PLAN_CACHE", str(cache))
+        if off:
+            monkeypatch.setenv("TAMD_AUTOTUNE", "0")
+        else:
+            monkeypatch.delenv("TAMD_AUTOTUNE", raising=False)
+        out, _, _ = plan(g, x)
+        outs.append(out)
+        assert cache.exists() == (not off), (i, off)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
