@@ -36,6 +36,8 @@ CASES = [
     (1, 256, 14, 14, 320, 1, 0, 0, False),       # five wave slices, no bias, batch 1 (the hcl depthwise epilogue)
     (3, 32, 10, 10, 64, 0, -1, 0, True),         # no padding: 8 x 8 outputs
     (2, 384, 12, 13, 448, 1, 0, 6, True),        # three stages, seven wave slices
+    (2, 1024, 7, 7, 128, 1, 0, 0, True),         # round 6: 1024 depthwise channels -- more per-channel constants than two LDS units per thread (the copy's tail loop), eight stages
+    (1, 2048, 5, 6, 64, 1, 6, 0, False),         # .. the largest channel count whose constants fit (cw = 2048: 57 KB of LDS), sixteen stages
 ]
 
 
@@ -69,8 +71,8 @@ def test_the_depthwise_map_is_refused_when_fused():
 
 
 def test_unsupported_pairs_keep_two_launches():
-    """stride-2 depthwise, a 20-wide map, cout not in wave slices: two launches, still bit-exact (TAMD_FUSE_DWPW=2 only forces where it applies)"""
-    for args in [(2, 64, 20, 20, 64), (2, 64, 12, 12, 48)]:
+    """a 20-wide map, cout not in wave slices, more than 2048 channels: two launches, still bit-exact (TAMD_FUSE_DWPW=2 only forces where it applies)"""
+    for args in [(2, 64, 20, 20, 64), (2, 64, 12, 12, 48), (1, 2064, 4, 4, 64)]:      # (.. 2064 channels: their constants do not fit the LDS block)
         g, x = dwpw_graph(71 + args[2], *args)
         want = oracle.run_graph(g, x)[0]
         got, names, gr = run(g, x, 2)
