@@ -595,6 +595,7 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
         gr.set_input(x)
         gr.upload()
         gr.sync()
+        prerun_ms = gr.prerun_ms()
         for _ in range(warmup):
             gr.launch()
         gr.sync()
@@ -610,16 +611,77 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
         outs = gr.download()
         sha, want = output_sha(outs), golden_sha(model, dtype, batch)
         r = roofline_of(gr, model, dtype, batch, False, el / steps)
-        return {"what": what, "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el,
+        dispatch = "direct AQL dispatch (%d packets per step)" % gr.direct_packets() if gr.direct_packets() else "hipGraph replay"
+        gr.close()
+        gr = None
+        try:
+            halves = two_half_batches(model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want)
+        except Exception as e:                     # a side measurement of a side configuration: never at the cost of the line
+            halves = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        return {"what": what, "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "two_half_batches": halves,
                 "ms_per_step_min": 1e3 * els[0] / steps, "ms_per_step_max": 1e3 * els[-1] / steps, "steps": steps * regions, "regions": regions,
-                "dispatch": "direct AQL dispatch (%d packets per step)" % gr.direct_packets() if gr.direct_packets() else "hipGraph replay",
+                "dispatch": dispatch,
                 "roofline": {k: r[k] for k in ("bound", "kernel", "frac", "achieved", "peak", "unit", "traffic", "algorithmic_bytes_per_launch",
                                                "algorithmic_macs_per_launch", "avg_launch_us", "launches_per_step", "mfma_util_pct",
                                                "step_roofline_us", "step_frac")},
                 "output_sha256": sha, "golden_sha256": want, "golden_match": (sha == want) if want else None,
-                "prerun_ms": gr.prerun_ms(), "shipped_plan": shipped}
+                "prerun_ms": prerun_ms, "shipped_plan": shipped}
     finally:
         if gr is not None:
+            gr.close()
+        if os.path.exists(plan):
+            os.remove(plan)
+
+
+def two_half_batches(model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want):
+    """The same batch as TWO graphs of half the batch each, submitted side by side on their own queues (the C ABI as a serving host
+    can use it today: graphs are independent objects): the launch boundaries and tile tails of one half overlap the other's work.
+    Same images, same region protocol as side_config, outputs of the two halves concatenated and compared with the same golden.
+    A SIDE figure: `ms_per_step` / `images_per_s` of the configuration stay the one-graph numbers.  profiles/r06_split_batch_direct.txt"""
+    import tempfile
+
+    import numpy as np
+
+    from tengine_amd import capi, models, plans, tm2
+    if batch < 2 or batch % 2:
+        return None
+    half, u8 = batch // 2, dtype == "uint8"
+    plan = os.path.join(tempfile.gettempdir(), "tamd_plan_%d_%s_%s_b%d.txt" % (os.getpid(), model, dtype, half))
+    shipped = plans.seed(plan, model, dtype, half)
+    os.environ["TAMD_PLAN_CACHE"] = plan
+    grs = []
+    try:
+        g = models.build(model, dtype, half)
+        tm_bytes = tm2.write_tm2(g)
+        for h in range(2):
+            gr = capi.Graph(tm_bytes, batch=half, gpu_index=gpu_index, direct_dispatch=bool(direct))
+            grs.append(gr)
+            gr.set_input(np.ascontiguousarray(x[h * half:(h + 1) * half]))
+            gr.upload()
+            gr.sync()
+        for _ in range(warmup):
+            for gr in grs:
+                gr.launch()
+        for gr in grs:
+            gr.sync()
+        els = []
+        for _ in range(regions):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                for gr in grs:
+                    gr.launch()
+            for gr in grs:
+                gr.sync()
+            els.append(time.perf_counter() - t0)
+        els.sort()
+        el = els[len(els) // 2]
+        o0, o1 = grs[0].download(), grs[1].download()
+        sha = output_sha([np.concatenate([a.reshape(half, -1), b.reshape(half, -1)]) for a, b in zip(o0, o1)])
+        return {"what": "two concurrent graphs of batch %d, each on its own queue; same images, same %d x %d steps" % (half, regions, steps),
+                "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "ms_per_step_min": 1e3 * els[0] / steps,
+                "ms_per_step_max": 1e3 * els[-1] / steps, "golden_match": (sha == want) if want else None, "shipped_plan": shipped}
+    finally:
+        for gr in grs:
             gr.close()
         if os.path.exists(plan):
             os.remove(plan)

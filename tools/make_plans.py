@@ -4,7 +4,7 @@ configuration under a fresh TAMD_PLAN_CACHE -- several of them, the plan with th
 autotune chooses there, plus the step time the plan gives (direct dispatch, device-resident) so the file can be judged against the
 evidence tables.
 
-usage: make_plans.py [out_dir]      (default tengine_amd/plans; TAMD_U8_INT plans get the dtype suffix _int)"""
+usage: make_plans.py [out_dir [all|main|half]]      (default tengine_amd/plans, all; TAMD_U8_INT plans get the dtype suffix _int)"""
 import os
 import sys
 
@@ -14,6 +14,9 @@ from tengine_amd import capi, models, plans, tm2  # noqa: E402
 
 CONFIGS = [("mobilenet_v1", "int8", 1, False), ("mobilenet_v1", "int8", 64, False), ("resnet50", "int8", 32, False),
            ("yolov3_tiny", "uint8", 8, False), ("mssd", "uint8", 16, False), ("yolov3_tiny", "uint8", 8, True), ("mssd", "uint8", 16, True)]
+# the half batches of the four batched configurations: bench.py's `two_half_batches` side measurement (two concurrent graphs of half the
+# batch each, on their own queues -- profiles/r06_split_batch_direct.txt) plans from these.  `make_plans.py out_dir half` writes only these.
+HALF_CONFIGS = [("mobilenet_v1", "int8", 32, False), ("resnet50", "int8", 16, False), ("yolov3_tiny", "uint8", 4, False), ("mssd", "uint8", 8, False)]
 
 
 def plan_once(name, dtype, batch, integer, path):
@@ -42,11 +45,13 @@ def plan_once(name, dtype, batch, integer, path):
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else plans.PLAN_DIR
+    which = sys.argv[2] if len(sys.argv) > 2 else "all"
+    configs = HALF_CONFIGS if which == "half" else CONFIGS + HALF_CONFIGS if which == "all" else CONFIGS
     os.makedirs(out, exist_ok=True)
     import shutil
     import tempfile
     tmp = tempfile.mkdtemp(prefix="make_plans_")
-    for name, dtype, batch, integer in CONFIGS:
+    for name, dtype, batch, integer in configs:
         path = os.path.join(out, "%s_%s%s_b%d.txt" % (name, dtype, "_int" if integer else "", batch))
         # The plan-time races time isolated launches; a race between microsecond kernels (and every fuse / do-not-fuse decision
         # behind one) can fall the wrong way for the STEP: the planner runs several times, the plan whose step is the fastest ships
