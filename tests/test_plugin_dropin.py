@@ -222,6 +222,51 @@ def test_hip_device_equals_reference_cpu_device(ref, case):
         assert np.array_equal(w, o) and np.array_equal(w, a)
 
 
+def _split_count():
+    P = C.CDLL(PLUGIN)
+    P.hip_device_split_subgraphs.restype = C.c_int
+    return P.hip_device_split_subgraphs()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,env,split", [("conv3x3_b2", "2", True), ("resblock_tail_b2", "2", True), ("resnet50_prob_b2", "2", True),
+                                            ("mobilenet_v1_b16", None, True), ("mobilenet_v1_b16", "0", False), ("conv3x3_b2", None, False),
+                                            ("conv3x3_b3", "2", False)])
+def test_batched_subgraph_as_two_half_batch_graphs(ref, case, env, split, monkeypatch):
+    """round 6: a subgraph of batch-wise independent operators whose activations all carry an even batch runs as TWO device graphs of half
+    the batch, side by side on their own queues (from batch 16 on; TAMD_SPLIT_BATCH=2: wherever possible, =0: never): the reference CPU
+    device's bytes either way, on the first run and on a second one (input pointers re-read), and the split is asserted, not assumed."""
+    _load_plugin(ref)
+    if env is None:
+        monkeypatch.delenv("TAMD_SPLIT_BATCH", raising=False)
+    else:
+        monkeypatch.setenv("TAMD_SPLIT_BATCH", env)
+    if case.startswith("conv3x3"):
+        g, x = conv_graph(31, int(case[-1]), 64, 20, 20, 96, 3, 1, 1)
+    elif case == "resblock_tail_b2":
+        g, x = eltwise_relu_graph(9, 2, 64, 14, 14, True)
+    elif case == "resnet50_prob_b2":
+        g = models.build("resnet50", "int8", 2)
+        x = models.synth_input(g, 8)
+    else:
+        g = models.build("mobilenet_v1", "int8", 16)
+        x = models.synth_input(g, 7)
+    b = tm2.write_tm2(g)
+    want = ref.run_model(b, x, ref.MODE_INT8, 4)
+    before = _split_count()
+    rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
+    rg.set_input(x)
+    rg.run()
+    assert_all_on_hip(rg)
+    assert (_split_count() - before >= 1) == split, (case, env, _split_count() - before)
+    got = rg.outputs()
+    rg.run()
+    again = rg.outputs()
+    rg.close()
+    for w, o, a in zip(want, got, again):
+        assert np.array_equal(w, o) and np.array_equal(w, a)
+
+
 @pytest.mark.gpu
 def test_unsupported_tail_falls_back_to_cpu_subgraph(ref):
     """int8 graph with a tail the device does not run -- a Softmax over the batch axis; until round 5 this test used the rows of the map,
@@ -350,8 +395,8 @@ def test_int8_rescaling_concat_runs_on_the_device_and_matches_cpu(ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["conv", "mobilenet_v1"])
-def test_async_run_graph_through_the_plugins_scheduler(ref, model):
+@pytest.mark.parametrize("model", ["conv", "mobilenet_v1", "conv_split"])
+def test_async_run_graph_through_the_plugins_scheduler(ref, model, monkeypatch):
     """SURVEY 8(f)4, the scheduler half: the reference's own run_graph(graph, 0) reaches interface.async_run through the scheduler
     the plugin installs on the context; two runs in flight, a third is refused; results in submission order, reference bytes.
     wait_graph() itself cannot work in the unmodified reference (its status test is always true, c_api.c:588): asserted as is,
@@ -362,7 +407,9 @@ def test_async_run_graph_through_the_plugins_scheduler(ref, model):
     P.hip_wait_graph.argtypes = [C.c_void_p, C.c_int]
     L.wait_graph.restype = C.c_int
     L.wait_graph.argtypes = [C.c_void_p, C.c_int]
-    if model == "conv":
+    if model == "conv_split":                      # (round 6) the same protocol on a subgraph that runs as two half-batch graphs
+        monkeypatch.setenv("TAMD_SPLIT_BATCH", "2")
+    if model in ("conv", "conv_split"):
         g, x1 = conv_graph(61, 2, 64, 14, 14, 96, 3, 1, 1)
     else:
         g = models.build("mobilenet_v1", "int8", 1)
@@ -374,9 +421,11 @@ def test_async_run_graph_through_the_plugins_scheduler(ref, model):
     want2 = ref.run_model(b, x2, ref.MODE_INT8, 4)[0]
     assert not np.array_equal(want1, want2)
     rg = ref.RefGraph(b, ref.MODE_INT8, 1, device="HIP", dev_opt=HipOpt(b"HIP", C.sizeof(HipOpt), 0, 1, 0))
+    before = _split_count()
     rg.set_input(x1)
     rg.prerun()
     assert_all_on_hip(rg)
+    assert (_split_count() - before >= 1) == (model == "conv_split")
     buf = np.ascontiguousarray(x1).copy()           # ONE application buffer, refilled between submissions
     t = L.get_graph_input_tensor(rg.g, 0, 0)
     assert L.set_tensor_buffer(t, buf.ctypes.data, buf.nbytes) == 0
