@@ -139,7 +139,7 @@ int hip_dev_init(struct device* dev)
 int g_split_subgraphs = 0;       // subgraphs preran as two half-batch graphs since the plugin was loaded (hip_device_split_subgraphs: tests)
 
 // Does this subgraph run as two half-batch device graphs?  TAMD_SPLIT_BATCH=0: never; =2: whenever it is possible (tests); default: from
-// batch 16 on.  Possible = an even batch B carried as dimension 0 by EVERY activation tensor of the subgraph (inputs and outputs included:
+// batch 8 on.  Possible = an even batch B carried as dimension 0 by EVERY activation tensor of the subgraph (inputs and outputs included:
 // their host buffers are then two contiguous halves), and only operators that treat the images of a batch independently.
 bool split_wanted(struct graph* ir, struct subgraph* subgraph)
 {
@@ -164,7 +164,7 @@ bool split_wanted(struct graph* ir, struct subgraph* subgraph)
             if (t->dims[0] != B) return false;
         }
     }
-    return B >= (mode == 2 ? 2 : 16) && B % 2 == 0;
+    return B >= (mode == 2 ? 2 : 8) && B % 2 == 0;          // (profiles/r06_plugin_split_threshold.txt: batch 8 +1 .. +22 %, batch 4 0 .. +3 %, batch 2 -3 .. +2 %)
 }
 
 int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)

@@ -231,10 +231,11 @@ def _split_count():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,env,split", [("conv3x3_b2", "2", True), ("resblock_tail_b2", "2", True), ("resnet50_prob_b2", "2", True),
                                             ("mobilenet_v1_b16", None, True), ("mobilenet_v1_b16", "0", False), ("conv3x3_b2", None, False),
+                                            ("conv3x3_b8", None, True), ("conv3x3_b6", None, False),
                                             ("conv3x3_b3", "2", False)])
 def test_batched_subgraph_as_two_half_batch_graphs(ref, case, env, split, monkeypatch):
     """round 6: a subgraph of batch-wise independent operators whose activations all carry an even batch runs as TWO device graphs of half
-    the batch, side by side on their own queues (from batch 16 on; TAMD_SPLIT_BATCH=2: wherever possible, =0: never): the reference CPU
+    the batch, side by side on their own queues (from batch 8 on; TAMD_SPLIT_BATCH=2: wherever possible, =0: never): the reference CPU
     device's bytes either way, on the first run and on a second one (input pointers re-read), and the split is asserted, not assumed."""
     _load_plugin(ref)
     if env is None:
@@ -242,7 +243,7 @@ def test_batched_subgraph_as_two_half_batch_graphs(ref, case, env, split, monkey
     else:
         monkeypatch.setenv("TAMD_SPLIT_BATCH", env)
     if case.startswith("conv3x3"):
-        g, x = conv_graph(31, int(case[-1]), 64, 20, 20, 96, 3, 1, 1)
+        g, x = conv_graph(31, int(case[-1]), 64, 20, 20, 96, 3, 1, 1)      # (batch = the case's last digit: 2, 3, 6, 8)
     elif case == "resblock_tail_b2":
         g, x = eltwise_relu_graph(9, 2, 64, 14, 14, True)
     elif case == "resnet50_prob_b2":

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The plugin's two-half-batch form against its one-graph form, host to host through the UNMODIFIED reference library
 (create_graph / prerun_graph / run_graph on device "HIP"): blocking run_graph() calls timed on the host, TAMD_SPLIT_BATCH=0 against the
-default, fresh graph each, interleaved; outputs compared.   usage: plugin_split_ab.py model batch runs rounds"""
+default, fresh graph each, interleaved; outputs compared.   usage: plugin_split_ab.py model batch runs rounds [2 = force the split below the default threshold]"""
 import ctypes as C
 import os
 import sys
@@ -23,6 +23,7 @@ class HipOpt(C.Structure):
 
 def main():
     name, batch, runs, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    force = len(sys.argv) > 5 and sys.argv[5] == "2"
     L = ref.lib()
     assert L.load_tengine_plugin(b"hip", PLUGIN.encode(), b"register_hip_device") == 0
     P = C.CDLL(PLUGIN)
@@ -36,6 +37,8 @@ def main():
         for mode in ("0", "default"):
             if mode == "0":
                 os.environ["TAMD_SPLIT_BATCH"] = "0"
+            elif force:
+                os.environ["TAMD_SPLIT_BATCH"] = "2"
             else:
                 os.environ.pop("TAMD_SPLIT_BATCH", None)
             before = P.hip_device_split_subgraphs()
