@@ -515,7 +515,8 @@ def roofline_of(gr, model, dtype, batch, u8_integer, step_s):
         roofline = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TOP/s", "frac": ach / mfma_peak}
     sum_ms = max(sum(f["ms"] for f in fam.values()), 1e-12)
     roofline.update({"kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
-                     "traffic": pmc_traffic(model, dtype + ("_int" if u8_integer else ""), batch, dom),
+                     # (a graph compiled as two half-batch device graphs launches half-batch kernels: their PMC pass is the half batch's)
+                     "traffic": pmc_traffic(model, dtype + ("_int" if u8_integer else ""), batch // 2 if gr.halves() else batch, dom),
                      "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                      "algorithmic_macs_per_launch": d["macs"] / d["launches"],
                      # whole-step matrix-core utilisation (BASELINE metric's second half): all MACs of the step
@@ -612,13 +613,17 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
         sha, want = output_sha(outs), golden_sha(model, dtype, batch)
         r = roofline_of(gr, model, dtype, batch, False, el / steps)
         dispatch = "direct AQL dispatch (%d packets per step)" % gr.direct_packets() if gr.direct_packets() else "hipGraph replay"
+        halves = gr.halves()
+        if halves:
+            dispatch += ", as two device graphs of batch %d side by side on their own queues behind one handle (tamd_options.split_batch)" % (batch // 2)
         gr.close()
         gr = None
         try:
-            halves = two_half_batches(model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want)
+            other = other_form(tm_bytes, model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want, 1 if halves else 2)
         except Exception as e:                     # a side measurement of a side configuration: never at the cost of the line
-            halves = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-        return {"what": what, "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "two_half_batches": halves,
+            other = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        return {"what": what, "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "halves": halves,
+                ("one_launch_list" if halves else "two_half_batches"): other,
                 "ms_per_step_min": 1e3 * els[0] / steps, "ms_per_step_max": 1e3 * els[-1] / steps, "steps": steps * regions, "regions": regions,
                 "dispatch": dispatch,
                 "roofline": {k: r[k] for k in ("bound", "kernel", "frac", "achieved", "peak", "unit", "traffic", "algorithmic_bytes_per_launch",
@@ -633,58 +638,36 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
             os.remove(plan)
 
 
-def two_half_batches(model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want):
-    """The same batch as TWO graphs of half the batch each, submitted side by side on their own queues (the C ABI as a serving host
-    can use it today: graphs are independent objects): the launch boundaries and tile tails of one half overlap the other's work.
-    Same images, same region protocol as side_config, outputs of the two halves concatenated and compared with the same golden.
-    A SIDE figure: `ms_per_step` / `images_per_s` of the configuration stay the one-graph numbers.  profiles/r06_split_batch_direct.txt"""
-    import tempfile
-
-    import numpy as np
-
-    from tengine_amd import capi, models, plans, tm2
-    if batch < 2 or batch % 2:
-        return None
-    half, u8 = batch // 2, dtype == "uint8"
-    plan = os.path.join(tempfile.gettempdir(), "tamd_plan_%d_%s_%s_b%d.txt" % (os.getpid(), model, dtype, half))
-    shipped = plans.seed(plan, model, dtype, half)
-    os.environ["TAMD_PLAN_CACHE"] = plan
-    grs = []
+def other_form(tm_bytes, model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want, split_batch):
+    """The same configuration in the OTHER form the library has for a batch -- one launch list (split_batch = 1) when the configuration's
+    own graph took the two-half-batch form, two half-batch graphs side by side (split_batch = 2) when it did not -- through the same
+    single handle, same images, same region protocol, outputs against the same golden.  A SIDE figure: it shows inside the driver's own
+    run what the form costs or buys; `ms_per_step` / `images_per_s` of the configuration are its default form's."""
+    from tengine_amd import capi
+    gr = capi.Graph(tm_bytes, batch=batch, gpu_index=gpu_index, direct_dispatch=bool(direct), split_batch=split_batch)
     try:
-        g = models.build(model, dtype, half)
-        tm_bytes = tm2.write_tm2(g)
-        for h in range(2):
-            gr = capi.Graph(tm_bytes, batch=half, gpu_index=gpu_index, direct_dispatch=bool(direct))
-            grs.append(gr)
-            gr.set_input(np.ascontiguousarray(x[h * half:(h + 1) * half]))
-            gr.upload()
-            gr.sync()
+        gr.set_input(x)
+        gr.upload()
+        gr.sync()
         for _ in range(warmup):
-            for gr in grs:
-                gr.launch()
-        for gr in grs:
-            gr.sync()
+            gr.launch()
+        gr.sync()
         els = []
         for _ in range(regions):
             t0 = time.perf_counter()
             for _ in range(steps):
-                for gr in grs:
-                    gr.launch()
-            for gr in grs:
-                gr.sync()
+                gr.launch()
+            gr.sync()
             els.append(time.perf_counter() - t0)
         els.sort()
         el = els[len(els) // 2]
-        o0, o1 = grs[0].download(), grs[1].download()
-        sha = output_sha([np.concatenate([a.reshape(half, -1), b.reshape(half, -1)]) for a, b in zip(o0, o1)])
-        return {"what": "two concurrent graphs of batch %d, each on its own queue; same images, same %d x %d steps" % (half, regions, steps),
-                "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "ms_per_step_min": 1e3 * els[0] / steps,
-                "ms_per_step_max": 1e3 * els[-1] / steps, "golden_match": (sha == want) if want else None, "shipped_plan": shipped}
+        sha = output_sha(gr.download())
+        return {"what": "tamd_options.split_batch = %d: %s; same images, same %d x %d steps"
+                        % (split_batch, "two device graphs of batch %d side by side on their own queues" % (batch // 2) if gr.halves() else "one launch list", regions, steps),
+                "halves": gr.halves(), "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "ms_per_step_min": 1e3 * els[0] / steps,
+                "ms_per_step_max": 1e3 * els[-1] / steps, "golden_match": (sha == want) if want else None}
     finally:
-        for gr in grs:
-            gr.close()
-        if os.path.exists(plan):
-            os.remove(plan)
+        gr.close()
 
 
 def kernel_family(step_kernel):

@@ -159,6 +159,16 @@ typedef struct tamd_options {
                            * in fp32, conv_kernel_x86.c:68-80,1703-1794).  The bound is per layer, NOT end to end: errors compound,
                            * MobileNet-SSD's outputs differ from the reference's by up to 4-5 steps in 33-36 % of the bytes
                            * (profiles/r04_u8int_pytest.txt).  0 (default): the byte-exact fp32 chains.  TAMD_U8_INT=0|1 overrides. */
+    int split_batch;      /* A batched graph whose operators treat the images of a batch independently (Convolution, FullyConnected,
+                           * Pooling, ReLU, Eltwise, Dropout, Concat / Softmax on an axis >= 1) and whose activation tensors all carry
+                           * the same even batch B as dimension 0 can be compiled as TWO device graphs of B / 2 images each, run side by
+                           * side on their own HSA queues behind this one tamd_graph: launch boundaries and tile tails of one half
+                           * overlap the other half's work (ResNet-50 b32 +8 %, MobileNet-v1 b64 +6 %, outputs identical:
+                           * profiles/r06_split_batch_direct.txt).  Every entry point behaves as for one graph; host buffers are used
+                           * as two contiguous halves.  0 (default): where it pays -- int8 graphs with direct_dispatch from batch 16
+                           * on; 1: never (final: a caller that splits batches by itself, as the plugin does); 2: wherever it is possible.
+                           * TAMD_SPLIT_BATCH=0|1|2 overrides 0 and 2 (0: never, 1: default rule, 2: wherever possible -- the values the
+                           * plugin's switch of the same name takes).  tamd_graph_halves() tells which form a graph took. */
 } tamd_options;
 
 typedef struct tamd_graph tamd_graph;
@@ -201,6 +211,8 @@ TAMD_API int tamd_graph_set_batch(tamd_graph* g, int batch);
  * run     <- interface.run       (device.h:49, scheduler.c:134; must return with outputs complete)
  * destroy <- interface.post_run / release_graph (device.h:52-58, scheduler.c:201, subgraph.c:53-56) */
 TAMD_API int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt);
+/* 2: the graph was compiled as two half-batch device graphs (tamd_options.split_batch); 0: one launch list */
+TAMD_API int tamd_graph_halves(const tamd_graph* g);
 TAMD_API int tamd_graph_input_num(const tamd_graph* g);
 TAMD_API int tamd_graph_output_num(const tamd_graph* g);
 /* dims/dtype of graph input / output `idx` (NCHW); returns dim_num */

@@ -22,7 +22,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "pwdw_slices.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8_conv_gemm.hip", "u8_conv_patch.hip", "u8_conv_small.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_infer.hip", "graph_plan.hip", "graph_plan_pairs.hip", "plan_cache.hip", "graph_exec.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
+SOURCES = ["conv_igemm.hip", "conv_igemm2.hip", "conv_pgemm.hip", "conv_pgemm_w.hip", "gemm_direct.hip", "pw_stream.hip", "pw_rows.hip", "conv_first.hip", "conv_first_pool.hip", "dwconv.hip", "dwpw.hip", "pwdw.hip", "pwdw_slices.hip", "conv_direct.hip", "misc_kernels.hip", "u8_kernels.hip", "u8_conv_gemm.hip", "u8_conv_patch.hip", "u8_conv_small.hip", "u8i_kernels.hip", "conv_f32_mfma.hip", "winograd_f32.hip", "f32_kernels.hip", "graph.hip", "graph_infer.hip", "graph_plan.hip", "graph_plan_pairs.hip", "plan_cache.hip", "graph_exec.hip", "graph_pair.hip", "graph_u8.hip", "graph_f32.hip", "tm2_reader.cc", "direct.cc"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 # int8 GEMM kernels: MFMA accumulators in architectural VGPRs.  hipcc's heuristic keeps them in AccVGPRs and every value

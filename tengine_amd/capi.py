@@ -17,7 +17,7 @@ _NP = {DT_FP32: np.float32, DT_FP16: np.float16, DT_INT8: np.int8, DT_UINT8: np.
 
 class Options(C.Structure):           # tamd_options
     _fields_ = [("dev_name", C.c_char_p), ("size", C.c_int), ("gpu_index", C.c_int), ("use_hip_graph", C.c_int), ("profile", C.c_int),
-                ("direct_dispatch", C.c_int), ("keep_tensors", C.c_int), ("u8_integer", C.c_int)]
+                ("direct_dispatch", C.c_int), ("keep_tensors", C.c_int), ("u8_integer", C.c_int), ("split_batch", C.c_int)]
 
 
 class KernelInfo(C.Structure):        # tamd_kernel_info
@@ -28,7 +28,7 @@ class KernelInfo(C.Structure):        # tamd_kernel_info
 EXPORTS = [
     "tamd_device_count", "tamd_init", "tamd_shutdown", "tamd_last_error", "tamd_version", "tamd_op_supported", "tamd_node_supported",
     "tamd_graph_create", "tamd_graph_add_tensor", "tamd_graph_add_node", "tamd_graph_set_inputs",
-    "tamd_graph_set_outputs", "tamd_graph_load_tm2", "tamd_graph_set_batch", "tamd_graph_prerun",
+    "tamd_graph_set_outputs", "tamd_graph_load_tm2", "tamd_graph_set_batch", "tamd_graph_prerun", "tamd_graph_halves",
     "tamd_graph_input_num", "tamd_graph_output_num", "tamd_graph_input_desc", "tamd_graph_output_desc",
     "tamd_graph_set_input", "tamd_graph_set_output", "tamd_graph_run", "tamd_graph_run_async", "tamd_graph_wait", "tamd_graph_inflight", "tamd_graph_upload_inputs",
     "tamd_graph_launch", "tamd_graph_sync", "tamd_graph_direct_packets", "tamd_graph_direct_meta_packets", "tamd_graph_download_outputs", "tamd_graph_output_device",
@@ -68,7 +68,7 @@ def lib():
         L.tamd_graph_prerun_ms.argtypes = [vp]
         for name, args in {
             "tamd_graph_set_batch": [vp, ci], "tamd_graph_prerun": [vp, C.POINTER(Options)],
-            "tamd_graph_input_num": [vp], "tamd_graph_output_num": [vp],
+            "tamd_graph_input_num": [vp], "tamd_graph_output_num": [vp], "tamd_graph_halves": [vp],
             "tamd_graph_input_desc": [vp, ci, C.POINTER(ci), C.POINTER(ci)],
             "tamd_graph_output_desc": [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_float), C.POINTER(ci)],
             "tamd_graph_set_input": [vp, ci, vp, C.c_size_t], "tamd_graph_set_output": [vp, ci, vp, C.c_size_t],
@@ -101,7 +101,7 @@ def device_count():
 class Graph:
     """A device graph loaded from tmfile bytes (same bytes the reference's `tengine:m` loader takes)."""
 
-    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False, direct_dispatch=False, keep_tensors=False, u8_integer=False):
+    def __init__(self, tm_bytes: bytes, batch=None, gpu_index=0, use_hip_graph=True, profile=False, direct_dispatch=False, keep_tensors=False, u8_integer=False, split_batch=0):
         L = lib()
         self._h = L.tamd_graph_load_tm2(tm_bytes, len(tm_bytes))
         if not self._h:
@@ -109,7 +109,7 @@ class Graph:
         if batch is not None:
             _check(L.tamd_graph_set_batch(self._h, batch), "set_batch")
         opt = Options(b"HIP", C.sizeof(Options), gpu_index, 1 if use_hip_graph else 0, 1 if profile else 0, 1 if direct_dispatch else 0,
-                      1 if keep_tensors else 0, 1 if u8_integer else 0)
+                      1 if keep_tensors else 0, 1 if u8_integer else 0, int(split_batch))
         _check(L.tamd_graph_prerun(self._h, C.byref(opt)), "prerun")
         self._in, self._out = [], []
         for i in range(L.tamd_graph_output_num(self._h)):
@@ -119,6 +119,10 @@ class Graph:
             arr = np.zeros([dims[k] for k in range(nd)], _NP[dt.value])
             self._out.append(arr)
             _check(L.tamd_graph_set_output(self._h, i, arr.ctypes.data, arr.nbytes), "set_output")
+
+    def halves(self):
+        """2: compiled as two half-batch device graphs behind this one handle (tamd_options.split_batch); 0: one launch list"""
+        return lib().tamd_graph_halves(self._h)
 
     def input_desc(self, idx=0):
         dims = (C.c_int * 8)()

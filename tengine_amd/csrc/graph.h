@@ -190,6 +190,12 @@ struct tamd_graph {
     tamd_options opt{};
     bool prepared = false;
     int gpu = 0;
+    // round 6: a batched graph of batch-wise independent operators is compiled as TWO device graphs of half the batch each
+    // (graph_pair.hip): half[0] runs images [0, B / 2), half[1] the rest, side by side on their own HSA queues.  This object then
+    // keeps the IR (descriptions, constants) and forwards every entry point; it owns no stream, launch list or device tensor.
+    tamd_graph* half[2] = {nullptr, nullptr};
+    bool is_half = false;                      // one of the two halves of such a pair: never split again
+    std::vector<void*> pair_out;               // tamd_graph_output_device of a pair: the two halves gathered into one buffer per output
 };
 
 namespace tamd {

@@ -265,6 +265,8 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
     TAMD_ONE_THREAD(g);
     if (!g) return -1;
     if (g->prepared) return 0;
+    // a batched graph of batch-wise independent operators: two half-batch device graphs side by side (graph_pair.hip)
+    if (const int pr = pair_try_prerun(g, opt)) return pr < 0 ? -1 : 0;
     std::lock_guard<std::mutex> lk(g_capture_mutex);
     tamd_options o{};
     o.dev_name = "HIP"; o.size = (int)sizeof(tamd_options); o.gpu_index = 0; o.use_hip_graph = 1; o.profile = 0;
@@ -393,6 +395,7 @@ int tamd_graph_prerun(tamd_graph* g, const tamd_options* opt)
     return 0;
 }
 
+int tamd_graph_halves(const tamd_graph* g) { return g && g->half[0] ? 2 : 0; }
 int tamd_graph_input_num(const tamd_graph* g) { return (int)g->inputs.size(); }
 int tamd_graph_output_num(const tamd_graph* g) { return (int)g->outputs.size(); }
 
@@ -426,6 +429,7 @@ int tamd_graph_set_input(tamd_graph* g, int idx, const void* host, size_t bytes)
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->inputs.size()) { set_error("bad input index"); return -1; }
     if (g->prepared && bytes != g->inputs[idx].bytes) { set_error("input %d: %zu bytes given, %zu expected", idx, bytes, g->inputs[idx].bytes); return -1; }
+    if (g->half[0]) return pair_set_input(g, idx, host, bytes);
     g->inputs[idx].host_in = host;
     return 0;
 }
@@ -436,18 +440,20 @@ int tamd_graph_set_output(tamd_graph* g, int idx, void* host, size_t bytes)
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->outputs.size()) { set_error("bad output index"); return -1; }
     if (g->prepared && bytes != g->outputs[idx].bytes) { set_error("output %d: %zu bytes given, %zu expected", idx, bytes, g->outputs[idx].bytes); return -1; }
+    if (g->half[0]) return pair_set_output(g, idx, host, bytes);
     g->outputs[idx].host_out = host;
     return 0;
 }
 
 
-int tamd_graph_kernel_num(const tamd_graph* g) { return (int)g->steps.size(); }
+int tamd_graph_kernel_num(const tamd_graph* g) { return g->half[0] ? pair_kernel_num(g) : (int)g->steps.size(); }
 
 int tamd_graph_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out)
 {
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    if (g->half[0]) return pair_profile(g, iters, out, max_out);
     if (!g->inflight.empty()) { set_error("tamd_graph_profile while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     g->out_fresh_in = 0;                       // the launches below (and the closing pass) write the staging buffers themselves
@@ -501,6 +507,7 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->tensors.size() || !g->prepared) return -1;
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_read_tensor(g, idx, host, bytes);
     HTensor& t = g->tensors[idx];
     if (t.ttype == TAMD_TT_CONST) { memcpy(host, t.data.data(), std::min(bytes, t.data.size())); return 0; }
     if ((size_t)idx < g->fused_away.size() && g->fused_away[idx]) {
@@ -546,6 +553,7 @@ int tamd_graph_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes)
 void tamd_graph_destroy(tamd_graph* g)
 {
     if (!g) return;
+    if (g->half[0]) { pair_destroy(g); return; }          // (the halves print their own tables, release their own queues and memory)
     if (g->prepared) (void)bind_device(g);
     if (g->prepared && g->opt.profile) dump_profile(g);
     if (g->h2h_runs > 0)

@@ -301,6 +301,7 @@ int tamd_graph_upload_inputs(tamd_graph* g)
 {
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_both(g, tamd_graph_upload_inputs);
     if (!g->inflight.empty()) { set_error("tamd_graph_upload_inputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
@@ -318,6 +319,7 @@ int tamd_graph_launch(tamd_graph* g)
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
     if (!g->prepared) { set_error("graph not prepared"); return -1; }
+    if (g->half[0]) return pair_both(g, tamd_graph_launch);
     g->out_fresh_in = 0;                       // the pass writes the staging buffers itself
     if (g->direct) {
         // the pass reads what the stream wrote (uploaded inputs): drain it before the first packet of a burst
@@ -336,15 +338,16 @@ int tamd_graph_launch(tamd_graph* g)
     return run_steps(g, g->stream);
 }
 
-int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->direct ? direct_packets(g->direct) : 0; }
-int tamd_graph_direct_meta_packets(const tamd_graph* g) { return g && g->direct ? direct_meta_packets(g->direct) : 0; }
-const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i) { return g && g->direct ? direct_packet_name(g->direct, i) : ""; }
+int tamd_graph_direct_packets(const tamd_graph* g) { return g && g->half[0] ? pair_direct_packets(g, false) : g && g->direct ? direct_packets(g->direct) : 0; }
+int tamd_graph_direct_meta_packets(const tamd_graph* g) { return g && g->half[0] ? pair_direct_packets(g, true) : g && g->direct ? direct_meta_packets(g->direct) : 0; }
+const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i) { return g && g->half[0] ? pair_direct_packet_name(g, i) : g && g->direct ? direct_packet_name(g->direct, i) : ""; }
 
 int tamd_graph_direct_timestamps(tamd_graph* g, int passes, double* dur_us, double* gap_us, int max_packets)
 {
     if (!g) { set_error("null graph"); return -1; }
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_direct_timestamps(g, passes, dur_us, gap_us, max_packets);
     if (!g->prepared || !g->direct) { set_error("tamd_graph_direct_timestamps: the graph does not dispatch directly (tamd_options.direct_dispatch)"); return -1; }
     if (!g->inflight.empty()) { set_error("tamd_graph_direct_timestamps while asynchronous runs are in flight"); return -1; }
     if (max_packets < direct_packets(g->direct)) { set_error("tamd_graph_direct_timestamps: %d packets, room for %d", direct_packets(g->direct), max_packets); return -1; }
@@ -362,6 +365,7 @@ int tamd_graph_sync(tamd_graph* g)
 {
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_both(g, tamd_graph_sync);
     if (direct_drain(g)) return -1;
     // asynchronous runs that were submitted and not collected yet are device work too (their outputs stay in the pinned slots
     // until tamd_graph_wait delivers them)
@@ -375,6 +379,7 @@ int tamd_graph_download_outputs(tamd_graph* g)
 {
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_both(g, tamd_graph_download_outputs);
     if (!g->inflight.empty()) { set_error("tamd_graph_download_outputs while asynchronous runs are in flight (they own the pinned buffers): collect them with tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     if (g->out_fresh_in) {                     // the last pass was a zero-copy host-to-host run: its pinned slot IS the newest copy
@@ -393,6 +398,7 @@ int tamd_graph_run(tamd_graph* g)
 {
     TAMD_ONE_THREAD(g);
     if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
+    if (g->half[0]) return pair_run(g);
     if (!g->inflight.empty()) { set_error("tamd_graph_run while asynchronous runs are in flight: collect them with tamd_graph_wait first"); return -1; }
     if (bind_device(g)) return -1;
     if (direct_drain(g)) return -1;
@@ -446,6 +452,7 @@ int tamd_graph_run_async(tamd_graph* g)
     TAMD_ONE_THREAD(g);
     if (!g || !g->prepared) { set_error("graph not prepared"); return -1; }
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_run_async(g);
     if (g->inflight.size() >= 2) { set_error("two runs are already in flight: call tamd_graph_wait first"); return -1; }
     if (direct_drain(g)) return -1;
     const int slot = g->next_slot;
@@ -487,6 +494,7 @@ int tamd_graph_run_async(tamd_graph* g)
 int tamd_graph_wait(tamd_graph* g)
 {
     TAMD_ONE_THREAD(g);
+    if (g && g->half[0]) return pair_wait(g);
     if (!g || g->inflight.empty()) { set_error("tamd_graph_wait: no run in flight"); return -1; }
     if (bind_device(g)) return -1;
     const Inflight f = g->inflight.front();
@@ -507,13 +515,14 @@ int tamd_graph_wait(tamd_graph* g)
     return 0;
 }
 
-int tamd_graph_inflight(const tamd_graph* g) { return g ? (int)g->inflight.size() : 0; }
+int tamd_graph_inflight(const tamd_graph* g) { return !g ? 0 : g->half[0] ? tamd_graph_inflight(g->half[0]) : (int)g->inflight.size(); }
 
 int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 {
     if (!g) { set_error("null graph"); return -1; }
     TAMD_ONE_THREAD(g);
     if (idx < 0 || idx >= (int)g->outputs.size() || !g->prepared) return -1;
+    if (g->half[0]) return pair_output_device(g, idx, dptr, bytes);
     if (g->out_fresh_in && (bind_device(g) || stage_from_pinned(g))) return -1;
     *dptr = g->outputs[idx].stage;
     *bytes = g->outputs[idx].bytes;
@@ -521,12 +530,18 @@ int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes)
 }
 
 // once the caller holds the stream it may queue work there that this library cannot see: every direct burst drains it first again
-void* tamd_graph_stream(tamd_graph* g) { g->stream_exposed = true; g->stream_dirty = true; return (void*)g->stream; }
+void* tamd_graph_stream(tamd_graph* g)
+{
+    if (g->half[0]) { (void)tamd_graph_stream(g->half[1]); return tamd_graph_stream(g->half[0]); }   // (a pair: the first half's stream; both halves drain theirs from now on)
+    g->stream_exposed = true; g->stream_dirty = true;
+    return (void*)g->stream;
+}
 
 int tamd_graph_time_launches(tamd_graph* g, int iters, float* total_ms)
 {
     TAMD_ONE_THREAD(g);
     if (bind_device(g)) return -1;
+    if (g->half[0]) return pair_time_launches(g, iters, total_ms);
     if (g->direct) {        // the passes are not on the stream: host clock around submit .. complete
         if (direct_drain(g)) return -1;
         HIPCHK(hipStreamSynchronize(g->stream));

@@ -4,6 +4,7 @@
 //   graph_plan.hip        the int8 planner (arena, requantisation folds, plan-time timing, conv / pool planners, plan_i8)
 //   graph_plan_pairs.hip  .. its pair fusions (pwdw, dwpw); graph_plan.h is what those two share
 //   plan_cache.hip        TAMD_PLAN_CACHE
+//   graph_pair.hip        a batched graph as two half-batch graphs side by side behind one handle (tamd_options.split_batch)
 //   graph_exec.hip        run_steps, the direct path's self-checks, zero-copy lists, the run-side entry points
 // (graph_u8.hip and graph_f32.hip are the uint8 / fp32 planners, as before.)
 #pragma once
@@ -39,6 +40,25 @@ int bind_device(tamd_graph* g);
 int direct_drain(tamd_graph* g);
 void direct_abandon(tamd_graph* g, const char* why);
 int stage_from_pinned(tamd_graph* g);
+
+// graph_pair.hip: a batched graph as two half-batch device graphs behind one tamd_graph (tamd_options.split_batch); every entry point
+// of the C ABI forwards to these when g->half[0] is set
+int pair_try_prerun(tamd_graph* g, const tamd_options* opt);     // 0: stays one launch list; 1: a pair now, prepared; < 0: error
+int pair_set_input(tamd_graph* g, int idx, const void* host, size_t bytes);
+int pair_set_output(tamd_graph* g, int idx, void* host, size_t bytes);
+int pair_both(tamd_graph* g, int (*fn)(tamd_graph*));
+int pair_run(tamd_graph* g);
+int pair_run_async(tamd_graph* g);
+int pair_wait(tamd_graph* g);
+int pair_direct_packets(const tamd_graph* g, bool meta);
+const char* pair_direct_packet_name(const tamd_graph* g, int i);
+int pair_direct_timestamps(tamd_graph* g, int passes, double* dur_us, double* gap_us, int max_packets);
+int pair_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);
+int pair_time_launches(tamd_graph* g, int iters, float* total_ms);
+int pair_kernel_num(const tamd_graph* g);
+int pair_profile(tamd_graph* g, int iters, tamd_kernel_info* out, int max_out);
+int pair_read_tensor(tamd_graph* g, int idx, void* host, size_t bytes);
+void pair_destroy(tamd_graph* g);
 
 // One graph = one thread at a time: every entry point that changes the graph or touches its buffers holds the graph for the
 // duration of the call (nested entry points of the SAME thread pass).  Calls from different threads one after the other are fine --

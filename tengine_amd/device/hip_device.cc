@@ -313,6 +313,7 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
 
     tamd_options opt;
     opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
+    opt.split_batch = 1;          // batches are split HERE, per subgraph (split_wanted below: from batch 8 on host to host), not again inside the library
     opt.u8_integer = 0;           // byte-exact uint8 unless the application asks for the integer form
     opt.keep_tensors = 0;         // tensors of disjoint lifetimes share device memory (only subgraph outputs are visible to Tengine)
     opt.direct_dispatch = 1;      // the blocking host-to-host run as one AQL pass on the subgraph's own HSA queue (csrc/direct.cc:

@@ -16,9 +16,17 @@ def path_for(model, dtype, batch):
 
 def seed(dst, model, dtype, batch):
     """Copy the shipped plan of (model, dtype, per-GPU batch) to `dst` (this job's TAMD_PLAN_CACHE file) unless that file
-    already exists.  Returns the shipped file's name, or None when there is none (the job then times everything itself)."""
+    already exists.  Returns the shipped file's name, or None when there is none (the job then times everything itself).
+    The library may compile a batch as two graphs of half the batch (tamd_options.split_batch, csrc/graph_pair.hip): the shipped
+    plan of batch / 2 is merged in where there is one (every key carries its batch, so the entries cannot collide)."""
     src = path_for(model, dtype, batch)
     if not os.path.isfile(src) or os.path.exists(dst):
         return None
     shutil.copyfile(src, dst)
+    half = path_for(model, dtype, batch // 2) if batch >= 2 and batch % 2 == 0 else None
+    if half and os.path.isfile(half):
+        lines = open(half).read().splitlines()
+        if lines and lines[0] == open(src).readline().rstrip("\n"):          # same build and candidate list, or the file is void anyway
+            with open(dst, "a") as f:
+                f.write("".join(l + "\n" for l in lines[1:] if "\t" in l))
     return os.path.relpath(src, os.path.dirname(HERE))

@@ -264,7 +264,7 @@ def test_direct_dispatch_option_is_in_the_abi_and_size_guarded():
     body = hdr[hdr.index("typedef struct tamd_options {"):hdr.index("} tamd_options;")]
     fields = re.findall(r"^\s+(?:const\s+)?\w+\*?\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in capi.Options._fields_], (fields, capi.Options._fields_)
-    assert fields[-3:] == ["direct_dispatch", "keep_tensors", "u8_integer"] and ctypes.sizeof(capi.Options) == 40
+    assert fields[-4:] == ["direct_dispatch", "keep_tensors", "u8_integer", "split_batch"] and ctypes.sizeof(capi.Options) == 40   # (8 + 8 ints: no padding added)
 
 
 def test_environment_surface_is_the_documented_one():

@@ -14,8 +14,9 @@ from tengine_amd import capi, models, plans, tm2  # noqa: E402
 
 CONFIGS = [("mobilenet_v1", "int8", 1, False), ("mobilenet_v1", "int8", 64, False), ("resnet50", "int8", 32, False),
            ("yolov3_tiny", "uint8", 8, False), ("mssd", "uint8", 16, False), ("yolov3_tiny", "uint8", 8, True), ("mssd", "uint8", 16, True)]
-# the half batches of the four batched configurations: bench.py's `two_half_batches` side measurement (two concurrent graphs of half the
-# batch each, on their own queues -- profiles/r06_split_batch_direct.txt) plans from these.  `make_plans.py out_dir half` writes only these.
+# the half batches of the four batched configurations: the library compiles a batched int8 graph as two device graphs of half the batch
+# (tamd_options.split_batch, csrc/graph_pair.hip; bench.py's side figure forces the same form on the uint8 configs) -- tengine_amd/plans.py
+# merges these into the job's plan file.  `make_plans.py out_dir half` writes only these.
 HALF_CONFIGS = [("mobilenet_v1", "int8", 32, False), ("resnet50", "int8", 16, False), ("yolov3_tiny", "uint8", 4, False), ("mssd", "uint8", 8, False)]
 
 
@@ -28,7 +29,7 @@ def plan_once(name, dtype, batch, integer, path):
         os.environ["TAMD_U8_INT"] = "1"
     try:
         g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))
-        gr = capi.Graph(tm2.write_tm2(g), batch=batch, direct_dispatch=True)
+        gr = capi.Graph(tm2.write_tm2(g), batch=batch, direct_dispatch=True, split_batch=1)      # the plan OF THIS BATCH, as one launch list (its file's name)
         gr.set_input(models.synth_input(g, 3, tm2.DT_UINT8 if dtype == "uint8" else tm2.DT_INT8))
         gr.run()
         gr.upload()
