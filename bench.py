@@ -170,7 +170,10 @@ def main():
         # one HSA queue per graph: with several batch-1 streams the extra queues oversubscribe the hardware queues (measured: 4
         # streams 8.2 k img/s direct against 27.3 k on HIP streams), so the concurrent-streams mode stays on hipGraph replay
         direct = bool(direct) and S == 1
-        grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank, direct_dispatch=direct) for _ in range(S)]
+        # a per-step / final all-gather copies out of PERSISTENT views of the outputs' device buffers on the graph's own stream: a graph compiled
+        # as two half-batch device graphs has two streams and gathers its outputs only inside tamd_graph_output_device, so the gather regions
+        # (N > 1) keep the one-launch-list form; the N = 1 region takes the library's default form (tamd_options.split_batch = 0)
+        grs = [capi.Graph(tm_bytes, batch=args.batch, gpu_index=local_rank, direct_dispatch=direct, split_batch=0 if mode == "none" else 1) for _ in range(S)]
         gr = grs[0]
         for q in grs:
             q.set_input(x)
@@ -410,6 +413,7 @@ def main():
     head_sha = output_sha(outs_all) if rank == 0 else None
     head_golden = golden_sha(args.model, args.dtype, args.batch) if (rank == 0 and not args.u8_integer) else None
     n_direct = main_info["direct_packets"]
+    n_halves = gr.halves()
     prerun_ms = gr.prerun_ms()
     for q in grs:
         q.close()
@@ -441,8 +445,9 @@ def main():
             "config": {"workload": "%s %s batch=%d per GPU%s, weights = seeded synthetic tmfile, input resident in HBM, "
                                    "%s, %d stream(s)" % (args.model, args.dtype, args.batch,
                                                                       " (BASELINE configs[1])" if (args.model, args.dtype, args.batch) == ("mobilenet_v1", "int8", 1) else "",
-                                                                      "direct AQL dispatch of the launch list (%d packets per step)" % n_direct if n_direct else "hipGraph replay", S),
-                       "streams": S,
+                                                                      ("direct AQL dispatch of the launch list (%d packets per step)" % n_direct if n_direct else "hipGraph replay")
+                                                                      + (", the batch as two device graphs of %d images side by side on their own queues behind one handle (tamd_options.split_batch)" % (args.batch // 2) if n_halves else ""), S),
+                       "streams": S, "halves": n_halves,
                        "global_batch": total_images, "parallelism": "dp%d" % world,
                        "collectives": ("rccl broadcast(tmfile) once + one all_gather of all %d output(s) (%d B/image) %s"
                                        % (n_out, sum(per_image), "per step, overlapped with the next step" if gather_mode == "every"
@@ -620,6 +625,8 @@ def side_config(model, dtype, batch, what, gpu_index, direct, steps=100, regions
         gr = None
         try:
             other = other_form(tm_bytes, model, dtype, batch, x, gpu_index, direct, steps, regions, warmup, want, 1 if halves else 2)
+            if not halves and not other["halves"]:     # (YOLOv3-tiny's Upsample, the SSD heads: not in the batch-wise independent operator list)
+                other = {"halves": 0, "what": "this graph cannot be halved (operators outside the batch-wise independent list): one launch list is its only form"}
         except Exception as e:                     # a side measurement of a side configuration: never at the cost of the line
             other = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         return {"what": what, "ms_per_step": 1e3 * el / steps, "images_per_s": batch * steps / el, "halves": halves,

@@ -253,7 +253,9 @@ TAMD_API const char* tamd_graph_direct_packet_name(const tamd_graph* g, int i);
 TAMD_API int tamd_graph_download_outputs(tamd_graph* g);
 /* device pointer + byte size of graph output `idx` in the reference's NCHW order (for RCCL gather).  Valid after any pass: a
  * direct-dispatch tamd_graph_run / tamd_graph_wait leaves its outputs in the pinned host buffers only (zero-copy lists) and this
- * call refreshes the device copy from there first; it fails while asynchronous runs are in flight. */
+ * call refreshes the device copy from there first; it fails while asynchronous runs are in flight.  For a graph compiled as two
+ * half-batch device graphs (tamd_options.split_batch) the pointer is a buffer of the pair into which THIS CALL gathers the two halves'
+ * outputs (it waits for their passes first): call it after the pass whose outputs are wanted, not once before a loop of passes. */
 TAMD_API int tamd_graph_output_device(tamd_graph* g, int idx, void** dptr, size_t* bytes);
 TAMD_API void* tamd_graph_stream(tamd_graph* g);          /* hipStream_t                           */
 /* wall time tamd_graph_prerun took (planning incl. the plan-time autotune, capture, direct-dispatch programs), milliseconds */

@@ -18,7 +18,7 @@ from test_gpu_direct import hip_runtime_of_the_library
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NP = {"int8": np.int8, "uint8": np.uint8}
+DT = {"int8": tm2.DT_INT8, "uint8": tm2.DT_UINT8}
 
 
 def _both_forms(g, direct, **kw):
@@ -33,7 +33,7 @@ def _both_forms(g, direct, **kw):
 @pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 4), ("resnet50", "int8", 2), ("mobilenet_v1", "int8", 16)])
 def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype, batch, direct):
     g = models.build(name, dtype, batch)
-    x = models.synth_input(g, 31, NP[dtype])
+    x = models.synth_input(g, 31, DT[dtype])
     want = oracle.run_graph(g, x) if (name, batch) == ("mobilenet_v1", 4) else None      # (the others: against the one-list form, itself pinned elsewhere)
     one, two = _both_forms(g, direct)
     assert two.input_desc() == one.input_desc() == (list(x.shape), tm2.DT_INT8)
@@ -49,7 +49,7 @@ def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype
     # the images of the two halves really differ (a pair that ran one half twice would show here)
     assert not np.array_equal(got[0][:batch // 2], got[0][batch // 2:])
     # resident path: upload, launches, sync, download
-    x2 = models.synth_input(g, 32, NP[dtype])
+    x2 = models.synth_input(g, 32, DT[dtype])
     one.set_input(x2); two.set_input(x2)
     ref2 = one.run()
     two.upload()
@@ -101,7 +101,7 @@ def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype
 
 def test_read_tensor_of_a_pair_returns_the_whole_batch():
     g = helpers.pwdw_graph(5, 4, 16, 12, 12, 32)
-    x = models.synth_input(g, 3, np.int8)
+    x = models.synth_input(g, 3, tm2.DT_INT8)
     one, two = _both_forms(g, True, keep_tensors=True)
     for gr in (one, two):
         gr.set_input(x)
@@ -124,7 +124,7 @@ def test_read_tensor_of_a_pair_returns_the_whole_batch():
 
 def test_uint8_conv_as_a_pair_is_byte_exact():
     g = helpers.u8_conv_graph(9, 6, 16, 14, 14, 32, 3, p=1)
-    x = models.synth_input(g, 4, np.uint8)
+    x = models.synth_input(g, 4, tm2.DT_UINT8)
     want = oracle.run_graph(g, x)
     one, two = _both_forms(g, True)
     for gr in (one, two):
@@ -142,7 +142,7 @@ def test_graphs_that_cannot_be_halved_stay_one_launch_list():
     assert gr.halves() == 0
     gr.close()
     g = helpers.i8_head_graph(3, 2, 16, 5, 5)
-    x = models.synth_input(g, 1, np.int8)
+    x = models.synth_input(g, 1, tm2.DT_INT8)
     gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True, split_batch=2)
     assert gr.halves() == 0
     gr.set_input(x)
