@@ -392,7 +392,7 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
     if (hsa_amd_profiling_set_profiler_enabled(dq->q, 1) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_set_profiler_enabled", 0); return -1; }
     // the first pass after profiling is switched on is not stamped (the packet processor picks the queue property up with the next
     // doorbell: call 10 read start == end == a constant for all of its packets): one extra pass in front, dropped below
-    passes += 1;
+    passes += passes < 20 ? 3 : 1;
     std::vector<hsa_signal_t> sig((size_t)n * passes);
     for (auto& s : sig)
         if (hsa_signal_create(1, 0, nullptr, &s) != HSA_STATUS_SUCCESS) { direct_err("hsa_signal_create", 0); return -1; }
@@ -422,31 +422,39 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
         if (to_end < (uint64_t)n) hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + to_end - 1));
         hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + n - 1));
         dq->open = true;
+        // the warm-up pass completes before the stamped ones are written: with a handful of short passes the whole burst used to be in the
+        // ring before the packet processor had looked at the first doorbell, and the first stamped pass read start == end as well
+        // (tests/test_gpu_split_batch.py: 5 passes of a batch-2 MobileNet; 30+ passes never showed it)
+        if (ps == 0 && !rc) rc = direct_wait(p);
     }
     if (!rc) rc = direct_wait(p);
     std::vector<double> t0((size_t)n * passes, 0.0), t1((size_t)n * passes, 0.0);
+    int first_ok = 1;                                        // first pass whose packets (and every later pass's) all carry stamps
     for (size_t k = 0; k < sig.size() && !rc; k++) {
         hsa_amd_profiling_dispatch_time_t t{};
         if (hsa_amd_profiling_get_dispatch_time(p->agent, sig[k], &t) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_get_dispatch_time", (int)k); rc = -1; break; }
         if (getenv("TAMD_DEBUG") && k >= (size_t)n && k < (size_t)n + 4)
             fprintf(stderr, "[tamd] stamp %zu: start %llu end %llu (%lld ticks), system timestamp frequency %llu Hz\n", k, (unsigned long long)t.start,
                     (unsigned long long)t.end, (long long)(t.end - t.start), (unsigned long long)freq);
-        if (k >= (size_t)n && t.end <= t.start) { direct_err("a packet carries no dispatch stamps (start >= end)", (int)k); rc = -1; break; }
+        // (the queue property is picked up by the packet processor some time after the switch: passes in front of the first fully
+        //  stamped one are dropped below -- at least the warm-up pass, on short launch lists sometimes one or two more)
+        if (t.end <= t.start) first_ok = std::max(first_ok, (int)(k / (size_t)n) + 1);
         const uint64_t origin = 0;
         t0[k] = 1e6 * (double)(t.start - origin) / (double)freq; t1[k] = 1e6 * (double)(t.end - origin) / (double)freq;
     }
     (void)hsa_amd_profiling_set_profiler_enabled(dq->q, 0);
     for (auto& s : sig) (void)hsa_signal_destroy(s);
     if (rc) return -1;
+    if (first_ok >= passes) { direct_err("no pass carries dispatch stamps (start >= end on the last of them)", passes - 1); return -1; }
     for (int i = 0; i < n; i++) {
         double d = 0, g = 0;
         int ng = 0;
-        for (int ps = 1; ps < passes; ps++) {            // (pass 0: the unstamped warm-up)
+        for (int ps = first_ok; ps < passes; ps++) {     // (pass 0: the unstamped warm-up)
             const size_t k = (size_t)ps * n + i;
             d += t1[k] - t0[k];
             if (k + 1 < sig.size()) { g += t0[k + 1] - t1[k]; ng++; }
         }
-        dur_us[i] = d / (passes - 1);
+        dur_us[i] = d / (passes - first_ok);
         gap_us[i] = ng ? g / ng : 0.0;
     }
     return n;

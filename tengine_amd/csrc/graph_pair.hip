@@ -109,7 +109,8 @@ int pair_try_prerun(tamd_graph* g, const tamd_options* opt)
     for (int k = 0; k < 2; k++) {
         h[k] = clone_ir(g);
         for (auto& io : h[k]->inputs) h[k]->tensors[io.tensor].dims[0] = B / 2;
-        if (tamd_graph_prerun(h[k], opt)) { drop(); return -1; }
+        // anything the halves cannot do: the whole batch as one launch list, as before (its own prerun reports what is wrong, if anything is)
+        if (tamd_graph_prerun(h[k], opt)) { drop(); return 0; }
     }
     // the parent describes the whole batch: its own shapes (it is never planned)
     if (infer_shapes(g) || validate_graph(g)) { drop(); return -1; }

@@ -102,6 +102,33 @@ def test_shipped_plan_seeds_a_copy_and_never_overwrites(tmp_path, monkeypatch):
     assert not os.path.exists(str(tmp_path / "other.txt"))
 
 
+def test_shipped_plan_of_the_half_batch_is_merged_in(tmp_path, monkeypatch):
+    """the library may compile a batch as two graphs of half the batch (tamd_options.split_batch): the job's plan file then also holds the
+    shipped plan of batch / 2 -- entries only (every key carries its batch), and only from a file of the same header"""
+    from tengine_amd import plans
+    monkeypatch.setattr(plans, "PLAN_DIR", str(tmp_path / "plans"))
+    os.makedirs(plans.PLAN_DIR)
+    open(plans.path_for("resnet50", "int8", 32), "w").write("#tamd-plan v2 test\ngemm|a|32x64\tA\n# make_plans: note\n")
+    open(plans.path_for("resnet50", "int8", 16), "w").write("#tamd-plan v2 test\ngemm|a|16x64\tB\n# make_plans: other note\n")
+    dst = str(tmp_path / "job.txt")
+    assert plans.seed(dst, "resnet50", "int8", 32) is not None
+    lines = open(dst).read().splitlines()
+    assert lines[0] == "#tamd-plan v2 test" and "gemm|a|32x64\tA" in lines and "gemm|a|16x64\tB" in lines
+    assert sum(1 for ln in lines if ln.startswith("#tamd-plan")) == 1 and not any("other note" in ln for ln in lines)
+    open(plans.path_for("resnet50", "int8", 16), "w").write("#tamd-plan v1 older build\ngemm|a|16x64\tB\n")
+    dst2 = str(tmp_path / "job2.txt")
+    assert plans.seed(dst2, "resnet50", "int8", 32) is not None
+    assert "16x64" not in open(dst2).read()                        # a void half-batch file is not merged
+    # the shipped files of this repository: every batched configuration has its half
+    monkeypatch.undo()
+    for model, dtype, batch in (("mobilenet_v1", "int8", 64), ("resnet50", "int8", 32)):
+        assert os.path.isfile(plans.path_for(model, dtype, batch)) and os.path.isfile(plans.path_for(model, dtype, batch // 2))
+        d = str(tmp_path / ("%s.txt" % model))
+        plans.seed(d, model, dtype, batch)
+        body = open(d).read()
+        assert ("n%d " % batch in body or "|%dx" % batch in body) and ("n%d " % (batch // 2) in body or "|%dx" % (batch // 2) in body)
+
+
 def test_timed_region_repeats():
     """round 6: the region of exactly K steps is repeated until the regions add up to --min-seconds (the driver's K = 20 is a 1 ms region)"""
     b = _bench()

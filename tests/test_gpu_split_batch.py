@@ -32,7 +32,7 @@ def _both_forms(g, direct, **kw):
 @pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 4), ("resnet50", "int8", 2), ("mobilenet_v1", "int8", 16)])
 def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype, batch, direct):
-    g = models.build(name, dtype, batch)
+    g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))      # logits-only (a softmaxed output is mostly zeros)
     x = models.synth_input(g, 31, DT[dtype])
     want = oracle.run_graph(g, x) if (name, batch) == ("mobilenet_v1", 4) else None      # (the others: against the one-list form, itself pinned elsewhere)
     one, two = _both_forms(g, direct)
@@ -79,16 +79,15 @@ def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype
     for a, c in zip(ref2, outs[1]):
         assert np.array_equal(a, c)
     # launch lists, packets, timing entry points
-    assert two.kernel_num() > 0 and two.kernel_num() % 2 == 0
+    # (the two halves plan on their own: without a plan file their timing races may choose different members of a kernel family --
+    #  the same bytes either way -- so only the sums are asserted)
+    assert two.kernel_num() >= 2
     prof = two.profile(3)
     assert len(prof) == two.kernel_num() and all(k["ms"] > 0 for k in prof)
-    assert [k["kernel"] for k in prof[:len(prof) // 2]] == [k["kernel"] for k in prof[len(prof) // 2:]]
+    assert abs(sum(k["macs"] for k in prof) - sum(k["macs"] for k in one.profile(1))) < 1e-6 * sum(k["macs"] for k in prof)
     assert two.time_launches(5) > 0
     if direct:
-        assert two.direct_packets() > 0 and two.direct_packets() % 2 == 0
-        rows = two.direct_timestamps(5)
-        assert len(rows) == two.direct_packets() and all(d > 0 for _, d, _ in rows)
-        assert [r[0] for r in rows[:len(rows) // 2]] == [r[0] for r in rows[len(rows) // 2:]]
+        assert two.direct_packets() >= 2
     else:
         assert two.direct_packets() == 0
     # ... and the passes above left the graph usable
@@ -99,9 +98,29 @@ def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype
     one.close(); two.close()
 
 
+def test_direct_timestamps_of_a_pair_list_both_halves():
+    """tamd_graph_direct_timestamps of a pair: the first half's packets stamped alone, then the second's (per-packet durations of the path
+    the timed loop runs; the overlap of the two lists is what the host's clock sees).  A graph of its own: with the queues of a third
+    graph alive in the process a SHORT stamped burst came back without stamps on the call-36..38 boxes -- the entry point then returns an
+    error (never numbers), which is why this is not part of the all-entry-points test above."""
+    g = models.build("mobilenet_v1", "int8", 4)
+    gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True, split_batch=2)
+    assert gr.halves() == 2
+    gr.set_input(models.synth_input(g, 1, tm2.DT_INT8))
+    gr.upload()
+    gr.sync()
+    step_us = min(1e3 * gr.time_launches(100) / 100 for _ in range(3))
+    for passes in (5, 30):
+        rows = gr.direct_timestamps(passes)
+        assert len(rows) == gr.direct_packets() and all(d > 0.2 for _, d, _ in rows), rows
+    alone = sum(d + gp for _, d, gp in rows)
+    print("pair, HSA stamps: the two lists alone %.2f us; host clock of the overlapped step %.2f us" % (alone, step_us))
+    assert step_us < alone                                    # the halves overlap: the step is shorter than the two lists one after the other
+    gr.close()
+
+
 def test_read_tensor_of_a_pair_returns_the_whole_batch():
-    g = helpers.pwdw_graph(5, 4, 16, 12, 12, 32)
-    x = models.synth_input(g, 3, tm2.DT_INT8)
+    g, x = helpers.pwdw_graph(5, 4, 16, 12, 12, 32)
     one, two = _both_forms(g, True, keep_tensors=True)
     for gr in (one, two):
         gr.set_input(x)
@@ -123,8 +142,7 @@ def test_read_tensor_of_a_pair_returns_the_whole_batch():
 
 
 def test_uint8_conv_as_a_pair_is_byte_exact():
-    g = helpers.u8_conv_graph(9, 6, 16, 14, 14, 32, 3, p=1)
-    x = models.synth_input(g, 4, tm2.DT_UINT8)
+    g, x = helpers.u8_conv_graph(9, 6, 16, 14, 14, 32, 3, p=1)
     want = oracle.run_graph(g, x)
     one, two = _both_forms(g, True)
     for gr in (one, two):
@@ -141,8 +159,7 @@ def test_graphs_that_cannot_be_halved_stay_one_launch_list():
     gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True, split_batch=2)
     assert gr.halves() == 0
     gr.close()
-    g = helpers.i8_head_graph(3, 2, 16, 5, 5)
-    x = models.synth_input(g, 1, tm2.DT_INT8)
+    g, x = helpers.i8_head_graph(3, 2, 16, 5, 5)
     gr = capi.Graph(tm2.write_tm2(g), direct_dispatch=True, split_batch=2)
     assert gr.halves() == 0
     gr.set_input(x)
@@ -163,8 +180,8 @@ def halves(g, **kw):
     h = gr.halves()
     gr.close()
     return h
-i8 = lambda n: helpers.conv_graph(1, n, 16, 10, 10, 32, 3, p=1)
-u8 = lambda n: helpers.u8_conv_graph(1, n, 16, 10, 10, 32, 3, p=1)
+i8 = lambda n: helpers.conv_graph(1, n, 16, 10, 10, 32, 3, p=1)[0]
+u8 = lambda n: helpers.u8_conv_graph(1, n, 16, 10, 10, 32, 3, p=1)[0]
 out = [halves(i8(16), direct_dispatch=True), halves(i8(8), direct_dispatch=True), halves(i8(16), direct_dispatch=False),
        halves(u8(16), direct_dispatch=True), halves(i8(16), direct_dispatch=True, split_batch=1), halves(i8(2), direct_dispatch=False, split_batch=2)]
 print("HALVES", *out)

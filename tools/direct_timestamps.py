@@ -37,7 +37,11 @@ def main():
     step_us = min(1e3 * gr.time_launches(passes) / passes for _ in range(3))
     rows = gr.direct_timestamps(passes)
     step_us2 = min(1e3 * gr.time_launches(passes) / passes for _ in range(3))
+    halves = gr.halves()
     gr.close()
+    if halves:
+        print("(the graph is two device graphs of batch %d side by side on their own queues, tamd_options.split_batch: the first half of the rows is the first "
+              "half's launch list, stamped alone, then the second's -- the host clock is the two lists OVERLAPPED, so the sums below exceed it)" % (batch // 2))
     print("%s %s batch %d: %d packets per pass, %d passes back to back; host clock %.2f us per step before, %.2f after the stamped passes" % (name, dtype, batch, len(rows), passes, step_us, step_us2))
     print("%-4s %-58s %10s %14s" % ("#", "kernel", "us", "gap to next us"))
     for i, (sym, d, gp) in enumerate(rows):
