@@ -429,7 +429,7 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
     }
     if (!rc) rc = direct_wait(p);
     std::vector<double> t0((size_t)n * passes, 0.0), t1((size_t)n * passes, 0.0);
-    int first_ok = 1;                                        // first pass whose packets (and every later pass's) all carry stamps
+    int first_ok = 1, n_bad = 0, last_bad = -1;              // first pass whose packets (and every later pass's) all carry stamps
     for (size_t k = 0; k < sig.size() && !rc; k++) {
         hsa_amd_profiling_dispatch_time_t t{};
         if (hsa_amd_profiling_get_dispatch_time(p->agent, sig[k], &t) != HSA_STATUS_SUCCESS) { direct_err("hsa_amd_profiling_get_dispatch_time", (int)k); rc = -1; break; }
@@ -438,14 +438,20 @@ int direct_timestamps(DirectProgram* p, int passes, double* dur_us, double* gap_
                     (unsigned long long)t.end, (long long)(t.end - t.start), (unsigned long long)freq);
         // (the queue property is picked up by the packet processor some time after the switch: passes in front of the first fully
         //  stamped one are dropped below -- at least the warm-up pass, on short launch lists sometimes one or two more)
-        if (t.end <= t.start) first_ok = std::max(first_ok, (int)(k / (size_t)n) + 1);
+        if (t.end <= t.start) { first_ok = std::max(first_ok, (int)(k / (size_t)n) + 1); n_bad++; last_bad = (int)k; }
         const uint64_t origin = 0;
         t0[k] = 1e6 * (double)(t.start - origin) / (double)freq; t1[k] = 1e6 * (double)(t.end - origin) / (double)freq;
     }
     (void)hsa_amd_profiling_set_profiler_enabled(dq->q, 0);
     for (auto& s : sig) (void)hsa_signal_destroy(s);
     if (rc) return -1;
-    if (first_ok >= passes) { direct_err("no pass carries dispatch stamps (start >= end on the last of them)", passes - 1); return -1; }
+    if (first_ok >= passes) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "no pass carries dispatch stamps throughout: %d of %d packets without (the last one: packet %d of pass %d, %s)", n_bad, n * passes,
+                 last_bad % n, last_bad / n, direct_packet_name(p, last_bad % n));
+        direct_err(msg, passes - 1);
+        return -1;
+    }
     for (int i = 0; i < n; i++) {
         double d = 0, g = 0;
         int ng = 0;
