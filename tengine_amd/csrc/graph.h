@@ -195,6 +195,11 @@ struct tamd_graph {
     // keeps the IR (descriptions, constants) and forwards every entry point; it owns no stream, launch list or device tensor.
     tamd_graph* half[2] = {nullptr, nullptr};
     bool is_half = false;                      // one of the two halves of such a pair: never split again
+    // ... and the batch of the WHOLE graph it is a part of (0: its own).  The reference picks the formula of a 3x3 depthwise
+    // convolution by batch == 1 (conv_dw_hcl_x86.c:508-543 score(): the hand-written kernel at batch 1, ref_conv_int8 otherwise --
+    // another requantisation chain, graph_plan.hip: conv_mode): the halves of a 2-image graph run ONE image each and must still
+    // produce the 2-image graph's bytes (found by tools/fuzz_split.py: 7 of 931 graphs differed before this field existed)
+    int formula_batch = 0;
     std::vector<void*> pair_out;               // tamd_graph_output_device of a pair: the two halves gathered into one buffer per output
 };
 

@@ -108,6 +108,7 @@ int pair_try_prerun(tamd_graph* g, const tamd_options* opt)
     auto drop = [&]() { for (auto*& c : h) if (c) { tamd_graph_destroy(c); c = nullptr; } };
     for (int k = 0; k < 2; k++) {
         h[k] = clone_ir(g);
+        h[k]->formula_batch = B;               // batch-dependent reference formulas follow the WHOLE batch (graph.h)
         for (auto& io : h[k]->inputs) h[k]->tensors[io.tensor].dims[0] = B / 2;
         // anything the halves cannot do: the whole batch as one launch list, as before (its own prerun reports what is wrong, if anything is)
         if (tamd_graph_prerun(h[k], opt)) { drop(); return 0; }

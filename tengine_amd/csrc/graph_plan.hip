@@ -312,7 +312,7 @@ static int plan_conv(tamd_graph* g, HNode& n, bool as_fc, const FusedElt* fz = n
         if ((size_t)w.elems() != (size_t)y.c * x.c * x.h * x.w) { set_error("fc %s: weight size mismatch", n.name.c_str()); return -1; }
     } else {
         p = n.p.conv;
-        mode = conv_mode(p, x.n, x.c, y.c);
+        mode = conv_mode(p, g->formula_batch ? g->formula_batch : x.n, x.c, y.c);      // (a half of a pair: the whole graph's batch decides, graph.h)
     }
     const int cout = y.c, cin = x.c, group = p.group;
     const int cin_g = cin / group;

@@ -135,7 +135,7 @@ int plan_pwdw(tamd_graph* g, HNode& pw, HNode& tl, int tmode, int prod, size_t s
         HTensor& dwt = g->tensors[tl.in[1]];
         HTensor* db = tl.in.size() > 2 ? &g->tensors[tl.in[2]] : nullptr;
         if (dwt.elems() != (size_t)C * 9 || (db && db->elems() < (size_t)C)) return 0;
-        const RqFold rq = fold_requant(conv_mode(q, mid.n, C, C), q.activation, mid.scales[0], y.scales[0], dwt, C);
+        const RqFold rq = fold_requant(conv_mode(q, g->formula_batch ? g->formula_batch : mid.n, C, C), q.activation, mid.scales[0], y.scales[0], dwt, C);
         const int8_t* wd = (const int8_t*)dwt.data.data();
         std::vector<int8_t> wp((size_t)3 * cw * 4, 0);
         for (int c = 0; c < C; c++)

@@ -66,7 +66,7 @@ struct HipSubgraph {
     // round 6: a batched subgraph of batch-wise independent operators runs as TWO device graphs of half the batch each, side by side
     // on their own HSA queues (g: images [0, B / 2), g2: the rest): the launch boundaries and tile tails of one half overlap the
     // other half's work -- ResNet-50 b32 +7-8 %, MobileNet-v1 b64 +5-6 % (profiles/r06_split_batch_direct.txt).  nullptr: one graph.
-    tamd_graph* g2 = nullptr;
+    tamd_graph* g2 = nullptr;      // (always nullptr since the library compiles the pair behind ONE tamd_graph -- hip_dev_prerun; the two-object paths below stay for a caller-made pair)
     std::vector<uint16_t> in_ir, out_ir;   // ir tensor indices of the subgraph inputs / outputs, in tamd order
 };
 
@@ -313,7 +313,6 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
 
     tamd_options opt;
     opt.dev_name = HIP_DEV_NAME; opt.size = (int)sizeof(opt); opt.gpu_index = 0; opt.use_hip_graph = 1; opt.profile = 0;
-    opt.split_batch = 1;          // batches are split HERE, per subgraph (split_wanted below: from batch 8 on host to host), not again inside the library
     opt.u8_integer = 0;           // byte-exact uint8 unless the application asks for the integer form
     opt.keep_tensors = 0;         // tensors of disjoint lifetimes share device memory (only subgraph outputs are visible to Tengine)
     opt.direct_dispatch = 1;      // the blocking host-to-host run as one AQL pass on the subgraph's own HSA queue (csrc/direct.cc:
@@ -333,25 +332,17 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
     }
     const char* env = getenv("TG_HIP_DEVICE");
     if (env) opt.gpu_index = atoi(env);
-    if (opt.direct_dispatch && split_wanted(ir, subgraph)) {      // two half-batch graphs instead of one
-        tamd_graph* whole = hs->g;
-        tamd_graph* h1 = build(2);
-        tamd_graph* h2 = h1 ? build(2) : nullptr;
-        if (h1 && h2 && tamd_graph_prerun(h1, &opt) == 0 && tamd_graph_prerun(h2, &opt) == 0) {
-            tamd_graph_destroy(whole);
-            hs->g = h1; hs->g2 = h2;
-            g_split_subgraphs++;
-        } else {                                                  // anything the halves cannot do: the whole batch as one graph, as before
-            if (h1) tamd_graph_destroy(h1);
-            if (h2) tamd_graph_destroy(h2);
-        }
-    }
-    if (!hs->g2 && tamd_graph_prerun(hs->g, &opt) != 0) {
+    // two half-batch device graphs instead of one: decided HERE per subgraph (split_wanted: from batch 8 on host to host), done by the library
+    // behind the one tamd_graph (csrc/graph_pair.hip: it also keeps the reference's batch-dependent formulas on the WHOLE batch -- the
+    // plugin's own pair of graphs, earlier this round, could not: halves of one image each took the batch-1 depthwise formula)
+    opt.split_batch = (opt.direct_dispatch && split_wanted(ir, subgraph)) ? 2 : 1;
+    if (tamd_graph_prerun(hs->g, &opt) != 0) {
         TLOG_ERR("Tengine HIP: prerun failed: %s\n", tamd_last_error());
         tamd_graph_destroy(hs->g);
         delete hs;
         return -1;
     }
+    if (tamd_graph_halves(hs->g)) g_split_subgraphs++;
     // subgraph outputs must leave valid host bytes in ir_tensor->data (SURVEY §8b "Ownership")
     for (uint16_t t : hs->out_ir) {
         struct tensor* ot = get_ir_graph_tensor(ir, t);

@@ -30,11 +30,13 @@ def _both_forms(g, direct, **kw):
 
 
 @pytest.mark.parametrize("direct", [False, True])
-@pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 4), ("resnet50", "int8", 2), ("mobilenet_v1", "int8", 16)])
+# (mobilenet_v1 batch 2: halves of ONE image -- the reference's depthwise formula depends on batch == 1, conv_dw_hcl_x86.c:508-543, and the
+#  halves must follow the whole batch's: tamd_graph.formula_batch, found by tools/fuzz_split.py)
+@pytest.mark.parametrize("name,dtype,batch", [("mobilenet_v1", "int8", 2), ("mobilenet_v1", "int8", 4), ("resnet50", "int8", 2), ("mobilenet_v1", "int8", 16)])
 def test_two_halves_give_the_one_graphs_bytes_through_every_run_path(name, dtype, batch, direct):
     g = models.build(name, dtype, batch, device_only=(name != "mobilenet_v1"))      # logits-only (a softmaxed output is mostly zeros)
     x = models.synth_input(g, 31, DT[dtype])
-    want = oracle.run_graph(g, x) if (name, batch) == ("mobilenet_v1", 4) else None      # (the others: against the one-list form, itself pinned elsewhere)
+    want = oracle.run_graph(g, x) if (name == "mobilenet_v1" and batch <= 4) else None      # (the others: against the one-list form, itself pinned elsewhere)
     one, two = _both_forms(g, direct)
     assert two.input_desc() == one.input_desc() == (list(x.shape), tm2.DT_INT8)
     for gr in (one, two):

@@ -229,7 +229,7 @@ def _split_count():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,env,split", [("conv3x3_b2", "2", True), ("resblock_tail_b2", "2", True), ("resnet50_prob_b2", "2", True),
+@pytest.mark.parametrize("case,env,split", [("conv3x3_b2", "2", True), ("mobilenet_v1_b2", "2", True), ("resblock_tail_b2", "2", True), ("resnet50_prob_b2", "2", True),
                                             ("mobilenet_v1_b16", None, True), ("mobilenet_v1_b16", "0", False), ("conv3x3_b2", None, False),
                                             ("conv3x3_b8", None, True), ("conv3x3_b6", None, False),
                                             ("conv3x3_b3", "2", False)])
@@ -249,6 +249,9 @@ def test_batched_subgraph_as_two_half_batch_graphs(ref, case, env, split, monkey
     elif case == "resnet50_prob_b2":
         g = models.build("resnet50", "int8", 2)
         x = models.synth_input(g, 8)
+    elif case == "mobilenet_v1_b2":        # halves of ONE image: the depthwise layers must still follow the batch-2 formula of the reference
+        g = models.build("mobilenet_v1", "int8", 2)
+        x = models.synth_input(g, 7)
     else:
         g = models.build("mobilenet_v1", "int8", 16)
         x = models.synth_input(g, 7)
