@@ -42,3 +42,27 @@ def test_gpu_only_tool_fails_loudly_without_a_gpu():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "no HIP device" in r.stderr or "no CPU fallback" in r.stderr, r.stderr[-400:]
+
+
+def test_pair_fuzz_graphs_have_an_even_batch_and_the_oracle_runs_them():
+    """tools/fuzz_split.py (the two-half-batch form's device campaign): its generator only hands out graphs the library can halve by batch --
+    an even batch >= 2 on the graph input -- and the oracle, its checker, evaluates every one of them (both dtypes)"""
+    import importlib
+
+    import numpy as np
+
+    from oracle import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    fs = importlib.import_module("fuzz_split")
+    for dtype in ("int8", "uint8"):
+        rng = np.random.default_rng(11)
+        kinds = set()
+        for _ in range(25):
+            g, x = fs.even_batch_graph(rng, dtype)
+            assert x.shape[0] >= 2 and x.shape[0] % 2 == 0
+            outs = oracle.run_graph(g, x)
+            assert outs and outs[0].shape[0] == x.shape[0]
+            assert len(tm2.write_tm2(g)) > 100
+            kinds.add(g.name)
+        assert len(kinds) >= 2, kinds
