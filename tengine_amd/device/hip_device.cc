@@ -63,10 +63,8 @@ namespace {
 
 struct HipSubgraph {
     tamd_graph* g = nullptr;
-    // round 6: a batched subgraph of batch-wise independent operators runs as TWO device graphs of half the batch each, side by side
-    // on their own HSA queues (g: images [0, B / 2), g2: the rest): the launch boundaries and tile tails of one half overlap the
-    // other half's work -- ResNet-50 b32 +7-8 %, MobileNet-v1 b64 +5-6 % (profiles/r06_split_batch_direct.txt).  nullptr: one graph.
-    tamd_graph* g2 = nullptr;      // (always nullptr since the library compiles the pair behind ONE tamd_graph -- hip_dev_prerun; the two-object paths below stay for a caller-made pair)
+    // (round 6: a batched subgraph of batch-wise independent operators is TWO device graphs of half the batch each behind this one handle,
+    //  side by side on their own HSA queues -- tamd_options.split_batch, decided in hip_dev_prerun, done by the library: csrc/graph_pair.hip)
     std::vector<uint16_t> in_ir, out_ir;   // ir tensor indices of the subgraph inputs / outputs, in tamd order
 };
 
@@ -355,23 +353,17 @@ int hip_dev_prerun(struct device* dev, struct subgraph* subgraph, void* options)
     return 0;
 }
 
-// host buffers of the subgraph's inputs / outputs -> the device graph(s); a split subgraph hands each half its half of every buffer
+// host buffers of the subgraph's inputs / outputs -> the device graph (a graph compiled as two halves uses each buffer as two contiguous halves itself)
 static int bind_io(HipSubgraph* hs, struct graph* ir)
 {
-    const int parts = hs->g2 ? 2 : 1;
-    for (int h = 0; h < parts; h++) {
-        tamd_graph* g = h ? hs->g2 : hs->g;
-        for (size_t i = 0; i < hs->in_ir.size(); i++) {
-            struct tensor* t = get_ir_graph_tensor(ir, hs->in_ir[i]);
-            if (!t->data) { TLOG_ERR("Tengine HIP: input tensor %s has no buffer\n", t->name); return -1; }
-            const size_t bytes = (size_t)t->elem_num * t->elem_size / parts;
-            if (tamd_graph_set_input(g, (int)i, (const char*)t->data + h * bytes, bytes) != 0) return -1;
-        }
-        for (size_t i = 0; i < hs->out_ir.size(); i++) {
-            struct tensor* t = get_ir_graph_tensor(ir, hs->out_ir[i]);
-            const size_t bytes = (size_t)t->elem_num * t->elem_size / parts;
-            if (tamd_graph_set_output(g, (int)i, (char*)t->data + h * bytes, bytes) != 0) return -1;
-        }
+    for (size_t i = 0; i < hs->in_ir.size(); i++) {
+        struct tensor* t = get_ir_graph_tensor(ir, hs->in_ir[i]);
+        if (!t->data) { TLOG_ERR("Tengine HIP: input tensor %s has no buffer\n", t->name); return -1; }
+        if (tamd_graph_set_input(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) return -1;
+    }
+    for (size_t i = 0; i < hs->out_ir.size(); i++) {
+        struct tensor* t = get_ir_graph_tensor(ir, hs->out_ir[i]);
+        if (tamd_graph_set_output(hs->g, (int)i, t->data, (size_t)t->elem_num * t->elem_size) != 0) return -1;
     }
     return 0;
 }
@@ -386,13 +378,6 @@ int hip_dev_run(struct device* dev, struct subgraph* subgraph)
         TLOG_ERR("Tengine HIP: %s\n", tamd_last_error());
         return -1;
     }
-    if (hs->g2) {      // the two halves side by side: both submitted before either is waited for
-        if (tamd_graph_run_async(hs->g) != 0 || tamd_graph_run_async(hs->g2) != 0 || tamd_graph_wait(hs->g) != 0 || tamd_graph_wait(hs->g2) != 0) {
-            TLOG_ERR("Tengine HIP: run failed: %s\n", tamd_last_error());
-            return -1;
-        }
-        return 0;
-    }
     if (tamd_graph_run(hs->g) != 0) {
         TLOG_ERR("Tengine HIP: run failed: %s\n", tamd_last_error());
         return -1;
@@ -406,7 +391,7 @@ int hip_dev_async_run(struct device* dev, struct subgraph* subgraph)
 {
     (void)dev;
     HipSubgraph* hs = (HipSubgraph*)subgraph->device_graph;
-    if (!hs || bind_io(hs, subgraph->graph) != 0 || tamd_graph_run_async(hs->g) != 0 || (hs->g2 && tamd_graph_run_async(hs->g2) != 0)) {
+    if (!hs || bind_io(hs, subgraph->graph) != 0 || tamd_graph_run_async(hs->g) != 0) {
         TLOG_ERR("Tengine HIP: async_run failed: %s\n", tamd_last_error());
         return -1;
     }
@@ -418,8 +403,8 @@ int hip_dev_async_wait(struct device* dev, struct subgraph* subgraph, int try_wa
     (void)dev;
     HipSubgraph* hs = (HipSubgraph*)subgraph->device_graph;
     if (!hs) return -1;
-    if (try_wait && tamd_graph_inflight(hs->g) == 0 && (!hs->g2 || tamd_graph_inflight(hs->g2) == 0)) return 0;
-    if (tamd_graph_wait(hs->g) != 0 || (hs->g2 && tamd_graph_wait(hs->g2) != 0)) {
+    if (try_wait && tamd_graph_inflight(hs->g) == 0) return 0;
+    if (tamd_graph_wait(hs->g) != 0) {
         TLOG_ERR("Tengine HIP: async_wait failed: %s\n", tamd_last_error());
         return -1;
     }
@@ -432,7 +417,6 @@ int hip_release_graph(struct device* dev, void* device_graph)
     HipSubgraph* hs = (HipSubgraph*)device_graph;
     if (hs) {
         tamd_graph_destroy(hs->g);
-        if (hs->g2) tamd_graph_destroy(hs->g2);
         delete hs;
     }
     return 0;
